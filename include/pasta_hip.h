@@ -1,0 +1,147 @@
+/*
+ * pasta_hip.h -- C ABI of libpasta_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for the PASTA-GAN generator/discriminator hot path.  Every
+ * entry point replaces one native (or ATen-delegated) call of the reference;
+ * the reference interface it stands in for is cited per function as
+ * <file>:<line> relative to the reference repository root.
+ *
+ * Conventions (all entry points)
+ *   - plain pointers + sizes, no torch types.  Device pointers unless noted.
+ *   - the CALLER allocates every output and workspace; the library never
+ *     allocates device memory and keeps no mutable global state after load.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); the
+ *     caller has already selected the device.
+ *   - return 0 on success, non-zero on error; pasta_last_error() then returns a
+ *     thread-local, NUL-terminated description (the Python shim raises
+ *     RuntimeError with it, mirroring TORCH_CHECK in the reference wrappers).
+ *   - dtype codes: PASTA_F32 = 0, PASTA_F16 = 1, PASTA_F64 = 2.
+ */
+#ifndef PASTA_HIP_H
+#define PASTA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { PASTA_F32 = 0, PASTA_F16 = 1, PASTA_F64 = 2 };
+
+/* Library identification / error reporting. */
+const char* pasta_last_error(void);
+int         pasta_abi_version(void);           /* bumps when a signature changes   */
+const char* pasta_build_info(void);            /* "gfx950 <date> <hip version>"    */
+
+/* ------------------------------------------------------------------------- *
+ * upfirdn2d -- pad, zero-stuff upsample, 2-D FIR, decimate (one launch).
+ * Replaces: upfirdn2d_plugin.upfirdn2d(x, f, upx, upy, downx, downy, padx0,
+ *           padx1, pady0, pady1, flip, gain)  torch_utils/ops/upfirdn2d.cpp:16
+ *           (kernels torch_utils/ops/upfirdn2d.cu:29-200).
+ * x: [N,C,inH,inW] with element strides in_stride[4] (N,C,H,W order);
+ * f: float32 [fH,fW] dense row-major (always fp32, upfirdn2d.cpp:21);
+ * y: [N,C,outH,outW] with out_stride[4]; outH/outW must equal
+ *    (in*up + pad0 + pad1 - f + down) / down  (upfirdn2d.cpp:32-33).
+ * ------------------------------------------------------------------------- */
+int pasta_upfirdn2d(const void* x, const float* f, void* y, int dtype,
+                    const int32_t in_size[4], const int64_t in_stride[4],
+                    const int32_t f_size[2],
+                    const int32_t out_size[4], const int64_t out_stride[4],
+                    int upx, int upy, int downx, int downy,
+                    int padx0, int padx1, int pady0, int pady1,
+                    int flip, float gain, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * bias_act -- fused bias + activation + gain + clamp, and its 1st/2nd grads.
+ * Replaces: bias_act_plugin.bias_act(x, b, xref, yref, dy, grad, dim, act,
+ *           alpha, gain, clamp)  torch_utils/ops/bias_act.cpp:32
+ *           (kernel torch_utils/ops/bias_act.cu:23-147).
+ * All tensors are dense with identical layout, n elements; NULL = absent
+ * (the reference passes an empty tensor).  b has size_b elements and is
+ * indexed by (i / step_b) % size_b.  act = 1..9 (bias_act.py:23-33 cuda_idx).
+ * grad = 0 forward, 1 first derivative (x is dy), 2 second derivative.
+ * clamp < 0 disables clamping.
+ * ------------------------------------------------------------------------- */
+int pasta_bias_act(const void* x, const void* b, const void* xref,
+                   const void* yref, const void* dy, void* y, int dtype,
+                   int64_t n, int size_b, int64_t step_b, int grad, int act,
+                   float alpha, float gain, float clamp, void* stream);
+
+/* Column sums used for the bias gradient (bias_act.py:173 `dx.sum(...)`):
+ * db[c] = sum over all i with (i / step_b) % size_b == c of dx[i].
+ * fp32 accumulate; db has dtype of dx.  work: size_b*nsplit floats scratch
+ * (nsplit returned by pasta_bias_grad_workspace). */
+int64_t pasta_bias_grad_workspace(int64_t n, int size_b, int64_t step_b);
+int pasta_bias_grad(const void* dx, void* db, float* work, int dtype, int64_t n,
+                    int size_b, int64_t step_b, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Dense convolution family on fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+ * Replaces the ATen/cuDNN calls behind torch_utils/ops/conv2d_gradfix.py:38,43
+ * (forward), :125-128 (input gradient) and :140-148 (weight gradient).
+ *
+ * One descriptor covers conv2d, conv_transpose2d and both of their gradients:
+ *   y[n, g*Og + o, oy, ox] = sum_{i,r,s} x[n, g*Ig + i, iy, ix] * w[...]
+ * `transposed` selects conv_transpose2d semantics (weight [I, O/g, kh, kw]).
+ * ------------------------------------------------------------------------- */
+typedef struct pasta_conv_desc {
+    int32_t N, C_in, H, W;        /* input  x: [N, C_in, H, W]  contiguous NCHW      */
+    int32_t C_out, OH, OW;        /* output y: [N, C_out, OH, OW] contiguous NCHW    */
+    int32_t kh, kw;               /* kernel size                                      */
+    int32_t stride;               /* conv stride (conv2d) or upsampling (transposed) */
+    int32_t pad_h, pad_w;         /* symmetric zero padding                           */
+    int32_t groups;               /* 1 (training) or N-style grouped (eval modconv)   */
+    int32_t transposed;           /* 0 = conv2d, 1 = conv_transpose2d                 */
+    int32_t flip;                 /* 1 = true convolution (flip taps), 0 = correlation */
+} pasta_conv_desc;
+
+/* Bytes of scratch the forward / weight-gradient launches need (caller allocs). */
+int64_t pasta_conv2d_workspace(const pasta_conv_desc* d);
+int64_t pasta_conv2d_wgrad_workspace(const pasta_conv_desc* d);
+
+/* y = conv(x, w).  w is the PyTorch-layout weight ([C_out, C_in/g, kh, kw], or
+ * [C_in, C_out/g, kh, kw] when transposed).  Optional fused epilogue:
+ *   y = y * oscale[n, c] (NULL = 1)  -- demodulation, networks.py:77-79
+ * and optional fused prologue on x:
+ *   x'[n, c, :, :] = x * iscale[n, c] (NULL = 1) -- modulation, networks.py:74. */
+int pasta_conv2d(const float* x, const float* w, float* y,
+                 const float* iscale, const float* oscale,
+                 const pasta_conv_desc* d, void* workspace, int64_t workspace_bytes,
+                 void* stream);
+
+/* dw = d(conv)/dw given x and dy (same descriptor as the forward). */
+int pasta_conv2d_wgrad(const float* x, const float* dy, float* dw,
+                       const pasta_conv_desc* d, void* workspace,
+                       int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Modulated-convolution helpers (training/networks.py:36-94).  The demodulation
+ * coefficients themselves are an [N,I]x[I,O] product of squared styles and
+ * squared-weight sums, left to the host's BLAS (tiny).
+ * ------------------------------------------------------------------------- */
+/* y[n,c,h,w] = x[n,c,h,w] * a[n,c] + (b ? b[n,0,h,w] : 0)   fma.py:15 with the
+ * broadcast shapes modulated_conv2d uses (a: [N,C], b: [N,HW] or [HW], or NULL) */
+int pasta_scale_add(const float* x, const float* a, const float* b, float* y,
+                    int N, int C, int64_t HW, int b_per_sample, void* stream);
+
+/* Per-(n,c) plane reductions used by fma / modulation backward:
+ * out[n,c] = sum_hw p[n,c,hw] * q[n,c,hw]   (q NULL => sum of p) */
+int pasta_plane_dot(const float* p, const float* q, float* out, int64_t planes,
+                    int64_t HW, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * SPADE normalisation (training/networks.py:4371-4379):
+ *   out = InstanceNorm(x) * (1 + gamma) + beta, eps 1e-5, biased variance.
+ * stats: [N*C, 2] (mean, rstd) written by the forward, read by the backward.
+ * ------------------------------------------------------------------------- */
+int pasta_spade_norm(const float* x, const float* gamma, const float* beta,
+                     float* out, float* stats, int64_t planes, int64_t HW,
+                     float eps, void* stream);
+int pasta_spade_norm_bwd(const float* dout, const float* x, const float* gamma,
+                         const float* stats, float* dx, float* dgamma,
+                         float* dbeta, int64_t planes, int64_t HW, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PASTA_HIP_H */

@@ -1,0 +1,229 @@
+"""CPU restatement of the PASTA-GAN op layer -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import this module, and only as the checker / timed CPU baseline; nothing under
+``pasta-gan_amd/`` imports it.
+
+Each function restates, with stock PyTorch CPU ops (any float dtype, autograd-able to any
+order), what the reference computes; the reference lines followed are cited per function
+(paths relative to the reference repository). Parity status: PINNED -- ``oracle/make_golden.py``
+runs the reference itself in the build container and stores its outputs under
+``tests/golden/``; ``tests/test_oracle_golden.py`` checks this file against them.
+"""
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+#----------------------------------------------------------------------------
+# upfirdn2d family  (torch_utils/ops/upfirdn2d.py)
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+def _pad4(padding):
+    if isinstance(padding, int):
+        return padding, padding, padding, padding
+    padding = list(padding)
+    if len(padding) == 2:
+        return padding[0], padding[0], padding[1], padding[1]
+    return tuple(padding)
+
+def filter_size(f):
+    """(fw, fh); None is the identity tap.  upfirdn2d.py:57-68"""
+    if f is None:
+        return 1, 1
+    return int(f.shape[-1]), int(f.shape[0])
+
+def setup_filter(f, normalize=True, flip_filter=False, gain=1, separable=None):
+    """upfirdn2d.py:72-116"""
+    f = torch.as_tensor(1 if f is None else f, dtype=torch.float32)
+    if f.ndim == 0:
+        f = f[None]
+    if separable is None:
+        separable = f.ndim == 1 and f.numel() >= 8
+    if f.ndim == 1 and not separable:
+        f = f[:, None] * f[None, :]
+    if normalize:
+        f = f / f.sum()
+    if flip_filter:
+        f = f.flip(list(range(f.ndim)))
+    return f * (gain ** (f.ndim / 2))
+
+def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):
+    """Zero-stuff, pad/crop, FIR, decimate.  upfirdn2d.py:169-208 (the reference specification),
+    written here as an explicit sum of shifted windows instead of a depthwise convolution."""
+    upx, upy = _pair(up)
+    downx, downy = _pair(down)
+    px0, px1, py0, py1 = _pad4(padding)
+    n, c, h, w = x.shape
+    if f is None:
+        f = torch.ones([1, 1], dtype=torch.float32)
+    f = f.to(x.dtype)
+    if f.ndim == 1:                       # separable filter == its outer product
+        f = f[:, None] * f[None, :]
+    fh, fw = f.shape
+    z = x.new_zeros([n, c, h * upy, w * upx])
+    z[:, :, ::upy, ::upx] = x
+    z = F.pad(z, [px0, px1, py0, py1])    # negative entries crop
+    taps = f if flip_filter else f.flip([0, 1])
+    oh, ow = z.shape[2] - fh + 1, z.shape[3] - fw + 1
+    assert oh >= 1 and ow >= 1
+    y = x.new_zeros([n, c, oh, ow])
+    for a in range(fh):
+        for b in range(fw):
+            y = y + taps[a, b] * z[:, :, a:a + oh, b:b + ow]
+    return y[:, :, ::downy, ::downx] * gain
+
+def filter2d(x, f, padding=0, flip_filter=False, gain=1):
+    """upfirdn2d.py:272-304"""
+    px0, px1, py0, py1 = _pad4(padding)
+    fw, fh = filter_size(f)
+    p = [px0 + fw // 2, px1 + (fw - 1) // 2, py0 + fh // 2, py1 + (fh - 1) // 2]
+    return upfirdn2d(x, f, padding=p, flip_filter=flip_filter, gain=gain)
+
+def upsample2d(x, f, up=2, padding=0, flip_filter=False, gain=1):
+    """upfirdn2d.py:308-343"""
+    upx, upy = _pair(up)
+    px0, px1, py0, py1 = _pad4(padding)
+    fw, fh = filter_size(f)
+    p = [px0 + (fw + upx - 1) // 2, px1 + (fw - upx) // 2, py0 + (fh + upy - 1) // 2, py1 + (fh - upy) // 2]
+    return upfirdn2d(x, f, up=up, padding=p, flip_filter=flip_filter, gain=gain * upx * upy)
+
+def downsample2d(x, f, down=2, padding=0, flip_filter=False, gain=1):
+    """upfirdn2d.py:347-382"""
+    downx, downy = _pair(down)
+    px0, px1, py0, py1 = _pad4(padding)
+    fw, fh = filter_size(f)
+    p = [px0 + (fw - downx + 1) // 2, px1 + (fw - downx) // 2, py0 + (fh - downy + 1) // 2, py1 + (fh - downy) // 2]
+    return upfirdn2d(x, f, down=down, padding=p, flip_filter=flip_filter, gain=gain)
+
+#----------------------------------------------------------------------------
+# bias_act  (torch_utils/ops/bias_act.py:23-33, 94-123)
+
+ACT_DEFAULTS = {   # name: (def_alpha, def_gain)
+    'linear': (0, 1), 'relu': (0, np.sqrt(2)), 'lrelu': (0.2, np.sqrt(2)), 'tanh': (0, 1), 'sigmoid': (0, 1),
+    'elu': (0, 1), 'selu': (0, 1), 'softplus': (0, 1), 'swish': (0, np.sqrt(2)),
+}
+
+def _activation(x, act, alpha):
+    if act == 'linear':   return x
+    if act == 'relu':     return torch.relu(x)
+    if act == 'lrelu':    return torch.where(x > 0, x, x * alpha)
+    if act == 'tanh':     return torch.tanh(x)
+    if act == 'sigmoid':  return torch.sigmoid(x)
+    if act == 'elu':      return F.elu(x)
+    if act == 'selu':     return F.selu(x)
+    if act == 'softplus': return F.softplus(x)
+    if act == 'swish':    return torch.sigmoid(x) * x
+    raise KeyError(act)
+
+def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None):
+    """clamp(act(x + b) * gain).  bias_act.py:94-123"""
+    def_alpha, def_gain = ACT_DEFAULTS[act]
+    alpha = float(def_alpha if alpha is None else alpha)
+    gain = float(def_gain if gain is None else gain)
+    if b is not None:
+        shape = [1] * x.ndim
+        shape[dim] = -1
+        x = x + b.reshape(shape)
+    x = _activation(x, act, alpha)
+    if gain != 1:
+        x = x * gain
+    if clamp is not None and clamp >= 0:
+        x = x.clamp(-clamp, clamp)
+    return x
+
+#----------------------------------------------------------------------------
+# fma  (torch_utils/ops/fma.py:15-16)
+
+def fma(a, b, c):
+    return a * b + c
+
+#----------------------------------------------------------------------------
+# conv2d_resample  (torch_utils/ops/conv2d_resample.py)
+
+def _conv(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True):
+    """conv2d_resample.py:31-54: conv2d is a correlation; flip_weight=False asks for a true convolution."""
+    if not flip_weight:
+        w = w.flip([2, 3])
+    if transpose:
+        return F.conv_transpose2d(x, w, stride=stride, padding=padding, groups=groups)
+    return F.conv2d(x, w, stride=stride, padding=padding, groups=groups)
+
+def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False, fast=True):
+    """conv2d_resample.py:59-154.  ``fast=True`` takes the same branch the reference takes (needed for a
+    faithful CPU timing); ``fast=False`` always evaluates the defining composition of lines 150-154."""
+    oc, icg, kh, kw = w.shape
+    fw, fh = filter_size(f)
+    px0, px1, py0, py1 = _pad4(padding)
+    if up > 1:       # :94-99
+        px0 += (fw + up - 1) // 2; px1 += (fw - up) // 2
+        py0 += (fh + up - 1) // 2; py1 += (fh - up) // 2
+    if down > 1:     # :100-104
+        px0 += (fw - down + 1) // 2; px1 += (fw - down) // 2
+        py0 += (fh - down + 1) // 2; py1 += (fh - down) // 2
+
+    if fast:
+        if kw == 1 and kh == 1 and down > 1 and up == 1:          # :107-110
+            x = upfirdn2d(x, f, down=down, padding=[px0, px1, py0, py1], flip_filter=flip_filter)
+            return _conv(x, w, groups=groups, flip_weight=flip_weight)
+        if kw == 1 and kh == 1 and up > 1 and down == 1:          # :113-116
+            x = _conv(x, w, groups=groups, flip_weight=flip_weight)
+            return upfirdn2d(x, f, up=up, padding=[px0, px1, py0, py1], gain=up ** 2, flip_filter=flip_filter)
+        if down > 1 and up == 1:                                   # :119-122
+            x = upfirdn2d(x, f, padding=[px0, px1, py0, py1], flip_filter=flip_filter)
+            return _conv(x, w, stride=down, groups=groups, flip_weight=flip_weight)
+        if up > 1:                                                 # :125-142
+            if groups == 1:
+                wt = w.transpose(0, 1)
+            else:
+                wt = w.reshape(groups, oc // groups, icg, kh, kw).transpose(1, 2).reshape(groups * icg, oc // groups, kh, kw)
+            qx0, qx1, qy0, qy1 = px0 - (kw - 1), px1 - (kw - up), py0 - (kh - 1), py1 - (kh - up)
+            pxt = max(min(-qx0, -qx1), 0)
+            pyt = max(min(-qy0, -qy1), 0)
+            x = _conv(x, wt, stride=up, padding=[pyt, pxt], groups=groups, transpose=True, flip_weight=(not flip_weight))
+            x = upfirdn2d(x, f, padding=[qx0 + pxt, qx1 + pxt, qy0 + pyt, qy1 + pyt], gain=up ** 2, flip_filter=flip_filter)
+            if down > 1:
+                x = upfirdn2d(x, f, down=down, flip_filter=flip_filter)
+            return x
+        if px0 == px1 and py0 == py1 and px0 >= 0 and py0 >= 0:   # :145-147
+            return _conv(x, w, padding=[py0, px0], groups=groups, flip_weight=flip_weight)
+
+    x = upfirdn2d(x, (f if up > 1 else None), up=up, padding=[px0, px1, py0, py1], gain=up ** 2, flip_filter=flip_filter)
+    x = _conv(x, w, groups=groups, flip_weight=flip_weight)
+    if down > 1:
+        x = upfirdn2d(x, f, down=down, flip_filter=flip_filter)
+    return x
+
+#----------------------------------------------------------------------------
+# modulated_conv2d  (training/networks.py:36-94)
+
+def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None,
+                     demodulate=True, flip_weight=True, fused_modconv=True):
+    n = x.shape[0]
+    oc, ic, kh, kw = weight.shape
+    if x.dtype == torch.float16 and demodulate:   # :57-59
+        weight = weight * (1 / np.sqrt(ic * kh * kw) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
+        styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)
+    wmod = weight[None] * styles.reshape(n, 1, ic, 1, 1)                      # :65-66
+    dcoefs = (wmod.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt() if demodulate else None   # :68
+    if not fused_modconv:                                                     # :72-82
+        x = x * styles.to(x.dtype).reshape(n, ic, 1, 1)
+        x = conv2d_resample(x, weight.to(x.dtype), f=resample_filter, up=up, down=down, padding=padding, flip_weight=flip_weight)
+        if demodulate:
+            x = x * dcoefs.to(x.dtype).reshape(n, oc, 1, 1)
+        if noise is not None:
+            x = x + noise.to(x.dtype)
+        return x
+    if demodulate:                                                            # :69-70
+        wmod = wmod * dcoefs.reshape(n, oc, 1, 1, 1)
+    x = x.reshape(1, n * ic, *x.shape[2:])                                    # :84-94
+    x = conv2d_resample(x, wmod.reshape(n * oc, ic, kh, kw).to(x.dtype), f=resample_filter, up=up, down=down,
+                        padding=padding, groups=n, flip_weight=flip_weight)
+    x = x.reshape(n, oc, *x.shape[2:])
+    if noise is not None:
+        x = x + noise
+    return x
+
+#----------------------------------------------------------------------------

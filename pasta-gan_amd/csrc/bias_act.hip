@@ -1,0 +1,243 @@
+// bias_act for gfx950: y = clamp(act(x + b) * gain) and its first / second derivatives,
+// one pass over HBM with 16-byte accesses.
+//
+// Semantics follow torch_utils/ops/bias_act.py:94-123 (forward) and the derivative /
+// clamp-mask rules of torch_utils/ops/bias_act.cu:38-146:
+//   grad 0: u = x + b;            y = act(u) * gain;                 clamp the value
+//   grad 1: x is dy; yy = yref/gain (u = xref + b for swish);
+//           y = x * act'(.) * gain;                                  zero where |yref| >= clamp
+//   grad 2: x is d_dx; y = x * act''(.) * gain * dy;                 same mask
+// act codes 1..9 = linear, relu, lrelu, tanh, sigmoid, elu, selu, softplus, swish
+// (torch_utils/ops/bias_act.py:23-33, field cuda_idx).
+#include "common.h"
+
+namespace pasta {
+
+struct BiasActParams {
+    const void* x; const void* b; const void* xref; const void* yref; const void* dy; void* y;
+    int64_t n; int size_b; int64_t step_b;
+    float alpha, gain, clamp;
+};
+
+template <int A, int G, class S>
+__device__ __forceinline__ S bias_act_point(S x, S b, S xref, S yref, S dy, S alpha, S gain, S clamp) {
+    const S one = (S)1, two = (S)2;
+    const S exp_range = (S)80, half_exp_range = (S)40;
+    const S selu_scale = (S)1.0507009873554804934193349852946;
+    const S selu_alpha = (S)1.6732632423543772848170429916717;
+    S y = 0;
+    if (G == 0) x += b; else xref += b;
+    const S yy = (gain != 0) ? yref / gain : (S)0;
+
+    if (A == 1) {            // linear
+        if (G <= 1) y = x;
+    } else if (A == 2) {     // relu
+        if (G == 0) y = x > 0 ? x : (S)0;
+        if (G == 1) y = yy > 0 ? x : (S)0;
+    } else if (A == 3) {     // leaky relu
+        if (G == 0) y = x > 0 ? x : x * alpha;
+        if (G == 1) y = yy > 0 ? x : x * alpha;
+    } else if (A == 4) {     // tanh
+        if (G == 0) { S c = exp(x), d = one / c; y = x < -exp_range ? -one : x > exp_range ? one : (c - d) / (c + d); }
+        if (G == 1) y = x * (one - yy * yy);
+        if (G == 2) y = x * (one - yy * yy) * (-two * yy);
+    } else if (A == 5) {     // sigmoid
+        if (G == 0) y = x < -exp_range ? (S)0 : one / (exp(-x) + one);
+        if (G == 1) y = x * yy * (one - yy);
+        if (G == 2) y = x * yy * (one - yy) * (one - two * yy);
+    } else if (A == 6) {     // elu
+        if (G == 0) y = x >= 0 ? x : exp(x) - one;
+        if (G == 1) y = yy >= 0 ? x : x * (yy + one);
+        if (G == 2) y = yy >= 0 ? (S)0 : x * (yy + one);
+    } else if (A == 7) {     // selu
+        if (G == 0) y = x >= 0 ? selu_scale * x : (selu_scale * selu_alpha) * (exp(x) - one);
+        if (G == 1) y = yy >= 0 ? x * selu_scale : x * (yy + selu_scale * selu_alpha);
+        if (G == 2) y = yy >= 0 ? (S)0 : x * (yy + selu_scale * selu_alpha);
+    } else if (A == 8) {     // softplus
+        if (G == 0) y = x > exp_range ? x : log(exp(x) + one);
+        if (G == 1) y = x * (one - exp(-yy));
+        if (G == 2) { S c = exp(-yy); y = x * c * (one - c); }
+    } else if (A == 9) {     // swish
+        if (G == 0) {
+            y = x < -exp_range ? (S)0 : x / (exp(-x) + one);
+        } else {
+            S c = exp(xref), d = c + one;
+            if (G == 1) y = xref > half_exp_range ? x : x * c * (xref + d) / (d * d);
+            else        y = xref > half_exp_range ? (S)0 : x * c * (xref * (two - d) + two * d) / (d * d * d);
+            yref = xref < -exp_range ? (S)0 : xref / (exp(-xref) + one) * gain;
+        }
+    }
+
+    y *= gain * dy;
+    if (clamp >= 0) {
+        if (G == 0) y = (y > -clamp && y < clamp) ? y : (y >= 0 ? clamp : -clamp);
+        else        y = (yref > -clamp && yref < clamp) ? y : (S)0;
+    }
+    return y;
+}
+
+// V elements per thread per step (16 bytes); when V > 1 the host guarantees n % V == 0,
+// step_b % V == 0 and 16-byte aligned pointers, so a pack never straddles a bias index.
+template <class T, int A, int G, int V>
+__global__ __launch_bounds__(256) void bias_act_kernel(BiasActParams p) {
+    typedef typename acc_of<T>::type S;
+    const S alpha = (S)p.alpha, gain = (S)p.gain, clamp = (S)p.clamp;
+    const int64_t nv = p.n / V;
+    const Pack<T, V>* xs = (const Pack<T, V>*)p.x;
+    const Pack<T, V>* xr = (const Pack<T, V>*)p.xref;
+    const Pack<T, V>* yr = (const Pack<T, V>*)p.yref;
+    const Pack<T, V>* dys = (const Pack<T, V>*)p.dy;
+    Pack<T, V>* ys = (Pack<T, V>*)p.y;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+        Pack<T, V> vx = xs[i], vxr, vyr, vdy, out;
+        if (xr) vxr = xr[i];
+        if (yr) vyr = yr[i];
+        if (dys) vdy = dys[i];
+        S b = 0;
+        if (p.b) b = ld<T>((const T*)p.b + ((i * V) / p.step_b) % p.size_b);
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            S r = bias_act_point<A, G, S>(ld<T>(&vx.v[k]), b, xr ? ld<T>(&vxr.v[k]) : (S)0, yr ? ld<T>(&vyr.v[k]) : (S)0,
+                                          dys ? ld<T>(&vdy.v[k]) : (S)1, alpha, gain, clamp);
+            st<T>(&out.v[k], r);
+        }
+        ys[i] = out;
+    }
+}
+
+template <class T, int A, int G>
+static void launch(const BiasActParams& p, hipStream_t s) {
+    constexpr int V = 16 / sizeof(T);
+    auto aligned = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    const bool vec = p.n % V == 0 && (!p.b || p.step_b % V == 0) && aligned(p.x) && aligned(p.y) && aligned(p.xref) &&
+                     aligned(p.yref) && aligned(p.dy);
+    const int64_t work = vec ? p.n / V : p.n;
+    int64_t blocks = ceil_div64(work, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;   // grid-stride beyond 16 workgroups per CU
+    if (blocks < 1) blocks = 1;
+    if (vec) hipLaunchKernelGGL((bias_act_kernel<T, A, G, V>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else     hipLaunchKernelGGL((bias_act_kernel<T, A, G, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+}
+
+template <class T, int A>
+static void launch_grad(const BiasActParams& p, int grad, hipStream_t s) {
+    if (grad == 0) launch<T, A, 0>(p, s);
+    else if (grad == 1) launch<T, A, 1>(p, s);
+    else launch<T, A, 2>(p, s);
+}
+
+template <class T>
+static int launch_act(const BiasActParams& p, int act, int grad, hipStream_t s) {
+    switch (act) {
+        case 1: launch_grad<T, 1>(p, grad, s); break;
+        case 2: launch_grad<T, 2>(p, grad, s); break;
+        case 3: launch_grad<T, 3>(p, grad, s); break;
+        case 4: launch_grad<T, 4>(p, grad, s); break;
+        case 5: launch_grad<T, 5>(p, grad, s); break;
+        case 6: launch_grad<T, 6>(p, grad, s); break;
+        case 7: launch_grad<T, 7>(p, grad, s); break;
+        case 8: launch_grad<T, 8>(p, grad, s); break;
+        case 9: launch_grad<T, 9>(p, grad, s); break;
+        default: return fail("bias_act: no kernel for activation code %d", act);
+    }
+    return launch_status("bias_act");
+}
+
+//------------------------------------------------------------------------------------
+// Bias gradient: db[c] = sum of dx over every element whose bias index is c.
+// Element i belongs to c = (i / step_b) % size_b, i.e. dx is viewed as
+// [outer, size_b, step_b].  Stage 1: one workgroup per (c, slice of outer) -> partial;
+// stage 2: one wave per c sums the partials in a fixed order (bitwise reproducible).
+
+template <class T>
+__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const T* dx, float* work, int64_t outer, int size_b,
+                                                                int64_t step_b, int nsplit) {
+    const int c = blockIdx.x, sp = blockIdx.y;
+    const int64_t o0 = outer * sp / nsplit, o1 = outer * (sp + 1) / nsplit;
+    float acc = 0.f;
+    for (int64_t o = o0; o < o1; o++) {
+        const T* row = dx + (o * size_b + c) * step_b;
+        for (int64_t j = threadIdx.x; j < step_b; j += 256) acc += (float)ld<T>(row + j);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) work[(int64_t)c * nsplit + sp] = part[0] + part[1] + part[2] + part[3];
+}
+
+template <class T>
+__global__ __launch_bounds__(64) void bias_grad_final_kernel(const float* work, T* db, int nsplit) {
+    const int c = blockIdx.x;
+    float acc = 0.f;
+    for (int j = threadIdx.x; j < nsplit; j += 64) acc += work[(int64_t)c * nsplit + j];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (threadIdx.x == 0) st<T>(db + c, (typename acc_of<T>::type)acc);
+}
+
+static int bias_grad_nsplit(int64_t n, int size_b, int64_t step_b) {
+    const int64_t outer = n / ((int64_t)size_b * step_b);
+    int64_t want = 2048 / (size_b > 0 ? size_b : 1);   // ~8 workgroups per CU in total
+    if (want < 1) want = 1;
+    if (want > outer) want = outer;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+}  // namespace pasta
+
+extern "C" int pasta_bias_act(const void* x, const void* b, const void* xref, const void* yref, const void* dy, void* y,
+                              int dtype, int64_t n, int size_b, int64_t step_b, int grad, int act, float alpha,
+                              float gain, float clamp, void* stream) {
+    using namespace pasta;
+    PASTA_CHECK(n >= 0, "bias_act: negative element count");
+    if (n == 0) return 0;
+    PASTA_CHECK(x && y, "bias_act: null pointer");
+    PASTA_CHECK(n <= INT32_MAX, "bias_act: x is too large");
+    PASTA_CHECK(grad >= 0 && grad <= 2, "bias_act: grad must be 0, 1 or 2");
+    PASTA_CHECK(!b || (size_b >= 1 && step_b >= 1), "bias_act: b has wrong number of elements");
+    BiasActParams p;
+    p.x = x; p.b = b; p.xref = xref; p.yref = yref; p.dy = dy; p.y = y;
+    p.n = n; p.size_b = b ? size_b : 1; p.step_b = b ? step_b : 1;
+    p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case PASTA_F32: return launch_act<float>(p, act, grad, s);
+        case PASTA_F16: return launch_act<__half>(p, act, grad, s);
+        case PASTA_F64: return launch_act<double>(p, act, grad, s);
+        default: return fail("bias_act: unsupported dtype code %d", dtype);
+    }
+}
+
+extern "C" int64_t pasta_bias_grad_workspace(int64_t n, int size_b, int64_t step_b) {
+    if (n <= 0 || size_b <= 0 || step_b <= 0) return 0;
+    return (int64_t)size_b * pasta::bias_grad_nsplit(n, size_b, step_b) * (int64_t)sizeof(float);
+}
+
+extern "C" int pasta_bias_grad(const void* dx, void* db, float* work, int dtype, int64_t n, int size_b, int64_t step_b,
+                               void* stream) {
+    using namespace pasta;
+    PASTA_CHECK(dx && db && work, "bias_grad: null pointer");
+    PASTA_CHECK(size_b >= 1 && step_b >= 1 && n >= 1 && n % ((int64_t)size_b * step_b) == 0,
+                "bias_grad: n=%lld is not a multiple of size_b*step_b", (long long)n);
+    const int64_t outer = n / ((int64_t)size_b * step_b);
+    const int nsplit = bias_grad_nsplit(n, size_b, step_b);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(size_b, nsplit);
+    switch (dtype) {
+        case PASTA_F32:
+            hipLaunchKernelGGL((bias_grad_partial_kernel<float>), grid, dim3(256), 0, s, (const float*)dx, work, outer, size_b, step_b, nsplit);
+            hipLaunchKernelGGL((bias_grad_final_kernel<float>), dim3(size_b), dim3(64), 0, s, work, (float*)db, nsplit);
+            break;
+        case PASTA_F16:
+            hipLaunchKernelGGL((bias_grad_partial_kernel<__half>), grid, dim3(256), 0, s, (const __half*)dx, work, outer, size_b, step_b, nsplit);
+            hipLaunchKernelGGL((bias_grad_final_kernel<__half>), dim3(size_b), dim3(64), 0, s, work, (__half*)db, nsplit);
+            break;
+        case PASTA_F64:
+            hipLaunchKernelGGL((bias_grad_partial_kernel<double>), grid, dim3(256), 0, s, (const double*)dx, work, outer, size_b, step_b, nsplit);
+            hipLaunchKernelGGL((bias_grad_final_kernel<double>), dim3(size_b), dim3(64), 0, s, work, (double*)db, nsplit);
+            break;
+        default: return fail("bias_grad: unsupported dtype code %d", dtype);
+    }
+    return launch_status("bias_grad");
+}

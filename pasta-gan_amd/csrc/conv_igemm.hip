@@ -1,0 +1,578 @@
+// Dense convolution family for gfx950 on the fp32 matrix cores (v_mfma_f32_32x32x2_f32):
+// conv2d, conv_transpose2d and the weight gradient of either, NCHW fp32, exact-f32 products.
+//
+// Stands where the reference hands its convolutions to ATen/cuDNN
+// (torch_utils/ops/conv2d_gradfix.py:38,43 forward; :125-128 input gradient through the
+// transposed operator; :140-148 weight gradient).  Everything here is an implicit GEMM:
+//
+//   forward-type kernel   C[o][pix] = sum_{tap,i} Wp[tap][i][o] * X[i][pix + tap offset]
+//       rows    = output channels of one group          (MFMA "A" operand = packed weights)
+//       columns = a lattice of output pixels            (MFMA "B" operand = gathered activations)
+//     conv2d is one lattice (all output pixels, input step = stride); conv_transpose2d with
+//     stride u is u*u lattices (one per output parity class) so no multiply ever meets a
+//     stuffed zero.  Optional per-(n,channel) input and output scales carry the StyleGAN2
+//     modulation / demodulation (training/networks.py:74, 77-79).
+//
+//   weight-gradient kernel  dW[tap][a][b] = sum_pix S[a][pix] * L[b][pix*stride + tap offset]
+//       S = the smaller-resolution tensor (dy for conv2d, x for conv_transpose2d), L the other.
+//     K (= pixels) is split across workgroups; partial slabs are summed in a fixed order by a
+//     second kernel that also writes PyTorch's [.., .., kh, kw] layout (bitwise reproducible).
+//
+// C/D fragment map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
+#include "common.h"
+
+namespace pasta {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int MAX_TAPS = 49;   // up to 7x7
+
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+//------------------------------------------------------------------------------------
+// Weight packing: PyTorch layout -> [G][kh*kw][I_pad][O_pad] (O contiguous), zero padded so
+// the GEMM's A-operand staging needs no bounds checks.
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int G, int Ig,
+                                                           int Og, int Ig_pad, int Og_pad, int kh, int kw, int transposed,
+                                                           int flip) {
+    const int64_t total = (int64_t)G * kh * kw * Ig_pad * Og_pad;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        int o = (int)(idx % Og_pad);
+        int64_t r = idx / Og_pad;
+        int i = (int)(r % Ig_pad); r /= Ig_pad;
+        int t = (int)(r % (kh * kw));
+        int g = (int)(r / (kh * kw));
+        float v = 0.f;
+        if (i < Ig && o < Og) {
+            int ty = t / kw, tx = t - ty * kw;
+            if (flip) { ty = kh - 1 - ty; tx = kw - 1 - tx; }
+            int64_t src = transposed ? (((int64_t)(g * Ig + i) * Og + o) * kh + ty) * kw + tx
+                                     : (((int64_t)(g * Og + o) * Ig + i) * kh + ty) * kw + tx;
+            v = w[src];
+        }
+        wp[idx] = v;
+    }
+}
+
+//------------------------------------------------------------------------------------
+// Forward-type implicit GEMM.
+
+struct ConvFwdParams {
+    const float* x; const float* wp; float* y;
+    const float* iscale; const float* oscale;
+    int N, Cin, H, W;
+    int Cout, OH, OW;
+    int G, Ig, Og, Ig_pad, Og_pad, KK;   // KK = kh*kw slabs per group in wp
+    int P, Q;                             // lattice extent
+    int oy0, ox0, osy, osx;               // output pixel = (oy0 + p*osy, ox0 + q*osx)
+    int isy, isx;                         // input base   = (p*isy, q*isx)
+    int T;                                // taps of this lattice
+    short tap_dy[MAX_TAPS], tap_dx[MAX_TAPS], tap_slab[MAX_TAPS];
+};
+
+template <int BM, int BN, int WMT, int WNT, int KC>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
+    constexpr int WAVES_N = BN / (32 * WNT);
+    static_assert((BM / (32 * WMT)) * WAVES_N == 4, "four waves per workgroup");
+    constexpr int RSTEP = 256 / BN > 0 ? 256 / BN : 1;      // k-rows covered by one pass of the workgroup (B tile)
+    constexpr int BPT = KC * BN / 256;                       // B elements per thread per chunk
+    constexpr int A4_PER_ROW = BM / 4;
+    constexpr int APT = (KC * A4_PER_ROW + 255) / 256;       // float4 A loads per thread per chunk
+    static_assert(BN <= 256 && BPT >= 1, "tile/thread mapping");
+
+    __shared__ float As[2][KC][BM];
+    __shared__ float Bs[2][KC][BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int g = blockIdx.z;
+    const int o_blk = blockIdx.y * BM;
+    const int64_t npix = (int64_t)p.N * p.P * p.Q;
+    const int64_t pix_blk = (int64_t)blockIdx.x * BN;
+    const int HW = p.H * p.W;
+    const int NC = p.Ig_pad / KC;
+    const int nchunks = p.T * NC;
+
+    // ---- B staging: this thread's pixel column is fixed for the whole K loop.
+    const int bcol = tid % BN, brow0 = tid / BN;
+    const int64_t mypix = pix_blk + bcol;
+    const bool pix_ok = mypix < npix;
+    int n_in = 0, py = 0, px = 0;
+    if (pix_ok) {
+        n_in = (int)(mypix / (p.P * p.Q));
+        int rem = (int)(mypix - (int64_t)n_in * p.P * p.Q);
+        py = rem / p.Q; px = rem - py * p.Q;
+    }
+    const float* xb = p.x + ((int64_t)n_in * p.Cin + (int64_t)g * p.Ig) * HW;
+    const float* isb = p.iscale ? p.iscale + (int64_t)n_in * p.Cin + (int64_t)g * p.Ig : nullptr;
+    const int iy_base = py * p.isy, ix_base = px * p.isx;
+
+    // ---- A staging.
+    const float* wb = p.wp + (int64_t)g * p.KK * p.Ig_pad * p.Og_pad + o_blk;
+
+    float  breg[BPT];
+    float4 areg[APT];
+
+    auto load_chunk = [&](int ch) {
+        const int t = ch / NC, c0 = (ch - t * NC) * KC;
+        const int iy = iy_base + p.tap_dy[t], ix = ix_base + p.tap_dx[t];
+        const bool ok = pix_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const float* xp = xb + iy * p.W + ix;
+#pragma unroll
+        for (int j = 0; j < BPT; j++) {
+            const int c = c0 + brow0 + j * RSTEP;
+            float v = 0.f;
+            if (ok && c < p.Ig) {
+                v = xp[(int64_t)c * HW];
+                if (isb) v *= isb[c];
+            }
+            breg[j] = v;
+        }
+        const float* wt = wb + ((int64_t)p.tap_slab[t] * p.Ig_pad + c0) * p.Og_pad;
+#pragma unroll
+        for (int j = 0; j < APT; j++) {
+            const int e = tid + j * 256, row = e / A4_PER_ROW, c4 = e - row * A4_PER_ROW;
+            if (row < KC) areg[j] = *(const float4*)(wt + (int64_t)row * p.Og_pad + c4 * 4);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < BPT; j++) Bs[buf][brow0 + j * RSTEP][bcol] = breg[j];
+#pragma unroll
+        for (int j = 0; j < APT; j++) {
+            const int e = tid + j * 256, row = e / A4_PER_ROW, c4 = e - row * A4_PER_ROW;
+            if (row < KC) *(float4*)&As[buf][row][c4 * 4] = areg[j];
+        }
+    };
+
+    f32x16 acc[WMT][WNT];
+#pragma unroll
+    for (int a = 0; a < WMT; a++)
+#pragma unroll
+        for (int b = 0; b < WNT; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    const int kl = lane >> 5, jl = lane & 31;
+    for (int ch = 0; ch < nchunks; ch++) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) load_chunk(ch + 1);
+#pragma unroll
+        for (int kk = 0; kk < KC / 2; kk++) {
+            float af[WMT], bf[WNT];
+#pragma unroll
+            for (int a = 0; a < WMT; a++) af[a] = As[buf][kk * 2 + kl][(wm * WMT + a) * 32 + jl];
+#pragma unroll
+            for (int b = 0; b < WNT; b++) bf[b] = Bs[buf][kk * 2 + kl][(wn * WNT + b) * 32 + jl];
+#pragma unroll
+            for (int a = 0; a < WMT; a++)
+#pragma unroll
+                for (int b = 0; b < WNT; b++)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        if (ch + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: registers -> NCHW, rows = channels, lanes = consecutive pixels.
+    const int OHW = p.OH * p.OW;
+#pragma unroll
+    for (int b = 0; b < WNT; b++) {
+        const int64_t pix = pix_blk + (wn * WNT + b) * 32 + jl;
+        if (pix >= npix) continue;
+        const int n = (int)(pix / (p.P * p.Q));
+        const int rem = (int)(pix - (int64_t)n * p.P * p.Q);
+        const int pp = rem / p.Q, qq = rem - pp * p.Q;
+        float* yb = p.y + ((int64_t)n * p.Cout + (int64_t)g * p.Og) * OHW + (p.oy0 + pp * p.osy) * p.OW + p.ox0 + qq * p.osx;
+        const float* osb = p.oscale ? p.oscale + (int64_t)n * p.Cout + (int64_t)g * p.Og : nullptr;
+#pragma unroll
+        for (int a = 0; a < WMT; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
+                if (o < p.Og) {
+                    float v = acc[a][b][r];
+                    if (osb) v *= osb[o];
+                    yb[(int64_t)o * OHW] = v;
+                }
+            }
+    }
+}
+
+template <int BM, int BN, int WMT, int WNT, int KC>
+static void launch_fwd(const ConvFwdParams& p, hipStream_t s) {
+    const int64_t npix = (int64_t)p.N * p.P * p.Q;
+    dim3 grid((unsigned)ceil_div64(npix, BN), (p.Og + BM - 1) / BM, p.G);
+    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WMT, WNT, KC>), grid, dim3(256), 0, s, p);
+}
+
+// Tile choice.  O_pad multiple returned so that the caller can pack weights accordingly.
+enum FwdTile { T128x128 = 0, T64x256 = 1, T32x256 = 2, T64x64 = 3 };
+
+static FwdTile choose_fwd_tile(int Og, int64_t npix) {
+    if (Og <= 32) return T32x256;        // ToRGB / parsing heads: HBM-bound, few rows
+    if (npix <= 8192) return T64x64;     // 4..16 pixel layers: more, smaller workgroups
+    if (Og <= 64) return T64x256;
+    return T128x128;
+}
+static int fwd_tile_bm(FwdTile t) { return t == T128x128 ? 128 : t == T32x256 ? 32 : 64; }
+
+constexpr int FWD_KC = 8;
+
+static void dispatch_fwd(FwdTile t, const ConvFwdParams& p, hipStream_t s) {
+    switch (t) {
+        case T128x128: launch_fwd<128, 128, 2, 2, FWD_KC>(p, s); break;
+        case T64x256:  launch_fwd<64, 256, 2, 2, FWD_KC>(p, s); break;
+        case T32x256:  launch_fwd<32, 256, 1, 2, FWD_KC>(p, s); break;
+        case T64x64:   launch_fwd<64, 64, 1, 1, FWD_KC>(p, s); break;
+    }
+}
+
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+//------------------------------------------------------------------------------------
+// Weight gradient.
+//   dW[g*Ag + a][b][r][s] = sum_{n,p,q} S[n, g*Ag + a, p, q] * L[n, g*Bg + b, p*st + r - pad_h, q*st + s - pad_w]
+// Workgroup: 64 (a) x 64 (b) x TR*TS taps, over a slice of K = pixels.  K is walked in chunks of
+// CHH x CW = 32 lattice pixels (CW a power of two <= 32 chosen from Q).
+
+struct WgradParams {
+    const float* S; const float* L; float* slab;
+    int N, SC, P, Q;        // S: [N, SC, P, Q]
+    int LC, LH, LW;         // L: [N, LC, LH, LW]
+    int G, Ag, Bg;
+    int kh, kw, st, pad_h, pad_w;
+    int cw_log2;            // chunk width = 1 << cw_log2, chunk height = 32 >> cw_log2
+    int rows_total;         // N * P rows of S
+    int qblocks;            // ceil(Q / CW)
+    int chunks_total;       // ceil(rows_total / CHH) * qblocks
+    int ksplit;             // K slices
+    int a_tiles, b_tiles, tap_groups_r, tap_groups_s;
+};
+
+template <int TR, int TS>   // taps handled per workgroup: TR rows x TS columns of the kernel
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+    constexpr int NT = TR * TS;
+    constexpr int KP = 32;                    // pixels per chunk
+    constexpr int SPITCH = KP + 1;            // odd pitch: column-of-channels reads hit 32 banks
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave >> 1, wb = wave & 1;  // 2 x 2 waves over the 64 x 64 tile
+    const int CW = 1 << p.cw_log2, CHH = KP >> p.cw_log2;
+    const int LWID = (CW - 1) * p.st + TS;    // halo width per chunk row
+    const int LPITCH = LWID | 1;
+    const int LROWS = CHH * TR;               // halo rows per channel: one set of TR rows per chunk row
+    const int LCH = (LROWS * LPITCH) | 1;     // odd per-channel pitch
+    float* Ss = smem;                         // [64][SPITCH]
+    float* Ls = smem + 64 * SPITCH;           // [64][LCH]
+
+    // block coordinates
+    int bid = blockIdx.x;
+    const int ks = bid % p.ksplit; bid /= p.ksplit;
+    const int tgs = bid % p.tap_groups_s; bid /= p.tap_groups_s;
+    const int tgr = bid % p.tap_groups_r; bid /= p.tap_groups_r;
+    const int bt = bid % p.b_tiles; bid /= p.b_tiles;
+    const int at = bid % p.a_tiles; bid /= p.a_tiles;
+    const int g = bid;
+    const int r0 = tgr * TR, s0 = tgs * TS;
+    const int a_blk = at * 64, b_blk = bt * 64;
+    const int PQ = p.P * p.Q, LHW = p.LH * p.LW;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+
+    const int c_begin = (int)((int64_t)p.chunks_total * ks / p.ksplit);
+    const int c_end = (int)((int64_t)p.chunks_total * (ks + 1) / p.ksplit);
+    const int kl = lane >> 5, jl = lane & 31;
+
+    for (int ch = c_begin; ch < c_end; ch++) {
+        const int rb = ch / p.qblocks, qb = ch - rb * p.qblocks;
+        const int row0 = rb * CHH, q0 = qb * CW;     // first (n*P + p) row and first column of the chunk
+        __syncthreads();
+        // ---- stage S: 64 channels x 32 pixels (pixel k -> chunk row k >> cw_log2, column k & (CW-1))
+        for (int e = tid; e < 64 * KP; e += 256) {
+            const int a = e >> 5, k = e & 31;
+            const int row = row0 + (k >> p.cw_log2), q = q0 + (k & (CW - 1));
+            float v = 0.f;
+            if (a_blk + a < p.Ag && row < p.rows_total && q < p.Q) {
+                const int n = row / p.P, pp = row - n * p.P;
+                v = p.S[((int64_t)n * p.SC + (int64_t)g * p.Ag + a_blk + a) * PQ + pp * p.Q + q];
+            }
+            Ss[a * SPITCH + k] = v;
+        }
+        // ---- stage L halo: 64 channels x (CHH*TR) rows x LWID columns
+        const int per_ch = LROWS * LWID;
+        for (int e = tid; e < 64 * per_ch; e += 256) {
+            const int b = e / per_ch, rem = e - b * per_ch;
+            const int lr = rem / LWID, lc = rem - lr * LWID;
+            const int cr = lr / TR, tr = lr - cr * TR;
+            const int row = row0 + cr;
+            float v = 0.f;
+            if (b_blk + b < p.Bg && row < p.rows_total) {
+                const int n = row / p.P, pp = row - n * p.P;
+                const int ly = pp * p.st + r0 + tr - p.pad_h, lx = q0 * p.st + s0 + lc - p.pad_w;
+                if ((unsigned)ly < (unsigned)p.LH && (unsigned)lx < (unsigned)p.LW && r0 + tr < p.kh)
+                    v = p.L[((int64_t)n * p.LC + (int64_t)g * p.Bg + b_blk + b) * LHW + ly * p.LW + lx];
+            }
+            Ls[b * LCH + lr * LPITCH + lc] = v;
+        }
+        __syncthreads();
+        // ---- 16 k-steps of 2 pixels; per step one A fragment feeds NT MFMAs
+#pragma unroll 4
+        for (int kk = 0; kk < KP / 2; kk++) {
+            const int k = kk * 2 + kl;
+            const float af = Ss[(wa * 32 + jl) * SPITCH + k];
+            const int cr = k >> p.cw_log2, cc = k & (CW - 1);
+            const float* lb = Ls + (wb * 32 + jl) * LCH + cr * TR * LPITCH + cc * p.st;
+#pragma unroll
+            for (int tr = 0; tr < TR; tr++)
+#pragma unroll
+                for (int ts = 0; ts < TS; ts++)
+                    acc[tr * TS + ts] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, lb[tr * LPITCH + ts], acc[tr * TS + ts], 0, 0, 0);
+        }
+    }
+
+    // ---- partial slab: [ksplit][G][kh*kw][Ag_pad][Bg_pad], b contiguous
+    const int Ag_pad = p.a_tiles * 64, Bg_pad = p.b_tiles * 64;
+    float* out = p.slab + ((int64_t)ks * p.G + g) * p.kh * p.kw * Ag_pad * Bg_pad;
+#pragma unroll
+    for (int tr = 0; tr < TR; tr++)
+#pragma unroll
+        for (int ts = 0; ts < TS; ts++) {
+            if (r0 + tr >= p.kh || s0 + ts >= p.kw) continue;
+            float* ot = out + (int64_t)((r0 + tr) * p.kw + s0 + ts) * Ag_pad * Bg_pad;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int a = a_blk + wa * 32 + acc_row(r, lane), b = b_blk + wb * 32 + jl;
+                ot[(int64_t)a * Bg_pad + b] = acc[tr * TS + ts][r];
+            }
+        }
+}
+
+// dW[(g*Ag + a)][b][ty][tx] = sum_ks slab[ks][g][t][a][b]   (tap index optionally mirrored)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int ksplit,
+                                                           int G, int Ag, int Bg, int Ag_pad, int Bg_pad, int kh, int kw,
+                                                           int flip) {
+    const int KK = kh * kw;
+    const int64_t total = (int64_t)G * KK * Ag * Bg;
+    const int64_t slab_stride = (int64_t)G * KK * Ag_pad * Bg_pad;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int b = (int)(idx % Bg);
+        int64_t r = idx / Bg;
+        const int a = (int)(r % Ag); r /= Ag;
+        const int t = (int)(r % KK);
+        const int g = (int)(r / KK);
+        const float* src = slab + (((int64_t)g * KK + t) * Ag_pad + a) * Bg_pad + b;
+        float v = 0.f;
+        for (int k = 0; k < ksplit; k++) v += src[k * slab_stride];
+        int ty = t / kw, tx = t - ty * kw;
+        if (flip) { ty = kh - 1 - ty; tx = kw - 1 - tx; }
+        dw[(((int64_t)(g * Ag + a) * Bg + b) * kh + ty) * kw + tx] = v;
+    }
+}
+
+struct WgradPlan {
+    int TR, TS, tgr, tgs, a_tiles, b_tiles, cw_log2, qblocks, chunks_total, ksplit, rows_total;
+    int64_t slab_floats; size_t lds_bytes;
+};
+
+static WgradPlan plan_wgrad(int N, int P, int Q, int G, int Ag, int Bg, int kh, int kw, int st) {
+    WgradPlan w;
+    if (kh == 3 && kw == 3) { w.TR = 3; w.TS = 3; }
+    else if (kw == 7) { w.TR = 1; w.TS = 7; }
+    else if (kw == 4) { w.TR = 1; w.TS = 4; }
+    else { w.TR = 1; w.TS = 1; }
+    w.tgr = (kh + w.TR - 1) / w.TR; w.tgs = (kw + w.TS - 1) / w.TS;
+    w.a_tiles = (Ag + 63) / 64; w.b_tiles = (Bg + 63) / 64;
+    int cw = 32, lg = 5;
+    while (cw > 1 && cw / 2 >= Q) { cw /= 2; lg--; }     // smallest power of two >= Q, capped at 32
+    w.cw_log2 = lg;
+    const int chh = 32 >> lg;
+    w.rows_total = N * P;
+    w.qblocks = (Q + cw - 1) / cw;
+    w.chunks_total = ((w.rows_total + chh - 1) / chh) * w.qblocks;
+    const int64_t base_blocks = (int64_t)G * w.a_tiles * w.b_tiles * w.tgr * w.tgs;
+    int64_t ks = (512 + base_blocks - 1) / base_blocks;  // aim at ~2 workgroups per CU
+    if (ks > w.chunks_total / 4) ks = w.chunks_total / 4; // at least four chunks per slice
+    if (ks < 1) ks = 1;
+    if (ks > 256) ks = 256;
+    w.ksplit = (int)ks;
+    w.slab_floats = (int64_t)w.ksplit * G * kh * kw * w.a_tiles * 64 * w.b_tiles * 64;
+    const int lwid = (cw - 1) * st + w.TS, lpitch = lwid | 1, lch = (chh * w.TR * lpitch) | 1;
+    w.lds_bytes = (size_t)(64 * 33 + 64 * lch) * sizeof(float);
+    return w;
+}
+
+//------------------------------------------------------------------------------------
+// Descriptor validation shared by the entry points.
+
+static int check_desc(const pasta_conv_desc* d, const char* who) {
+    PASTA_CHECK(d, "%s: null descriptor", who);
+    PASTA_CHECK(d->N >= 1 && d->C_in >= 1 && d->H >= 1 && d->W >= 1 && d->C_out >= 1 && d->OH >= 1 && d->OW >= 1,
+                "%s: empty tensor in descriptor", who);
+    PASTA_CHECK(d->kh >= 1 && d->kw >= 1 && d->kh * d->kw <= MAX_TAPS, "%s: kernel %dx%d unsupported (max %d taps)", who, d->kh, d->kw, MAX_TAPS);
+    PASTA_CHECK(d->stride >= 1 && d->stride <= 4, "%s: stride %d unsupported", who, d->stride);
+    PASTA_CHECK(d->pad_h >= 0 && d->pad_w >= 0, "%s: negative padding", who);
+    PASTA_CHECK(d->groups >= 1 && d->C_in % d->groups == 0 && d->C_out % d->groups == 0, "%s: channels not divisible by groups=%d", who, d->groups);
+    if (!d->transposed) {
+        const int oh = (d->H + 2 * d->pad_h - d->kh) / d->stride + 1, ow = (d->W + 2 * d->pad_w - d->kw) / d->stride + 1;
+        PASTA_CHECK(d->H + 2 * d->pad_h >= d->kh && d->W + 2 * d->pad_w >= d->kw && oh == d->OH && ow == d->OW,
+                    "%s: conv2d output is %dx%d, descriptor says %dx%d", who, oh, ow, d->OH, d->OW);
+    } else {
+        const int oh = (d->H - 1) * d->stride - 2 * d->pad_h + d->kh, ow = (d->W - 1) * d->stride - 2 * d->pad_w + d->kw;
+        PASTA_CHECK(d->OH >= oh && d->OH < oh + d->stride && d->OW >= ow && d->OW < ow + d->stride,
+                    "%s: conv_transpose2d output %dx%d not in [%d,%d)x[%d,%d)", who, d->OH, d->OW, oh, oh + d->stride, ow, ow + d->stride);
+    }
+    PASTA_CHECK((int64_t)d->N * d->C_in * d->H * d->W <= INT32_MAX && (int64_t)d->N * d->C_out * d->OH * d->OW <= INT32_MAX,
+                "%s: tensor too large", who);
+    return 0;
+}
+
+static int64_t fwd_lattice_pixels(const pasta_conv_desc* d) {
+    if (!d->transposed) return (int64_t)d->N * d->OH * d->OW;
+    return (int64_t)d->N * ((d->OH + d->stride - 1) / d->stride) * ((d->OW + d->stride - 1) / d->stride);
+}
+
+}  // namespace pasta
+
+//------------------------------------------------------------------------------------
+// C ABI.
+
+extern "C" int64_t pasta_conv2d_workspace(const pasta_conv_desc* d) {
+    using namespace pasta;
+    if (check_desc(d, "conv2d_workspace")) return -1;
+    const int Ig = d->C_in / d->groups, Og = d->C_out / d->groups;
+    const FwdTile t = choose_fwd_tile(Og, fwd_lattice_pixels(d));
+    return (int64_t)d->groups * d->kh * d->kw * round_up(Ig, FWD_KC) * round_up(Og, fwd_tile_bm(t)) * (int64_t)sizeof(float);
+}
+
+extern "C" int pasta_conv2d(const float* x, const float* w, float* y, const float* iscale, const float* oscale,
+                            const pasta_conv_desc* d, void* workspace, int64_t workspace_bytes, void* stream) {
+    using namespace pasta;
+    if (int e = check_desc(d, "conv2d")) return e;
+    PASTA_CHECK(x && w && y, "conv2d: null pointer");
+    const int64_t need = pasta_conv2d_workspace(d);
+    PASTA_CHECK(workspace && workspace_bytes >= need, "conv2d: workspace of %lld bytes needed, %lld given", (long long)need, (long long)workspace_bytes);
+    PASTA_CHECK(((uintptr_t)workspace & 15) == 0, "conv2d: workspace must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+
+    ConvFwdParams p;
+    p.x = x; p.y = y; p.wp = (const float*)workspace; p.iscale = iscale; p.oscale = oscale;
+    p.N = d->N; p.Cin = d->C_in; p.H = d->H; p.W = d->W;
+    p.Cout = d->C_out; p.OH = d->OH; p.OW = d->OW;
+    p.G = d->groups; p.Ig = d->C_in / d->groups; p.Og = d->C_out / d->groups;
+    const FwdTile tile = choose_fwd_tile(p.Og, fwd_lattice_pixels(d));
+    p.Ig_pad = round_up(p.Ig, FWD_KC); p.Og_pad = round_up(p.Og, fwd_tile_bm(tile));
+    p.KK = d->kh * d->kw;
+
+    {   // pack weights
+        const int64_t total = (int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad;
+        int64_t blocks = ceil_div64(total, 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, (float*)workspace, p.G, p.Ig, p.Og,
+                           p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip);
+    }
+
+    if (!d->transposed) {
+        p.P = d->OH; p.Q = d->OW; p.oy0 = 0; p.ox0 = 0; p.osy = 1; p.osx = 1; p.isy = d->stride; p.isx = d->stride;
+        p.T = p.KK;
+        for (int r = 0; r < d->kh; r++)
+            for (int c = 0; c < d->kw; c++) {
+                const int t = r * d->kw + c;
+                p.tap_dy[t] = (short)(r - d->pad_h); p.tap_dx[t] = (short)(c - d->pad_w); p.tap_slab[t] = (short)t;
+            }
+        dispatch_fwd(tile, p, s);
+    } else {
+        // output row oy = iy*u - pad + r.  For parity class a (oy = a + u*pp): taps r with (a + pad - r) % u == 0,
+        // input row = pp + (a + pad - r)/u.
+        const int u = d->stride;
+        for (int a = 0; a < u && a < d->OH; a++)
+            for (int b = 0; b < u && b < d->OW; b++) {
+                p.P = (d->OH - a + u - 1) / u; p.Q = (d->OW - b + u - 1) / u;
+                p.oy0 = a; p.ox0 = b; p.osy = u; p.osx = u; p.isy = 1; p.isx = 1;
+                int T = 0;
+                for (int r = 0; r < d->kh; r++) {
+                    if (posmod(a + d->pad_h - r, u) != 0) continue;
+                    for (int c = 0; c < d->kw; c++) {
+                        if (posmod(b + d->pad_w - c, u) != 0) continue;
+                        p.tap_dy[T] = (short)floordiv(a + d->pad_h - r, u);
+                        p.tap_dx[T] = (short)floordiv(b + d->pad_w - c, u);
+                        p.tap_slab[T] = (short)(r * d->kw + c);
+                        T++;
+                    }
+                }
+                p.T = T;
+                if (T == 0) {   // no tap reaches this class: the outputs are zero
+                    return fail("conv_transpose2d: kernel %dx%d smaller than stride %d leaves empty output classes (unsupported)", d->kh, d->kw, u);
+                }
+                dispatch_fwd(tile, p, s);
+            }
+    }
+    return launch_status("conv2d");
+}
+
+extern "C" int64_t pasta_conv2d_wgrad_workspace(const pasta_conv_desc* d) {
+    using namespace pasta;
+    if (check_desc(d, "conv2d_wgrad_workspace")) return -1;
+    const int Ig = d->C_in / d->groups, Og = d->C_out / d->groups;
+    const WgradPlan w = d->transposed ? plan_wgrad(d->N, d->H, d->W, d->groups, Ig, Og, d->kh, d->kw, d->stride)
+                                      : plan_wgrad(d->N, d->OH, d->OW, d->groups, Og, Ig, d->kh, d->kw, d->stride);
+    return w.slab_floats * (int64_t)sizeof(float);
+}
+
+extern "C" int pasta_conv2d_wgrad(const float* x, const float* dy, float* dw, const pasta_conv_desc* d, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+    using namespace pasta;
+    if (int e = check_desc(d, "conv2d_wgrad")) return e;
+    PASTA_CHECK(x && dy && dw, "conv2d_wgrad: null pointer");
+    const int64_t need = pasta_conv2d_wgrad_workspace(d);
+    PASTA_CHECK(workspace && workspace_bytes >= need, "conv2d_wgrad: workspace of %lld bytes needed, %lld given", (long long)need, (long long)workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const int Ig = d->C_in / d->groups, Og = d->C_out / d->groups;
+
+    WgradParams p;
+    p.slab = (float*)workspace;
+    p.G = d->groups; p.kh = d->kh; p.kw = d->kw; p.st = d->stride; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
+    p.N = d->N;
+    if (!d->transposed) {   // dw[o][i]: S = dy, L = x
+        p.S = dy; p.SC = d->C_out; p.P = d->OH; p.Q = d->OW; p.Ag = Og;
+        p.L = x;  p.LC = d->C_in;  p.LH = d->H; p.LW = d->W; p.Bg = Ig;
+    } else {                // dw[i][o]: S = x, L = dy
+        p.S = x;  p.SC = d->C_in;  p.P = d->H; p.Q = d->W; p.Ag = Ig;
+        p.L = dy; p.LC = d->C_out; p.LH = d->OH; p.LW = d->OW; p.Bg = Og;
+    }
+    const WgradPlan w = plan_wgrad(p.N, p.P, p.Q, p.G, p.Ag, p.Bg, p.kh, p.kw, p.st);
+    p.cw_log2 = w.cw_log2; p.rows_total = w.rows_total; p.qblocks = w.qblocks; p.chunks_total = w.chunks_total;
+    p.ksplit = w.ksplit; p.a_tiles = w.a_tiles; p.b_tiles = w.b_tiles; p.tap_groups_r = w.tgr; p.tap_groups_s = w.tgs;
+    PASTA_CHECK(w.lds_bytes <= 160 * 1024, "conv2d_wgrad: LDS footprint %zu too large", w.lds_bytes);
+
+    const int64_t blocks = (int64_t)p.G * w.a_tiles * w.b_tiles * w.tgr * w.tgs * w.ksplit;
+    PASTA_CHECK(blocks <= INT32_MAX, "conv2d_wgrad: grid too large");
+#define PASTA_WGRAD(TR_, TS_)                                                                                             \
+    do {                                                                                                                  \
+        if (w.lds_bytes > 64 * 1024)                                                                                      \
+            PASTA_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_kernel<TR_, TS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds_bytes)); \
+        hipLaunchKernelGGL((conv_wgrad_kernel<TR_, TS_>), dim3((unsigned)blocks), dim3(256), w.lds_bytes, s, p);          \
+    } while (0)
+    if (w.TR == 3 && w.TS == 3) PASTA_WGRAD(3, 3);
+    else if (w.TS == 7) PASTA_WGRAD(1, 7);
+    else if (w.TS == 4) PASTA_WGRAD(1, 4);
+    else PASTA_WGRAD(1, 1);
+#undef PASTA_WGRAD
+    {
+        const int64_t total = (int64_t)p.G * p.kh * p.kw * p.Ag * p.Bg;
+        int64_t rb = ceil_div64(total, 256);
+        if (rb > 8192) rb = 8192;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, s, (const float*)workspace, dw, w.ksplit, p.G,
+                           p.Ag, p.Bg, w.a_tiles * 64, w.b_tiles * 64, p.kh, p.kw, d->flip);
+    }
+    return launch_status("conv2d_wgrad");
+}

@@ -1,0 +1,266 @@
+// Per-(sample, channel)-plane kernels: channel scaling (+ noise), plane dot products and the
+// SPADE instance-norm modulation.  All HBM-bound; each reads/writes its operands exactly once.
+//
+//   scale_add    y = x * a[n,c] + b[n,hw]        modulation / demodulation + noise
+//                                                 (training/networks.py:74, 77-79; fma.py:15)
+//   plane_dot    out[n,c] = sum_hw p * q          gradients of the per-channel scales (fma.py:44-50)
+//   spade_norm   out = (x-mean)*rstd*(1+gamma)+beta   (training/networks.py:4371-4379)
+#include "common.h"
+
+namespace pasta {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Sum over a workgroup of NT threads; every thread gets the total. `red` holds NT/64 floats.
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();                       // protect `red` from the previous use
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; i++) t += red[i];
+    return t;
+}
+
+//------------------------------------------------------------------------------------
+// y[plane, hw] = x[plane, hw] * a[plane] + b[(per_sample ? n : 0), hw]
+// grid.x = chunks of a plane, grid.y = planes (strided).  16-byte accesses when HW % 4 == 0.
+
+template <int V>
+__global__ __launch_bounds__(256) void scale_add_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                                        const float* __restrict__ b, float* __restrict__ y,
+                                                        int64_t planes, int C, int64_t HW, int b_per_sample) {
+    typedef Pack<float, V> P;
+    const int64_t hwv = HW / V;
+    for (int64_t plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+        const float s = a ? a[plane] : 1.f;
+        const P* xp = (const P*)(x + plane * HW);
+        P* yp = (P*)(y + plane * HW);
+        const P* bp = b ? (const P*)(b + (b_per_sample ? (plane / C) * HW : 0)) : nullptr;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hwv; i += (int64_t)gridDim.x * 256) {
+            P v = xp[i];
+            if (bp) {
+                P w = bp[i];
+#pragma unroll
+                for (int k = 0; k < V; k++) v.v[k] = fmaf(v.v[k], s, w.v[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < V; k++) v.v[k] *= s;
+            }
+            yp[i] = v;
+        }
+    }
+}
+
+//------------------------------------------------------------------------------------
+// out[plane] = sum_hw p*q (q may be null).  One workgroup per plane, fixed summation order.
+
+__global__ __launch_bounds__(256) void plane_dot_kernel(const float* __restrict__ p, const float* __restrict__ q,
+                                                        float* __restrict__ out, int64_t planes, int64_t HW) {
+    __shared__ float red[4];
+    for (int64_t plane = blockIdx.x; plane < planes; plane += gridDim.x) {
+        const float* pp = p + plane * HW;
+        const float* qp = q ? q + plane * HW : nullptr;
+        float acc = 0.f;
+        if ((HW & 3) == 0) {
+            const float4* p4 = (const float4*)pp;
+            const float4* q4 = (const float4*)qp;
+            for (int64_t i = threadIdx.x; i < HW / 4; i += 256) {
+                float4 a = p4[i];
+                if (qp) { float4 b = q4[i]; acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+                else acc += a.x + a.y + a.z + a.w;
+            }
+        } else {
+            for (int64_t i = threadIdx.x; i < HW; i += 256) acc += qp ? pp[i] * qp[i] : pp[i];
+        }
+        float t = block_sum<256>(acc, red);
+        if (threadIdx.x == 0) out[plane] = t;
+    }
+}
+
+//------------------------------------------------------------------------------------
+// SPADE normalisation.  One 1024-thread workgroup per plane; when the plane is exactly
+// EPT*1024 floats (EPT = 16 is the 128x128 plane of the generator) it lives in registers
+// between the statistics and the apply pass, otherwise later passes re-read it through L2.
+
+template <int EPT>   // EPT == 0: generic loops
+__global__ __launch_bounds__(1024) void spade_norm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ out,
+                                                          float* __restrict__ stats, int64_t planes, int64_t HW, float eps) {
+    __shared__ float red[16];
+    const int tid = threadIdx.x;
+    for (int64_t plane = blockIdx.x; plane < planes; plane += gridDim.x) {
+        const float* xp = x + plane * HW;
+        const float inv = 1.f / (float)HW;
+        float mean, rstd;
+        if constexpr (EPT > 0) {
+            float4 r[EPT / 4];
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < EPT / 4; k++) { r[k] = ((const float4*)xp)[k * 1024 + tid]; s += r[k].x + r[k].y + r[k].z + r[k].w; }
+            mean = block_sum<1024>(s, red) * inv;
+            float q = 0.f;
+#pragma unroll
+            for (int k = 0; k < EPT / 4; k++) {
+                float a = r[k].x - mean, b = r[k].y - mean, c = r[k].z - mean, d = r[k].w - mean;
+                q += a * a + b * b + c * c + d * d;
+            }
+            rstd = rsqrtf(block_sum<1024>(q, red) * inv + eps);
+#pragma unroll
+            for (int k = 0; k < EPT / 4; k++) {
+                const int64_t i = k * 1024 + tid;
+                float4 g = gamma ? ((const float4*)(gamma + plane * HW))[i] : make_float4(0, 0, 0, 0);
+                float4 b = beta ? ((const float4*)(beta + plane * HW))[i] : make_float4(0, 0, 0, 0);
+                float4 o;
+                o.x = fmaf((r[k].x - mean) * rstd, 1.f + g.x, b.x);
+                o.y = fmaf((r[k].y - mean) * rstd, 1.f + g.y, b.y);
+                o.z = fmaf((r[k].z - mean) * rstd, 1.f + g.z, b.z);
+                o.w = fmaf((r[k].w - mean) * rstd, 1.f + g.w, b.w);
+                ((float4*)(out + plane * HW))[i] = o;
+            }
+        } else {
+            float s = 0.f;
+            for (int64_t i = tid; i < HW; i += 1024) s += xp[i];
+            mean = block_sum<1024>(s, red) * inv;
+            float q = 0.f;
+            for (int64_t i = tid; i < HW; i += 1024) { float d = xp[i] - mean; q += d * d; }
+            rstd = rsqrtf(block_sum<1024>(q, red) * inv + eps);
+            for (int64_t i = tid; i < HW; i += 1024) {
+                float g = gamma ? gamma[plane * HW + i] : 0.f, b = beta ? beta[plane * HW + i] : 0.f;
+                out[plane * HW + i] = fmaf((xp[i] - mean) * rstd, 1.f + g, b);
+            }
+        }
+        if (tid == 0 && stats) { stats[2 * plane] = mean; stats[2 * plane + 1] = rstd; }
+    }
+}
+
+// Backward.  xhat = (x-mean)*rstd, t = dout*(1+gamma):
+//   dgamma = dout*xhat, dbeta = dout, dx = rstd*(t - mean(t) - xhat*mean(t*xhat)).
+// dgamma/dbeta/dx may each be null (not needed).
+template <int EPT>
+__global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x,
+                                                              const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                              float* __restrict__ dx, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int64_t planes, int64_t HW) {
+    __shared__ float red[16];
+    const int tid = threadIdx.x;
+    for (int64_t plane = blockIdx.x; plane < planes; plane += gridDim.x) {
+        const float mean = stats[2 * plane], rstd = stats[2 * plane + 1];
+        const float inv = 1.f / (float)HW;
+        const int64_t base = plane * HW;
+        if constexpr (EPT > 0) {
+            float xh[EPT], t[EPT];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < EPT / 4; k++) {
+                const int64_t i = k * 1024 + tid;
+                float4 xv = ((const float4*)(x + base))[i];
+                float4 dv = ((const float4*)(dout + base))[i];
+                float4 gv = gamma ? ((const float4*)(gamma + base))[i] : make_float4(0, 0, 0, 0);
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+                float dg[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float h = (xs[j] - mean) * rstd;
+                    float tt = ds[j] * (1.f + gs[j]);
+                    xh[k * 4 + j] = h; t[k * 4 + j] = tt;
+                    dg[j] = ds[j] * h;
+                    s1 += tt; s2 += tt * h;
+                }
+                if (dgamma) ((float4*)(dgamma + base))[i] = make_float4(dg[0], dg[1], dg[2], dg[3]);
+                if (dbeta) ((float4*)(dbeta + base))[i] = dv;
+            }
+            if (dx) {
+                const float m1 = block_sum<1024>(s1, red) * inv, m2 = block_sum<1024>(s2, red) * inv;
+#pragma unroll
+                for (int k = 0; k < EPT / 4; k++) {
+                    float4 o;
+                    o.x = rstd * (t[k * 4 + 0] - m1 - xh[k * 4 + 0] * m2);
+                    o.y = rstd * (t[k * 4 + 1] - m1 - xh[k * 4 + 1] * m2);
+                    o.z = rstd * (t[k * 4 + 2] - m1 - xh[k * 4 + 2] * m2);
+                    o.w = rstd * (t[k * 4 + 3] - m1 - xh[k * 4 + 3] * m2);
+                    ((float4*)(dx + base))[k * 1024 + tid] = o;
+                }
+            }
+        } else {
+            float s1 = 0.f, s2 = 0.f;
+            for (int64_t i = tid; i < HW; i += 1024) {
+                float h = (x[base + i] - mean) * rstd, d = dout[base + i];
+                float tt = d * (1.f + (gamma ? gamma[base + i] : 0.f));
+                s1 += tt; s2 += tt * h;
+                if (dgamma) dgamma[base + i] = d * h;
+                if (dbeta) dbeta[base + i] = d;
+            }
+            if (dx) {
+                const float m1 = block_sum<1024>(s1, red) * inv, m2 = block_sum<1024>(s2, red) * inv;
+                for (int64_t i = tid; i < HW; i += 1024) {
+                    float h = (x[base + i] - mean) * rstd;
+                    float tt = dout[base + i] * (1.f + (gamma ? gamma[base + i] : 0.f));
+                    dx[base + i] = rstd * (tt - m1 - h * m2);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace pasta
+
+extern "C" int pasta_scale_add(const float* x, const float* a, const float* b, float* y, int N, int C, int64_t HW,
+                               int b_per_sample, void* stream) {
+    using namespace pasta;
+    PASTA_CHECK(x && y, "scale_add: null pointer");
+    PASTA_CHECK(N >= 1 && C >= 1 && HW >= 1, "scale_add: empty tensor");
+    const int64_t planes = (int64_t)N * C;
+    const bool vec = HW % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)b) & 15) == 0;
+    const int64_t per_plane = vec ? HW / 4 : HW;
+    int gx = (int)(ceil_div64(per_plane, 256) < 64 ? ceil_div64(per_plane, 256) : 64);
+    int gy = (int)(planes < 65535 ? planes : 65535);
+    hipStream_t s = (hipStream_t)stream;
+    if (vec) hipLaunchKernelGGL((scale_add_kernel<4>), dim3(gx, gy), dim3(256), 0, s, x, a, b, y, planes, C, HW, b_per_sample);
+    else     hipLaunchKernelGGL((scale_add_kernel<1>), dim3(gx, gy), dim3(256), 0, s, x, a, b, y, planes, C, HW, b_per_sample);
+    return launch_status("scale_add");
+}
+
+extern "C" int pasta_plane_dot(const float* p, const float* q, float* out, int64_t planes, int64_t HW, void* stream) {
+    using namespace pasta;
+    PASTA_CHECK(p && out, "plane_dot: null pointer");
+    PASTA_CHECK(planes >= 1 && HW >= 1, "plane_dot: empty tensor");
+    PASTA_CHECK((((uintptr_t)p | (uintptr_t)q) & 15) == 0 || (HW & 3) != 0, "plane_dot: operands must be 16-byte aligned");
+    int grid = (int)(planes < 65535 ? planes : 65535);
+    hipLaunchKernelGGL(plane_dot_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, q, out, planes, HW);
+    return launch_status("plane_dot");
+}
+
+extern "C" int pasta_spade_norm(const float* x, const float* gamma, const float* beta, float* out, float* stats,
+                                int64_t planes, int64_t HW, float eps, void* stream) {
+    using namespace pasta;
+    PASTA_CHECK(x && out, "spade_norm: null pointer");
+    PASTA_CHECK(planes >= 1 && HW >= 1, "spade_norm: empty tensor");
+    int grid = (int)(planes < 65535 ? planes : 65535);
+    hipStream_t s = (hipStream_t)stream;
+    const bool al = (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out) & 15) == 0;
+    if (HW == 16384 && al) hipLaunchKernelGGL((spade_norm_kernel<16>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, stats, planes, HW, eps);
+    else if (HW == 4096 && al) hipLaunchKernelGGL((spade_norm_kernel<4>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, stats, planes, HW, eps);
+    else hipLaunchKernelGGL((spade_norm_kernel<0>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, stats, planes, HW, eps);
+    return launch_status("spade_norm");
+}
+
+extern "C" int pasta_spade_norm_bwd(const float* dout, const float* x, const float* gamma, const float* stats, float* dx,
+                                    float* dgamma, float* dbeta, int64_t planes, int64_t HW, void* stream) {
+    using namespace pasta;
+    PASTA_CHECK(dout && x && stats, "spade_norm_bwd: null pointer");
+    PASTA_CHECK(planes >= 1 && HW >= 1, "spade_norm_bwd: empty tensor");
+    int grid = (int)(planes < 65535 ? planes : 65535);
+    hipStream_t s = (hipStream_t)stream;
+    const bool al = (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dout | (uintptr_t)dx | (uintptr_t)dgamma | (uintptr_t)dbeta) & 15) == 0;
+    if (HW == 16384 && al) hipLaunchKernelGGL((spade_norm_bwd_kernel<16>), dim3(grid), dim3(1024), 0, s, dout, x, gamma, stats, dx, dgamma, dbeta, planes, HW);
+    else if (HW == 4096 && al) hipLaunchKernelGGL((spade_norm_bwd_kernel<4>), dim3(grid), dim3(1024), 0, s, dout, x, gamma, stats, dx, dgamma, dbeta, planes, HW);
+    else hipLaunchKernelGGL((spade_norm_bwd_kernel<0>), dim3(grid), dim3(1024), 0, s, dout, x, gamma, stats, dx, dgamma, dbeta, planes, HW);
+    return launch_status("spade_norm_bwd");
+}

@@ -1,0 +1,267 @@
+// upfirdn2d for gfx950: pad -> zero-stuff upsample -> 2-D FIR -> decimate.
+//
+// Semantics follow the reference specification torch_utils/ops/upfirdn2d.py:169-208
+// (output size: torch_utils/ops/upfirdn2d.cpp:32-33).  In one dimension:
+//     y[o] = gain * sum_{t=0}^{F-1} g[t] * Z[o*D + t - pad0]
+//     Z[u] = x[u/U] if u % U == 0 and 0 <= u/U < W, else 0
+//     g[t] = f[F-1-t]   (flip == 0, true convolution)   or   f[t]  (flip == 1)
+//
+// Two kernels:
+//   * tile kernel  -- NCHW-contiguous planes, compile-time (U, D, F, phase):
+//     a 256-thread workgroup stages the input footprint of one output tile in LDS
+//     with row-coalesced loads, every thread produces an MX x MY micro-tile whose
+//     tap positions are all compile-time constants, filter taps live in SGPRs.
+//     HBM traffic = read each input once (+ halo) and write each output once.
+//   * generic kernel -- any strides / factors / filter size / dtype, one output per
+//     thread, no LDS (correctness net for every configuration the API admits).
+#include "common.h"
+
+namespace pasta {
+
+struct UpfirdnParams {
+    const void*  x;
+    const float* f;
+    void*        y;
+    int inW, inH, C, N;
+    int outW, outH;
+    int64_t isx, isy, isc, isn;   // input element strides
+    int64_t osx, osy, osc, osn;   // output element strides
+    int fw, fh;
+    int upx, upy, downx, downy;
+    int padx0, pady0;
+    int flip;
+    float gain;
+};
+
+//------------------------------------------------------------------------------------
+// Generic kernel.
+
+template <class T>
+__global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(UpfirdnParams p) {
+    typedef typename acc_of<T>::type A;
+    const int64_t total = (int64_t)p.N * p.C * p.outH * p.outW;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        int ox = (int)(idx % p.outW);
+        int64_t r = idx / p.outW;
+        int oy = (int)(r % p.outH);
+        r /= p.outH;
+        int c = (int)(r % p.C);
+        int n = (int)(r / p.C);
+
+        const int ux0 = ox * p.downx - p.padx0;   // upsampled coordinate of tap 0
+        const int uy0 = oy * p.downy - p.pady0;
+        const int tx0 = posmod(-ux0, p.upx);
+        const int ty0 = posmod(-uy0, p.upy);
+        const T* xp = (const T*)p.x + n * p.isn + c * p.isc;
+
+        A v = 0;
+        for (int ty = ty0; ty < p.fh; ty += p.upy) {
+            int iy = (uy0 + ty) / p.upy;   // exact division
+            if (uy0 + ty < 0) continue;
+            if (iy >= p.inH) break;
+            int gy = p.flip ? ty : p.fh - 1 - ty;
+            for (int tx = tx0; tx < p.fw; tx += p.upx) {
+                int ix = (ux0 + tx) / p.upx;
+                if (ux0 + tx < 0) continue;
+                if (ix >= p.inW) break;
+                int gx = p.flip ? tx : p.fw - 1 - tx;
+                v += ld<T>(xp + iy * p.isy + ix * p.isx) * (A)p.f[gy * p.fw + gx];
+            }
+        }
+        v *= (A)p.gain;
+        st<T>((T*)p.y + n * p.osn + c * p.osc + oy * p.osy + ox * p.osx, v);
+    }
+}
+
+//------------------------------------------------------------------------------------
+// Tile kernel.
+
+__host__ __device__ constexpr int c_posmod(int a, int b) { return ((a % b) + b) % b; }
+// first tap index hit by output a of a micro-tile (phase PH = pad0 mod U)
+__host__ __device__ constexpr int c_tap0(int a, int D, int U, int PH) { return c_posmod(PH - a * D, U); }
+// input offset (relative to the micro-tile base) read by tap 0 of output a
+__host__ __device__ constexpr int c_in0(int a, int D, int U, int PH) { return (a * D + c_tap0(a, D, U, PH) - PH) / U; }
+// number of taps of output a
+__host__ __device__ constexpr int c_ntaps(int a, int D, int U, int PH, int F) { return (F - c_tap0(a, D, U, PH) + U - 1) / U; }
+
+template <class T, int UX, int UY, int DX, int DY, int FW, int FH, int PHX, int PHY,
+          int MX, int MY, int BX, int BY>
+__global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p) {
+    static_assert(MX % UX == 0 && MY % UY == 0, "micro-tile must cover whole phases");
+    static_assert((BX * BY) % 64 == 0, "whole wavefronts");
+    constexpr int TOW = BX * MX, TOH = BY * MY;
+    constexpr int TIW = ((TOW - 1) * DX + FW - 1) / UX + 2;
+    constexpr int TIH = ((TOH - 1) * DY + FH - 1) / UY + 2;
+    constexpr int LDW = TIW | 1;   // odd row pitch keeps strided column reads off one bank
+    __shared__ float sx[TIH * LDW];
+
+    const int tid = threadIdx.x;
+    const int tx = tid % BX, ty = tid / BX;
+    const int ox_blk = blockIdx.x * TOW, oy_blk = blockIdx.y * TOH;
+    // input coordinate held by LDS element (0,0); exact divisions by construction
+    const int ix0 = (ox_blk * DX - p.padx0 + PHX) / UX;
+    const int iy0 = (oy_blk * DY - p.pady0 + PHY) / UY;
+
+    // filter taps, flipped as requested; uniform -> scalar registers
+    float g[FH][FW];
+#pragma unroll
+    for (int a = 0; a < FH; a++)
+#pragma unroll
+        for (int b = 0; b < FW; b++)
+            g[a][b] = p.f[(p.flip ? a : FH - 1 - a) * FW + (p.flip ? b : FW - 1 - b)];
+
+    const int64_t planes = (int64_t)p.N * p.C;
+    for (int64_t plane = blockIdx.z; plane < planes; plane += gridDim.z) {
+        const T* xp = (const T*)p.x + plane * (int64_t)p.inH * p.inW;
+        T*       yp = (T*)p.y + plane * (int64_t)p.outH * p.outW;
+
+        __syncthreads();   // previous iteration's reads are done
+        for (int i = tid; i < TIH * TIW; i += BX * BY) {
+            int ry = i / TIW, rx = i - ry * TIW;
+            int iy = iy0 + ry, ix = ix0 + rx;
+            float v = 0.f;
+            if (iy >= 0 && iy < p.inH && ix >= 0 && ix < p.inW) v = ld<T>(xp + (int64_t)iy * p.inW + ix);
+            sx[ry * LDW + rx] = v;
+        }
+        __syncthreads();
+
+        const int rx = tx * (MX * DX / UX), ry = ty * (MY * DY / UY);
+        float acc[MY][MX];
+#pragma unroll
+        for (int b = 0; b < MY; b++)
+#pragma unroll
+            for (int a = 0; a < MX; a++) {
+                float v = 0.f;
+#pragma unroll
+                for (int jy = 0; jy < c_ntaps(b, DY, UY, PHY, FH); jy++)
+#pragma unroll
+                    for (int jx = 0; jx < c_ntaps(a, DX, UX, PHX, FW); jx++)
+                        v = fmaf(g[c_tap0(b, DY, UY, PHY) + jy * UY][c_tap0(a, DX, UX, PHX) + jx * UX],
+                                 sx[(ry + c_in0(b, DY, UY, PHY) + jy) * LDW + rx + c_in0(a, DX, UX, PHX) + jx], v);
+                acc[b][a] = v * p.gain;
+            }
+
+        const int ox = ox_blk + tx * MX, oy = oy_blk + ty * MY;
+#pragma unroll
+        for (int b = 0; b < MY; b++) {
+            if (oy + b >= p.outH) break;
+#pragma unroll
+            for (int a = 0; a < MX; a++)
+                if (ox + a < p.outW) st<T>(yp + (int64_t)(oy + b) * p.outW + ox + a, acc[b][a]);
+        }
+    }
+}
+
+template <class T, int UX, int UY, int DX, int DY, int FW, int FH, int PHX, int PHY, int MX, int MY, int BX, int BY>
+static void launch_tile(const UpfirdnParams& p, hipStream_t s) {
+    constexpr int TOW = BX * MX, TOH = BY * MY;
+    const int64_t planes = (int64_t)p.N * p.C;
+    dim3 grid((p.outW + TOW - 1) / TOW, (p.outH + TOH - 1) / TOH, (unsigned)(planes < 32768 ? planes : 32768));
+    hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, UX, UY, DX, DY, FW, FH, PHX, PHY, MX, MY, BX, BY>), grid, dim3(BX * BY), 0, s, p);
+}
+
+// Phase dispatch (runtime pad0 mod U -> template constant).
+template <class T, int UX, int UY, int DX, int DY, int FW, int FH, int MX, int MY, int BX, int BY>
+static void launch_phase(const UpfirdnParams& p, hipStream_t s) {
+    const int phx = posmod(p.padx0, UX), phy = posmod(p.pady0, UY);
+    if constexpr (UX == 1 && UY == 1) {
+        launch_tile<T, UX, UY, DX, DY, FW, FH, 0, 0, MX, MY, BX, BY>(p, s);
+    } else if constexpr (UX == 2 && UY == 1) {
+        if (phx == 0) launch_tile<T, UX, UY, DX, DY, FW, FH, 0, 0, MX, MY, BX, BY>(p, s);
+        else          launch_tile<T, UX, UY, DX, DY, FW, FH, 1, 0, MX, MY, BX, BY>(p, s);
+    } else if constexpr (UX == 1 && UY == 2) {
+        if (phy == 0) launch_tile<T, UX, UY, DX, DY, FW, FH, 0, 0, MX, MY, BX, BY>(p, s);
+        else          launch_tile<T, UX, UY, DX, DY, FW, FH, 0, 1, MX, MY, BX, BY>(p, s);
+    } else {
+        static_assert(UX == 2 && UY == 2, "unsupported phase set");
+        if (phx == 0 && phy == 0)      launch_tile<T, UX, UY, DX, DY, FW, FH, 0, 0, MX, MY, BX, BY>(p, s);
+        else if (phx == 1 && phy == 0) launch_tile<T, UX, UY, DX, DY, FW, FH, 1, 0, MX, MY, BX, BY>(p, s);
+        else if (phx == 0 && phy == 1) launch_tile<T, UX, UY, DX, DY, FW, FH, 0, 1, MX, MY, BX, BY>(p, s);
+        else                           launch_tile<T, UX, UY, DX, DY, FW, FH, 1, 1, MX, MY, BX, BY>(p, s);
+    }
+}
+
+// Shapes on the PASTA-GAN path: 4x4 taps at 1:1, x2 up, /2 down
+// (and the mirrored gradients), separable 12-tap x2 up / /2 down in x or y (ADA).
+// Returns true when a tile kernel was launched.
+template <class T>
+static bool try_tile(const UpfirdnParams& p, hipStream_t s) {
+    // Planes narrower than half a wavefront (the 4..16 pixel layers) carry a few MB at
+    // most; the generic kernel keeps every lane busy there.
+    if (p.outW < 24) return false;
+#define PASTA_UPF(UX, UY, DX, DY, FW_, FH_, MX, MY)                                                           \
+    if (p.upx == UX && p.upy == UY && p.downx == DX && p.downy == DY && p.fw == FW_ && p.fh == FH_) {        \
+        if (p.outW <= 40 * MX) launch_phase<T, UX, UY, DX, DY, FW_, FH_, MX, MY, 32, 8>(p, s);               \
+        else                   launch_phase<T, UX, UY, DX, DY, FW_, FH_, MX, MY, 64, 4>(p, s);               \
+        return true;                                                                                          \
+    }
+    PASTA_UPF(1, 1, 1, 1, 4, 4, 1, 4)
+    PASTA_UPF(2, 2, 1, 1, 4, 4, 2, 2)
+    PASTA_UPF(1, 1, 2, 2, 4, 4, 1, 2)
+    PASTA_UPF(1, 1, 1, 1, 3, 3, 1, 4)
+    PASTA_UPF(2, 1, 1, 1, 12, 1, 2, 2)
+    PASTA_UPF(1, 2, 1, 1, 1, 12, 1, 2)
+    PASTA_UPF(1, 1, 2, 1, 12, 1, 1, 2)
+    PASTA_UPF(1, 1, 1, 2, 1, 12, 1, 2)
+#undef PASTA_UPF
+    return false;
+}
+
+template <class T>
+static int run(const UpfirdnParams& p, bool dense_nchw, hipStream_t s) {
+    if (!(dense_nchw && try_tile<T>(p, s))) {
+        const int64_t total = (int64_t)p.N * p.C * p.outH * p.outW;
+        int64_t blocks = ceil_div64(total, 256);
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        hipLaunchKernelGGL((upfirdn2d_generic_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    }
+    return launch_status("upfirdn2d");
+}
+
+}  // namespace pasta
+
+extern "C" int pasta_upfirdn2d(const void* x, const float* f, void* y, int dtype,
+                               const int32_t in_size[4], const int64_t in_stride[4],
+                               const int32_t f_size[2],
+                               const int32_t out_size[4], const int64_t out_stride[4],
+                               int upx, int upy, int downx, int downy,
+                               int padx0, int padx1, int pady0, int pady1,
+                               int flip, float gain, void* stream) {
+    using namespace pasta;
+    PASTA_CHECK(x && f && y, "upfirdn2d: null pointer");
+    PASTA_CHECK(upx >= 1 && upy >= 1, "upfirdn2d: upsampling factor must be at least 1");
+    PASTA_CHECK(downx >= 1 && downy >= 1, "upfirdn2d: downsampling factor must be at least 1");
+    PASTA_CHECK(f_size[0] >= 1 && f_size[1] >= 1, "upfirdn2d: f must be at least 1x1");
+    for (int i = 0; i < 4; i++) PASTA_CHECK(in_size[i] >= 1, "upfirdn2d: empty input dimension %d", i);
+
+    UpfirdnParams p;
+    p.x = x; p.f = f; p.y = y;
+    p.N = in_size[0]; p.C = in_size[1]; p.inH = in_size[2]; p.inW = in_size[3];
+    p.fh = f_size[0]; p.fw = f_size[1];
+    p.outW = (p.inW * upx + padx0 + padx1 - p.fw + downx) / downx;
+    p.outH = (p.inH * upy + pady0 + pady1 - p.fh + downy) / downy;
+    PASTA_CHECK(p.inW * upx + padx0 + padx1 - p.fw >= 0 && p.inH * upy + pady0 + pady1 - p.fh >= 0 && p.outW >= 1 && p.outH >= 1,
+                "upfirdn2d: output must be at least 1x1");
+    PASTA_CHECK(out_size[0] == p.N && out_size[1] == p.C && out_size[2] == p.outH && out_size[3] == p.outW,
+                "upfirdn2d: output buffer is [%d,%d,%d,%d], expected [%d,%d,%d,%d]",
+                out_size[0], out_size[1], out_size[2], out_size[3], p.N, p.C, p.outH, p.outW);
+    PASTA_CHECK((int64_t)p.N * p.C * p.inH * p.inW <= INT32_MAX, "upfirdn2d: x is too large");
+    PASTA_CHECK((int64_t)p.N * p.C * p.outH * p.outW <= INT32_MAX, "upfirdn2d: output is too large");
+    p.isn = in_stride[0]; p.isc = in_stride[1]; p.isy = in_stride[2]; p.isx = in_stride[3];
+    p.osn = out_stride[0]; p.osc = out_stride[1]; p.osy = out_stride[2]; p.osx = out_stride[3];
+    p.upx = upx; p.upy = upy; p.downx = downx; p.downy = downy;
+    p.padx0 = padx0; p.pady0 = pady0; p.flip = flip ? 1 : 0; p.gain = gain;
+
+    const bool dense_nchw =
+        p.isx == 1 && p.isy == p.inW && p.isc == (int64_t)p.inH * p.inW && (p.N == 1 || p.isn == p.isc * p.C) &&
+        p.osx == 1 && p.osy == p.outW && p.osc == (int64_t)p.outH * p.outW && (p.N == 1 || p.osn == p.osc * p.C);
+
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case PASTA_F32: return run<float>(p, dense_nchw, s);
+        case PASTA_F16: return run<__half>(p, dense_nchw, s);
+        case PASTA_F64: return run<double>(p, false, s);
+        default: return fail("upfirdn2d: unsupported dtype code %d", dtype);
+    }
+}

@@ -1,0 +1,145 @@
+"""Build and load the native HIP library behind ``torch_utils.ops``.
+
+Stands where the reference's JIT plugin loader stands (torch_utils/custom_ops.py:46-124,
+``get_plugin(module_name, sources, **build_kwargs)``), but for one ahead-of-time library:
+``csrc/*.hip`` -> ``hipcc --offload-arch=gfx950`` -> ``lib/libpasta_hip.so`` kept in-tree,
+loaded with ``ctypes`` through the C ABI declared in ``include/pasta_hip.h``.
+
+There is no fallback: if the library cannot be built or loaded, every op raises.
+"""
+
+import ctypes
+import hashlib
+import os
+import shutil
+import subprocess
+import threading
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # .../pasta-gan_amd
+_CSRC = os.path.join(_ROOT, 'csrc')
+_LIBDIR = os.path.join(_ROOT, 'lib')
+_OBJDIR = os.path.join(_ROOT, 'build')
+_INCLUDE = os.path.join(os.path.dirname(_ROOT), 'include')
+LIB_NAME = 'libpasta_hip.so'
+ARCH = 'gfx950'
+
+_lock = threading.Lock()
+_cached_plugins = dict()
+
+#----------------------------------------------------------------------------
+
+def _sources():
+    return sorted(os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith('.hip'))
+
+def _digest(sources):
+    h = hashlib.md5()
+    extra = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith('.h')]
+    extra.append(os.path.join(_INCLUDE, 'pasta_hip.h'))
+    for path in list(sources) + extra:
+        h.update(os.path.basename(path).encode())
+        with open(path, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+def _hipcc():
+    return shutil.which('hipcc') or ('/opt/rocm/bin/hipcc' if os.path.exists('/opt/rocm/bin/hipcc') else None)
+
+def build(force=False, verbose=False, extra_flags=()):
+    """Compile every ``csrc/*.hip`` for gfx950 and link ``lib/libpasta_hip.so``.
+
+    Skips the work when the stored source digest matches. Returns the library path."""
+    sources = _sources()
+    lib_path = os.path.join(_LIBDIR, LIB_NAME)
+    stamp = lib_path + '.md5'
+    digest = _digest(sources)
+    if not force and os.path.exists(lib_path) and os.path.exists(stamp):
+        with open(stamp) as f:
+            if f.read().strip() == digest:
+                return lib_path
+    hipcc = _hipcc()
+    if hipcc is None:
+        raise RuntimeError('hipcc not found: cannot build ' + LIB_NAME)
+    os.makedirs(_LIBDIR, exist_ok=True)
+    os.makedirs(_OBJDIR, exist_ok=True)
+    flags = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast', '-I', _INCLUDE] + list(extra_flags)
+    objs, procs = [], []
+    for src in sources:
+        obj = os.path.join(_OBJDIR, os.path.basename(src)[:-4] + '.o')
+        objs.append(obj)
+        cmd = [hipcc] + flags + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, proc in procs:
+        out, _ = proc.communicate()
+        if proc.returncode != 0:
+            raise RuntimeError('hipcc failed on %s:\n%s' % (src, out.decode(errors='replace')))
+    tmp = lib_path + '.tmp%d' % os.getpid()
+    cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', tmp] + objs
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if res.returncode != 0:
+        raise RuntimeError('link failed:\n' + res.stdout.decode(errors='replace'))
+    os.replace(tmp, lib_path)
+    with open(stamp, 'w') as f:
+        f.write(digest)
+    return lib_path
+
+#----------------------------------------------------------------------------
+
+_c_i32 = ctypes.c_int32
+_c_i64 = ctypes.c_int64
+_c_f32 = ctypes.c_float
+_c_ptr = ctypes.c_void_p
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of ``pasta_conv_desc`` (include/pasta_hip.h)."""
+    _fields_ = [(name, _c_i32) for name in (
+        'N', 'C_in', 'H', 'W', 'C_out', 'OH', 'OW', 'kh', 'kw', 'stride',
+        'pad_h', 'pad_w', 'groups', 'transposed', 'flip')]
+
+# name -> (restype, argtypes); exactly the symbols include/pasta_hip.h declares.
+ABI = {
+    'pasta_last_error':   (ctypes.c_char_p, []),
+    'pasta_abi_version':  (ctypes.c_int, []),
+    'pasta_build_info':   (ctypes.c_char_p, []),
+    'pasta_upfirdn2d':    (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, ctypes.c_int,
+                                          ctypes.POINTER(_c_i32), ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i32),
+                                          ctypes.POINTER(_c_i32), ctypes.POINTER(_c_i64)] + [ctypes.c_int] * 9 + [_c_f32, _c_ptr]),
+    'pasta_bias_act':     (ctypes.c_int, [_c_ptr] * 6 + [ctypes.c_int, _c_i64, ctypes.c_int, _c_i64, ctypes.c_int, ctypes.c_int,
+                                                           _c_f32, _c_f32, _c_f32, _c_ptr]),
+    'pasta_bias_grad_workspace': (_c_i64, [_c_i64, ctypes.c_int, _c_i64]),
+    'pasta_bias_grad':    (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, ctypes.c_int, _c_i64, ctypes.c_int, _c_i64, _c_ptr]),
+    'pasta_conv2d_workspace':       (_c_i64, [ctypes.POINTER(ConvDesc)]),
+    'pasta_conv2d_wgrad_workspace': (_c_i64, [ctypes.POINTER(ConvDesc)]),
+    'pasta_conv2d':       (ctypes.c_int, [_c_ptr] * 5 + [ctypes.POINTER(ConvDesc), _c_ptr, _c_i64, _c_ptr]),
+    'pasta_conv2d_wgrad': (ctypes.c_int, [_c_ptr] * 3 + [ctypes.POINTER(ConvDesc), _c_ptr, _c_i64, _c_ptr]),
+    'pasta_scale_add':    (ctypes.c_int, [_c_ptr] * 4 + [ctypes.c_int, ctypes.c_int, _c_i64, ctypes.c_int, _c_ptr]),
+    'pasta_plane_dot':    (ctypes.c_int, [_c_ptr] * 3 + [_c_i64, _c_i64, _c_ptr]),
+    'pasta_spade_norm':   (ctypes.c_int, [_c_ptr] * 5 + [_c_i64, _c_i64, _c_f32, _c_ptr]),
+    'pasta_spade_norm_bwd': (ctypes.c_int, [_c_ptr] * 7 + [_c_i64, _c_i64, _c_ptr]),
+}
+
+def get_plugin(module_name='pasta_hip', sources=None, **build_kwargs):
+    """Return the loaded library (a ``ctypes.CDLL`` with typed entry points).
+
+    ``sources`` is accepted for signature compatibility with the reference loader and
+    ignored: the library always contains every kernel under ``csrc/``."""
+    del sources
+    with _lock:
+        if module_name in _cached_plugins:
+            return _cached_plugins[module_name]
+        lib_path = build(**build_kwargs)
+        lib = ctypes.CDLL(lib_path)
+        for name, (restype, argtypes) in ABI.items():
+            fn = getattr(lib, name)       # AttributeError here = header/library mismatch
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _cached_plugins[module_name] = lib
+        return lib
+
+def check(lib, status):
+    """Turn a non-zero status into the RuntimeError the reference's TORCH_CHECK raises."""
+    if status != 0:
+        raise RuntimeError(lib.pasta_last_error().decode(errors='replace'))
+
+#----------------------------------------------------------------------------

@@ -1,0 +1,213 @@
+"""``conv2d`` / ``conv_transpose2d`` on the MI355X implicit-GEMM kernels, with gradients of any order.
+
+Public surface mirrors the reference module torch_utils/ops/conv2d_gradfix.py (``enabled`` :22,
+``weight_gradients_disabled`` :23, ``no_weight_gradients`` :25-31, ``conv2d`` :35-38,
+``conv_transpose2d`` :40-43). Where the reference forwards to ATen/cuDNN, this module launches
+``pasta_conv2d`` / ``pasta_conv2d_wgrad`` (csrc/conv_igemm.hip, fp32 matrix cores). The autograd
+structure is the reference's (:107-165): the input gradient is the transposed operator applied
+to ``dy``; the weight gradient is its own Function whose backward is again expressed with the
+forward operators, so R1's double backward works.
+"""
+
+import contextlib
+import ctypes
+
+import torch
+
+from . import _native
+from .. import custom_ops
+
+#----------------------------------------------------------------------------
+
+enabled = True                      # Kept for API compatibility; the HIP path is always used for GPU tensors.
+weight_gradients_disabled = False   # Forcefully disable computation of gradients with respect to the weights.
+
+@contextlib.contextmanager
+def no_weight_gradients():
+    """Skip weight gradients inside the block (used around R1 / path-length ``autograd.grad``)."""
+    global weight_gradients_disabled
+    old = weight_gradients_disabled
+    weight_gradients_disabled = True
+    try:
+        yield
+    finally:
+        weight_gradients_disabled = old
+
+#----------------------------------------------------------------------------
+
+def _pair(v):
+    v = tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+    assert len(v) == 2 and all(isinstance(e, int) for e in v)
+    return v
+
+class _Cfg(tuple):
+    """(transposed, stride, pad_h, pad_w, outpad_h, outpad_w, groups) -- hashable op configuration."""
+    __slots__ = ()
+    transposed = property(lambda s: s[0]); stride = property(lambda s: s[1])
+    pad_h = property(lambda s: s[2]); pad_w = property(lambda s: s[3])
+    outpad_h = property(lambda s: s[4]); outpad_w = property(lambda s: s[5]); groups = property(lambda s: s[6])
+
+def _out_hw(cfg, h, w, kh, kw):
+    if cfg.transposed:
+        return ((h - 1) * cfg.stride - 2 * cfg.pad_h + kh + cfg.outpad_h,
+                (w - 1) * cfg.stride - 2 * cfg.pad_w + kw + cfg.outpad_w)
+    return ((h + 2 * cfg.pad_h - kh) // cfg.stride + 1, (w + 2 * cfg.pad_w - kw) // cfg.stride + 1)
+
+def _desc(cfg, x_shape, c_out, oh, ow, kh, kw):
+    n, c_in, h, w = x_shape
+    return custom_ops.ConvDesc(N=n, C_in=c_in, H=h, W=w, C_out=c_out, OH=oh, OW=ow, kh=kh, kw=kw, stride=cfg.stride,
+                               pad_h=cfg.pad_h, pad_w=cfg.pad_w, groups=cfg.groups, transposed=int(cfg.transposed), flip=0)
+
+def _f32(t):
+    return t if t.dtype == torch.float32 else t.float()
+
+def _launch_conv(x, w, cfg, iscale=None, oscale=None):
+    """y = conv(x * iscale[n,c]) * oscale[n,c'] through ``pasta_conv2d``; fp32 arithmetic."""
+    _native.require_gpu(x, 'conv2d')
+    if x.ndim != 4 or w.ndim != 4:
+        raise RuntimeError('conv2d: x and w must be rank 4')
+    out_dtype = x.dtype
+    x = _f32(x).contiguous()
+    w = _f32(w).contiguous()
+    kh, kw = w.shape[2], w.shape[3]
+    if cfg.transposed:
+        if w.shape[0] != x.shape[1]:
+            raise RuntimeError(f'conv_transpose2d: weight {tuple(w.shape)} does not match input channels {x.shape[1]}')
+        c_out = w.shape[1] * cfg.groups
+    else:
+        if w.shape[1] * cfg.groups != x.shape[1]:
+            raise RuntimeError(f'conv2d: weight {tuple(w.shape)} does not match input channels {x.shape[1]} (groups={cfg.groups})')
+        c_out = w.shape[0]
+    oh, ow = _out_hw(cfg, x.shape[2], x.shape[3], kh, kw)
+    if oh < 1 or ow < 1:
+        raise RuntimeError('conv2d: output must be at least 1x1')
+    y = torch.empty([x.shape[0], c_out, oh, ow], dtype=torch.float32, device=x.device)
+    if y.numel() == 0 or x.numel() == 0:
+        return y.zero_().to(out_dtype)
+    desc = _desc(cfg, x.shape, c_out, oh, ow, kh, kw)
+    lib = _native.lib()
+    nbytes = lib.pasta_conv2d_workspace(ctypes.byref(desc))
+    if nbytes < 0:
+        _native.check(1)
+    work = torch.empty([max(nbytes // 4, 4)], dtype=torch.float32, device=x.device)
+    if iscale is not None:
+        iscale = _f32(iscale).contiguous()
+        assert iscale.shape == (x.shape[0], x.shape[1])
+    if oscale is not None:
+        oscale = _f32(oscale).contiguous()
+        assert oscale.shape == (x.shape[0], c_out)
+    with torch.cuda.device(x.device):
+        st = lib.pasta_conv2d(_native.ptr(x), _native.ptr(w), _native.ptr(y), _native.ptr(iscale), _native.ptr(oscale),
+                              ctypes.byref(desc), _native.ptr(work), work.numel() * 4, _native.stream())
+    _native.check(st)
+    return y.to(out_dtype)
+
+def _launch_wgrad(x, dy, cfg, w_shape):
+    """dw of ``conv(x, w)`` given dy through ``pasta_conv2d_wgrad``."""
+    _native.require_gpu(x, 'conv2d_wgrad')
+    out_dtype = dy.dtype
+    x = _f32(x).contiguous()
+    dy = _f32(dy).contiguous()
+    kh, kw = w_shape[2], w_shape[3]
+    dw = torch.empty(list(w_shape), dtype=torch.float32, device=x.device)
+    if dw.numel() == 0:
+        return dw.to(out_dtype)
+    if x.numel() == 0 or dy.numel() == 0:
+        return dw.zero_().to(out_dtype)
+    desc = _desc(cfg, x.shape, dy.shape[1], dy.shape[2], dy.shape[3], kh, kw)
+    lib = _native.lib()
+    nbytes = lib.pasta_conv2d_wgrad_workspace(ctypes.byref(desc))
+    if nbytes < 0:
+        _native.check(1)
+    work = torch.empty([max(nbytes // 4, 4)], dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        st = lib.pasta_conv2d_wgrad(_native.ptr(x), _native.ptr(dy), _native.ptr(dw), ctypes.byref(desc),
+                                    _native.ptr(work), work.numel() * 4, _native.stream())
+    _native.check(st)
+    return dw.to(out_dtype)
+
+#----------------------------------------------------------------------------
+
+def _grad_cfg(cfg, x_hw, y_hw, kh, kw):
+    """Configuration of the operator that maps dy back to dx (reference :95-104, :125-128)."""
+    if cfg.transposed:
+        return _Cfg((False, cfg.stride, cfg.pad_h, cfg.pad_w, 0, 0, cfg.groups))
+    oph = x_hw[0] - ((y_hw[0] - 1) * cfg.stride - 2 * cfg.pad_h + kh)
+    opw = x_hw[1] - ((y_hw[1] - 1) * cfg.stride - 2 * cfg.pad_w + kw)
+    return _Cfg((True, cfg.stride, cfg.pad_h, cfg.pad_w, oph, opw, cfg.groups))
+
+class _ConvHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, cfg):
+        y = _launch_conv(x, w, cfg)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = cfg
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        cfg = ctx.cfg
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            gcfg = _grad_cfg(cfg, x.shape[2:], dy.shape[2:], w.shape[2], w.shape[3])
+            dx = _ConvHip.apply(dy, w, gcfg)
+            assert dx.shape == x.shape
+        if ctx.needs_input_grad[1] and not weight_gradients_disabled:
+            dw = _ConvWgradHip.apply(dy, x, cfg, tuple(w.shape))
+        return dx, dw, None
+
+class _ConvWgradHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dy, x, cfg, w_shape):
+        dw = _launch_wgrad(x, dy, cfg, w_shape)
+        ctx.save_for_backward(dy, x)
+        ctx.cfg = cfg
+        return dw
+
+    @staticmethod
+    def backward(ctx, d_dw):
+        dy, x = ctx.saved_tensors
+        cfg = ctx.cfg
+        d_dy = d_x = None
+        if ctx.needs_input_grad[0]:     # y is linear in w: d_dy = conv(x, d_dw)
+            d_dy = _ConvHip.apply(x, d_dw, cfg)
+            assert d_dy.shape == dy.shape
+        if ctx.needs_input_grad[1]:     # and dx is linear in w as well
+            gcfg = _grad_cfg(cfg, x.shape[2:], dy.shape[2:], d_dw.shape[2], d_dw.shape[3])
+            d_x = _ConvHip.apply(dy, d_dw, gcfg)
+            assert d_x.shape == x.shape
+        return d_dy, d_x, None, None
+
+#----------------------------------------------------------------------------
+
+def _check_common(input, weight, dilation):
+    assert isinstance(input, torch.Tensor) and isinstance(weight, torch.Tensor)
+    if _pair(dilation) != (1, 1):
+        raise NotImplementedError('conv2d_gradfix: dilation != 1 is not on the PASTA-GAN path and is not implemented')
+
+def _add_bias(y, bias):
+    return y if bias is None else y + bias.to(y.dtype).reshape(1, -1, 1, 1)
+
+def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+    """Same contract as ``torch.nn.functional.conv2d`` (reference :35-38); equal strides in x and y."""
+    _check_common(input, weight, dilation)
+    sh, sw = _pair(stride)
+    if sh != sw:
+        raise NotImplementedError('conv2d_gradfix: anisotropic stride is not implemented')
+    ph, pw = _pair(padding)
+    cfg = _Cfg((False, sh, ph, pw, 0, 0, int(groups)))
+    return _add_bias(_ConvHip.apply(input, weight, cfg), bias)
+
+def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
+    """Same contract as ``torch.nn.functional.conv_transpose2d`` (reference :40-43)."""
+    _check_common(input, weight, dilation)
+    sh, sw = _pair(stride)
+    if sh != sw:
+        raise NotImplementedError('conv2d_gradfix: anisotropic stride is not implemented')
+    ph, pw = _pair(padding)
+    oph, opw = _pair(output_padding)
+    cfg = _Cfg((True, sh, ph, pw, oph, opw, int(groups)))
+    return _add_bias(_ConvHip.apply(input, weight, cfg), bias)
+
+#----------------------------------------------------------------------------

@@ -1,0 +1,109 @@
+"""2-D convolution with optional x``up`` / ÷``down`` resampling.
+
+Public surface mirrors the reference module torch_utils/ops/conv2d_resample.py
+(``conv2d_resample`` :59-154, ``_get_weight_shape`` :21-25, ``_conv2d_wrapper`` :29-54): the same
+six-way decomposition into a dense convolution (``conv2d_gradfix`` -> fp32 MFMA implicit GEMM) and
+an ``upfirdn2d`` low-pass, with padding applied once, up front. The cuDNN channels_last
+work-around of the reference (:38-50) has no counterpart here.
+"""
+
+import torch
+
+from . import conv2d_gradfix
+from . import upfirdn2d
+from .upfirdn2d import _parse_padding
+from .upfirdn2d import _get_filter_size
+
+#----------------------------------------------------------------------------
+
+def _get_weight_shape(w):
+    return [int(sz) for sz in w.shape]
+
+def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True):
+    """Dispatch to ``conv2d`` / ``conv_transpose2d``. Both are correlations, so a true convolution
+    (``flip_weight=False``) mirrors the taps first."""
+    if not flip_weight:
+        w = w.flip([2, 3])
+    if transpose:
+        return conv2d_gradfix.conv_transpose2d(x, w, stride=stride, padding=padding, groups=groups)
+    return conv2d_gradfix.conv2d(x, w, stride=stride, padding=padding, groups=groups)
+
+#----------------------------------------------------------------------------
+
+def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False):
+    """Convolve ``x`` [N,C,H,W] with ``w`` [O,C//groups,kh,kw], upsampling by ``up`` before and/or
+    downsampling by ``down`` after, low-pass filtered with ``f`` (from ``upfirdn2d.setup_filter``).
+
+    ``padding`` is relative to the upsampled image (int, [x, y] or [x0, x1, y0, y1]).
+    ``flip_weight=True`` is correlation (``torch.nn.functional.conv2d``), ``False`` convolution."""
+    assert isinstance(x, torch.Tensor) and x.ndim == 4
+    assert isinstance(w, torch.Tensor) and w.ndim == 4 and w.dtype == x.dtype
+    assert f is None or (isinstance(f, torch.Tensor) and f.ndim in [1, 2] and f.dtype == torch.float32)
+    assert isinstance(up, int) and up >= 1
+    assert isinstance(down, int) and down >= 1
+    assert isinstance(groups, int) and groups >= 1
+    out_channels, in_channels_per_group, kh, kw = _get_weight_shape(w)
+    fw, fh = _get_filter_size(f)
+    px0, px1, py0, py1 = _parse_padding(padding)
+
+    # The filter's own footprint counts as padding (reference :94-104).
+    if up > 1:
+        px0 += (fw + up - 1) // 2
+        px1 += (fw - up) // 2
+        py0 += (fh + up - 1) // 2
+        py1 += (fh - up) // 2
+    if down > 1:
+        px0 += (fw - down + 1) // 2
+        px1 += (fw - down) // 2
+        py0 += (fh - down + 1) // 2
+        py1 += (fh - down) // 2
+    pad = [px0, px1, py0, py1]
+    pointwise = (kw == 1 and kh == 1)
+
+    # 1x1 kernel, downsampling: decimate first, then mix channels on the small image.
+    if pointwise and down > 1 and up == 1:
+        x = upfirdn2d.upfirdn2d(x=x, f=f, down=down, padding=pad, flip_filter=flip_filter)
+        return _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight)
+
+    # 1x1 kernel, upsampling: mix channels on the small image, then interpolate.
+    if pointwise and up > 1 and down == 1:
+        x = _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight)
+        return upfirdn2d.upfirdn2d(x=x, f=f, up=up, padding=pad, gain=up ** 2, flip_filter=flip_filter)
+
+    # Downsampling only: low-pass at full resolution, strided convolution.
+    if down > 1 and up == 1:
+        x = upfirdn2d.upfirdn2d(x=x, f=f, padding=pad, flip_filter=flip_filter)
+        return _conv2d_wrapper(x=x, w=w, stride=down, groups=groups, flip_weight=flip_weight)
+
+    # Upsampling (optionally followed by downsampling): transposed strided convolution, then low-pass.
+    if up > 1:
+        if groups == 1:
+            w = w.transpose(0, 1)
+        else:
+            w = w.reshape(groups, out_channels // groups, in_channels_per_group, kh, kw)
+            w = w.transpose(1, 2)
+            w = w.reshape(groups * in_channels_per_group, out_channels // groups, kh, kw)
+        px0 -= kw - 1
+        px1 -= kw - up
+        py0 -= kh - 1
+        py1 -= kh - up
+        pxt = max(min(-px0, -px1), 0)
+        pyt = max(min(-py0, -py1), 0)
+        x = _conv2d_wrapper(x=x, w=w, stride=up, padding=[pyt, pxt], groups=groups, transpose=True, flip_weight=(not flip_weight))
+        x = upfirdn2d.upfirdn2d(x=x, f=f, padding=[px0 + pxt, px1 + pxt, py0 + pyt, py1 + pyt], gain=up ** 2, flip_filter=flip_filter)
+        if down > 1:
+            x = upfirdn2d.upfirdn2d(x=x, f=f, down=down, flip_filter=flip_filter)
+        return x
+
+    # No resampling and symmetric non-negative padding: a plain convolution.
+    if up == 1 and down == 1 and px0 == px1 and py0 == py1 and px0 >= 0 and py0 >= 0:
+        return _conv2d_wrapper(x=x, w=w, padding=[py0, px0], groups=groups, flip_weight=flip_weight)
+
+    # Anything else: pad/upsample, convolve, downsample as three separate steps.
+    x = upfirdn2d.upfirdn2d(x=x, f=(f if up > 1 else None), up=up, padding=pad, gain=up ** 2, flip_filter=flip_filter)
+    x = _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight)
+    if down > 1:
+        x = upfirdn2d.upfirdn2d(x=x, f=f, down=down, flip_filter=flip_filter)
+    return x
+
+#----------------------------------------------------------------------------

@@ -1,0 +1,318 @@
+"""HIP op layer (through the C ABI) against the reference's golden vectors and the CPU oracle."""
+
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+
+# Stated tolerance of the parity bar (BASELINE.json north_star): 1e-3 relative, fp32.  The op-level
+# checks below are held far tighter; only fp16 storage cases use the looser figure.
+TOL = 1e-5
+TOL_FP16 = 2e-3
+
+
+def dev(a, grad=False, dtype=None):
+    x = torch.from_numpy(np.asarray(a)).to('cuda')
+    if dtype is not None:
+        x = x.to(dtype)
+    return x.requires_grad_(True) if grad else x
+
+
+def _cases(fname):
+    g = load_golden(fname)
+    return g, json.loads(str(g['manifest']))
+
+
+def test_native_library_is_loaded():
+    from torch_utils.ops import _native
+    lib = _native.lib()
+    assert lib.pasta_abi_version() >= 1
+    assert b'gfx950' in lib.pasta_build_info()
+
+
+# ----------------------------------------------------------------------------- upfirdn2d
+
+@pytest.mark.parametrize('idx', range(18))
+def test_upfirdn2d_golden(idx):
+    from torch_utils.ops import upfirdn2d
+    g, cases = _cases('ops_upfirdn2d.npz')
+    c = cases[idx]
+    n = c['name']
+    x = dev(g[n + '.x'], True)
+    f = dev(g[n + '.f']) if c['f'] is not None else None
+    y = upfirdn2d.upfirdn2d(x, f, **c['call'])
+    assert rel_err(y, g[n + '.y']) < TOL, n
+    dx, = torch.autograd.grad(y, x, dev(g[n + '.dy']))
+    assert rel_err(dx, g[n + '.dx']) < TOL, n
+
+
+LIVE_UPFIRDN = [   # shapes of SURVEY.md 2.2 / 8(a1), scaled down in N and C only
+    dict(shape=[2, 8, 256, 256], kw=dict(padding=[2, 2, 2, 2])),
+    dict(shape=[2, 8, 257, 257], kw=dict(padding=[1, 1, 1, 1], gain=4)),
+    dict(shape=[2, 16, 129, 129], kw=dict(padding=[1, 1, 1, 1], gain=4)),
+    dict(shape=[2, 3, 128, 128], kw=dict(up=2, padding=[2, 1, 2, 1], gain=4)),
+    dict(shape=[2, 8, 256, 256], kw=dict(down=2, padding=[1, 1, 1, 1])),
+    dict(shape=[4, 32, 9, 9], kw=dict(padding=[1, 1, 1, 1], gain=4)),
+    dict(shape=[4, 32, 8, 8], kw=dict(padding=[2, 2, 2, 2])),
+    dict(shape=[2, 16, 33, 33], kw=dict(padding=[1, 1, 1, 1], gain=4)),
+    dict(shape=[2, 16, 32, 32], kw=dict(down=2, padding=[1, 1, 1, 1])),
+    dict(shape=[2, 3, 4, 4], kw=dict(up=2, padding=[2, 1, 2, 1], gain=4)),
+]
+
+
+@pytest.mark.parametrize('idx', range(len(LIVE_UPFIRDN)))
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_upfirdn2d_live_shapes(idx, dtype):
+    from torch_utils.ops import upfirdn2d
+    c = LIVE_UPFIRDN[idx]
+    gen = torch.Generator().manual_seed(idx)
+    xc = torch.randn(c['shape'], generator=gen)
+    if dtype == torch.float16:
+        xc = xc.half().float()
+    f = R.setup_filter([1, 3, 3, 1])
+    xr = xc.clone().requires_grad_(True)
+    yr = R.upfirdn2d(xr, f, **c['kw'])
+    dyc = torch.randn(yr.shape, generator=gen)
+    if dtype == torch.float16:
+        dyc = dyc.half().float()
+    dxr, = torch.autograd.grad(yr, xr, dyc)
+    x = xc.to('cuda', dtype).requires_grad_(True)
+    y = upfirdn2d.upfirdn2d(x, f.cuda(), **c['kw'])
+    assert y.dtype == dtype and y.shape == yr.shape
+    dx, = torch.autograd.grad(y, x, dyc.to('cuda', dtype))
+    tol = TOL if dtype == torch.float32 else TOL_FP16
+    assert rel_err(y.float(), yr) < tol
+    assert rel_err(dx.float(), dxr) < tol
+
+
+def test_upfirdn2d_channels_last_and_fp64():
+    from torch_utils.ops import upfirdn2d
+    gen = torch.Generator().manual_seed(7)
+    xc = torch.randn([2, 6, 20, 18], generator=gen, dtype=torch.float64)
+    f = R.setup_filter([1, 3, 3, 1])
+    ref = R.upfirdn2d(xc, f, up=2, padding=[2, 1, 2, 1], gain=4)
+    y = upfirdn2d.upfirdn2d(xc.cuda(), f.cuda(), up=2, padding=[2, 1, 2, 1], gain=4)
+    assert y.dtype == torch.float64 and rel_err(y, ref) < 1e-12
+    xcl = xc.float().cuda().contiguous(memory_format=torch.channels_last)
+    ycl = upfirdn2d.upfirdn2d(xcl, f.cuda(), up=2, padding=[2, 1, 2, 1], gain=4)
+    assert ycl.is_contiguous(memory_format=torch.channels_last)
+    assert rel_err(ycl, ref) < TOL
+
+
+def test_upfirdn2d_double_backward_and_wrappers():
+    from torch_utils.ops import upfirdn2d
+    gen = torch.Generator().manual_seed(3)
+    xc = torch.randn([1, 2, 12, 12], generator=gen)
+    f = R.setup_filter([1, 3, 3, 1])
+    for name in ['upsample2d', 'downsample2d', 'filter2d']:
+        xr = xc.clone().requires_grad_(True)
+        yr = getattr(R, name)(xr, f)
+        v = torch.randn(yr.shape, generator=gen).requires_grad_(True)
+        gr, = torch.autograd.grad(yr, xr, v, create_graph=True)
+        ggr, = torch.autograd.grad(gr.square().sum(), v)
+        x = xc.cuda().requires_grad_(True)
+        y = getattr(upfirdn2d, name)(x, f.cuda())
+        vg = v.detach().cuda().requires_grad_(True)
+        gh, = torch.autograd.grad(y, x, vg, create_graph=True)
+        ggh, = torch.autograd.grad(gh.square().sum(), vg)
+        assert rel_err(y, yr) < TOL and rel_err(gh, gr) < TOL and rel_err(ggh, ggr) < TOL, name
+
+
+def test_upfirdn2d_errors():
+    from torch_utils.ops import upfirdn2d
+    f = R.setup_filter([1, 3, 3, 1])
+    with pytest.raises(RuntimeError):
+        upfirdn2d.upfirdn2d(torch.zeros(1, 1, 4, 4), f)          # CPU tensor: no fallback
+    with pytest.raises(RuntimeError):
+        upfirdn2d.upfirdn2d(torch.zeros(1, 1, 2, 2).cuda(), f.cuda())   # output smaller than 1x1
+    with pytest.raises(NotImplementedError):
+        upfirdn2d.upfirdn2d(torch.zeros(1, 1, 8, 8).cuda(), f.cuda(), impl='ref')
+
+
+# ----------------------------------------------------------------------------- bias_act
+
+@pytest.mark.parametrize('idx', range(24))
+def test_bias_act_golden(idx):
+    from torch_utils.ops import bias_act
+    g, cases = _cases('ops_bias_act.npz')
+    c = cases[idx]
+    n = c['name']
+    x = dev(g[n + '.x'], True)
+    b = dev(g[n + '.b'], True) if c['bias'] else None
+    dy = dev(g[n + '.dy'], True)
+    y = bias_act.bias_act(x, b, act=c['act'], **c['kw'])
+    assert rel_err(y, g[n + '.y']) < TOL, n
+    grads = torch.autograd.grad(y, [x] + ([b] if b is not None else []), dy, create_graph=True)
+    assert rel_err(grads[0], g[n + '.dx']) < TOL, n
+    if b is not None:
+        assert rel_err(grads[1], g[n + '.db']) < TOL, n
+    gg = torch.autograd.grad(grads[0], [dy, x], dev(g[n + '.ddx']), allow_unused=True)
+    assert rel_err(gg[0], g[n + '.g_dy']) < TOL, n
+    g_x = gg[1] if gg[1] is not None else torch.zeros_like(x)
+    assert rel_err(g_x, g[n + '.g_x']) < 2e-5 or float(np.abs(g[n + '.g_x']).max()) == 0.0, n
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.float64])
+@pytest.mark.parametrize('shape', [[4, 64, 64, 64], [3, 7, 33, 31], [16, 512]])
+def test_bias_act_large(shape, dtype):
+    from torch_utils.ops import bias_act
+    gen = torch.Generator().manual_seed(11)
+    xc = torch.randn(shape, generator=gen).to(dtype)
+    bc = torch.randn([shape[1]], generator=gen).to(dtype)
+    xr = xc.double().requires_grad_(True)
+    br = bc.double().requires_grad_(True)
+    yr = R.bias_act(xr, br, act='lrelu', gain=np.sqrt(2), clamp=1.5)
+    dyc = torch.randn(shape, generator=gen).to(dtype)
+    dxr, dbr = torch.autograd.grad(yr, [xr, br], dyc.double())
+    x = xc.cuda().requires_grad_(True)
+    b = bc.cuda().requires_grad_(True)
+    y = bias_act.bias_act(x, b, act='lrelu', gain=np.sqrt(2), clamp=1.5)
+    dx, db = torch.autograd.grad(y, [x, b], dyc.cuda())
+    tol = {torch.float32: TOL, torch.float16: TOL_FP16, torch.float64: 1e-6}[dtype]
+    assert y.dtype == dtype
+    assert rel_err(y, yr) < tol and rel_err(dx, dxr) < tol and rel_err(db, dbr) < max(tol, 1e-4)
+
+
+def test_bias_act_errors():
+    from torch_utils.ops import bias_act
+    with pytest.raises(RuntimeError):
+        bias_act.bias_act(torch.zeros(2, 3), torch.zeros(3))             # CPU tensor
+    with pytest.raises(AssertionError):
+        bias_act.bias_act(torch.zeros(2, 3).cuda(), torch.zeros(4).cuda())
+    y = bias_act.bias_act(torch.zeros(0, 3).cuda(), torch.zeros(3).cuda(), act='relu')
+    assert y.shape == (0, 3)
+
+
+# ----------------------------------------------------------------------------- conv2d_resample / conv2d_gradfix
+
+@pytest.mark.parametrize('idx', range(15))
+def test_conv2d_resample_golden(idx):
+    from torch_utils.ops import conv2d_resample, upfirdn2d
+    g, cases = _cases('ops_conv2d_resample.npz')
+    c = cases[idx]
+    n = c['name']
+    x, w = dev(g[n + '.x'], True), dev(g[n + '.w'], True)
+    f = upfirdn2d.setup_filter(c['f']).cuda() if c.get('f') is not None else None
+    y = conv2d_resample.conv2d_resample(x, w, f=f, **c['kw'])
+    assert rel_err(y, g[n + '.y']) < TOL, n
+    dx, dw = torch.autograd.grad(y, [x, w], dev(g[n + '.dy']))
+    assert rel_err(dx, g[n + '.dx']) < TOL, n
+    assert rel_err(dw, g[n + '.dw']) < TOL, n
+
+
+LIVE_CONV = [   # (x shape, w shape, kwargs): the tile configurations and layer types of the G/D path
+    ([2, 128, 32, 32], [128, 128, 3, 3], dict(padding=1)),                 # 128x128 tile
+    ([2, 64, 64, 64], [64, 64, 3, 3], dict(padding=1)),                    # 64x256 tile
+    ([2, 64, 32, 32], [3, 64, 1, 1], dict()),                              # ToRGB, 32x256 tile
+    ([4, 512, 4, 4], [512, 512, 3, 3], dict(padding=1)),                   # 64x64 tile
+    ([2, 513, 4, 4], [512, 513, 3, 3], dict(padding=1)),                   # D epilogue (mbstd channel)
+    ([2, 3, 64, 64], [64, 3, 7, 7], dict(padding=3)),                      # spade encoder stem
+    ([2, 6, 64, 64], [64, 6, 1, 1], dict()),                               # encoder stem
+    ([2, 192, 32, 32], [128, 192, 1, 1], dict()),                          # merge conv
+    ([2, 64, 64, 64], [128, 64, 3, 3], dict(down=2, padding=1)),           # strided conv
+    ([2, 64, 64, 64], [128, 64, 1, 1], dict(down=2)),                      # D skip
+    ([2, 128, 32, 32], [64, 128, 3, 3], dict(up=2, padding=1, flip_weight=False)),   # synthesis conv0
+    ([1, 2 * 32, 16, 16], [2 * 48, 32, 3, 3], dict(padding=1, groups=2)),  # eval-mode grouped modconv
+    ([1, 2 * 32, 16, 16], [2 * 48, 32, 3, 3], dict(up=2, padding=1, groups=2, flip_weight=False)),
+]
+
+
+@pytest.mark.parametrize('idx', range(len(LIVE_CONV)))
+def test_conv2d_resample_live_shapes(idx):
+    from torch_utils.ops import conv2d_resample
+    xs, ws, kw = LIVE_CONV[idx]
+    gen = torch.Generator().manual_seed(100 + idx)
+    xc = torch.randn(xs, generator=gen)
+    wc = torch.randn(ws, generator=gen) / np.sqrt(ws[1] * ws[2] * ws[3])
+    f = R.setup_filter([1, 3, 3, 1])
+    xr, wr = xc.clone().requires_grad_(True), wc.clone().requires_grad_(True)
+    yr = R.conv2d_resample(xr, wr, f=f, **kw)
+    dyc = torch.randn(yr.shape, generator=gen)
+    dxr, dwr = torch.autograd.grad(yr, [xr, wr], dyc)
+    x, w = xc.cuda().requires_grad_(True), wc.cuda().requires_grad_(True)
+    y = conv2d_resample.conv2d_resample(x, w, f=f.cuda(), **kw)
+    dx, dw = torch.autograd.grad(y, [x, w], dyc.cuda())
+    assert rel_err(y, yr) < TOL and rel_err(dx, dxr) < TOL and rel_err(dw, dwr) < 5e-5
+
+
+def test_conv2d_double_backward_r1_pattern():
+    """grad of |d out / d x|^2 wrt the weight: the R1 penalty's path (loss_wo_flow_fullbody.py:246-254)."""
+    from torch_utils.ops import conv2d_resample, conv2d_gradfix, bias_act
+    gen = torch.Generator().manual_seed(5)
+    xc = torch.randn([2, 8, 16, 16], generator=gen)
+    w1c = torch.randn([16, 8, 3, 3], generator=gen) * 0.2
+    w2c = torch.randn([16, 16, 3, 3], generator=gen) * 0.2
+    f = R.setup_filter([1, 3, 3, 1])
+
+    def run(x, w1, w2, conv, act, ctx):
+        h = act(conv(x, w1, padding=1), act='lrelu')
+        out = conv(h, w2, f=f.to(x.device), down=2, padding=1)
+        with ctx():
+            gx, = torch.autograd.grad(out.sum(), x, create_graph=True)
+        pen = gx.square().sum()
+        return (out, gx, pen) + torch.autograd.grad(pen, [w1, w2])
+
+    import contextlib
+    ref = run(xc.clone().requires_grad_(True), w1c.clone().requires_grad_(True), w2c.clone().requires_grad_(True),
+              R.conv2d_resample, R.bias_act, contextlib.nullcontext)
+    got = run(xc.cuda().requires_grad_(True), w1c.cuda().requires_grad_(True), w2c.cuda().requires_grad_(True),
+              conv2d_resample.conv2d_resample, bias_act.bias_act, conv2d_gradfix.no_weight_gradients)
+    for a, b in zip(got, ref):
+        assert rel_err(a, b) < 5e-5
+
+
+def test_conv2d_gradfix_api():
+    from torch_utils.ops import conv2d_gradfix
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn([2, 5, 11, 9], generator=gen)
+    w = torch.randn([7, 5, 3, 3], generator=gen)
+    b = torch.randn([7], generator=gen)
+    ref = torch.nn.functional.conv2d(x, w, b, stride=2, padding=1)
+    got = conv2d_gradfix.conv2d(x.cuda(), w.cuda(), b.cuda(), stride=2, padding=1)
+    assert rel_err(got, ref) < TOL
+    wt = torch.randn([5, 4, 3, 3], generator=gen)
+    ref = torch.nn.functional.conv_transpose2d(x, wt, stride=2, padding=1, output_padding=1)
+    got = conv2d_gradfix.conv_transpose2d(x.cuda(), wt.cuda(), stride=2, padding=1, output_padding=1)
+    assert rel_err(got, ref) < TOL
+    with pytest.raises(RuntimeError):
+        conv2d_gradfix.conv2d(x.cuda(), torch.randn(7, 4, 3, 3).cuda())
+    with pytest.raises(RuntimeError):
+        conv2d_gradfix.conv2d(x, w)   # CPU tensors are refused
+
+
+# ----------------------------------------------------------------------------- fma / plane kernels
+
+def test_fma_golden():
+    from torch_utils.ops import fma
+    g = load_golden('ops_fma.npz')
+    a, b, c = dev(g['a'], True), dev(g['b'], True), dev(g['c'], True)
+    y = fma.fma(a, b, c)
+    assert rel_err(y, g['y']) < TOL
+    da, db, dc = torch.autograd.grad(y, [a, b, c], dev(g['dy']))
+    assert rel_err(da, g['da']) < TOL and rel_err(db, g['db']) < TOL and rel_err(dc, g['dc']) < TOL
+
+
+@pytest.mark.parametrize('hw', [(128, 128), (64, 64), (17, 13)])
+def test_spade_norm(hw):
+    from training import networks
+    gen = torch.Generator().manual_seed(21)
+    shape = [2, 5, hw[0], hw[1]]
+    xc = torch.randn(shape, generator=gen) * 2 + 0.5
+    gc = torch.randn(shape, generator=gen) * 0.3
+    bc = torch.randn(shape, generator=gen) * 0.3
+    dc = torch.randn(shape, generator=gen)
+    xr, gr, br = [t.double().requires_grad_(True) for t in (xc, gc, bc)]
+    yr = torch.nn.functional.instance_norm(xr, eps=1e-5) * (1 + gr) + br
+    dr = torch.autograd.grad(yr, [xr, gr, br], dc.double())
+    x, g_, b = [t.cuda().requires_grad_(True) for t in (xc, gc, bc)]
+    y = networks.spade_modulate(x, g_, b)
+    d = torch.autograd.grad(y, [x, g_, b], dc.cuda())
+    assert rel_err(y, yr) < TOL
+    for a, r in zip(d, dr):
+        assert rel_err(a, r) < 2e-5
