@@ -102,7 +102,11 @@ class _BiasActHip(torch.autograd.Function):
         if act != 'linear' or gain != 1 or clamp >= 0 or b is not None:
             y = _launch(x, b, None, None, None, 0, dim, spec.cuda_idx, alpha, gain, clamp)
         keep_x = 'x' in spec.ref or spec.has_2nd_grad
-        ctx.save_for_backward(x if keep_x else None, b if keep_x else None, y if 'y' in spec.ref else None)
+        # The clamp mask of the gradient is taken from y. The reference's CUDA wrapper drops y for
+        # 'linear' (bias_act.py:160) and so lets gradients through a clamped ToRGB output; its CPU
+        # path (bias_act.py:121-122, torch.clamp) does not. The CPU path is the parity target.
+        keep_y = 'y' in spec.ref or (clamp >= 0 and 'x' not in spec.ref)
+        ctx.save_for_backward(x if keep_x else None, b if keep_x else None, y if keep_y else None)
         ctx.cfg = cfg
         ctx.fmt = fmt
         return y

@@ -1,0 +1,108 @@
+"""Generator / discriminator on the HIP path against the reference's golden vectors (and the oracle)."""
+
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import param_fill as PF
+from oracle.make_golden_models import GRAD_KEYS_D, GRAD_KEYS_G
+
+pytestmark = pytest.mark.gpu
+
+# Parity bar of BASELINE.json: 1e-3 relative in fp32 on fixed inputs.  Forward tensors are checked
+# 10x tighter; parameter gradients (sums over up to 10^5 pixels) at the stated 1e-3.
+TOL_FWD = 1e-4
+TOL_GRAD = 1e-3
+
+
+def _summary_ok(g, key, tensor, tol):
+    s = PF.summarize(tensor)
+    e = rel_err(s['sample'], g[key + '.sample'])
+    m, mg = s['moments'], g[key + '.moments']
+    assert e < tol, (key, e)
+    assert abs(m[1] - mg[1]) <= tol * abs(mg[1]) + 1e-12, key
+    assert abs(m[2] - mg[2]) <= 2 * tol * abs(mg[2]) + 1e-12, key
+
+
+def _cuda(inp):
+    return {k: v.cuda() for k, v in inp.items()}
+
+
+@pytest.mark.parametrize('fused', [False, True])
+@pytest.mark.parametrize('idx', range(5))
+def test_modulated_conv2d_golden(idx, fused):
+    from training import networks
+    from torch_utils.ops import upfirdn2d
+    g = load_golden('layers_modconv.npz')
+    c = json.loads(str(g['manifest']))[idx]
+    n = c['name']
+    dev = lambda a, grad=False: torch.from_numpy(np.asarray(a)).cuda().requires_grad_(grad)
+    x, w, s = dev(g[n + '.x'], True), dev(g[n + '.w'], True), dev(g[n + '.s'], True)
+    noise = dev(g[n + '.noise']) if c['noise'] is not None else None
+    f = upfirdn2d.setup_filter(c['f']).cuda() if c.get('f') is not None else None
+    y = networks.modulated_conv2d(x=x, weight=w, styles=s, noise=noise, resample_filter=f, fused_modconv=fused, **c['kw'])
+    tag = n + ('.fused' if fused else '.plain')
+    assert rel_err(y, g[tag + '.y']) < 1e-5
+    dx, dw, ds = torch.autograd.grad(y, [x, w, s], dev(g[n + '.dy']))
+    assert rel_err(dx, g[tag + '.dx']) < 1e-5 and rel_err(dw, g[tag + '.dw']) < 2e-5 and rel_err(ds, g[tag + '.ds']) < 2e-5
+
+
+def test_generator_full_golden():
+    from training import networks
+    g = load_golden('models_fullbody.npz')
+    G = PF.fill_module(networks.GeneratorFull(**PF.G_KWARGS)).cuda().train().requires_grad_(True)
+    inp = _cuda(PF.make_inputs(n=2, seed=0))
+    args = (inp['gen_z'], inp['style_input'], inp['retain'], inp['pose'], inp['denorm_upper_input'], inp['denorm_lower_input'],
+            inp['denorm_upper_mask'], inp['denorm_lower_mask'])
+    img, fin, par = G(*args, noise_mode='const')
+    _summary_ok(g, 'G.img', img, TOL_FWD)
+    _summary_ok(g, 'G.pred_parsing', par, TOL_FWD)
+    _summary_ok(g, 'G.finetune_img', fin, TOL_FWD)
+    probe = (img * inp['real_img']).mean() + fin.square().mean() + 0.1 * par.abs().mean()
+    assert abs(probe.item() - float(g['G.probe'][0])) < TOL_FWD * abs(float(g['G.probe'][0]))
+    probe.backward()
+    sd = dict(G.named_parameters())
+    for k in GRAD_KEYS_G:
+        _summary_ok(g, 'G.grad.' + k, sd[k].grad, TOL_GRAD)
+    G.eval()
+    with torch.no_grad():
+        img_e, fin_e, _ = G(*args, noise_mode='const')
+    _summary_ok(g, 'G.eval.img', img_e, TOL_FWD)
+    _summary_ok(g, 'G.eval.finetune_img', fin_e, TOL_FWD)
+
+
+def test_discriminator_golden_with_r1():
+    from training import networks
+    from torch_utils.ops import conv2d_gradfix
+    g = load_golden('models_fullbody.npz')
+    D = PF.fill_module(networks.Discriminator(**PF.D_KWARGS)).cuda().train().requires_grad_(True)
+    c = torch.tanh(PF.make_inputs(n=4, seed=1)['style_input'].mean(dim=[2, 3]).repeat(1, 13)[:, :512]).cuda()
+    x = PF.make_inputs(n=4, seed=1)['real_img'].cuda().requires_grad_(True)
+    logits = D(x, c)
+    assert rel_err(logits, g['D.logits']) < TOL_FWD
+    with conv2d_gradfix.no_weight_gradients():
+        gx, = torch.autograd.grad(logits.sum(), x, create_graph=True)
+    _summary_ok(g, 'D.r1_grads', gx, TOL_FWD)
+    pen = gx.square().sum([1, 2, 3])
+    assert rel_err(pen, g['D.r1_penalty']) < TOL_FWD
+    loss = torch.nn.functional.softplus(-logits).mean() + 5.0 * pen.mean()
+    loss.backward()
+    sd = dict(D.named_parameters())
+    for k in GRAD_KEYS_D:
+        _summary_ok(g, 'D.grad.' + k, sd[k].grad, TOL_GRAD)
+
+
+def test_generator_random_noise_and_state_dict_names():
+    """noise_mode='random' runs (not comparable across devices), and parameter names match the golden run's."""
+    from training import networks
+    G = networks.GeneratorFull(**PF.G_KWARGS).cuda()
+    inp = _cuda(PF.make_inputs(n=2, seed=3))
+    img, fin, par = G(inp['gen_z'], inp['style_input'], inp['retain'], inp['pose'], inp['denorm_upper_input'],
+                      inp['denorm_lower_input'], inp['denorm_upper_mask'], inp['denorm_lower_mask'])
+    assert img.shape == (2, 3, 256, 256) and fin.shape == (2, 3, 256, 256) and par.shape == (2, 6, 256, 256)
+    assert torch.isfinite(img).all() and torch.isfinite(fin).all()
+    g = load_golden('models_fullbody.npz')
+    assert len(dict(G.named_parameters())) == len(g['G.gradnorms'])
