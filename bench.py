@@ -1,0 +1,206 @@
+"""Benchmark: PASTA-GAN 256x192 (tensor 256x256) training images/sec on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched through torch.distributed.run)
+
+A step = one iteration of the reference hot loop (training_loop_wo_flow_fullbody.py:484-529) on a
+synthetic, HBM-resident batch of 16 images per GPU: Gmain + Dmain every iteration, Dreg every 16th,
+Greg (a no-op besides the style encoder, pl_weight 0) every 4th, Adam steps and the EMA update.
+Prints ONE JSON line (rank 0) with the whole-job throughput, the roofline of the dominant kernel
+(measured with HIP events on the launch stream, inside the timed region) and a CPU baseline
+(the oracle restatement on the host cores, config 1 of BASELINE.json).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, 'pasta-gan_amd'), ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0
+
+TILE_NAMES = {0: 'conv_fwd_kernel<128,128,2,2,8>', 1: 'conv_fwd_kernel<64,256,2,2,8>',
+              2: 'conv_fwd_kernel<32,256,1,2,8>', 3: 'conv_fwd_kernel<64,64,1,1,8>'}
+
+
+class ConvMeter:
+    """Brackets every native convolution launch of the timed region with HIP events on the launch stream
+    and accumulates algorithmic FLOPs per kernel family."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.records = []          # (family, flops, kernels, start_event, end_event)
+        self.enabled = False
+
+    def __call__(self, kind, desc, launch):
+        if not self.enabled:
+            return launch()
+        import ctypes
+        g = desc.groups
+        macs = desc.N * desc.C_out * (desc.C_in // g) * desc.kh * desc.kw
+        macs *= (desc.H * desc.W) if desc.transposed else (desc.OH * desc.OW)
+        if kind == 'conv':
+            family = TILE_NAMES[self.lib.pasta_conv2d_tile(ctypes.byref(desc))]
+            kernels = desc.stride * desc.stride if desc.transposed else 1
+        else:
+            family = 'conv_wgrad_kernel'
+            kernels = 1
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        launch()
+        e.record()
+        self.records.append((family, 2.0 * macs, kernels, s, e))
+
+    def summary(self):
+        fam = {}
+        for family, flops, kernels, s, e in self.records:
+            f = fam.setdefault(family, dict(flops=0.0, ms=0.0, launches=0, kernels=0))
+            f['flops'] += flops
+            f['ms'] += s.elapsed_time(e)
+            f['launches'] += 1
+            f['kernels'] += kernels
+        return fam
+
+
+def cpu_baseline(budget_s=20.0):
+    """Config 1 of BASELINE.json on the host: batch 2, G fwd + D(img), D(finetune), D(real) fwd, GAN softplus
+    losses, one backward into G and D -- the oracle restatement (same torch-op composition as the reference's
+    CPU fallback), full 'fashion' widths, fp32."""
+    from oracle import ref_networks as RN, ref_ops
+    ref_ops.FIR_AS_DEPTHWISE_CONV = True      # the reference's own CPU formulation of the FIR step
+    from training.training_loop_wo_flow_fullbody import fashion_config, SyntheticFullBodyBatch
+    import dnnlib
+    cfg = fashion_config()
+    torch.manual_seed(0)
+    G = dnnlib.util.construct_class_by_name(**cfg.G_kwargs)
+    D = dnnlib.util.construct_class_by_name(**cfg.D_kwargs)
+    sdG = {k: v.detach().requires_grad_(v.dtype.is_floating_point and k in dict(G.named_parameters())) for k, v in list(G.named_parameters()) + list(G.named_buffers())}
+    sdD = {k: v.detach().requires_grad_(k in dict(D.named_parameters())) for k, v in list(D.named_parameters()) + list(D.named_buffers())}
+    data = SyntheticFullBodyBatch(2, torch.device('cpu'), seed=0).tensors
+    softplus = torch.nn.functional.softplus
+
+    def step():
+        img, fin, par = RN.generator_full(sdG, torch.zeros([2, 0]), data['style_input'], data['retain'], data['pose'],
+                                          data['denorm_upper_input'], data['denorm_lower_input'], data['denorm_upper_mask'],
+                                          data['denorm_lower_mask'], conv_clamp=256, mapping_layers=1, noise_mode='const')
+        c = torch.tanh(data['style_input'].mean(dim=[2, 3]).repeat(1, 13)[:, :512])
+        loss = softplus(-RN.discriminator(sdD, img, c)).mean() + softplus(-RN.discriminator(sdD, fin, c)).mean() + \
+            softplus(-RN.discriminator(sdD, data['real_img'], c)).mean()
+        params = [v for v in list(sdG.values()) + list(sdD.values()) if v.requires_grad]
+        torch.autograd.grad(loss, params, allow_unused=True)
+
+    cores = torch.get_num_threads()
+    step()                                   # warm-up
+    t0 = time.time()
+    n = 0
+    while n < 3 and (n == 0 or time.time() - t0 < budget_s * 0.6):
+        step()
+        n += 1
+    dt = time.time() - t0
+    return dict(value=round(2 * n / dt, 4), unit='images/sec', cores=cores, kind='port',
+                sample=f'BASELINE config 1: batch 2, G fwd + 3x D fwd + one backward, fp32, full fashion widths, '
+                       f'{n} timed step(s) of {dt / n:.2f} s after 1 warm-up (oracle/ref_networks.py on the host)')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch-gpu', type=int, default=16)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-meter', action='store_true', help='do not bracket convolution launches with events')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 through torch.distributed.run'
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.distributed.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=device)
+
+    from torch_utils.ops import conv2d_gradfix, _native
+    from training.training_loop_wo_flow_fullbody import TrainingStep, SyntheticFullBodyBatch, fashion_config
+
+    lib = _native.lib()       # raises if libpasta_hip.so is missing
+    cfg = fashion_config()
+    step = TrainingStep(device, cfg=cfg, num_gpus=world, rank=rank, batch_size=args.batch_gpu * world, batch_gpu=args.batch_gpu)
+    data = SyntheticFullBodyBatch(args.batch_gpu, device, seed=rank)
+    meter = ConvMeter(lib)
+    if not args.no_meter:
+        conv2d_gradfix.launch_hook = meter
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        step.run(data)
+    torch.cuda.synchronize()
+    barrier()
+    meter.enabled = not args.no_meter
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step.run(data)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    meter.enabled = False
+    conv2d_gradfix.launch_hook = None
+
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        images = args.steps * args.batch_gpu * world
+        out = {
+            'metric': 'training images/sec at 256x192 (tensor 256x256), batch 16 per GPU',
+            'value': round(images / dt, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1000 * dt / args.steps, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE config 2: full training_loop step (Gmain+Dmain every iter, Dreg/16, Greg/4, Adam, EMA), '
+                                   'GeneratorFull+Discriminator cfg=fashion 256x256, batch 16/GPU, G and D in fp32, '
+                                   'vgg_weight=0 (weights unavailable), no ADA, random-init weights',
+                       'global_batch': args.batch_gpu * world, 'parallelism': f'dp{world}' + (' (RCCL all-reduce)' if world > 1 else '')},
+        }
+        fam = meter.summary()
+        if fam:
+            dom = max(fam.items(), key=lambda kv: kv[1]['ms'])
+            name, f = dom
+            achieved = f['flops'] / (f['ms'] * 1e-3) / 1e12
+            out['roofline'] = {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
+                               'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                               'launches': f['launches'], 'kernels': f['kernels'],
+                               'avg_kernel_us': round(1000 * f['ms'] / f['kernels'], 1),
+                               'share_of_step': round(f['ms'] / (1000 * dt), 3),
+                               'peak_note': 'dense fp32-input MFMA (v_mfma_f32_32x32x2_f32), exact-f32 products'}
+            tot_flops = sum(v['flops'] for v in fam.values())
+            tot_ms = sum(v['ms'] for v in fam.values())
+            out['conv_families'] = {k: {'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2), 'ms_per_step': round(v['ms'] / args.steps, 2),
+                                        'launches_per_step': round(v['launches'] / args.steps, 1)} for k, v in sorted(fam.items())}
+            out['conv_total'] = {'tflop_per_step': round(tot_flops / args.steps / 1e12, 3), 'ms_per_step': round(tot_ms / args.steps, 2)}
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -99,6 +99,10 @@ typedef struct pasta_conv_desc {
 int64_t pasta_conv2d_workspace(const pasta_conv_desc* d);
 int64_t pasta_conv2d_wgrad_workspace(const pasta_conv_desc* d);
 
+/* Which forward-type kernel instance the launch will use: 0 = 128x128 tile, 1 = 64x256,
+ * 2 = 32x256, 3 = 64x64 (rows = output channels, columns = pixels).  Reporting only. */
+int pasta_conv2d_tile(const pasta_conv_desc* d);
+
 /* y = conv(x, w).  w is the PyTorch-layout weight ([C_out, C_in/g, kh, kw], or
  * [C_in, C_out/g, kh, kw] when transposed).  Optional fused epilogue:
  *   y = y * oscale[n, c] (NULL = 1)  -- demodulation, networks.py:77-79

@@ -454,6 +454,12 @@ extern "C" int64_t pasta_conv2d_workspace(const pasta_conv_desc* d) {
     return (int64_t)d->groups * d->kh * d->kw * round_up(Ig, FWD_KC) * round_up(Og, fwd_tile_bm(t)) * (int64_t)sizeof(float);
 }
 
+extern "C" int pasta_conv2d_tile(const pasta_conv_desc* d) {
+    using namespace pasta;
+    if (check_desc(d, "conv2d_tile")) return -1;
+    return (int)choose_fwd_tile(d->C_out / d->groups, fwd_lattice_pixels(d));
+}
+
 extern "C" int pasta_conv2d(const float* x, const float* w, float* y, const float* iscale, const float* oscale,
                             const pasta_conv_desc* d, void* workspace, int64_t workspace_bytes, void* stream) {
     using namespace pasta;

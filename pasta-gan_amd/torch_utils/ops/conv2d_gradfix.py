@@ -58,6 +58,10 @@ def _desc(cfg, x_shape, c_out, oh, ow, kh, kw):
     return custom_ops.ConvDesc(N=n, C_in=c_in, H=h, W=w, C_out=c_out, OH=oh, OW=ow, kh=kh, kw=kw, stride=cfg.stride,
                                pad_h=cfg.pad_h, pad_w=cfg.pad_w, groups=cfg.groups, transposed=int(cfg.transposed), flip=0)
 
+# Optional measurement hook (bench.py): when set, called as hook(kind, desc, launch) around every native
+# convolution launch; ``launch()`` performs it. None = no overhead.
+launch_hook = None
+
 def _f32(t):
     return t if t.dtype == torch.float32 else t.float()
 
@@ -96,10 +100,15 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None):
     if oscale is not None:
         oscale = _f32(oscale).contiguous()
         assert oscale.shape == (x.shape[0], c_out)
-    with torch.cuda.device(x.device):
-        st = lib.pasta_conv2d(_native.ptr(x), _native.ptr(w), _native.ptr(y), _native.ptr(iscale), _native.ptr(oscale),
-                              ctypes.byref(desc), _native.ptr(work), work.numel() * 4, _native.stream())
-    _native.check(st)
+    def launch():
+        with torch.cuda.device(x.device):
+            st = lib.pasta_conv2d(_native.ptr(x), _native.ptr(w), _native.ptr(y), _native.ptr(iscale), _native.ptr(oscale),
+                                  ctypes.byref(desc), _native.ptr(work), work.numel() * 4, _native.stream())
+        _native.check(st)
+    if launch_hook is None:
+        launch()
+    else:
+        launch_hook('conv', desc, launch)
     return y.to(out_dtype)
 
 def _launch_wgrad(x, dy, cfg, w_shape):
@@ -120,10 +129,15 @@ def _launch_wgrad(x, dy, cfg, w_shape):
     if nbytes < 0:
         _native.check(1)
     work = torch.empty([max(nbytes // 4, 4)], dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
-        st = lib.pasta_conv2d_wgrad(_native.ptr(x), _native.ptr(dy), _native.ptr(dw), ctypes.byref(desc),
-                                    _native.ptr(work), work.numel() * 4, _native.stream())
-    _native.check(st)
+    def launch():
+        with torch.cuda.device(x.device):
+            st = lib.pasta_conv2d_wgrad(_native.ptr(x), _native.ptr(dy), _native.ptr(dw), ctypes.byref(desc),
+                                        _native.ptr(work), work.numel() * 4, _native.stream())
+        _native.check(st)
+    if launch_hook is None:
+        launch()
+    else:
+        launch_hook('wgrad', desc, launch)
     return dw.to(out_dtype)
 
 #----------------------------------------------------------------------------

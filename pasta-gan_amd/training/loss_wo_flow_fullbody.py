@@ -1,0 +1,141 @@
+"""Loss and gradient accumulation for the full-body try-on generator / discriminator.
+
+Mirrors ``StyleGAN2Loss`` of the reference's training/loss_wo_flow_fullbody.py (constructor :33-72,
+``run_G`` :74-94, ``run_D`` :96-102, ``accumulate_gradients`` :106-254): non-saturating GAN terms on
+both generator outputs, L1, 6-class parsing cross-entropy and lazy R1, with DistributedDataParallel
+synchronisation gated exactly as there. Differences, all outside the G/D kernels:
+the VGG19 perceptual and contextual terms need weights that are not distributable
+(``./checkpoints/vgg19-dcbb9e9d.pth``) and are rejected unless their weight is 0; statistics
+reporting is a no-op hook; style mixing picks its cutoff without a host synchronisation.
+"""
+
+import numpy as np
+import torch
+
+from torch_utils import misc
+from torch_utils.ops import conv2d_gradfix
+
+#----------------------------------------------------------------------------
+
+class Loss:
+    def accumulate_gradients(self, phase, real_img, gen_z, style_input, retain, pose, denorm_upper_input, denorm_lower_input,
+                             denorm_upper_mask, denorm_lower_mask, gt_parsing, sync, gain): # to be overridden by subclass
+        raise NotImplementedError()
+
+#----------------------------------------------------------------------------
+
+class StyleGAN2Loss(Loss):
+    def __init__(self, device, G_mapping, G_synthesis, G_const_encoding, G_style_encoding, D, augment_pipe=None,
+                 style_mixing_prob=0.9, r1_gamma=10, pl_batch_shrink=2, pl_decay=0.01, pl_weight=0, l1_weight=50,
+                 vgg_weight=50, contextual_weight=1.0, mask_weight=1.0, report_fn=None):
+        super().__init__()
+        if vgg_weight > 0 or contextual_weight > 0:
+            raise NotImplementedError('VGG19 perceptual / contextual terms need ./checkpoints/vgg19*.pth, which cannot be '
+                                      'obtained here; pass vgg_weight=0, contextual_weight=0 (SURVEY.md 8f-2)')
+        if pl_weight != 0:
+            raise NotImplementedError('path-length regularisation is unreachable in the reference (wrong arity at '
+                                      'loss_wo_flow_fullbody.py:185-205; train.sh sets --pl_weight 0)')
+        self.device = device
+        self.G_mapping = G_mapping
+        self.G_synthesis = G_synthesis
+        self.G_const_encoding = G_const_encoding
+        self.G_style_encoding = G_style_encoding
+        self.D = D
+        self.augment_pipe = augment_pipe
+        self.style_mixing_prob = style_mixing_prob
+        self.r1_gamma = r1_gamma
+        self.pl_weight = pl_weight
+        self.l1_weight = l1_weight
+        self.vgg_weight = vgg_weight
+        self.mask_weight = mask_weight
+        self.report = report_fn if report_fn is not None else (lambda name, value: None)
+        class_weight = torch.tensor([1, 2, 2, 3, 3, 3], dtype=torch.float32, device=device)
+        self.ce_parsing = torch.nn.CrossEntropyLoss(ignore_index=255, weight=class_weight)
+
+    def run_G(self, z, c, pose, const_feats, denorm_upper_mask, denorm_lower_mask, denorm_upper_input, denorm_lower_input, sync):
+        cat_feats = {str(f.shape[2]): f for f in const_feats}
+        with misc.ddp_sync(self.G_const_encoding, sync):
+            pose_feat = self.G_const_encoding(pose)
+        with misc.ddp_sync(self.G_mapping, sync):
+            ws = self.G_mapping(z, c)
+            if self.style_mixing_prob > 0:
+                num_ws = ws.shape[1]
+                cutoff = torch.empty([], dtype=torch.int64, device=ws.device).random_(1, num_ws)
+                cutoff = torch.where(torch.rand([], device=ws.device) < self.style_mixing_prob, cutoff, torch.full_like(cutoff, num_ws))
+                ws2 = self.G_mapping(torch.randn_like(z), c, skip_w_avg_update=True)
+                keep = (torch.arange(num_ws, device=ws.device) < cutoff).reshape(1, num_ws, 1)
+                ws = torch.where(keep, ws, ws2)          # ws[:, cutoff:] = ws2[:, cutoff:] without reading cutoff on the host
+        with misc.ddp_sync(self.G_synthesis, sync):
+            img, finetune_img, pred_parsing = self.G_synthesis(ws, pose_feat, cat_feats, denorm_upper_input, denorm_lower_input,
+                                                               denorm_upper_mask, denorm_lower_mask)
+        return img, finetune_img, pred_parsing, ws
+
+    def run_D(self, img, c, sync):
+        if self.augment_pipe is not None:
+            img = self.augment_pipe(img)
+        with misc.ddp_sync(self.D, sync):
+            logits = self.D(img, c)
+        return logits
+
+    def accumulate_gradients(self, phase, real_img, gen_z, style_input, retain, pose, denorm_upper_input, denorm_lower_input,
+                             denorm_upper_mask, denorm_lower_mask, gt_parsing, sync, gain):
+        assert phase in ['Gmain', 'Greg', 'Gboth', 'Dmain', 'Dreg', 'Dboth']
+        do_Gmain = (phase in ['Gmain', 'Gboth'])
+        do_Dmain = (phase in ['Dmain', 'Dboth'])
+        do_Dr1   = (phase in ['Dreg', 'Dboth']) and (self.r1_gamma != 0)
+        softplus = torch.nn.functional.softplus
+
+        # The style code doubles as the conditioning label of both real and generated images (:114-116).
+        with misc.ddp_sync(self.G_style_encoding, sync):
+            real_c, cat_feats = self.G_style_encoding(style_input, retain)
+            gen_c = real_c
+        g_args = (denorm_upper_mask, denorm_lower_mask, denorm_upper_input, denorm_lower_input)
+
+        # Gmain: maximise logits for both generated images, plus reconstruction terms (:119-182).
+        if do_Gmain:
+            gen_img, gen_finetune_img, pred_parsing, _ws = self.run_G(gen_z, gen_c, pose, cat_feats, *g_args, sync=sync)
+            gen_logits = self.run_D(gen_img, gen_c, sync=False)
+            gen_finetune_logits = self.run_D(gen_finetune_img, gen_c, sync=False)
+            self.report('Loss/scores/fake', gen_logits)
+            loss_Gmain = softplus(-gen_logits).mean()
+            loss_Gmain_finetune = softplus(-gen_finetune_logits).mean()
+            loss_G_L1 = loss_G_finetune_L1 = 0
+            if self.l1_weight > 0:
+                loss_G_L1 = torch.nn.functional.l1_loss(gen_img, real_img) * self.l1_weight
+                loss_G_finetune_L1 = torch.nn.functional.l1_loss(gen_finetune_img, real_img) * self.l1_weight
+            loss_mask = 0
+            if self.mask_weight > 0:
+                loss_mask = torch.mean(self.ce_parsing(pred_parsing, gt_parsing.long()[:, 0, ...])) * self.mask_weight
+            loss_G = (loss_Gmain + loss_Gmain_finetune) / 2 + (loss_G_L1 + loss_G_finetune_L1) / 2 + loss_mask
+            self.report('Loss/G/loss', loss_Gmain)
+            loss_G.mul(gain).backward()
+
+        # Dmain: minimise logits for generated images (:210-228).
+        loss_Dgen = 0
+        if do_Dmain:
+            gen_img, gen_finetune_img, _, _ws = self.run_G(gen_z, gen_c, pose, cat_feats, *g_args, sync=False)
+            gen_logits = self.run_D(gen_img, gen_c, sync=False)   # gets synced by loss_Dreal
+            gen_finetune_logits = self.run_D(gen_finetune_img, gen_c, sync=False)
+            loss_Dgen = softplus(gen_logits)
+            loss_Dgen_finetune = softplus(gen_finetune_logits)
+            ((loss_Dgen.mean() + loss_Dgen_finetune.mean()) / 2).mul(gain).backward()
+
+        # Dmain: maximise logits for real images.  Dr1: R1 penalty on real images (:232-254).
+        if do_Dmain or do_Dr1:
+            real_img_tmp = real_img.detach().requires_grad_(do_Dr1)
+            real_logits = self.run_D(real_img_tmp, real_c, sync=sync)
+            self.report('Loss/scores/real', real_logits)
+            loss_Dreal = 0
+            if do_Dmain:
+                loss_Dreal = softplus(-real_logits)
+                self.report('Loss/D/loss', loss_Dgen + loss_Dreal)
+            loss_Dr1 = 0
+            if do_Dr1:
+                with conv2d_gradfix.no_weight_gradients():
+                    r1_grads = torch.autograd.grad(outputs=[real_logits.sum()], inputs=[real_img_tmp], create_graph=True, only_inputs=True)[0]
+                r1_penalty = r1_grads.square().sum([1, 2, 3])
+                loss_Dr1 = r1_penalty * (self.r1_gamma / 2)
+                self.report('Loss/r1_penalty', r1_penalty)
+            (real_logits * 0 + loss_Dreal + loss_Dr1).mean().mul(gain).backward()
+
+#----------------------------------------------------------------------------

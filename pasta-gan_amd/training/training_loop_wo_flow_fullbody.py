@@ -1,0 +1,176 @@
+"""The data-parallel training step of PASTA-GAN's full-body model.
+
+Mirrors the hot loop of the reference's training/training_loop_wo_flow_fullbody.py: module
+construction (:274-277), one DistributedDataParallel wrapper per sub-module with
+``broadcast_buffers=False`` (:312-324), lazily regularised Adam phases Gmain/Greg/Dmain/Dreg
+(:332-349), gradient accumulation with ``sync`` only on the last round (:484-505), gradient
+``nan_to_num`` + optimiser step (:508-516) and the generator EMA (:521-529). One process per GPU;
+gradients are all-reduced by RCCL (``backend='nccl'`` on ROCm) over xGMI, overlapped with backward.
+
+Dataset loading, snapshots, image grids, ADA and metrics of the reference loop are host
+orchestration outside this path; ``SyntheticFullBodyBatch`` supplies tensors of the dataset's
+shapes (training_loop...:289-297, 425-456) directly in HBM.
+"""
+
+import copy
+
+import numpy as np
+import torch
+
+import dnnlib
+from torch_utils import misc
+
+#----------------------------------------------------------------------------
+
+def fashion_config(channel_base=16384, d_fp16_res=0, mbstd_group_size=4):
+    """G/D/optimiser/loss options of ``--cfg fashion`` (train_wo_flow_fullbody.py:166-215, train.sh:3-10)."""
+    G_kwargs = dnnlib.EasyDict(class_name='training.networks.GeneratorFull', z_dim=0, c_dim=512, w_dim=512, img_resolution=256,
+                               img_channels=3, mapping_kwargs=dnnlib.EasyDict(num_layers=1),
+                               synthesis_kwargs=dnnlib.EasyDict(channel_base=channel_base, channel_max=512, num_fp16_res=3,
+                                                                conv_clamp=256, use_noise=True))
+    D_kwargs = dnnlib.EasyDict(class_name='training.networks.Discriminator', c_dim=512, img_resolution=256, img_channels=3,
+                               channel_base=channel_base, channel_max=512, num_fp16_res=d_fp16_res, conv_clamp=256,
+                               block_kwargs=dnnlib.EasyDict(), mapping_kwargs=dnnlib.EasyDict(),
+                               epilogue_kwargs=dnnlib.EasyDict(mbstd_group_size=mbstd_group_size))
+    opt = dnnlib.EasyDict(class_name='torch.optim.Adam', lr=0.002, betas=[0, 0.99], eps=1e-8)
+    loss_kwargs = dnnlib.EasyDict(class_name='training.loss_wo_flow_fullbody.StyleGAN2Loss', r1_gamma=10, l1_weight=40,
+                                  vgg_weight=0, contextual_weight=0, pl_weight=0, mask_weight=20)
+    return dnnlib.EasyDict(G_kwargs=G_kwargs, D_kwargs=D_kwargs, G_opt_kwargs=opt, D_opt_kwargs=dnnlib.EasyDict(opt),
+                           loss_kwargs=loss_kwargs, ema_kimg=10, ema_rampup=None, G_reg_interval=4, D_reg_interval=16)
+
+#----------------------------------------------------------------------------
+
+class SyntheticFullBodyBatch:
+    """Device-resident synthetic batch with the dataset's tensor shapes and value ranges."""
+    KEYS = ['real_img', 'style_input', 'retain', 'pose', 'denorm_upper_input', 'denorm_lower_input',
+            'denorm_upper_mask', 'denorm_lower_mask', 'gt_parsing']
+
+    def __init__(self, batch, device, seed=0, res=256):
+        g = torch.Generator(device='cpu').manual_seed(1234 + seed)
+        n = batch
+        def u(*shape):
+            return torch.rand(shape, generator=g) * 2 - 1
+        def blobs(p):
+            coarse = torch.rand([n, 1, res // 16, res // 16], generator=g)
+            return (torch.nn.functional.interpolate(coarse, size=(res, res), mode='bilinear', align_corners=False) < p).float()
+        real_img = u(n, 3, res, res)
+        real_img[..., : res // 8] = 1.0               # 192-wide content, white padded to a square (dataset.py:520-524)
+        real_img[..., res - res // 8:] = 1.0
+        mask = blobs(0.5)
+        retain = mask * real_img - (1 - mask)
+        lines = (torch.rand([n, 3, res, res], generator=g) < 0.02).float() * 2 - 1
+        style = u(n, 42, res // 4, res // 4)
+        drop = (torch.rand([n, 14, 1, 1], generator=g) < 0.3).repeat_interleave(3, dim=1)
+        style = torch.where(drop, -torch.ones_like(style), style)
+        du_mask, dl_mask = blobs(0.35), blobs(0.35)
+        gt = torch.randint(0, 6, [n, 1, res // 8, res // 8], generator=g).float()
+        t = dict(real_img=real_img, style_input=style, retain=retain, pose=torch.cat([lines, retain], dim=1),
+                 denorm_upper_input=u(n, 3, res, res) * du_mask - (1 - du_mask),
+                 denorm_lower_input=u(n, 3, res, res) * dl_mask - (1 - dl_mask),
+                 denorm_upper_mask=du_mask, denorm_lower_mask=dl_mask,
+                 gt_parsing=torch.nn.functional.interpolate(gt, size=(res, res), mode='nearest'))
+        self.tensors = {k: v.to(device) for k, v in t.items()}
+        self.batch = n
+
+    def split(self, batch_gpu):
+        parts = {k: v.split(batch_gpu) for k, v in self.tensors.items()}
+        return [{k: parts[k][i] for k in self.KEYS} for i in range(len(parts['real_img']))]
+
+#----------------------------------------------------------------------------
+
+class TrainingStep:
+    """Owns G, D, G_ema, the DDP wrappers, the loss and the four optimiser phases; ``run()`` executes one
+    iteration of the reference's hot loop on a device-resident batch."""
+
+    def __init__(self, device, cfg=None, num_gpus=1, rank=0, batch_size=16, batch_gpu=16, random_seed=0, ddp_bucket_mb=25):
+        cfg = cfg if cfg is not None else fashion_config()
+        self.device, self.num_gpus, self.rank = device, num_gpus, rank
+        self.batch_size, self.batch_gpu = batch_size, batch_gpu
+        assert batch_size % (batch_gpu * num_gpus) == 0
+        np.random.seed(random_seed * num_gpus + rank)
+        torch.manual_seed(random_seed * num_gpus + rank)
+
+        self.G = dnnlib.util.construct_class_by_name(**cfg.G_kwargs).train().requires_grad_(False).to(device)
+        self.D = dnnlib.util.construct_class_by_name(**cfg.D_kwargs).train().requires_grad_(False).to(device)
+        self.G_ema = copy.deepcopy(self.G).eval()
+        self.ema_kimg, self.ema_rampup = cfg.ema_kimg, cfg.ema_rampup
+
+        # One DDP wrapper per sub-module so that loss code can gate their all-reduces separately (:316-324).
+        G, D = self.G, self.D
+        ddp = dict()
+        for name, module in [('G_mapping', G.mapping), ('G_synthesis', G.synthesis), ('G_const_encoding', G.const_encoding),
+                             ('G_style_encoding', G.style_encoding), ('D', D), (None, self.G_ema)]:
+            if num_gpus > 1 and len(list(module.parameters())) != 0:
+                module.requires_grad_(True)
+                ids = [device] if device.type == 'cuda' else None
+                module = torch.nn.parallel.DistributedDataParallel(module, device_ids=ids, broadcast_buffers=False,
+                                                                   find_unused_parameters=True, bucket_cap_mb=ddp_bucket_mb)
+                module.requires_grad_(False)
+            if name is not None:
+                ddp[name] = module
+        self.ddp_modules = ddp
+        self.loss = dnnlib.util.construct_class_by_name(device=device, **ddp, **cfg.loss_kwargs)
+
+        self.phases = []
+        for name, module, opt_kwargs, reg_interval in [('G', G, cfg.G_opt_kwargs, cfg.G_reg_interval), ('D', D, cfg.D_opt_kwargs, cfg.D_reg_interval)]:
+            if reg_interval is None:
+                opt = dnnlib.util.construct_class_by_name(params=module.parameters(), **opt_kwargs)
+                self.phases += [dnnlib.EasyDict(name=name + 'both', module=module, opt=opt, interval=1)]
+            else:   # lazy regularisation (:337-346)
+                mb_ratio = reg_interval / (reg_interval + 1)
+                opt_kwargs = dnnlib.EasyDict(opt_kwargs)
+                opt_kwargs.lr = opt_kwargs.lr * mb_ratio
+                opt_kwargs.betas = [beta ** mb_ratio for beta in opt_kwargs.betas]
+                opt = dnnlib.util.construct_class_by_name(module.parameters(), **opt_kwargs)
+                self.phases += [dnnlib.EasyDict(name=name + 'main', module=module, opt=opt, interval=1)]
+                self.phases += [dnnlib.EasyDict(name=name + 'reg', module=module, opt=opt, interval=reg_interval)]
+        self.batch_idx = 0
+        self.cur_nimg = 0
+
+    def run(self, data):
+        """One iteration: every due phase accumulates gradients over the local rounds, then steps its optimiser;
+        finally the EMA generator is updated. ``data`` is a ``SyntheticFullBodyBatch`` holding this rank's
+        ``batch_size // num_gpus`` samples."""
+        rounds = data.split(self.batch_gpu)
+        z_dim = self.G.z_dim
+        all_gen_z = torch.randn([len(self.phases), len(rounds) * self.batch_gpu, z_dim], device=self.device)
+        for phase, phase_gen_z in zip(self.phases, all_gen_z):
+            if self.batch_idx % phase.interval != 0:
+                continue
+            phase.opt.zero_grad(set_to_none=True)
+            phase.module.requires_grad_(True)
+            for round_idx, (r, gen_z) in enumerate(zip(rounds, phase_gen_z.split(self.batch_gpu))):
+                sync = (round_idx == self.batch_size // (self.batch_gpu * self.num_gpus) - 1)
+                self.loss.accumulate_gradients(phase=phase.name, gen_z=gen_z, sync=sync, gain=phase.interval, **r)
+            phase.module.requires_grad_(False)
+            for param in phase.module.parameters():
+                if param.grad is not None:
+                    misc.nan_to_num(param.grad, nan=0, posinf=1e5, neginf=-1e5, out=param.grad)
+            phase.opt.step()
+
+        ema_nimg = self.ema_kimg * 1000
+        if self.ema_rampup is not None:
+            ema_nimg = min(ema_nimg, self.cur_nimg * self.ema_rampup)
+        ema_beta = 0.5 ** (self.batch_size / max(ema_nimg, 1e-8))
+        with torch.no_grad():
+            for p_ema, p in zip(self.G_ema.parameters(), self.G.parameters()):
+                p_ema.copy_(p.lerp(p_ema, ema_beta))
+            for b_ema, b in zip(self.G_ema.buffers(), self.G.buffers()):
+                b_ema.copy_(b)
+        self.cur_nimg += self.batch_size
+        self.batch_idx += 1
+
+#----------------------------------------------------------------------------
+
+def training_loop(num_gpus=1, rank=0, batch_size=16, batch_gpu=16, random_seed=0, total_iters=4, cfg=None, device=None, progress_fn=None):
+    """Run ``total_iters`` iterations on synthetic data (the reference's loop runs until ``total_kimg``)."""
+    device = device if device is not None else torch.device('cuda', rank)
+    step = TrainingStep(device, cfg=cfg, num_gpus=num_gpus, rank=rank, batch_size=batch_size, batch_gpu=batch_gpu, random_seed=random_seed)
+    data = SyntheticFullBodyBatch(batch_size // num_gpus, device, seed=rank)
+    for it in range(total_iters):
+        step.run(data)
+        if progress_fn is not None:
+            progress_fn(it + 1, total_iters)
+    return step
+
+#----------------------------------------------------------------------------

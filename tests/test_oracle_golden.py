@@ -29,8 +29,10 @@ def test_setup_filter():
         assert rel_err(got, g[f'f{i}']) < 1e-7, s
 
 
+@pytest.mark.parametrize('as_conv', [False, True])
 @pytest.mark.parametrize('idx', range(18))
-def test_upfirdn2d(idx):
+def test_upfirdn2d(idx, as_conv, monkeypatch):
+    monkeypatch.setattr(R, 'FIR_AS_DEPTHWISE_CONV', as_conv)
     g, cases = _cases('ops_upfirdn2d.npz')
     c = cases[idx]
     n = c['name']
