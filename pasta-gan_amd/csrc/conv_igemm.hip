@@ -20,6 +20,7 @@
 //
 // C/D fragment map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
 #include "common.h"
+#include <stdlib.h>
 
 namespace pasta {
 
@@ -114,26 +115,40 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
     float  breg[BPT];
     float4 areg[APT];
 
-    auto load_chunk = [&](int ch) {
-        const int t = ch / NC, c0 = (ch - t * NC) * KC;
+    // Loader state: tap index and channel offset of the NEXT chunk to fetch, plus the per-tap
+    // quantities derived from them (recomputed only when the tap changes: T times, not per chunk).
+    int ld_t = 0, ld_c0 = 0;
+    bool ld_ok = false;
+    const float* ld_xp = xb;
+    const float* ld_wt = wb;
+    auto set_tap = [&](int t) {
         const int iy = iy_base + p.tap_dy[t], ix = ix_base + p.tap_dx[t];
-        const bool ok = pix_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const float* xp = xb + iy * p.W + ix;
+        ld_ok = pix_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        ld_xp = xb + iy * p.W + ix;
+        ld_wt = wb + (int64_t)p.tap_slab[t] * p.Ig_pad * p.Og_pad;
+    };
+    set_tap(0);
+    auto load_chunk = [&]() {
 #pragma unroll
         for (int j = 0; j < BPT; j++) {
-            const int c = c0 + brow0 + j * RSTEP;
+            const int c = ld_c0 + brow0 + j * RSTEP;
             float v = 0.f;
-            if (ok && c < p.Ig) {
-                v = xp[(int64_t)c * HW];
+            if (ld_ok && c < p.Ig) {
+                v = ld_xp[(int64_t)c * HW];
                 if (isb) v *= isb[c];
             }
             breg[j] = v;
         }
-        const float* wt = wb + ((int64_t)p.tap_slab[t] * p.Ig_pad + c0) * p.Og_pad;
+        const float* wt = ld_wt + (int64_t)ld_c0 * p.Og_pad;
 #pragma unroll
         for (int j = 0; j < APT; j++) {
             const int e = tid + j * 256, row = e / A4_PER_ROW, c4 = e - row * A4_PER_ROW;
             if (row < KC) areg[j] = *(const float4*)(wt + (int64_t)row * p.Og_pad + c4 * 4);
+        }
+        ld_c0 += KC;
+        if (ld_c0 >= p.Ig_pad) {
+            ld_c0 = 0;
+            if (++ld_t < p.T) set_tap(ld_t);
         }
     };
     auto store_chunk = [&](int buf) {
@@ -154,13 +169,13 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
-    load_chunk(0);
+    load_chunk();
     store_chunk(0);
     __syncthreads();
     const int kl = lane >> 5, jl = lane & 31;
     for (int ch = 0; ch < nchunks; ch++) {
         const int buf = ch & 1;
-        if (ch + 1 < nchunks) load_chunk(ch + 1);
+        if (ch + 1 < nchunks) load_chunk();
 #pragma unroll
         for (int kk = 0; kk < KC / 2; kk++) {
             float af[WMT], bf[WNT];
@@ -213,6 +228,13 @@ static void launch_fwd(const ConvFwdParams& p, hipStream_t s) {
 // Tile choice.  O_pad multiple returned so that the caller can pack weights accordingly.
 enum FwdTile { T128x128 = 0, T64x256 = 1, T32x256 = 2, T64x64 = 3 };
 
+// Experiment knob (tools/bench_conv.py): PASTA_FWD_VARIANT picks among instances of the large tile.
+static int fwd_variant() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PASTA_FWD_VARIANT"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 static FwdTile choose_fwd_tile(int Og, int64_t npix) {
     if (Og <= 32) return T32x256;        // ToRGB / parsing heads: HBM-bound, few rows
     if (npix <= 8192) return T64x64;     // 4..16 pixel layers: more, smaller workgroups
@@ -222,10 +244,18 @@ static FwdTile choose_fwd_tile(int Og, int64_t npix) {
 static int fwd_tile_bm(FwdTile t) { return t == T128x128 ? 128 : t == T32x256 ? 32 : 64; }
 
 constexpr int FWD_KC = 8;
+constexpr int FWD_IPAD = 16;    // packed input-channel padding: a multiple of every KC in use
 
 static void dispatch_fwd(FwdTile t, const ConvFwdParams& p, hipStream_t s) {
     switch (t) {
-        case T128x128: launch_fwd<128, 128, 2, 2, FWD_KC>(p, s); break;
+        case T128x128:
+            switch (fwd_variant()) {
+                case 1:  launch_fwd<128, 128, 2, 2, 16>(p, s); break;
+                case 2:  launch_fwd<128, 256, 2, 4, 8>(p, s); break;
+                case 3:  launch_fwd<128, 256, 2, 4, 16>(p, s); break;
+                default: launch_fwd<128, 128, 2, 2, FWD_KC>(p, s); break;
+            }
+            break;
         case T64x256:  launch_fwd<64, 256, 2, 2, FWD_KC>(p, s); break;
         case T32x256:  launch_fwd<32, 256, 1, 2, FWD_KC>(p, s); break;
         case T64x64:   launch_fwd<64, 64, 1, 1, FWD_KC>(p, s); break;
@@ -254,22 +284,23 @@ struct WgradParams {
     int a_tiles, b_tiles, tap_groups_r, tap_groups_s;
 };
 
-template <int TR, int TS>   // taps handled per workgroup: TR rows x TS columns of the kernel
+template <int TR, int TS, int WA, int WB>   // taps per workgroup: TR x TS; each wave owns WA x WB 32x32 tiles per tap
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     constexpr int NT = TR * TS;
-    constexpr int KP = 32;                    // pixels per chunk
-    constexpr int SPITCH = KP + 1;            // odd pitch: column-of-channels reads hit 32 banks
+    constexpr int BA = 64 * WA, BB = 64 * WB;  // workgroup tile: 2 x 2 waves
+    constexpr int KP = 32;                     // pixels per chunk
+    constexpr int SPITCH = KP + 1;             // odd pitch: column-of-channels reads hit 32 banks
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wa = wave >> 1, wb = wave & 1;  // 2 x 2 waves over the 64 x 64 tile
+    const int wa = wave >> 1, wb = wave & 1;
     const int CW = 1 << p.cw_log2, CHH = KP >> p.cw_log2;
-    const int LWID = (CW - 1) * p.st + TS;    // halo width per chunk row
+    const int LWID = (CW - 1) * p.st + TS;     // halo width per chunk row
     const int LPITCH = LWID | 1;
-    const int LROWS = CHH * TR;               // halo rows per channel: one set of TR rows per chunk row
-    const int LCH = (LROWS * LPITCH) | 1;     // odd per-channel pitch
-    float* Ss = smem;                         // [64][SPITCH]
-    float* Ls = smem + 64 * SPITCH;           // [64][LCH]
+    const int LROWS = CHH * TR;                // halo rows per channel: one set of TR rows per chunk row
+    const int LCH = (LROWS * LPITCH) | 1;      // odd per-channel pitch
+    float* Ss = smem;                          // [BA][SPITCH]
+    float* Ls = smem + BA * SPITCH;            // [BB][LCH]
 
     // block coordinates
     int bid = blockIdx.x;
@@ -280,14 +311,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     const int at = bid % p.a_tiles; bid /= p.a_tiles;
     const int g = bid;
     const int r0 = tgr * TR, s0 = tgs * TS;
-    const int a_blk = at * 64, b_blk = bt * 64;
+    const int a_blk = at * BA, b_blk = bt * BB;
     const int PQ = p.P * p.Q, LHW = p.LH * p.LW;
 
-    f32x16 acc[NT];
+    // ---- staging roles, fixed for the whole K loop.
+    // S: this thread's pixel of the chunk and every 8th channel.
+    constexpr int SPT = BA / 8;
+    const int s_k = tid & 31, s_a0 = tid >> 5;
+    const int s_dr = s_k >> p.cw_log2, s_dq = s_k & (CW - 1);
+    // L: one halo position (or a few) and every `lgroups`-th channel.
+    const int NPOS = LROWS * LWID;
+    int npos_pad = 64;
+    while (npos_pad < NPOS && npos_pad < 256) npos_pad <<= 1;
+    const int lgroups = 256 / npos_pad;                    // 4, 2 or 1 channel groups
+    const int l_pos0 = tid & (npos_pad - 1), l_cg = tid / npos_pad;
+    const int l_passes = (NPOS + 255) / 256;               // > 1 only for very wide halos
+    constexpr int LPT_MAX = BB;                            // channel loads per thread when lgroups == 1
+
+    f32x16 acc[NT][WA][WB];
 #pragma unroll
     for (int t = 0; t < NT; t++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+        for (int i = 0; i < WA; i++)
+#pragma unroll
+            for (int j = 0; j < WB; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[t][i][j][r] = 0.f;
 
     const int c_begin = (int)((int64_t)p.chunks_total * ks / p.ksplit);
     const int c_end = (int)((int64_t)p.chunks_total * (ks + 1) / p.ksplit);
@@ -297,51 +346,70 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
         const int rb = ch / p.qblocks, qb = ch - rb * p.qblocks;
         const int row0 = rb * CHH, q0 = qb * CW;     // first (n*P + p) row and first column of the chunk
         __syncthreads();
-        // ---- stage S: 64 channels x 32 pixels (pixel k -> chunk row k >> cw_log2, column k & (CW-1))
-        for (int e = tid; e < 64 * KP; e += 256) {
-            const int a = e >> 5, k = e & 31;
-            const int row = row0 + (k >> p.cw_log2), q = q0 + (k & (CW - 1));
-            float v = 0.f;
-            if (a_blk + a < p.Ag && row < p.rows_total && q < p.Q) {
-                const int n = row / p.P, pp = row - n * p.P;
-                v = p.S[((int64_t)n * p.SC + (int64_t)g * p.Ag + a_blk + a) * PQ + pp * p.Q + q];
+        {   // ---- stage S: BA channels x 32 pixels
+            const int row = row0 + s_dr, q = q0 + s_dq;
+            const bool ok = row < p.rows_total && q < p.Q;
+            const int n = ok ? row / p.P : 0, pp = row - n * p.P;
+            const float* sp = p.S + ((int64_t)n * p.SC + (int64_t)g * p.Ag + a_blk) * PQ + pp * p.Q + q;
+#pragma unroll
+            for (int j = 0; j < SPT; j++) {
+                const int a = s_a0 + 8 * j;
+                float v = 0.f;
+                if (ok && a_blk + a < p.Ag) v = sp[(int64_t)a * PQ];
+                Ss[a * SPITCH + s_k] = v;
             }
-            Ss[a * SPITCH + k] = v;
         }
-        // ---- stage L halo: 64 channels x (CHH*TR) rows x LWID columns
-        const int per_ch = LROWS * LWID;
-        for (int e = tid; e < 64 * per_ch; e += 256) {
-            const int b = e / per_ch, rem = e - b * per_ch;
-            const int lr = rem / LWID, lc = rem - lr * LWID;
+        // ---- stage L halo: BB channels x (CHH*TR) rows x LWID columns
+        for (int pass = 0; pass < l_passes; pass++) {
+            const int lpos = l_pos0 + pass * 256;
+            const bool act = lpos < NPOS;
+            const int lr = act ? lpos / LWID : 0, lc = lpos - lr * LWID;
             const int cr = lr / TR, tr = lr - cr * TR;
             const int row = row0 + cr;
-            float v = 0.f;
-            if (b_blk + b < p.Bg && row < p.rows_total) {
-                const int n = row / p.P, pp = row - n * p.P;
-                const int ly = pp * p.st + r0 + tr - p.pad_h, lx = q0 * p.st + s0 + lc - p.pad_w;
-                if ((unsigned)ly < (unsigned)p.LH && (unsigned)lx < (unsigned)p.LW && r0 + tr < p.kh)
-                    v = p.L[((int64_t)n * p.LC + (int64_t)g * p.Bg + b_blk + b) * LHW + ly * p.LW + lx];
+            const bool rok = act && row < p.rows_total;
+            const int n = rok ? row / p.P : 0, pp = row - n * p.P;
+            const int ly = pp * p.st + r0 + tr - p.pad_h, lx = q0 * p.st + s0 + lc - p.pad_w;
+            const bool ok = rok && (unsigned)ly < (unsigned)p.LH && (unsigned)lx < (unsigned)p.LW && r0 + tr < p.kh;
+            const float* lp = p.L + ((int64_t)n * p.LC + (int64_t)g * p.Bg + b_blk) * LHW + ly * p.LW + lx;
+            float* ld = Ls + lr * LPITCH + lc;
+            if (act) {
+#pragma unroll 8
+                for (int b = l_cg; b < BB; b += lgroups) {
+                    float v = 0.f;
+                    if (ok && b_blk + b < p.Bg) v = lp[(int64_t)b * LHW];
+                    ld[b * LCH] = v;
+                }
             }
-            Ls[b * LCH + lr * LPITCH + lc] = v;
         }
         __syncthreads();
-        // ---- 16 k-steps of 2 pixels; per step one A fragment feeds NT MFMAs
-#pragma unroll 4
+        // ---- 16 k-steps of 2 pixels; per step WA A-fragments feed NT*WA*WB MFMAs
+#pragma unroll 2
         for (int kk = 0; kk < KP / 2; kk++) {
             const int k = kk * 2 + kl;
-            const float af = Ss[(wa * 32 + jl) * SPITCH + k];
+            float af[WA];
+#pragma unroll
+            for (int i = 0; i < WA; i++) af[i] = Ss[((wa * WA + i) * 32 + jl) * SPITCH + k];
             const int cr = k >> p.cw_log2, cc = k & (CW - 1);
-            const float* lb = Ls + (wb * 32 + jl) * LCH + cr * TR * LPITCH + cc * p.st;
+            const float* lb = Ls + cr * TR * LPITCH + cc * p.st;
 #pragma unroll
-            for (int tr = 0; tr < TR; tr++)
+            for (int j = 0; j < WB; j++) {
+                const float* lbj = lb + ((wb * WB + j) * 32 + jl) * LCH;
 #pragma unroll
-                for (int ts = 0; ts < TS; ts++)
-                    acc[tr * TS + ts] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, lb[tr * LPITCH + ts], acc[tr * TS + ts], 0, 0, 0);
+                for (int tr = 0; tr < TR; tr++)
+#pragma unroll
+                    for (int ts = 0; ts < TS; ts++) {
+                        const float bf = lbj[tr * LPITCH + ts];
+#pragma unroll
+                        for (int i = 0; i < WA; i++)
+                            acc[tr * TS + ts][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf, acc[tr * TS + ts][i][j], 0, 0, 0);
+                    }
+            }
         }
     }
+    (void)LPT_MAX;
 
     // ---- partial slab: [ksplit][G][kh*kw][Ag_pad][Bg_pad], b contiguous
-    const int Ag_pad = p.a_tiles * 64, Bg_pad = p.b_tiles * 64;
+    const int Ag_pad = p.a_tiles * BA, Bg_pad = p.b_tiles * BB;
     float* out = p.slab + ((int64_t)ks * p.G + g) * p.kh * p.kw * Ag_pad * Bg_pad;
 #pragma unroll
     for (int tr = 0; tr < TR; tr++)
@@ -350,10 +418,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
             if (r0 + tr >= p.kh || s0 + ts >= p.kw) continue;
             float* ot = out + (int64_t)((r0 + tr) * p.kw + s0 + ts) * Ag_pad * Bg_pad;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int a = a_blk + wa * 32 + acc_row(r, lane), b = b_blk + wb * 32 + jl;
-                ot[(int64_t)a * Bg_pad + b] = acc[tr * TS + ts][r];
-            }
+            for (int i = 0; i < WA; i++)
+#pragma unroll
+                for (int j = 0; j < WB; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int a = a_blk + (wa * WA + i) * 32 + acc_row(r, lane), b = b_blk + (wb * WB + j) * 32 + jl;
+                        ot[(int64_t)a * Bg_pad + b] = acc[tr * TS + ts][i][j][r];
+                    }
         }
 }
 
@@ -380,7 +452,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 struct WgradPlan {
-    int TR, TS, tgr, tgs, a_tiles, b_tiles, cw_log2, qblocks, chunks_total, ksplit, rows_total;
+    int TR, TS, WA, WB, tgr, tgs, a_tiles, b_tiles, cw_log2, qblocks, chunks_total, ksplit, rows_total;
     int64_t slab_floats; size_t lds_bytes;
 };
 
@@ -390,8 +462,12 @@ static WgradPlan plan_wgrad(int N, int P, int Q, int G, int Ag, int Bg, int kh, 
     else if (kw == 7) { w.TR = 1; w.TS = 7; }
     else if (kw == 4) { w.TR = 1; w.TS = 4; }
     else { w.TR = 1; w.TS = 1; }
+    // single-tap kernels carry 16 accumulator registers per tile: give each wave 2 x 2 tiles when both
+    // channel counts fill a 128-wide workgroup tile
+    w.WA = w.WB = (w.TR * w.TS == 1 && Ag > 64 && Bg > 64) ? 2 : 1;
+    const int BA = 64 * w.WA, BB = 64 * w.WB;
     w.tgr = (kh + w.TR - 1) / w.TR; w.tgs = (kw + w.TS - 1) / w.TS;
-    w.a_tiles = (Ag + 63) / 64; w.b_tiles = (Bg + 63) / 64;
+    w.a_tiles = (Ag + BA - 1) / BA; w.b_tiles = (Bg + BB - 1) / BB;
     int cw = 32, lg = 5;
     while (cw > 1 && cw / 2 >= Q) { cw /= 2; lg--; }     // smallest power of two >= Q, capped at 32
     w.cw_log2 = lg;
@@ -405,9 +481,9 @@ static WgradPlan plan_wgrad(int N, int P, int Q, int G, int Ag, int Bg, int kh, 
     if (ks < 1) ks = 1;
     if (ks > 256) ks = 256;
     w.ksplit = (int)ks;
-    w.slab_floats = (int64_t)w.ksplit * G * kh * kw * w.a_tiles * 64 * w.b_tiles * 64;
+    w.slab_floats = (int64_t)w.ksplit * G * kh * kw * w.a_tiles * BA * w.b_tiles * BB;
     const int lwid = (cw - 1) * st + w.TS, lpitch = lwid | 1, lch = (chh * w.TR * lpitch) | 1;
-    w.lds_bytes = (size_t)(64 * 33 + 64 * lch) * sizeof(float);
+    w.lds_bytes = (size_t)(BA * 33 + BB * lch) * sizeof(float);
     return w;
 }
 
@@ -451,7 +527,7 @@ extern "C" int64_t pasta_conv2d_workspace(const pasta_conv_desc* d) {
     if (check_desc(d, "conv2d_workspace")) return -1;
     const int Ig = d->C_in / d->groups, Og = d->C_out / d->groups;
     const FwdTile t = choose_fwd_tile(Og, fwd_lattice_pixels(d));
-    return (int64_t)d->groups * d->kh * d->kw * round_up(Ig, FWD_KC) * round_up(Og, fwd_tile_bm(t)) * (int64_t)sizeof(float);
+    return (int64_t)d->groups * d->kh * d->kw * round_up(Ig, FWD_IPAD) * round_up(Og, fwd_tile_bm(t)) * (int64_t)sizeof(float);
 }
 
 extern "C" int pasta_conv2d_tile(const pasta_conv_desc* d) {
@@ -476,7 +552,7 @@ extern "C" int pasta_conv2d(const float* x, const float* w, float* y, const floa
     p.Cout = d->C_out; p.OH = d->OH; p.OW = d->OW;
     p.G = d->groups; p.Ig = d->C_in / d->groups; p.Og = d->C_out / d->groups;
     const FwdTile tile = choose_fwd_tile(p.Og, fwd_lattice_pixels(d));
-    p.Ig_pad = round_up(p.Ig, FWD_KC); p.Og_pad = round_up(p.Og, fwd_tile_bm(tile));
+    p.Ig_pad = round_up(p.Ig, FWD_IPAD); p.Og_pad = round_up(p.Og, fwd_tile_bm(tile));
     p.KK = d->kh * d->kw;
 
     {   // pack weights
@@ -562,23 +638,24 @@ extern "C" int pasta_conv2d_wgrad(const float* x, const float* dy, float* dw, co
 
     const int64_t blocks = (int64_t)p.G * w.a_tiles * w.b_tiles * w.tgr * w.tgs * w.ksplit;
     PASTA_CHECK(blocks <= INT32_MAX, "conv2d_wgrad: grid too large");
-#define PASTA_WGRAD(TR_, TS_)                                                                                             \
+#define PASTA_WGRAD(TR_, TS_, WA_, WB_)                                                                                   \
     do {                                                                                                                  \
         if (w.lds_bytes > 64 * 1024)                                                                                      \
-            PASTA_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_kernel<TR_, TS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds_bytes)); \
-        hipLaunchKernelGGL((conv_wgrad_kernel<TR_, TS_>), dim3((unsigned)blocks), dim3(256), w.lds_bytes, s, p);          \
+            PASTA_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_kernel<TR_, TS_, WA_, WB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds_bytes)); \
+        hipLaunchKernelGGL((conv_wgrad_kernel<TR_, TS_, WA_, WB_>), dim3((unsigned)blocks), dim3(256), w.lds_bytes, s, p); \
     } while (0)
-    if (w.TR == 3 && w.TS == 3) PASTA_WGRAD(3, 3);
-    else if (w.TS == 7) PASTA_WGRAD(1, 7);
-    else if (w.TS == 4) PASTA_WGRAD(1, 4);
-    else PASTA_WGRAD(1, 1);
+    if (w.TR == 3 && w.TS == 3) PASTA_WGRAD(3, 3, 1, 1);
+    else if (w.TS == 7) PASTA_WGRAD(1, 7, 1, 1);
+    else if (w.TS == 4) PASTA_WGRAD(1, 4, 1, 1);
+    else if (w.WA == 2) PASTA_WGRAD(1, 1, 2, 2);
+    else PASTA_WGRAD(1, 1, 1, 1);
 #undef PASTA_WGRAD
     {
         const int64_t total = (int64_t)p.G * p.kh * p.kw * p.Ag * p.Bg;
         int64_t rb = ceil_div64(total, 256);
         if (rb > 8192) rb = 8192;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, s, (const float*)workspace, dw, w.ksplit, p.G,
-                           p.Ag, p.Bg, w.a_tiles * 64, w.b_tiles * 64, p.kh, p.kw, d->flip);
+                           p.Ag, p.Bg, w.a_tiles * 64 * w.WA, w.b_tiles * 64 * w.WB, p.kh, p.kw, d->flip);
     }
     return launch_status("conv2d_wgrad");
 }

@@ -1,0 +1,90 @@
+"""Per-shape timing of the native convolution family (forward, input gradient, weight gradient) on the layer
+shapes of the 256x256 'fashion' model at batch 16; optionally next to MIOpen (torch.nn.functional.conv2d) as a
+same-hardware reference.  Usage: python tools/bench_conv.py [--miopen] [--reps 10] [--only fwd,dgrad,wgrad]"""
+
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'pasta-gan_amd'))
+import torch
+from torch_utils.ops import conv2d_gradfix as cg
+
+SHAPES = [  # name, N, Cin, H, Cout, k, stride, transposed
+    ('spade 128->128 3x3 @128', 16, 128, 128, 128, 3, 1, False),
+    ('spade 256->128 3x3 @128', 16, 256, 128, 128, 3, 1, False),
+    ('b256 64->64 3x3 @256', 16, 64, 256, 64, 3, 1, False),
+    ('enc 64->128 3x3 s2 @257', 16, 64, 257, 128, 3, 2, False),
+    ('b64 256->256 3x3 @64', 16, 256, 64, 256, 3, 1, False),
+    ('b32 512->512 3x3 @32', 16, 512, 32, 512, 3, 1, False),
+    ('b16 512->512 3x3 @16', 16, 512, 16, 512, 3, 1, False),
+    ('b8 512->512 3x3 @8', 16, 512, 8, 512, 3, 1, False),
+    ('b4 512->512 3x3 @4', 16, 512, 4, 512, 3, 1, False),
+    ('up 128->64 3x3 T2 @128', 16, 128, 128, 64, 3, 2, True),
+    ('up 512->512 3x3 T2 @16', 16, 512, 16, 512, 3, 2, True),
+    ('merge 192->128 1x1 @128', 16, 192, 128, 128, 1, 1, False),
+    ('skip 64->128 1x1 @128', 16, 64, 128, 128, 1, 1, False),
+    ('torgb 64->3 1x1 @256', 16, 64, 256, 3, 1, 1, False),
+    ('stem 3->64 7x7 @256', 16, 3, 256, 64, 7, 1, False),
+]
+
+
+def timeit(fn, reps):
+    fn(); fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--miopen', action='store_true')
+    ap.add_argument('--reps', type=int, default=10)
+    ap.add_argument('--only', default='fwd,dgrad,wgrad')
+    ap.add_argument('--match', default='')
+    args = ap.parse_args()
+    only = args.only.split(',')
+    dev = torch.device('cuda')
+    print(f"{'shape':28s} {'pass':6s} {'ms':>8s} {'TFLOP/s':>8s}" + (f" {'miopen ms':>10s} {'TF/s':>7s}" if args.miopen else ''))
+    for name, n, ci, h, co, k, st, tr in SHAPES:
+        if args.match and args.match not in name:
+            continue
+        pad = k // 2 if not tr else 0
+        x = torch.randn([n, ci, h, h], device=dev)
+        w = torch.randn([ci, co, k, k] if tr else [co, ci, k, k], device=dev) * 0.05
+        cfg = cg._Cfg((tr, st, pad, pad, 0, 0, 1))
+        y = cg._launch_conv(x, w, cfg)
+        dy = torch.randn_like(y)
+        flops = 2.0 * n * ci * co * k * k * ((h * h) if tr else (y.shape[2] * y.shape[3]))
+        gcfg = cg._grad_cfg(cfg, x.shape[2:], y.shape[2:], k, k)
+        runs = dict(fwd=lambda: cg._launch_conv(x, w, cfg), dgrad=lambda: cg._launch_conv(dy, w, gcfg),
+                    wgrad=lambda: cg._launch_wgrad(x, dy, cfg, tuple(w.shape)))
+        F = torch.nn.functional
+        if tr:
+            mi = dict(fwd=lambda: F.conv_transpose2d(x, w, stride=st, padding=pad),
+                      dgrad=lambda: F.conv2d(dy, w, stride=st, padding=pad),
+                      wgrad=lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [st, st], [pad, pad], [1, 1], True, [0, 0], 1, [False, True, False]))
+        else:
+            mi = dict(fwd=lambda: F.conv2d(x, w, stride=st, padding=pad),
+                      dgrad=lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [st, st], [pad, pad], [1, 1], False, [0, 0], 1, [True, False, False]),
+                      wgrad=lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [st, st], [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False]))
+        for ps in only:
+            ms = timeit(runs[ps], args.reps)
+            line = f'{name:28s} {ps:6s} {ms:8.3f} {flops / ms / 1e9:8.1f}'
+            if args.miopen:
+                try:
+                    m2 = timeit(mi[ps], args.reps)
+                    line += f' {m2:10.3f} {flops / m2 / 1e9:7.1f}'
+                except Exception as ex:  # noqa: BLE001
+                    line += f'  miopen failed: {type(ex).__name__}'
+            print(line, flush=True)
+
+
+if __name__ == '__main__':
+    main()
