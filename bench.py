@@ -58,17 +58,27 @@ class ConvMeter:
         s.record()
         launch()
         e.record()
-        self.records.append((family, 2.0 * macs, kernels, s, e))
+        shape = (kind, desc.N, desc.C_in, desc.H, desc.C_out, desc.OH, desc.kh, desc.stride, desc.transposed, desc.groups)
+        self.records.append((family, 2.0 * macs, kernels, s, e, shape))
 
     def summary(self):
         fam = {}
-        for family, flops, kernels, s, e in self.records:
+        for family, flops, kernels, s, e, _shape in self.records:
             f = fam.setdefault(family, dict(flops=0.0, ms=0.0, launches=0, kernels=0))
             f['flops'] += flops
             f['ms'] += s.elapsed_time(e)
             f['launches'] += 1
             f['kernels'] += kernels
         return fam
+
+
+    def by_shape(self):
+        """(kind, N, Cin, H, Cout, OH, k, stride, transposed, groups) -> [calls, total ms, TFLOP/s]"""
+        tab = {}
+        for family, flops, kernels, s, e, shape in self.records:
+            t = tab.setdefault(shape, [0, 0.0, 0.0])
+            t[0] += 1; t[1] += s.elapsed_time(e); t[2] += flops
+        return sorted(((k, v[0], v[1], v[2] / (v[1] * 1e-3) / 1e12) for k, v in tab.items()), key=lambda r: -r[2])
 
 
 def cpu_baseline(budget_s=20.0):
@@ -119,6 +129,7 @@ def main():
     ap.add_argument('--batch-gpu', type=int, default=16)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-meter', action='store_true', help='do not bracket convolution launches with events')
+    ap.add_argument('--by-shape', action='store_true', help='also print a per-shape convolution table to stderr')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -195,6 +206,9 @@ def main():
             out['conv_families'] = {k: {'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2), 'ms_per_step': round(v['ms'] / args.steps, 2),
                                         'launches_per_step': round(v['launches'] / args.steps, 1)} for k, v in sorted(fam.items())}
             out['conv_total'] = {'tflop_per_step': round(tot_flops / args.steps / 1e12, 3), 'ms_per_step': round(tot_ms / args.steps, 2)}
+        if args.by_shape:
+            for shape, calls, ms, tf in meter.by_shape()[:40]:
+                print(f'{str(shape):70s} calls/step={calls / args.steps:6.1f} ms/step={ms / args.steps:8.2f} TF/s={tf:7.1f}', file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -284,8 +284,10 @@ struct WgradParams {
     int a_tiles, b_tiles, tap_groups_r, tap_groups_s;
 };
 
-template <int TR, int TS, int WA, int WB>   // taps per workgroup: TR x TS; each wave owns WA x WB 32x32 tiles per tap
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+// TR x TS taps per workgroup; each wave owns WA x WB 32x32 tiles per tap; PIPE = prefetch the next chunk into
+// registers behind the MFMAs (needs a halo of at most 128 positions)
+template <int TR, int TS, int WA, int WB, bool PIPE>
+__global__ __launch_bounds__(256, PIPE ? 2 : 1) void conv_wgrad_kernel(WgradParams p) {
     constexpr int NT = TR * TS;
     constexpr int BA = 64 * WA, BB = 64 * WB;  // workgroup tile: 2 x 2 waves
     constexpr int KP = 32;                     // pixels per chunk
@@ -319,14 +321,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     constexpr int SPT = BA / 8;
     const int s_k = tid & 31, s_a0 = tid >> 5;
     const int s_dr = s_k >> p.cw_log2, s_dq = s_k & (CW - 1);
-    // L: one halo position (or a few) and every `lgroups`-th channel.
+    // L: one halo position and every `lgroups`-th channel (the host guarantees NPOS <= 256).
     const int NPOS = LROWS * LWID;
     int npos_pad = 64;
-    while (npos_pad < NPOS && npos_pad < 256) npos_pad <<= 1;
+    while (npos_pad < NPOS) npos_pad <<= 1;
     const int lgroups = 256 / npos_pad;                    // 4, 2 or 1 channel groups
-    const int l_pos0 = tid & (npos_pad - 1), l_cg = tid / npos_pad;
-    const int l_passes = (NPOS + 255) / 256;               // > 1 only for very wide halos
-    constexpr int LPT_MAX = BB;                            // channel loads per thread when lgroups == 1
+    const int l_pos = tid & (npos_pad - 1), l_cg = tid / npos_pad;
+    const bool l_act = l_pos < NPOS;
+    const int l_lr = l_act ? l_pos / LWID : 0, l_lc = l_pos - l_lr * LWID;
+    const int l_cr = l_lr / TR, l_tr = l_lr - l_cr * TR;
+    float* const l_dst = Ls + l_lr * LPITCH + l_lc;
+    const bool l_tap_ok = l_act && r0 + l_tr < p.kh;
+    constexpr int LPT = PIPE ? BB / 2 : 1;                 // prefetch registers (PIPE needs lgroups >= 2)
 
     f32x16 acc[NT][WA][WB];
 #pragma unroll
@@ -341,47 +347,88 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     const int c_begin = (int)((int64_t)p.chunks_total * ks / p.ksplit);
     const int c_end = (int)((int64_t)p.chunks_total * (ks + 1) / p.ksplit);
     const int kl = lane >> 5, jl = lane & 31;
+    const float* const Sg = p.S + ((int64_t)g * p.Ag + a_blk) * PQ;
+    const float* const Lg = p.L + ((int64_t)g * p.Bg + b_blk) * LHW;
 
-    for (int ch = c_begin; ch < c_end; ch++) {
+    float sreg[SPT];
+    float lreg[LPT];
+
+    // Per-chunk source offsets of this thread's S pixel and L halo position (element offsets fit in 31 bits).
+    auto s_source = [&](int ch, bool& ok) -> unsigned {
         const int rb = ch / p.qblocks, qb = ch - rb * p.qblocks;
-        const int row0 = rb * CHH, q0 = qb * CW;     // first (n*P + p) row and first column of the chunk
-        __syncthreads();
-        {   // ---- stage S: BA channels x 32 pixels
-            const int row = row0 + s_dr, q = q0 + s_dq;
-            const bool ok = row < p.rows_total && q < p.Q;
-            const int n = ok ? row / p.P : 0, pp = row - n * p.P;
-            const float* sp = p.S + ((int64_t)n * p.SC + (int64_t)g * p.Ag + a_blk) * PQ + pp * p.Q + q;
+        const int row = rb * CHH + s_dr, q = qb * CW + s_dq;
+        ok = row < p.rows_total && q < p.Q;
+        const int n = ok ? row / p.P : 0, pp = row - n * p.P;
+        return (unsigned)(n * p.SC) * (unsigned)PQ + (unsigned)(pp * p.Q + q);
+    };
+    auto l_source = [&](int ch, bool& ok) -> unsigned {
+        const int rb = ch / p.qblocks, qb = ch - rb * p.qblocks;
+        const int row = rb * CHH + l_cr;
+        const bool rok = l_tap_ok && row < p.rows_total;
+        const int n = rok ? row / p.P : 0, pp = row - n * p.P;
+        const int ly = pp * p.st + r0 + l_tr - p.pad_h, lx = qb * CW * p.st + s0 + l_lc - p.pad_w;
+        ok = rok && (unsigned)ly < (unsigned)p.LH && (unsigned)lx < (unsigned)p.LW;
+        return ok ? (unsigned)(n * p.LC) * (unsigned)LHW + (unsigned)(ly * p.LW + lx) : 0u;
+    };
+
+    const bool full_a = a_blk + BA <= p.Ag, full_b = b_blk + BB <= p.Bg;   // uniform: no per-channel bound checks
+    auto fetch = [&](int ch) {            // global -> registers (PIPE only)
+        bool ok;
+        const unsigned so = s_source(ch, ok);
+        {
+            const float* sp = Sg + so + (unsigned)s_a0 * (unsigned)PQ;
+            const unsigned step = 8u * (unsigned)PQ;
 #pragma unroll
             for (int j = 0; j < SPT; j++) {
-                const int a = s_a0 + 8 * j;
-                float v = 0.f;
-                if (ok && a_blk + a < p.Ag) v = sp[(int64_t)a * PQ];
-                Ss[a * SPITCH + s_k] = v;
+                sreg[j] = (ok && (full_a || a_blk + s_a0 + 8 * j < p.Ag)) ? *sp : 0.f;
+                sp += step;
             }
         }
-        // ---- stage L halo: BB channels x (CHH*TR) rows x LWID columns
-        for (int pass = 0; pass < l_passes; pass++) {
-            const int lpos = l_pos0 + pass * 256;
-            const bool act = lpos < NPOS;
-            const int lr = act ? lpos / LWID : 0, lc = lpos - lr * LWID;
-            const int cr = lr / TR, tr = lr - cr * TR;
-            const int row = row0 + cr;
-            const bool rok = act && row < p.rows_total;
-            const int n = rok ? row / p.P : 0, pp = row - n * p.P;
-            const int ly = pp * p.st + r0 + tr - p.pad_h, lx = q0 * p.st + s0 + lc - p.pad_w;
-            const bool ok = rok && (unsigned)ly < (unsigned)p.LH && (unsigned)lx < (unsigned)p.LW && r0 + tr < p.kh;
-            const float* lp = p.L + ((int64_t)n * p.LC + (int64_t)g * p.Bg + b_blk) * LHW + ly * p.LW + lx;
-            float* ld = Ls + lr * LPITCH + lc;
-            if (act) {
+        const unsigned lo = l_source(ch, ok);
+        {
+            const float* lp = Lg + lo + (unsigned)l_cg * (unsigned)LHW;
+            const unsigned step = (unsigned)lgroups * (unsigned)LHW;
+#pragma unroll
+            for (int j = 0; j < LPT; j++) {
+                const int b = l_cg + lgroups * j;
+                lreg[j] = (ok && b < BB && (full_b || b_blk + b < p.Bg)) ? *lp : 0.f;
+                lp += step;
+            }
+        }
+    };
+    auto stash = [&]() {                  // registers -> LDS (PIPE only)
+#pragma unroll
+        for (int j = 0; j < SPT; j++) Ss[(s_a0 + 8 * j) * SPITCH + s_k] = sreg[j];
+        if (l_act) {
+#pragma unroll
+            for (int j = 0; j < LPT; j++) {
+                const int b = l_cg + lgroups * j;
+                if (b < BB) l_dst[b * LCH] = lreg[j];
+            }
+        }
+    };
+    auto stage_direct = [&](int ch) {     // global -> LDS without the register stage (!PIPE)
+        bool ok;
+        const unsigned so = s_source(ch, ok);
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            const int a = s_a0 + 8 * j;
+            Ss[a * SPITCH + s_k] = (ok && a_blk + a < p.Ag) ? Sg[so + (unsigned)a * (unsigned)PQ] : 0.f;
+        }
+        const unsigned lo = l_source(ch, ok);
+        if (l_act) {
 #pragma unroll 8
-                for (int b = l_cg; b < BB; b += lgroups) {
-                    float v = 0.f;
-                    if (ok && b_blk + b < p.Bg) v = lp[(int64_t)b * LHW];
-                    ld[b * LCH] = v;
-                }
-            }
+            for (int b = l_cg; b < BB; b += lgroups)
+                l_dst[b * LCH] = (ok && b_blk + b < p.Bg) ? Lg[lo + (unsigned)b * (unsigned)LHW] : 0.f;
         }
+    };
+
+    if (PIPE && c_begin < c_end) fetch(c_begin);
+    for (int ch = c_begin; ch < c_end; ch++) {
+        __syncthreads();                  // the previous chunk's fragment reads are done
+        if (PIPE) stash(); else stage_direct(ch);
         __syncthreads();
+        if (PIPE && ch + 1 < c_end) fetch(ch + 1);   // in flight behind the MFMAs below
         // ---- 16 k-steps of 2 pixels; per step WA A-fragments feed NT*WA*WB MFMAs
 #pragma unroll 2
         for (int kk = 0; kk < KP / 2; kk++) {
@@ -406,7 +453,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
             }
         }
     }
-    (void)LPT_MAX;
 
     // ---- partial slab: [ksplit][G][kh*kw][Ag_pad][Bg_pad], b contiguous
     const int Ag_pad = p.a_tiles * BA, Bg_pad = p.b_tiles * BB;
@@ -452,7 +498,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 struct WgradPlan {
-    int TR, TS, WA, WB, tgr, tgs, a_tiles, b_tiles, cw_log2, qblocks, chunks_total, ksplit, rows_total;
+    int TR, TS, WA, WB, pipe, npos, tgr, tgs, a_tiles, b_tiles, cw_log2, qblocks, chunks_total, ksplit, rows_total;
     int64_t slab_floats; size_t lds_bytes;
 };
 
@@ -476,14 +522,16 @@ static WgradPlan plan_wgrad(int N, int P, int Q, int G, int Ag, int Bg, int kh, 
     w.qblocks = (Q + cw - 1) / cw;
     w.chunks_total = ((w.rows_total + chh - 1) / chh) * w.qblocks;
     const int64_t base_blocks = (int64_t)G * w.a_tiles * w.b_tiles * w.tgr * w.tgs;
-    int64_t ks = (512 + base_blocks - 1) / base_blocks;  // aim at ~2 workgroups per CU
-    if (ks > w.chunks_total / 4) ks = w.chunks_total / 4; // at least four chunks per slice
+    int64_t ks = (768 + base_blocks - 1) / base_blocks;  // aim at ~3 workgroups per CU
+    if (ks > w.chunks_total / 8) ks = w.chunks_total / 8; // at least eight chunks per slice
     if (ks < 1) ks = 1;
-    if (ks > 256) ks = 256;
+    if (ks > 1024) ks = 1024;
     w.ksplit = (int)ks;
     w.slab_floats = (int64_t)w.ksplit * G * kh * kw * w.a_tiles * BA * w.b_tiles * BB;
     const int lwid = (cw - 1) * st + w.TS, lpitch = lwid | 1, lch = (chh * w.TR * lpitch) | 1;
     w.lds_bytes = (size_t)(BA * 33 + BB * lch) * sizeof(float);
+    w.npos = chh * w.TR * lwid;
+    w.pipe = w.npos <= 128;
     return w;
 }
 
@@ -635,14 +683,19 @@ extern "C" int pasta_conv2d_wgrad(const float* x, const float* dy, float* dw, co
     p.cw_log2 = w.cw_log2; p.rows_total = w.rows_total; p.qblocks = w.qblocks; p.chunks_total = w.chunks_total;
     p.ksplit = w.ksplit; p.a_tiles = w.a_tiles; p.b_tiles = w.b_tiles; p.tap_groups_r = w.tgr; p.tap_groups_s = w.tgs;
     PASTA_CHECK(w.lds_bytes <= 160 * 1024, "conv2d_wgrad: LDS footprint %zu too large", w.lds_bytes);
+    PASTA_CHECK(w.npos <= 256, "conv2d_wgrad: halo of %d positions per chunk is not supported", w.npos);
 
     const int64_t blocks = (int64_t)p.G * w.a_tiles * w.b_tiles * w.tgr * w.tgs * w.ksplit;
     PASTA_CHECK(blocks <= INT32_MAX, "conv2d_wgrad: grid too large");
-#define PASTA_WGRAD(TR_, TS_, WA_, WB_)                                                                                   \
+#define PASTA_WGRAD1(TR_, TS_, WA_, WB_, PIPE_)                                                                           \
     do {                                                                                                                  \
         if (w.lds_bytes > 64 * 1024)                                                                                      \
-            PASTA_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_kernel<TR_, TS_, WA_, WB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds_bytes)); \
-        hipLaunchKernelGGL((conv_wgrad_kernel<TR_, TS_, WA_, WB_>), dim3((unsigned)blocks), dim3(256), w.lds_bytes, s, p); \
+            PASTA_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_kernel<TR_, TS_, WA_, WB_, PIPE_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds_bytes)); \
+        hipLaunchKernelGGL((conv_wgrad_kernel<TR_, TS_, WA_, WB_, PIPE_>), dim3((unsigned)blocks), dim3(256), w.lds_bytes, s, p); \
+    } while (0)
+#define PASTA_WGRAD(TR_, TS_, WA_, WB_)                                                                                   \
+    do {                                                                                                                  \
+        if (w.pipe) PASTA_WGRAD1(TR_, TS_, WA_, WB_, true); else PASTA_WGRAD1(TR_, TS_, WA_, WB_, false);                 \
     } while (0)
     if (w.TR == 3 && w.TS == 3) PASTA_WGRAD(3, 3, 1, 1);
     else if (w.TS == 7) PASTA_WGRAD(1, 7, 1, 1);
@@ -650,6 +703,7 @@ extern "C" int pasta_conv2d_wgrad(const float* x, const float* dy, float* dw, co
     else if (w.WA == 2) PASTA_WGRAD(1, 1, 2, 2);
     else PASTA_WGRAD(1, 1, 1, 1);
 #undef PASTA_WGRAD
+#undef PASTA_WGRAD1
     {
         const int64_t total = (int64_t)p.G * p.kh * p.kw * p.Ag * p.Bg;
         int64_t rb = ceil_div64(total, 256);
