@@ -86,7 +86,10 @@ class StyleGAN2Loss(Loss):
         softplus = torch.nn.functional.softplus
 
         # The style code doubles as the conditioning label of both real and generated images (:114-116).
-        with misc.ddp_sync(self.G_style_encoding, sync):
+        # Only Gmain back-propagates into the encoder. The reference passes `sync` here in every phase
+        # (:114); a DDP forward that announces a gradient reduction which never happens leaves the reducer
+        # armed and corrupts the next no_sync round on current PyTorch, so the other phases suppress it.
+        with misc.ddp_sync(self.G_style_encoding, sync and do_Gmain):
             real_c, cat_feats = self.G_style_encoding(style_input, retain)
             gen_c = real_c
         g_args = (denorm_upper_mask, denorm_lower_mask, denorm_upper_input, denorm_lower_input)

@@ -13,7 +13,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, 'pasta-gan_amd')
-for p in (PKG, ROOT):
+for p in (PKG, ROOT, os.path.join(ROOT, 'tests')):
     if p not in sys.path:
         sys.path.insert(0, p)
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')

@@ -1,0 +1,93 @@
+"""The data-parallel step at world size 2 over gloo (CPU): gradients are averaged across ranks exactly once per phase,
+replicas stay identical, and the style-encoder-only Greg phase does not wedge DistributedDataParallel."""
+
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, PKG
+
+
+def _worker(rank, world, port, out):
+    for p in (PKG, ROOT, os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import dnnlib
+        from training.training_loop_wo_flow_fullbody import TrainingStep, SyntheticFullBodyBatch, fashion_config
+        torch.set_num_threads(1)
+        cfg = fashion_config()
+        cfg.G_kwargs = dnnlib.EasyDict(class_name='tiny_models.TinyG')
+        cfg.D_kwargs = dnnlib.EasyDict(class_name='tiny_models.TinyD')
+        cfg.loss_kwargs.style_mixing_prob = 0
+        dev = torch.device('cpu')
+        step = TrainingStep(dev, cfg=cfg, num_gpus=world, rank=rank, batch_size=4 * world, batch_gpu=2, random_seed=0)
+        data = SyntheticFullBodyBatch(4, dev, seed=rank, res=16)
+
+        # replicas start identical (DDP constructor broadcast from rank 0), although seeds differ per rank
+        for name, p in list(step.G.named_parameters()) + list(step.D.named_parameters()):
+            ref = p.detach().clone()
+            dist.broadcast(ref, src=0)
+            assert torch.equal(ref, p.detach()), f'{name} differs after construction'
+
+        # expected D gradient of the Dmain phase = mean over ranks of each rank's two-round accumulated gradient
+        import copy
+        from training.loss_wo_flow_fullbody import StyleGAN2Loss
+        Gc, Dc = copy.deepcopy(step.G), copy.deepcopy(step.D)
+        local = StyleGAN2Loss(device=dev, G_mapping=Gc.mapping, G_synthesis=Gc.synthesis, G_const_encoding=Gc.const_encoding,
+                              G_style_encoding=Gc.style_encoding, D=Dc, **{k: v for k, v in cfg.loss_kwargs.items() if k != 'class_name'})
+        Dc.requires_grad_(True)
+        for r in data.split(2):
+            local.accumulate_gradients(phase='Dmain', gen_z=torch.zeros([2, 0]), sync=True, gain=1, **r)
+        expected = []
+        for p in Dc.parameters():
+            g = p.grad.clone()
+            dist.all_reduce(g)
+            expected.append(g / world)
+
+        # the same phase through the DDP-wrapped modules (rounds: no_sync on the first, all-reduce on the last)
+        step.D.requires_grad_(True)
+        for i, r in enumerate(data.split(2)):
+            step.loss.accumulate_gradients(phase='Dmain', gen_z=torch.zeros([2, 0]), sync=(i == 1), gain=1, **r)
+        for p, e in zip(step.D.parameters(), expected):
+            assert torch.allclose(p.grad, e, rtol=1e-5, atol=1e-7)
+        step.D.requires_grad_(False)
+        for p in step.D.parameters():
+            p.grad = None
+
+        # full iterations, including Greg (forward of the style encoder without a backward) and Dreg (R1)
+        for _ in range(5):
+            step.run(data)
+        for name, p in list(step.G.named_parameters()) + list(step.D.named_parameters()):
+            ref = p.detach().clone()
+            dist.broadcast(ref, src=0)
+            assert torch.equal(ref, p.detach()), f'{name} diverged across ranks'
+        from torch_utils import misc
+        misc.check_ddp_consistency(step.G, ignore_regex=r'.*\.w_avg')
+        out.put((rank, 'ok'))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        out.put((rank, 'FAIL: ' + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_data_parallel_step_world_size_2():
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == 'ok', f'rank {rank}: {msg}'
