@@ -69,6 +69,9 @@ struct ConvFwdParams {
     int oy0, ox0, osy, osx;               // output pixel = (oy0 + p*osy, ox0 + q*osx)
     int isy, isx;                         // input base   = (p*isy, q*isx)
     int T;                                // taps of this lattice
+    int ksplit;                           // > 1: K is cut into slices, partial sums go to `partial`
+    float* partial;                       // [ksplit][N*Cout*OH*OW] when ksplit > 1
+    int o_tiles;                          // output-channel tiles (blockIdx.y = ks * o_tiles + tile)
     short tap_dy[MAX_TAPS], tap_dx[MAX_TAPS], tap_slab[MAX_TAPS];
 };
 
@@ -88,12 +91,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int g = blockIdx.z;
-    const int o_blk = blockIdx.y * BM;
+    const int ks = blockIdx.y / p.o_tiles;
+    const int o_blk = (blockIdx.y - ks * p.o_tiles) * BM;
     const int64_t npix = (int64_t)p.N * p.P * p.Q;
     const int64_t pix_blk = (int64_t)blockIdx.x * BN;
     const int HW = p.H * p.W;
     const int NC = p.Ig_pad / KC;
-    const int nchunks = p.T * NC;
+    const int chunks_all = p.T * NC;
+    const int c_first = (int)((int64_t)chunks_all * ks / p.ksplit);
+    const int nchunks = (int)((int64_t)chunks_all * (ks + 1) / p.ksplit) - c_first;
 
     // ---- B staging: this thread's pixel column is fixed for the whole K loop.
     const int bcol = tid % BN, brow0 = tid / BN;
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
 
     // Loader state: tap index and channel offset of the NEXT chunk to fetch, plus the per-tap
     // quantities derived from them (recomputed only when the tap changes: T times, not per chunk).
-    int ld_t = 0, ld_c0 = 0;
+    int ld_t = c_first / NC, ld_c0 = (c_first - ld_t * NC) * KC;
     bool ld_ok = false;
     const float* ld_xp = xb;
     const float* ld_wt = wb;
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
         ld_xp = xb + iy * p.W + ix;
         ld_wt = wb + (int64_t)p.tap_slab[t] * p.Ig_pad * p.Og_pad;
     };
-    set_tap(0);
+    if (ld_t < p.T) set_tap(ld_t);
     auto load_chunk = [&]() {
 #pragma unroll
         for (int j = 0; j < BPT; j++) {
@@ -169,8 +175,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
-    load_chunk();
-    store_chunk(0);
+    if (nchunks > 0) {          // an empty K slice (more slices than chunks) contributes zeros
+        load_chunk();
+        store_chunk(0);
+    }
     __syncthreads();
     const int kl = lane >> 5, jl = lane & 31;
     for (int ch = 0; ch < nchunks; ch++) {
@@ -202,8 +210,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
         const int n = (int)(pix / (p.P * p.Q));
         const int rem = (int)(pix - (int64_t)n * p.P * p.Q);
         const int pp = rem / p.Q, qq = rem - pp * p.Q;
-        float* yb = p.y + ((int64_t)n * p.Cout + (int64_t)g * p.Og) * OHW + (p.oy0 + pp * p.osy) * p.OW + p.ox0 + qq * p.osx;
-        const float* osb = p.oscale ? p.oscale + (int64_t)n * p.Cout + (int64_t)g * p.Og : nullptr;
+        float* yb = (p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW : p.y) +
+                    ((int64_t)n * p.Cout + (int64_t)g * p.Og) * OHW + (p.oy0 + pp * p.osy) * p.OW + p.ox0 + qq * p.osx;
+        const float* osb = (p.oscale && p.ksplit == 1) ? p.oscale + (int64_t)n * p.Cout + (int64_t)g * p.Og : nullptr;
 #pragma unroll
         for (int a = 0; a < WMT; a++)
 #pragma unroll
@@ -221,8 +230,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
 template <int BM, int BN, int WMT, int WNT, int KC>
 static void launch_fwd(const ConvFwdParams& p, hipStream_t s) {
     const int64_t npix = (int64_t)p.N * p.P * p.Q;
-    dim3 grid((unsigned)ceil_div64(npix, BN), (p.Og + BM - 1) / BM, p.G);
-    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WMT, WNT, KC>), grid, dim3(256), 0, s, p);
+    ConvFwdParams q = p;
+    q.o_tiles = (p.Og + BM - 1) / BM;
+    dim3 grid((unsigned)ceil_div64(npix, BN), q.o_tiles * q.ksplit, p.G);
+    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WMT, WNT, KC>), grid, dim3(256), 0, s, q);
 }
 
 // Tile choice.  O_pad multiple returned so that the caller can pack weights accordingly.
@@ -244,7 +255,8 @@ static FwdTile choose_fwd_tile(int Og, int64_t npix) {
 static int fwd_tile_bm(FwdTile t) { return t == T128x128 ? 128 : t == T32x256 ? 32 : 64; }
 
 constexpr int FWD_KC = 8;
-constexpr int FWD_IPAD = 16;    // packed input-channel padding: a multiple of every KC in use
+// Packed input-channel padding: a multiple of the KC of the kernel instance that will run.
+static int fwd_ipad(int Ig, FwdTile t) { return (Ig <= 4 && t == T64x256) ? 4 : Ig <= 8 ? 8 : 16; }
 
 static void dispatch_fwd(FwdTile t, const ConvFwdParams& p, hipStream_t s) {
     switch (t) {
@@ -256,13 +268,42 @@ static void dispatch_fwd(FwdTile t, const ConvFwdParams& p, hipStream_t s) {
                 default: launch_fwd<128, 128, 2, 2, FWD_KC>(p, s); break;
             }
             break;
-        case T64x256:  launch_fwd<64, 256, 2, 2, FWD_KC>(p, s); break;
+        case T64x256:
+            if (p.Ig_pad == 4) launch_fwd<64, 256, 2, 2, 4>(p, s);      // RGB stems: 4-channel K chunks
+            else launch_fwd<64, 256, 2, 2, FWD_KC>(p, s);
+            break;
         case T32x256:  launch_fwd<32, 256, 1, 2, FWD_KC>(p, s); break;
         case T64x64:   launch_fwd<64, 64, 1, 1, FWD_KC>(p, s); break;
     }
 }
 
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// y[n,c,:] = oscale[n,c] * sum_ks partial[ks][n,c,:]   (fixed order; split-K epilogue)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ y,
+                                                            const float* __restrict__ oscale, int64_t numel, int ohw, int ksplit) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
+        float v = 0.f;
+        for (int k = 0; k < ksplit; k++) v += partial[(int64_t)k * numel + i];
+        if (oscale) v *= oscale[i / ohw];
+        y[i] = v;
+    }
+}
+
+// K slices for launches that would leave most CUs idle (the 4..17 pixel layers: K = 9*512 against <= 4624 pixels).
+static int choose_ksplit(const pasta_conv_desc* d, FwdTile tile) {
+    if (tile != T64x64) return 1;
+    const int Og = d->C_out / d->groups, Ig = d->C_in / d->groups;
+    const int64_t npix = d->transposed ? (int64_t)d->N * ((d->OH + d->stride - 1) / d->stride) * ((d->OW + d->stride - 1) / d->stride)
+                                        : (int64_t)d->N * d->OH * d->OW;
+    const int64_t blocks = ceil_div64(npix, 64) * ((Og + 63) / 64) * d->groups;
+    const int taps = d->transposed ? (d->kh * d->kw + d->stride * d->stride - 1) / (d->stride * d->stride) : d->kh * d->kw;
+    const int64_t chunks = (int64_t)taps * round_up(Ig, 16) / 8;
+    int64_t ks = 768 / (blocks > 0 ? blocks : 1);
+    if (ks > chunks / 8) ks = chunks / 8;
+    if (ks > 32) ks = 32;
+    return ks < 2 ? 1 : (int)ks;
+}
 
 //------------------------------------------------------------------------------------
 // Weight gradient.
@@ -286,11 +327,10 @@ struct WgradParams {
 
 // TR x TS taps per workgroup; each wave owns WA x WB 32x32 tiles per tap; PIPE = prefetch the next chunk into
 // registers behind the MFMAs (needs a halo of at most 128 positions)
-template <int TR, int TS, int WA, int WB, bool PIPE>
+template <int TR, int TS, int WA, int WB, int PIPE, int KP>   // PIPE: 0 = none, 1 = halo <= 128 positions; KP pixels per chunk
 __global__ __launch_bounds__(256, PIPE ? 2 : 1) void conv_wgrad_kernel(WgradParams p) {
     constexpr int NT = TR * TS;
     constexpr int BA = 64 * WA, BB = 64 * WB;  // workgroup tile: 2 x 2 waves
-    constexpr int KP = 32;                     // pixels per chunk
     constexpr int SPITCH = KP + 1;             // odd pitch: column-of-channels reads hit 32 banks
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -318,8 +358,9 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 1) void conv_wgrad_kernel(WgradPara
 
     // ---- staging roles, fixed for the whole K loop.
     // S: this thread's pixel of the chunk and every 8th channel.
-    constexpr int SPT = BA / 8;
-    const int s_k = tid & 31, s_a0 = tid >> 5;
+    constexpr int SROWS = 256 / KP;                        // channels covered by one pass of the workgroup
+    constexpr int SPT = BA / SROWS;
+    const int s_k = tid & (KP - 1), s_a0 = tid / KP;
     const int s_dr = s_k >> p.cw_log2, s_dq = s_k & (CW - 1);
     // L: one halo position and every `lgroups`-th channel (the host guarantees NPOS <= 256).
     const int NPOS = LROWS * LWID;
@@ -332,7 +373,7 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 1) void conv_wgrad_kernel(WgradPara
     const int l_cr = l_lr / TR, l_tr = l_lr - l_cr * TR;
     float* const l_dst = Ls + l_lr * LPITCH + l_lc;
     const bool l_tap_ok = l_act && r0 + l_tr < p.kh;
-    constexpr int LPT = PIPE ? BB / 2 : 1;                 // prefetch registers (PIPE needs lgroups >= 2)
+    constexpr int LPT = PIPE ? BB / 2 : 1;                 // prefetch registers per thread (PIPE needs lgroups >= 2)
 
     f32x16 acc[NT][WA][WB];
 #pragma unroll
@@ -377,10 +418,10 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 1) void conv_wgrad_kernel(WgradPara
         const unsigned so = s_source(ch, ok);
         {
             const float* sp = Sg + so + (unsigned)s_a0 * (unsigned)PQ;
-            const unsigned step = 8u * (unsigned)PQ;
+            const unsigned step = (unsigned)SROWS * (unsigned)PQ;
 #pragma unroll
             for (int j = 0; j < SPT; j++) {
-                sreg[j] = (ok && (full_a || a_blk + s_a0 + 8 * j < p.Ag)) ? *sp : 0.f;
+                sreg[j] = (ok && (full_a || a_blk + s_a0 + SROWS * j < p.Ag)) ? *sp : 0.f;
                 sp += step;
             }
         }
@@ -398,7 +439,7 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 1) void conv_wgrad_kernel(WgradPara
     };
     auto stash = [&]() {                  // registers -> LDS (PIPE only)
 #pragma unroll
-        for (int j = 0; j < SPT; j++) Ss[(s_a0 + 8 * j) * SPITCH + s_k] = sreg[j];
+        for (int j = 0; j < SPT; j++) Ss[(s_a0 + SROWS * j) * SPITCH + s_k] = sreg[j];
         if (l_act) {
 #pragma unroll
             for (int j = 0; j < LPT; j++) {
@@ -412,7 +453,7 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 1) void conv_wgrad_kernel(WgradPara
         const unsigned so = s_source(ch, ok);
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
-            const int a = s_a0 + 8 * j;
+            const int a = s_a0 + SROWS * j;
             Ss[a * SPITCH + s_k] = (ok && a_blk + a < p.Ag) ? Sg[so + (unsigned)a * (unsigned)PQ] : 0.f;
         }
         const unsigned lo = l_source(ch, ok);
@@ -429,7 +470,7 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 1) void conv_wgrad_kernel(WgradPara
         if (PIPE) stash(); else stage_direct(ch);
         __syncthreads();
         if (PIPE && ch + 1 < c_end) fetch(ch + 1);   // in flight behind the MFMAs below
-        // ---- 16 k-steps of 2 pixels; per step WA A-fragments feed NT*WA*WB MFMAs
+        // ---- KP/2 k-steps of 2 pixels; per step WA A-fragments feed NT*WA*WB MFMAs
 #pragma unroll 2
         for (int kk = 0; kk < KP / 2; kk++) {
             const int k = kk * 2 + kl;
@@ -497,8 +538,160 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+//------------------------------------------------------------------------------------
+// Weight gradient when the input has very few channels (RGB / pose stems: 3 or 6 channels, up to 7x7):
+// the (channel, tap) pairs become the GEMM's column index b' = (i*kh + r)*kw + s, so a 7x7x3 kernel fills
+// 147 of 160 MFMA columns instead of 3 of 64.  conv2d, stride 1, groups 1 only.
+//   dW[o][b'] = sum_{n,p,q} dy[n,o,p,q] * x[n, i, p + r - pad_h, q + s - pad_w]
+
+struct WgradSmallParams {
+    const float* S; const float* L; float* slab;
+    int N, Ag, P, Q;        // S = dy: [N, Ag, P, Q]
+    int Bg, LH, LW;         // L = x : [N, Bg, LH, LW]
+    int kh, kw, pad_h, pad_w;
+    int bprime, nb;         // Bg*kh*kw and its number of 32-column tiles (<= 5)
+    int cw_log2, rows_total, qblocks, chunks_total, ksplit, a_tiles;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_smallcin_kernel(WgradSmallParams p) {
+    constexpr int KP = 32, SPITCH = KP + 1, MAXT = 3;     // each wave owns column tiles wb, wb+2, wb+4
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave >> 1, wb = wave & 1;
+    const int CW = 1 << p.cw_log2, CHH = KP >> p.cw_log2;
+    const int HW_ = CW + p.kw - 1;           // halo width
+    const int RH = CHH * p.kh;               // halo rows per channel: kh rows for each chunk row (rows may straddle images)
+    float* Ss = smem;                        // [64][SPITCH]
+    float* Ls = smem + 64 * SPITCH;          // [Bg][RH][HW_], then one zero word
+    const int halo_elems = p.Bg * RH * HW_;
+
+    int bid = blockIdx.x;
+    const int ks = bid % p.ksplit; bid /= p.ksplit;
+    const int a_blk = bid * 64;
+    const int PQ = p.P * p.Q, LHW = p.LH * p.LW;
+    const int kl = lane >> 5, jl = lane & 31;
+
+    // this lane's (channel, tap) column in each of its tiles -> LDS offset of its halo element for chunk pixel (0,0);
+    // columns beyond Bg*kh*kw read the zero word
+    int boff[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+        const int bp = (wb + 2 * t) * 32 + jl;
+        if (bp < p.bprime) {
+            const int i = bp / (p.kh * p.kw), rs = bp - i * p.kh * p.kw, r = rs / p.kw, sx = rs - r * p.kw;
+            boff[t] = (i * RH + r) * HW_ + sx;
+        } else boff[t] = -1;
+    }
+    f32x16 acc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+
+    const int s_k = tid & 31, s_a0 = tid >> 5;
+    const int s_dr = s_k >> p.cw_log2, s_dq = s_k & (CW - 1);
+    const int c_begin = (int)((int64_t)p.chunks_total * ks / p.ksplit);
+    const int c_end = (int)((int64_t)p.chunks_total * (ks + 1) / p.ksplit);
+
+    for (int ch = c_begin; ch < c_end; ch++) {
+        const int rb = ch / p.qblocks, qb = ch - rb * p.qblocks;
+        const int row0 = rb * CHH, q0 = qb * CW;
+        __syncthreads();
+        {   // S: 64 channels x 32 pixels
+            const int row = row0 + s_dr, q = q0 + s_dq;
+            const bool ok = row < p.rows_total && q < p.Q;
+            const int n = ok ? row / p.P : 0, pp = row - n * p.P;
+            const float* sp = p.S + ((int64_t)n * p.Ag + a_blk) * PQ + pp * p.Q + q;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int a = s_a0 + 8 * j;
+                Ss[a * SPITCH + s_k] = (ok && a_blk + a < p.Ag) ? sp[(int64_t)a * PQ] : 0.f;
+            }
+        }
+        for (int e = tid; e < halo_elems; e += 256) {   // L halo, [i][cr*kh + r][hx]
+            int rem = e;
+            const int hx = rem % HW_; rem /= HW_;
+            const int r = rem % p.kh; rem /= p.kh;
+            const int cr = rem % CHH, i = rem / CHH;
+            const int row = row0 + cr;
+            float v = 0.f;
+            if (row < p.rows_total) {
+                const int n = row / p.P, pp = row - n * p.P;
+                const int ly = pp + r - p.pad_h, lx = q0 + hx - p.pad_w;
+                if ((unsigned)ly < (unsigned)p.LH && (unsigned)lx < (unsigned)p.LW)
+                    v = p.L[((int64_t)n * p.Bg + i) * LHW + ly * p.LW + lx];
+            }
+            Ls[e] = v;
+        }
+        if (tid == 0) Ls[halo_elems] = 0.f;
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < KP / 2; kk++) {
+            const int k = kk * 2 + kl;
+            const float af = Ss[(wa * 32 + jl) * SPITCH + k];
+            const int koff = (k >> p.cw_log2) * p.kh * HW_ + (k & (CW - 1));
+#pragma unroll
+            for (int t = 0; t < MAXT; t++) {
+                if (wb + 2 * t >= p.nb) continue;      // uniform per wave
+                const float bf = Ls[boff[t] >= 0 ? boff[t] + koff : halo_elems];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // slab [ksplit][a_pad][nb*32]
+    const int bpad = p.nb * 32;
+    float* out = p.slab + (int64_t)ks * p.a_tiles * 64 * bpad;
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+        if (wb + 2 * t >= p.nb) continue;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int a = a_blk + wa * 32 + acc_row(r, lane), b = (wb + 2 * t) * 32 + jl;
+            out[(int64_t)a * bpad + b] = acc[t][r];
+        }
+    }
+}
+
+// dw[o][b'] = sum_ks slab[ks][o][b']   (b' already in PyTorch's [i][r][s] order)
+__global__ __launch_bounds__(256) void wgrad_smallcin_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int ksplit,
+                                                                    int Ag, int bprime, int a_pad, int bpad) {
+    const int total = Ag * bprime;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int a = idx / bprime, b = idx - a * bprime;
+        const float* src = slab + (int64_t)a * bpad + b;
+        float v = 0.f;
+        for (int k = 0; k < ksplit; k++) v += src[(int64_t)k * a_pad * bpad];
+        dw[idx] = v;
+    }
+}
+
+struct WgradSmallPlan { bool use; int nb, bprime, cw_log2, qblocks, chunks_total, ksplit, a_tiles, rows_total; int64_t slab_floats; size_t lds_bytes; };
+
+static WgradSmallPlan plan_wgrad_small(const pasta_conv_desc* d) {
+    WgradSmallPlan w; w.use = false;
+    const int Ig = d->C_in / d->groups;
+    if (d->transposed || d->groups != 1 || d->stride != 1 || d->flip || Ig > 8 || Ig * d->kh * d->kw > 160) return w;
+    w.use = true;
+    w.bprime = Ig * d->kh * d->kw; w.nb = (w.bprime + 31) / 32;
+    int cw = 32, lg = 5;
+    while (cw > 1 && cw / 2 >= d->OW) { cw /= 2; lg--; }
+    const int chh = 32 / cw;
+    w.cw_log2 = lg; w.rows_total = d->N * d->OH;
+    w.qblocks = (d->OW + cw - 1) / cw;
+    w.chunks_total = ((w.rows_total + chh - 1) / chh) * w.qblocks;
+    w.a_tiles = (d->C_out + 63) / 64;
+    int64_t ks = (1024 + w.a_tiles - 1) / w.a_tiles;
+    if (ks > w.chunks_total / 8) ks = w.chunks_total / 8;
+    if (ks < 1) ks = 1;
+    w.ksplit = (int)ks;
+    w.slab_floats = (int64_t)w.ksplit * w.a_tiles * 64 * w.nb * 32;
+    w.lds_bytes = (size_t)(64 * 33 + Ig * chh * d->kh * (cw + d->kw - 1) + 4) * sizeof(float);
+    return w;
+}
+
 struct WgradPlan {
-    int TR, TS, WA, WB, pipe, npos, tgr, tgs, a_tiles, b_tiles, cw_log2, qblocks, chunks_total, ksplit, rows_total;
+    int TR, TS, WA, WB, pipe, npos, kp, tgr, tgs, a_tiles, b_tiles, cw_log2, qblocks, chunks_total, ksplit, rows_total;
     int64_t slab_floats; size_t lds_bytes;
 };
 
@@ -514,10 +707,19 @@ static WgradPlan plan_wgrad(int N, int P, int Q, int G, int Ag, int Bg, int kh, 
     const int BA = 64 * w.WA, BB = 64 * w.WB;
     w.tgr = (kh + w.TR - 1) / w.TR; w.tgs = (kw + w.TS - 1) / w.TS;
     w.a_tiles = (Ag + BA - 1) / BA; w.b_tiles = (Bg + BB - 1) / BB;
-    int cw = 32, lg = 5;
-    while (cw > 1 && cw / 2 >= Q) { cw /= 2; lg--; }     // smallest power of two >= Q, capped at 32
-    w.cw_log2 = lg;
-    const int chh = 32 >> lg;
+    // chunk = KP lattice pixels (CHH rows x CW columns, CW a power of two covering Q when Q is small); halve the
+    // chunk when the L halo of a 32-pixel chunk is too wide for the register-prefetch pipeline (stride 2)
+    int kp = 32;
+    for (;;) {
+        int cw = kp, lg = kp == 32 ? 5 : 4;
+        while (cw > 1 && cw / 2 >= Q) { cw /= 2; lg--; }
+        const int chh = kp / cw;
+        const int lwid = (cw - 1) * st + w.TS;
+        w.cw_log2 = lg; w.kp = kp; w.npos = chh * w.TR * lwid;
+        if (w.npos <= 128 || kp == 16) break;
+        kp = 16;
+    }
+    const int cw = 1 << w.cw_log2, chh = w.kp >> w.cw_log2;
     w.rows_total = N * P;
     w.qblocks = (Q + cw - 1) / cw;
     w.chunks_total = ((w.rows_total + chh - 1) / chh) * w.qblocks;
@@ -529,9 +731,8 @@ static WgradPlan plan_wgrad(int N, int P, int Q, int G, int Ag, int Bg, int kh, 
     w.ksplit = (int)ks;
     w.slab_floats = (int64_t)w.ksplit * G * kh * kw * w.a_tiles * BA * w.b_tiles * BB;
     const int lwid = (cw - 1) * st + w.TS, lpitch = lwid | 1, lch = (chh * w.TR * lpitch) | 1;
-    w.lds_bytes = (size_t)(BA * 33 + BB * lch) * sizeof(float);
-    w.npos = chh * w.TR * lwid;
-    w.pipe = w.npos <= 128;
+    w.lds_bytes = (size_t)(BA * (w.kp + 1) + BB * lch) * sizeof(float);
+    w.pipe = w.npos <= 128 ? 1 : 0;
     return w;
 }
 
@@ -575,7 +776,10 @@ extern "C" int64_t pasta_conv2d_workspace(const pasta_conv_desc* d) {
     if (check_desc(d, "conv2d_workspace")) return -1;
     const int Ig = d->C_in / d->groups, Og = d->C_out / d->groups;
     const FwdTile t = choose_fwd_tile(Og, fwd_lattice_pixels(d));
-    return (int64_t)d->groups * d->kh * d->kw * round_up(Ig, FWD_IPAD) * round_up(Og, fwd_tile_bm(t)) * (int64_t)sizeof(float);
+    const int ks = choose_ksplit(d, t);
+    const int64_t pack = (int64_t)d->groups * d->kh * d->kw * round_up(Ig, fwd_ipad(Ig, t)) * round_up(Og, fwd_tile_bm(t));
+    const int64_t partial = ks > 1 ? (int64_t)ks * d->N * d->C_out * d->OH * d->OW : 0;
+    return (round_up((int)pack, 4) + partial) * (int64_t)sizeof(float);
 }
 
 extern "C" int pasta_conv2d_tile(const pasta_conv_desc* d) {
@@ -600,8 +804,11 @@ extern "C" int pasta_conv2d(const float* x, const float* w, float* y, const floa
     p.Cout = d->C_out; p.OH = d->OH; p.OW = d->OW;
     p.G = d->groups; p.Ig = d->C_in / d->groups; p.Og = d->C_out / d->groups;
     const FwdTile tile = choose_fwd_tile(p.Og, fwd_lattice_pixels(d));
-    p.Ig_pad = round_up(p.Ig, FWD_IPAD); p.Og_pad = round_up(p.Og, fwd_tile_bm(tile));
+    p.Ig_pad = round_up(p.Ig, fwd_ipad(p.Ig, tile)); p.Og_pad = round_up(p.Og, fwd_tile_bm(tile));
     p.KK = d->kh * d->kw;
+    p.ksplit = choose_ksplit(d, tile);
+    p.o_tiles = 1;
+    p.partial = (float*)workspace + round_up(p.G * p.KK * p.Ig_pad * p.Og_pad, 4);
 
     {   // pack weights
         const int64_t total = (int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad;
@@ -646,6 +853,13 @@ extern "C" int pasta_conv2d(const float* x, const float* w, float* y, const floa
                 dispatch_fwd(tile, p, s);
             }
     }
+    if (p.ksplit > 1) {
+        const int64_t numel = (int64_t)d->N * d->C_out * d->OH * d->OW;
+        int64_t blocks = ceil_div64(numel, 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)p.partial, y, oscale, numel,
+                           d->OH * d->OW, p.ksplit);
+    }
     return launch_status("conv2d");
 }
 
@@ -653,6 +867,8 @@ extern "C" int64_t pasta_conv2d_wgrad_workspace(const pasta_conv_desc* d) {
     using namespace pasta;
     if (check_desc(d, "conv2d_wgrad_workspace")) return -1;
     const int Ig = d->C_in / d->groups, Og = d->C_out / d->groups;
+    const WgradSmallPlan ws = plan_wgrad_small(d);
+    if (ws.use) return ws.slab_floats * (int64_t)sizeof(float);
     const WgradPlan w = d->transposed ? plan_wgrad(d->N, d->H, d->W, d->groups, Ig, Og, d->kh, d->kw, d->stride)
                                       : plan_wgrad(d->N, d->OH, d->OW, d->groups, Og, Ig, d->kh, d->kw, d->stride);
     return w.slab_floats * (int64_t)sizeof(float);
@@ -667,6 +883,22 @@ extern "C" int pasta_conv2d_wgrad(const float* x, const float* dy, float* dw, co
     PASTA_CHECK(workspace && workspace_bytes >= need, "conv2d_wgrad: workspace of %lld bytes needed, %lld given", (long long)need, (long long)workspace_bytes);
     hipStream_t s = (hipStream_t)stream;
     const int Ig = d->C_in / d->groups, Og = d->C_out / d->groups;
+
+    const WgradSmallPlan ws = plan_wgrad_small(d);
+    if (ws.use) {
+        WgradSmallParams q;
+        q.S = dy; q.L = x; q.slab = (float*)workspace;
+        q.N = d->N; q.Ag = d->C_out; q.P = d->OH; q.Q = d->OW; q.Bg = Ig; q.LH = d->H; q.LW = d->W;
+        q.kh = d->kh; q.kw = d->kw; q.pad_h = d->pad_h; q.pad_w = d->pad_w;
+        q.bprime = ws.bprime; q.nb = ws.nb; q.cw_log2 = ws.cw_log2; q.rows_total = ws.rows_total; q.qblocks = ws.qblocks;
+        q.chunks_total = ws.chunks_total; q.ksplit = ws.ksplit; q.a_tiles = ws.a_tiles;
+        PASTA_CHECK(ws.lds_bytes <= 64 * 1024, "conv2d_wgrad: small-cin LDS footprint %zu too large", ws.lds_bytes);
+        hipLaunchKernelGGL(conv_wgrad_smallcin_kernel, dim3((unsigned)(ws.a_tiles * ws.ksplit)), dim3(256), ws.lds_bytes, s, q);
+        const int total = d->C_out * ws.bprime;
+        hipLaunchKernelGGL(wgrad_smallcin_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)workspace, dw,
+                           ws.ksplit, d->C_out, ws.bprime, ws.a_tiles * 64, ws.nb * 32);
+        return launch_status("conv2d_wgrad(small-cin)");
+    }
 
     WgradParams p;
     p.slab = (float*)workspace;
@@ -687,15 +919,16 @@ extern "C" int pasta_conv2d_wgrad(const float* x, const float* dy, float* dw, co
 
     const int64_t blocks = (int64_t)p.G * w.a_tiles * w.b_tiles * w.tgr * w.tgs * w.ksplit;
     PASTA_CHECK(blocks <= INT32_MAX, "conv2d_wgrad: grid too large");
-#define PASTA_WGRAD1(TR_, TS_, WA_, WB_, PIPE_)                                                                           \
+#define PASTA_WGRAD1(TR_, TS_, WA_, WB_, PIPE_, KP_)                                                                      \
     do {                                                                                                                  \
         if (w.lds_bytes > 64 * 1024)                                                                                      \
-            PASTA_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_kernel<TR_, TS_, WA_, WB_, PIPE_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds_bytes)); \
-        hipLaunchKernelGGL((conv_wgrad_kernel<TR_, TS_, WA_, WB_, PIPE_>), dim3((unsigned)blocks), dim3(256), w.lds_bytes, s, p); \
+            PASTA_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_kernel<TR_, TS_, WA_, WB_, PIPE_, KP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds_bytes)); \
+        hipLaunchKernelGGL((conv_wgrad_kernel<TR_, TS_, WA_, WB_, PIPE_, KP_>), dim3((unsigned)blocks), dim3(256), w.lds_bytes, s, p); \
     } while (0)
 #define PASTA_WGRAD(TR_, TS_, WA_, WB_)                                                                                   \
     do {                                                                                                                  \
-        if (w.pipe) PASTA_WGRAD1(TR_, TS_, WA_, WB_, true); else PASTA_WGRAD1(TR_, TS_, WA_, WB_, false);                 \
+        if (w.kp == 16) { if (w.pipe) PASTA_WGRAD1(TR_, TS_, WA_, WB_, 1, 16); else PASTA_WGRAD1(TR_, TS_, WA_, WB_, 0, 16); } \
+        else            { if (w.pipe) PASTA_WGRAD1(TR_, TS_, WA_, WB_, 1, 32); else PASTA_WGRAD1(TR_, TS_, WA_, WB_, 0, 32); } \
     } while (0)
     if (w.TR == 3 && w.TS == 3) PASTA_WGRAD(3, 3, 1, 1);
     else if (w.TS == 7) PASTA_WGRAD(1, 7, 1, 1);
