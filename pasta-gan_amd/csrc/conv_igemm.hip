@@ -75,8 +75,8 @@ struct ConvFwdParams {
     short tap_dy[MAX_TAPS], tap_dx[MAX_TAPS], tap_slab[MAX_TAPS];
 };
 
-template <int BM, int BN, int WMT, int WNT, int KC>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
+template <int BM, int BN, int WMT, int WNT, int KC, int OCC = 1>   // OCC = minimum waves per SIMD asked of the register allocator
+__global__ __launch_bounds__(256, OCC) void conv_fwd_kernel(ConvFwdParams p) {
     constexpr int WAVES_N = BN / (32 * WNT);
     static_assert((BM / (32 * WMT)) * WAVES_N == 4, "four waves per workgroup");
     constexpr int RSTEP = 256 / BN > 0 ? 256 / BN : 1;      // k-rows covered by one pass of the workgroup (B tile)
@@ -227,13 +227,13 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
     }
 }
 
-template <int BM, int BN, int WMT, int WNT, int KC>
+template <int BM, int BN, int WMT, int WNT, int KC, int OCC = 1>
 static void launch_fwd(const ConvFwdParams& p, hipStream_t s) {
     const int64_t npix = (int64_t)p.N * p.P * p.Q;
     ConvFwdParams q = p;
     q.o_tiles = (p.Og + BM - 1) / BM;
     dim3 grid((unsigned)ceil_div64(npix, BN), q.o_tiles * q.ksplit, p.G);
-    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WMT, WNT, KC>), grid, dim3(256), 0, s, q);
+    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WMT, WNT, KC, OCC>), grid, dim3(256), 0, s, q);
 }
 
 // Tile choice.  O_pad multiple returned so that the caller can pack weights accordingly.
@@ -262,15 +262,15 @@ static void dispatch_fwd(FwdTile t, const ConvFwdParams& p, hipStream_t s) {
     switch (t) {
         case T128x128:
             switch (fwd_variant()) {
-                case 1:  launch_fwd<128, 128, 2, 2, 16>(p, s); break;
+                case 1:  launch_fwd<128, 128, 2, 2, 8, 1>(p, s); break;
                 case 2:  launch_fwd<128, 256, 2, 4, 8>(p, s); break;
                 case 3:  launch_fwd<128, 256, 2, 4, 16>(p, s); break;
-                default: launch_fwd<128, 128, 2, 2, FWD_KC>(p, s); break;
+                default: launch_fwd<128, 128, 2, 2, FWD_KC, 4>(p, s); break;   // 4 waves/SIMD: 99-112 TFLOP/s vs 95-104 at 3
             }
             break;
         case T64x256:
             if (p.Ig_pad == 4) launch_fwd<64, 256, 2, 2, 4>(p, s);      // RGB stems: 4-channel K chunks
-            else launch_fwd<64, 256, 2, 2, FWD_KC>(p, s);
+            else launch_fwd<64, 256, 2, 2, FWD_KC, 4>(p, s);
             break;
         case T32x256:  launch_fwd<32, 256, 1, 2, FWD_KC>(p, s); break;
         case T64x64:   launch_fwd<64, 64, 1, 1, FWD_KC>(p, s); break;
@@ -681,7 +681,7 @@ static WgradSmallPlan plan_wgrad_small(const pasta_conv_desc* d) {
     w.qblocks = (d->OW + cw - 1) / cw;
     w.chunks_total = ((w.rows_total + chh - 1) / chh) * w.qblocks;
     w.a_tiles = (d->C_out + 63) / 64;
-    int64_t ks = (1024 + w.a_tiles - 1) / w.a_tiles;
+    int64_t ks = (512 + w.a_tiles - 1) / w.a_tiles;
     if (ks > w.chunks_total / 8) ks = w.chunks_total / 8;
     if (ks < 1) ks = 1;
     w.ksplit = (int)ks;
@@ -724,7 +724,7 @@ static WgradPlan plan_wgrad(int N, int P, int Q, int G, int Ag, int Bg, int kh, 
     w.qblocks = (Q + cw - 1) / cw;
     w.chunks_total = ((w.rows_total + chh - 1) / chh) * w.qblocks;
     const int64_t base_blocks = (int64_t)G * w.a_tiles * w.b_tiles * w.tgr * w.tgs;
-    int64_t ks = (768 + base_blocks - 1) / base_blocks;  // aim at ~3 workgroups per CU
+    int64_t ks = (512 + base_blocks / 2) / base_blocks;  // one full wave of workgroups at 2 per CU (register-limited)
     if (ks > w.chunks_total / 8) ks = w.chunks_total / 8; // at least eight chunks per slice
     if (ks < 1) ks = 1;
     if (ks > 1024) ks = 1024;
