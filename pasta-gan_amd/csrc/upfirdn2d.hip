@@ -87,21 +87,19 @@ __host__ __device__ constexpr int c_ntaps(int a, int D, int U, int PH, int F) { 
 
 template <class T, int UX, int UY, int DX, int DY, int FW, int FH, int PHX, int PHY,
           int MX, int MY, int BX, int BY>
-__global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p) {
+__global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p, int tiles_x, int tiles_y, int nitems) {
     static_assert(MX % UX == 0 && MY % UY == 0, "micro-tile must cover whole phases");
     static_assert((BX * BY) % 64 == 0, "whole wavefronts");
+    constexpr int NT = BX * BY;
     constexpr int TOW = BX * MX, TOH = BY * MY;
     constexpr int TIW = ((TOW - 1) * DX + FW - 1) / UX + 2;
     constexpr int TIH = ((TOH - 1) * DY + FH - 1) / UY + 2;
     constexpr int LDW = TIW | 1;   // odd row pitch keeps strided column reads off one bank
+    constexpr int NLOAD = (TIH * TIW + NT - 1) / NT;
     __shared__ float sx[TIH * LDW];
 
     const int tid = threadIdx.x;
     const int tx = tid % BX, ty = tid / BX;
-    const int ox_blk = blockIdx.x * TOW, oy_blk = blockIdx.y * TOH;
-    // input coordinate held by LDS element (0,0); exact divisions by construction
-    const int ix0 = (ox_blk * DX - p.padx0 + PHX) / UX;
-    const int iy0 = (oy_blk * DY - p.pady0 + PHY) / UY;
 
     // filter taps, flipped as requested; uniform -> scalar registers
     float g[FH][FW];
@@ -111,21 +109,46 @@ __global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p)
         for (int b = 0; b < FW; b++)
             g[a][b] = p.f[(p.flip ? a : FH - 1 - a) * FW + (p.flip ? b : FW - 1 - b)];
 
-    const int64_t planes = (int64_t)p.N * p.C;
-    for (int64_t plane = blockIdx.z; plane < planes; plane += gridDim.z) {
-        const T* xp = (const T*)p.x + plane * (int64_t)p.inH * p.inW;
-        T*       yp = (T*)p.y + plane * (int64_t)p.outH * p.outW;
+    // this thread's slots of the input tile (fixed): slot e = tid + j*NT -> (row, column)
+    int slot_row[NLOAD], slot_col[NLOAD];
+#pragma unroll
+    for (int j = 0; j < NLOAD; j++) {
+        const int e = tid + j * NT;
+        slot_row[j] = e / TIW; slot_col[j] = e - slot_row[j] * TIW;
+    }
 
-        __syncthreads();   // previous iteration's reads are done
-        for (int i = tid; i < TIH * TIW; i += BX * BY) {
-            int ry = i / TIW, rx = i - ry * TIW;
-            int iy = iy0 + ry, ix = ix0 + rx;
+    // A work item is one output tile of one plane; the workgroup walks items blockIdx.x, +gridDim.x, ... and
+    // fetches the next item's input tile into registers while it computes the current one from LDS.
+    float stage[NLOAD];
+    auto fetch = [&](int item) {
+        const int tile_x = item % tiles_x, r = item / tiles_x;
+        const int tile_y = r % tiles_y, plane = r / tiles_y;
+        const int ix0 = (tile_x * TOW * DX - p.padx0 + PHX) / UX;      // exact divisions by construction
+        const int iy0 = (tile_y * TOH * DY - p.pady0 + PHY) / UY;
+        const T* xp = (const T*)p.x + (int64_t)plane * p.inH * p.inW;
+#pragma unroll
+        for (int j = 0; j < NLOAD; j++) {
+            const int iy = iy0 + slot_row[j], ix = ix0 + slot_col[j];
             float v = 0.f;
-            if (iy >= 0 && iy < p.inH && ix >= 0 && ix < p.inW) v = ld<T>(xp + (int64_t)iy * p.inW + ix);
-            sx[ry * LDW + rx] = v;
+            if (slot_row[j] < TIH && iy >= 0 && iy < p.inH && ix >= 0 && ix < p.inW) v = ld<T>(xp + (int64_t)iy * p.inW + ix);
+            stage[j] = v;
         }
-        __syncthreads();
+    };
 
+    int item = blockIdx.x;
+    if (item < nitems) fetch(item);
+    while (item < nitems) {
+        __syncthreads();   // the previous item's LDS reads are done
+#pragma unroll
+        for (int j = 0; j < NLOAD; j++)
+            if (slot_row[j] < TIH) sx[slot_row[j] * LDW + slot_col[j]] = stage[j];
+        __syncthreads();
+        const int next = item + gridDim.x;
+        if (next < nitems) fetch(next);
+
+        const int tile_x = item % tiles_x, r_ = item / tiles_x;
+        const int tile_y = r_ % tiles_y, plane = r_ / tiles_y;
+        T* yp = (T*)p.y + (int64_t)plane * p.outH * p.outW;
         const int rx = tx * (MX * DX / UX), ry = ty * (MY * DY / UY);
         float acc[MY][MX];
 #pragma unroll
@@ -141,8 +164,7 @@ __global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p)
                                  sx[(ry + c_in0(b, DY, UY, PHY) + jy) * LDW + rx + c_in0(a, DX, UX, PHX) + jx], v);
                 acc[b][a] = v * p.gain;
             }
-
-        const int ox = ox_blk + tx * MX, oy = oy_blk + ty * MY;
+        const int ox = tile_x * TOW + tx * MX, oy = tile_y * TOH + ty * MY;
 #pragma unroll
         for (int b = 0; b < MY; b++) {
             if (oy + b >= p.outH) break;
@@ -150,15 +172,18 @@ __global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p)
             for (int a = 0; a < MX; a++)
                 if (ox + a < p.outW) st<T>(yp + (int64_t)(oy + b) * p.outW + ox + a, acc[b][a]);
         }
+        item = next;
     }
 }
 
 template <class T, int UX, int UY, int DX, int DY, int FW, int FH, int PHX, int PHY, int MX, int MY, int BX, int BY>
 static void launch_tile(const UpfirdnParams& p, hipStream_t s) {
     constexpr int TOW = BX * MX, TOH = BY * MY;
-    const int64_t planes = (int64_t)p.N * p.C;
-    dim3 grid((p.outW + TOW - 1) / TOW, (p.outH + TOH - 1) / TOH, (unsigned)(planes < 32768 ? planes : 32768));
-    hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, UX, UY, DX, DY, FW, FH, PHX, PHY, MX, MY, BX, BY>), grid, dim3(BX * BY), 0, s, p);
+    const int tiles_x = (p.outW + TOW - 1) / TOW, tiles_y = (p.outH + TOH - 1) / TOH;
+    const int64_t nitems = (int64_t)tiles_x * tiles_y * p.N * p.C;
+    const int64_t grid = nitems < 256 * 16 ? nitems : 256 * 16;     // up to 16 resident-or-queued workgroups per CU
+    hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, UX, UY, DX, DY, FW, FH, PHX, PHY, MX, MY, BX, BY>), dim3((unsigned)grid), dim3(BX * BY), 0, s,
+                       p, tiles_x, tiles_y, (int)nitems);
 }
 
 // Phase dispatch (runtime pad0 mod U -> template constant).
@@ -197,7 +222,7 @@ static bool try_tile(const UpfirdnParams& p, hipStream_t s) {
         return true;                                                                                          \
     }
     PASTA_UPF(1, 1, 1, 1, 4, 4, 1, 4)
-    PASTA_UPF(2, 2, 1, 1, 4, 4, 2, 2)
+    PASTA_UPF(2, 2, 1, 1, 4, 4, 2, 4)
     PASTA_UPF(1, 1, 2, 2, 4, 4, 1, 2)
     PASTA_UPF(1, 1, 1, 1, 3, 3, 1, 4)
     PASTA_UPF(2, 1, 1, 1, 12, 1, 2, 2)
