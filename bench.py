@@ -81,6 +81,32 @@ class ConvMeter:
         return sorted(((k, v[0], v[1], v[2] / (v[1] * 1e-3) / 1e12) for k, v in tab.items()), key=lambda r: -r[2])
 
 
+def pmc_traffic(kernel_family):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/r*_pmc.json; separate
+    --pmc runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950). None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json')))
+    if not files:
+        return None, None
+    want = kernel_family.replace(' ', '')
+    for name, v in json.load(open(files[-1])).items():
+        if want in name.replace(' ', ''):
+            return float(v['hbm_bytes_corrected']), os.path.basename(files[-1])
+    return None, None
+
+
+def host_threads():
+    """CPU threads this process may really use: the cgroup quota when there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(budget_s=20.0):
     """Config 1 of BASELINE.json on the host: batch 2, G fwd + D(img), D(finetune), D(real) fwd, GAN softplus
     losses, one backward into G and D -- the oracle restatement (same torch-op composition as the reference's
@@ -108,7 +134,8 @@ def cpu_baseline(budget_s=20.0):
         params = [v for v in list(sdG.values()) + list(sdD.values()) if v.requires_grad]
         torch.autograd.grad(loss, params, allow_unused=True)
 
-    cores = torch.get_num_threads()
+    cores = host_threads()
+    torch.set_num_threads(cores)
     step()                                   # warm-up
     t0 = time.time()
     n = 0
@@ -195,8 +222,10 @@ def main():
             dom = max(fam.items(), key=lambda kv: kv[1]['ms'])
             name, f = dom
             achieved = f['flops'] / (f['ms'] * 1e-3) / 1e12
+            traffic, src = pmc_traffic(name)
             out['roofline'] = {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
-                               'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                               'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
+                               'traffic_source': src, 'algorithmic_flop_per_launch': round(f['flops'] / f['launches']),
                                'launches': f['launches'], 'kernels': f['kernels'],
                                'avg_kernel_us': round(1000 * f['ms'] / f['kernels'], 1),
                                'share_of_step': round(f['ms'] / (1000 * dt), 3),
