@@ -51,6 +51,15 @@ def gen_models(ref_root, import_reference_networks):
                                 inp['denorm_lower_input'], inp['denorm_upper_mask'], inp['denorm_lower_mask'], noise_mode='const')
     put(out, 'G.eval.img', img_e); put(out, 'G.eval.finetune_img', fin_e)
 
+    # ---- GeneratorV18 (test.py's class): eval mode = fused modconv / grouped convolution, 60-channel patch input.
+    G18 = PF.fill_module(rn.GeneratorV18(**PF.G_KWARGS)).eval().requires_grad_(False)
+    c60 = PF.make_inputs(n=2, seed=5)['style_input'].repeat(1, 2, 1, 1)[:, :60]
+    with torch.no_grad():
+        o18 = G18(inp['gen_z'], c60, inp['retain'], inp['pose'], inp['denorm_upper_input'], inp['denorm_lower_input'],
+                  inp['denorm_upper_mask'], inp['denorm_lower_mask'], noise_mode='const')
+    for name, t in zip(['img', 'finetune_img', 'upper_mask', 'lower_mask'], o18):
+        put(out, 'G18.' + name, t)
+
     # ---- discriminator: logits, parameter gradients and the R1 double-backward path.
     D = PF.fill_module(rn.Discriminator(**PF.D_KWARGS)).train().requires_grad_(True)
     c = torch.tanh(PF.make_inputs(n=4, seed=1)['style_input'].mean(dim=[2, 3]).repeat(1, 13)[:, :512])

@@ -231,6 +231,63 @@ def generator_full(sd, z, c, retain, pose, du_in, dl_in, du_mask, dl_mask, img_r
                           noise_mode, fused_modconv)
 
 #----------------------------------------------------------------------------
+# GeneratorV18 (the released 256 inference model of test.py).
+
+def torgb_v18(sd, p, x, w, conv_clamp=None, fused_modconv=False):
+    """ToRGBLayerV18.forward, networks.py:5296-5310."""
+    weight = sd[p + '.weight']
+    styles = fc(sd, p + '.affine', w) * (1 / np.sqrt(weight.shape[1] * weight.shape[2] ** 2))
+    masks = [None, None]
+    if (p + '.m_weight1') in sd:
+        for i, tag in enumerate(['1', '2']):
+            m = R.modulated_conv2d(x, sd[p + '.m_weight' + tag], styles, demodulate=False, fused_modconv=fused_modconv)
+            masks[i] = R.bias_act(m, sd[p + '.m_bias' + tag].to(x.dtype), clamp=conv_clamp, act='sigmoid')
+    y = R.modulated_conv2d(x, weight, styles, demodulate=False, fused_modconv=fused_modconv)
+    return R.bias_act(y, sd[p + '.bias'].to(x.dtype), clamp=conv_clamp), masks[0], masks[1]
+
+def _block_v18(sd, p, x, img, ws, pose_feat, cat_feat, first, conv_clamp, noise_mode, fused_modconv):
+    """SynthesisBlockV18.forward, networks.py:5369-5418."""
+    wi = iter(ws.unbind(dim=1))
+    if first:
+        x = synthesis_layer(sd, p + '.conv1', pose_feat, next(wi), conv_clamp=conv_clamp, noise_mode=noise_mode, fused_modconv=fused_modconv)
+    else:
+        x = synthesis_layer(sd, p + '.conv0', x, next(wi), up=2, conv_clamp=conv_clamp, noise_mode=noise_mode, fused_modconv=fused_modconv)
+        x = synthesis_layer(sd, p + '.conv1', x, next(wi), conv_clamp=conv_clamp, noise_mode=noise_mode, fused_modconv=fused_modconv)
+        if x.shape[2] > 16:
+            x = conv2d_layer(sd, p + '.merge_conv', torch.cat([x, cat_feat[str(x.shape[2])]], dim=1))
+    if img is not None:
+        img = R.upsample2d(img, _filter())
+    y, um, lm = torgb_v18(sd, p + '.torgb', x, next(wi), conv_clamp=conv_clamp, fused_modconv=fused_modconv)
+    img = img + y if img is not None else y
+    return x, img, um, lm
+
+def generator_v18(sd, z, c, retain, pose, du_in, dl_in, du_mask, dl_mask, img_resolution=256, conv_clamp=256,
+                  mapping_layers=1, noise_mode='const', fused_modconv=True):
+    """GeneratorV18.forward + SynthesisNetworkV18.forward, networks.py:5481-5577."""
+    pose_feat = const_encoder(sd, 'const_encoding', pose)
+    code, feats = style_encoder(sd, 'style_encoding', c, retain)
+    num_ws = 2 * int(np.log2(img_resolution)) - 2
+    ws = mapping(sd, 'mapping', z, code, mapping_layers, num_ws, z_dim=(z.shape[1] if z is not None else 0), c_dim=code.shape[1])
+    cat = {str(f.shape[2]): f for f in feats}
+    resolutions = [2 ** i for i in range(2, int(np.log2(img_resolution)) + 1)]
+    x = img = um = lm = None
+    w_idx, block_ws = 0, []
+    for res in resolutions:
+        nconv = 1 if res == 4 else 2
+        block_ws.append(ws.narrow(1, w_idx, nconv + 1))
+        w_idx += nconv
+    for res, cur in zip(resolutions, block_ws):
+        x, img, um, lm = _block_v18(sd, f'synthesis.b{res}', x, img, cur, pose_feat, cat, res == 4, conv_clamp, noise_mode, fused_modconv)
+        if res == 128:
+            x_128, img_128 = x, img
+    feat = torch.cat([get_spade_feat(sd, 'synthesis', um.detach(), du_mask, du_in), get_spade_feat(sd, 'synthesis', lm.detach(), dl_mask, dl_in)], dim=1)
+    xs = spade_resblock(sd, 'synthesis.spade_b128_1', x_128, feat)
+    xs = spade_resblock(sd, 'synthesis.spade_b128_2', xs, feat)
+    xs = spade_resblock(sd, 'synthesis.spade_b128_3', xs, feat)
+    _, finetune, _, _ = _block_v18(sd, 'synthesis.texture_b256', xs, img_128, block_ws[-1], pose_feat, cat, False, conv_clamp, noise_mode, fused_modconv)
+    return img, finetune, um, lm
+
+#----------------------------------------------------------------------------
 # Discriminator.
 
 def minibatch_std(x, group_size=4, num_channels=1):

@@ -404,6 +404,37 @@ class ToRGBLayerFull(torch.nn.Module):
         x = bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
         return x, pred_parsing
 
+@persistence.persistent_class
+class ToRGBLayerV18(torch.nn.Module):
+    """ToRGB of the released 256 inference model: the last block also predicts sigmoid upper/lower clothing
+    masks (networks.py:5276-5310)."""
+    def __init__(self, in_channels, out_channels, w_dim, kernel_size=1, conv_clamp=None, channels_last=False, is_last=False):
+        super().__init__()
+        self.conv_clamp = conv_clamp
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        memory_format = torch.channels_last if channels_last else torch.contiguous_format
+        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=memory_format))
+        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
+        self.is_last = is_last
+        if self.is_last:
+            self.m_weight1 = torch.nn.Parameter(torch.randn([1, in_channels, kernel_size, kernel_size]).to(memory_format=memory_format))
+            self.m_bias1 = torch.nn.Parameter(torch.zeros([1]))
+            self.m_weight2 = torch.nn.Parameter(torch.randn([1, in_channels, kernel_size, kernel_size]).to(memory_format=memory_format))
+            self.m_bias2 = torch.nn.Parameter(torch.zeros([1]))
+
+    def forward(self, x, w, fused_modconv=True):
+        styles = self.affine(w) * self.weight_gain
+        upper_mask = lower_mask = None
+        if self.is_last:
+            upper_mask = modulated_conv2d(x=x, weight=self.m_weight1, styles=styles, demodulate=False, fused_modconv=fused_modconv)
+            upper_mask = bias_act.bias_act(upper_mask, self.m_bias1.to(x.dtype), clamp=self.conv_clamp, act='sigmoid')
+            lower_mask = modulated_conv2d(x=x, weight=self.m_weight2, styles=styles, demodulate=False, fused_modconv=fused_modconv)
+            lower_mask = bias_act.bias_act(lower_mask, self.m_bias2.to(x.dtype), clamp=self.conv_clamp, act='sigmoid')
+        x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
+        x = bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
+        return x, upper_mask, lower_mask
+
 #----------------------------------------------------------------------------
 # Encoders.
 
@@ -598,8 +629,7 @@ class SynthesisBlockFull(torch.nn.Module):
                                     conv_clamp=conv_clamp, channels_last=self.channels_last, **layer_kwargs)
         self.num_conv += 1
         if is_last or architecture == 'skip':
-            self.torgb = ToRGBLayerFull(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp,
-                                        channels_last=self.channels_last, is_last=is_last, is_style=is_style)
+            self.torgb = self._make_torgb(out_channels, img_channels, w_dim, conv_clamp, is_last, is_style)
             self.num_torgb += 1
         if in_channels != 0 and architecture == 'resnet':
             self.skip = Conv2dLayer(in_channels, out_channels, kernel_size=1, bias=False, up=2,
@@ -607,6 +637,12 @@ class SynthesisBlockFull(torch.nn.Module):
         if self.resolution > 16:
             self.merge_conv = Conv2dLayer(out_channels + 64, out_channels, kernel_size=1,
                                           resample_filter=resample_filter, channels_last=self.channels_last)
+
+    def _make_torgb(self, out_channels, img_channels, w_dim, conv_clamp, is_last, is_style):
+        return ToRGBLayerFull(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp,
+                              channels_last=self.channels_last, is_last=is_last, is_style=is_style)
+
+    _num_heads = 1      # extra outputs of the ToRGB layer besides the image (parsing logits)
 
     def forward(self, x, img, ws, pose_feature, cat_feat, force_fp32=False, fused_modconv=None, **layer_kwargs):
         misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
@@ -636,15 +672,15 @@ class SynthesisBlockFull(torch.nn.Module):
                 x = torch.cat([x, cat_feat[str(x.shape[2])].to(dtype=dtype, memory_format=memory_format)], dim=1)
                 x = self.merge_conv(x)
 
-        pred_parsing = None
+        heads = (None,) * self._num_heads
         if img is not None:
             misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
             img = upfirdn2d.upsample2d(img, self.resample_filter)
         if self.is_last or self.architecture == 'skip':
-            y, pred_parsing = self.torgb(x, next(w_iter), fused_modconv=fused_modconv)
+            y, *heads = self.torgb(x, next(w_iter), fused_modconv=fused_modconv)
             y = y.to(dtype=torch.float32, memory_format=torch.contiguous_format)
             img = img.add_(y) if img is not None else y
-        return x, img, pred_parsing
+        return (x, img, *heads)
 
 @persistence.persistent_class
 class SynthesisNetworkFull(torch.nn.Module):
@@ -767,6 +803,104 @@ class GeneratorFull(torch.nn.Module):
         self.mapping = MappingNetwork(z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=self.num_ws, **mapping_kwargs)
         self.const_encoding = ConstEncoderNetwork(input_nc=3 + 3, output_nc=512, ngf=64, n_downsampling=6)
         self.style_encoding = StyleEncoderNetworkV16(input_nc=(10 * 3 + 4 * 3), output_nc=512, ngf=64, n_downsampling=6)
+
+    def forward(self, z, c, retain, pose, denorm_upper_input, denorm_lower_input, denorm_upper_mask, denorm_lower_mask,
+                truncation_psi=1, truncation_cutoff=None, **synthesis_kwargs):
+        pose_feat = self.const_encoding(pose)
+        stylecode, feats = self.style_encoding(c, retain)
+        ws = self.mapping(z, stylecode, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
+        cat_feats = {str(feat.shape[2]): feat for feat in feats}
+        return self.synthesis(ws, pose_feat, cat_feats, denorm_upper_input, denorm_lower_input,
+                              denorm_upper_mask, denorm_lower_mask, **synthesis_kwargs)
+
+#----------------------------------------------------------------------------
+# The released 256x192 inference model (test.py): same skeleton, sigmoid mask heads instead of parsing logits.
+
+@persistence.persistent_class
+class SynthesisBlockV18(SynthesisBlockFull.__mro__[1]):
+    """networks.py:5313-5418: SynthesisBlockFull with ToRGBLayerV18 (returns x, img, upper_mask, lower_mask)."""
+    _num_heads = 2
+
+    def __init__(self, in_channels, out_channels, w_dim, resolution, img_channels, is_last, **kwargs):
+        super().__init__(in_channels, out_channels, w_dim, resolution, img_channels, is_last, **kwargs)
+
+    def _make_torgb(self, out_channels, img_channels, w_dim, conv_clamp, is_last, is_style):
+        return ToRGBLayerV18(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp, channels_last=self.channels_last, is_last=is_last)
+
+@persistence.persistent_class
+class SynthesisNetworkV18(torch.nn.Module):
+    """networks.py:5419-5531"""
+    def __init__(self, w_dim, img_resolution, img_channels, channel_base=32768, channel_max=512, num_fp16_res=0, **block_kwargs):
+        assert img_resolution >= 4 and img_resolution & (img_resolution - 1) == 0
+        super().__init__()
+        self.w_dim = w_dim
+        self.img_resolution = img_resolution
+        self.img_resolution_log2 = int(np.log2(img_resolution))
+        self.img_channels = img_channels
+        self.block_resolutions = [2 ** i for i in range(2, self.img_resolution_log2 + 1)]
+        channels_dict = {res: min(channel_base // res, channel_max) for res in self.block_resolutions}
+        self.num_ws = 0
+        for res in self.block_resolutions:
+            in_channels = channels_dict[res // 2] if res > 4 else 0
+            is_last = (res == self.img_resolution)
+            block = SynthesisBlockV18(in_channels, channels_dict[res], w_dim=w_dim, resolution=res, img_channels=img_channels,
+                                      is_last=is_last, use_fp16=False, **block_kwargs)
+            self.num_ws += block.num_conv
+            if is_last:
+                self.num_ws += block.num_torgb
+            setattr(self, f'b{res}', block)
+        res = self.block_resolutions[-2]
+        self.spade_b128_1 = Spade_ResBlockV2(channels_dict[res], channels_dict[res])
+        self.spade_b128_2 = Spade_ResBlockV2(channels_dict[res], channels_dict[res])
+        self.spade_b128_3 = Spade_ResBlockV2(channels_dict[res], channels_dict[res])
+        res = self.block_resolutions[-1]
+        self.texture_b256 = SynthesisBlockV18(channels_dict[res // 2], channels_dict[res], w_dim=w_dim, resolution=res,
+                                              img_channels=img_channels, is_last=True, use_fp16=False, **block_kwargs)
+        ngf = 64
+        self.spade_encoder = nn.Sequential(
+            Conv2dLayer(3, ngf, kernel_size=7, activation='relu'),
+            ResBlock(ngf, ngf, kernel_size=4, activation='relu'),
+            ResBlock(ngf, ngf * 2, kernel_size=4, activation='relu', down=2))
+
+    get_spade_feat = SynthesisNetworkFull.__mro__[1].get_spade_feat
+
+    def forward(self, ws, pose_feat, cat_feat, denorm_upper_input, denorm_lower_input, denorm_upper_mask, denorm_lower_mask, **block_kwargs):
+        misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
+        ws = ws.to(torch.float32)
+        block_ws = []
+        w_idx = 0
+        for res in self.block_resolutions:
+            block = getattr(self, f'b{res}')
+            block_ws.append(ws.narrow(1, w_idx, block.num_conv + block.num_torgb))
+            w_idx += block.num_conv
+        x = img = upper_mask = lower_mask = None
+        for res, cur_ws in zip(self.block_resolutions, block_ws):
+            x, img, upper_mask, lower_mask = getattr(self, f'b{res}')(x, img, cur_ws, pose_feat, cat_feat, force_fp32=True, **block_kwargs)
+            if res == 128:
+                x_128, img_128 = x.clone(), img.clone()
+        spade_feat = torch.cat([self.get_spade_feat(upper_mask.detach(), denorm_upper_mask, denorm_upper_input),
+                                self.get_spade_feat(lower_mask.detach(), denorm_lower_mask, denorm_lower_input)], dim=1)
+        x_spade_128 = self.spade_b128_1(x_128, spade_feat)
+        x_spade_128 = self.spade_b128_2(x_spade_128, spade_feat)
+        x_spade_128 = self.spade_b128_3(x_spade_128, spade_feat)
+        _, finetune_img, _, _ = self.texture_b256(x_spade_128, img_128, block_ws[-1], pose_feat, cat_feat, force_fp32=True, **block_kwargs)
+        return img, finetune_img, upper_mask, lower_mask
+
+@persistence.persistent_class
+class GeneratorV18(torch.nn.Module):
+    """networks.py:5534-5577 (the class test.py's pretrained pickle instantiates; 60-channel patch input)."""
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs={}, synthesis_kwargs={}):
+        super().__init__()
+        self.z_dim = z_dim
+        self.c_dim = c_dim
+        self.w_dim = w_dim
+        self.img_resolution = img_resolution
+        self.img_channels = img_channels
+        self.synthesis = SynthesisNetworkV18(w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels, **synthesis_kwargs)
+        self.num_ws = self.synthesis.num_ws
+        self.mapping = MappingNetwork(z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=self.num_ws, **mapping_kwargs)
+        self.const_encoding = ConstEncoderNetwork(input_nc=3 + 3, output_nc=512, ngf=64, n_downsampling=6)
+        self.style_encoding = StyleEncoderNetworkV16(input_nc=30 * 2, output_nc=512, ngf=64, n_downsampling=6)
 
     def forward(self, z, c, retain, pose, denorm_upper_input, denorm_lower_input, denorm_upper_mask, denorm_lower_mask,
                 truncation_psi=1, truncation_cutoff=None, **synthesis_kwargs):

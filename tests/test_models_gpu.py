@@ -106,3 +106,17 @@ def test_generator_random_noise_and_state_dict_names():
     assert torch.isfinite(img).all() and torch.isfinite(fin).all()
     g = load_golden('models_fullbody.npz')
     assert len(dict(G.named_parameters())) == len(g['G.gradnorms'])
+
+
+def test_generator_v18_inference_golden():
+    """The released 256 model's class (test.py:120-128): eval mode, fused modulated (grouped) convolutions, sigmoid heads."""
+    from training import networks
+    g = load_golden('models_fullbody.npz')
+    G = PF.fill_module(networks.GeneratorV18(**PF.G_KWARGS)).cuda().eval().requires_grad_(False)
+    inp = _cuda(PF.make_inputs(n=2, seed=0))
+    c60 = PF.make_inputs(n=2, seed=5)['style_input'].repeat(1, 2, 1, 1)[:, :60].cuda()
+    with torch.no_grad():
+        outs = G(inp['gen_z'], c60, inp['retain'], inp['pose'], inp['denorm_upper_input'], inp['denorm_lower_input'],
+                 inp['denorm_upper_mask'], inp['denorm_lower_mask'], noise_mode='const')
+    for name, t in zip(['img', 'finetune_img', 'upper_mask', 'lower_mask'], outs):
+        _summary_ok(g, 'G18.' + name, t, TOL_FWD)

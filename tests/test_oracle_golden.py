@@ -179,3 +179,23 @@ def test_discriminator_oracle():
     grads = torch.autograd.grad(loss, [sd[k] for k in GRAD_KEYS_D])
     for k, gr in zip(GRAD_KEYS_D, grads):
         _check_summary(g, 'D.grad.' + k, gr, 1e-3)
+
+
+def _v18_state_dict():
+    from oracle import param_fill as PF
+    from training import networks
+    m = PF.fill_module(networks.GeneratorV18(**PF.G_KWARGS))
+    return {k: v.detach().clone() for k, v in list(m.named_parameters()) + list(m.named_buffers())}
+
+
+def test_generator_v18_oracle():
+    from oracle import param_fill as PF, ref_networks as RN
+    g = load_golden('models_fullbody.npz')
+    sd = _v18_state_dict()
+    inp = PF.make_inputs(n=2, seed=0)
+    c60 = PF.make_inputs(n=2, seed=5)['style_input'].repeat(1, 2, 1, 1)[:, :60]
+    with torch.no_grad():
+        outs = RN.generator_v18(sd, inp['gen_z'], c60, inp['retain'], inp['pose'], inp['denorm_upper_input'], inp['denorm_lower_input'],
+                                inp['denorm_upper_mask'], inp['denorm_lower_mask'], fused_modconv=True, **_g_cfg())
+    for name, tns in zip(['img', 'finetune_img', 'upper_mask', 'lower_mask'], outs):
+        _check_summary(g, 'G18.' + name, tns, 1e-4)
