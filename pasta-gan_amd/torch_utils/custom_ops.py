@@ -15,6 +15,12 @@ import shutil
 import subprocess
 import threading
 
+# PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so) and puts it in the process-global symbol scope.
+# Importing torch BEFORE loading libpasta_hip.so makes the library's HIP calls bind to that same runtime, so its
+# kernels and PyTorch's share devices, streams and allocations. Loaded the other way round the process ends up with
+# two HIP runtimes and the second one finds no device.
+import torch  # noqa: F401  (must precede ctypes.CDLL below)
+
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # .../pasta-gan_amd
 _CSRC = os.path.join(_ROOT, 'csrc')
 _LIBDIR = os.path.join(_ROOT, 'lib')
