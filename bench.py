@@ -164,11 +164,22 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 through torch.distributed.run'
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # One rank per GPU. PASTA_DIST_BACKEND=gloo lets several ranks share one card for a rehearsal on a 1-GPU box.
+    backend = os.environ.get('PASTA_DIST_BACKEND', 'nccl')
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.distributed.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=device)
+        if backend == 'nccl':
+            torch.distributed.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            torch.distributed.init_process_group(backend=backend, rank=rank, world_size=world)
+        # the in-tree library is built (if stale) by rank 0 only, then loaded by everyone
+        if rank == 0:
+            from torch_utils import custom_ops
+            custom_ops.build()
+        torch.distributed.barrier()
 
     from torch_utils.ops import conv2d_gradfix, _native
     from training.training_loop_wo_flow_fullbody import TrainingStep, SyntheticFullBodyBatch, fashion_config

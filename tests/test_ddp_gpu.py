@@ -1,0 +1,61 @@
+"""The real generator / discriminator under DistributedDataParallel: two ranks sharing the one GPU of the test box
+(gloo transport, device tensors), so that the native autograd Functions meet DDP's hooks, no_sync rounds and
+find_unused_parameters before the multi-GPU run on RCCL."""
+
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, PKG
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, out):
+    for p in (PKG, ROOT, os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from training.training_loop_wo_flow_fullbody import TrainingStep, SyntheticFullBodyBatch, fashion_config
+        torch.cuda.set_device(0)
+        dev = torch.device('cuda', 0)
+        cfg = fashion_config(channel_base=2048)
+        step = TrainingStep(dev, cfg=cfg, num_gpus=world, rank=rank, batch_size=8 * world, batch_gpu=4, random_seed=0)
+        data = SyntheticFullBodyBatch(8, dev, seed=rank)
+        for _ in range(2):      # iteration 0 runs all four phases (incl. R1), two accumulation rounds each
+            step.run(data)
+        torch.cuda.synchronize()
+        for name, p in list(step.G.named_parameters()) + list(step.D.named_parameters()):
+            ref = p.detach().clone()
+            dist.broadcast(ref, src=0)
+            assert torch.equal(ref, p.detach()), f'{name} diverged across ranks'
+            assert torch.isfinite(p).all(), name
+        moved = sum(float((a - b).abs().sum()) for a, b in zip(step.G.parameters(), step.G_ema.parameters()))
+        assert moved > 0
+        out.put((rank, 'ok'))
+    except Exception:  # noqa: BLE001
+        import traceback
+        out.put((rank, 'FAIL: ' + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_generator_discriminator_ddp_two_ranks_one_gpu():
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=500) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == 'ok', f'rank {rank}: {msg}'
