@@ -151,7 +151,7 @@ def cpu_baseline(budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--steps', type=int, default=16, help='timed iterations; 16 = one full lazy-regularisation period (Dreg runs every 16th)')
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch-gpu', type=int, default=16)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -222,10 +222,10 @@ def main():
             'metric': 'training images/sec at 256x192 (tensor 256x256), batch 16 per GPU',
             'value': round(images / dt, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1000 * dt / args.steps, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32', 'data': 'synthetic', 'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
             'config': {'workload': 'BASELINE config 2: full training_loop step (Gmain+Dmain every iter, Dreg/16, Greg/4, Adam, EMA), '
                                    'GeneratorFull+Discriminator cfg=fashion 256x256, batch 16/GPU, G and D in fp32, '
-                                   'vgg_weight=0 (weights unavailable), no ADA, random-init weights',
+                                   'vgg_weight=0 (weights unavailable), no ADA, random-init weights; timed iterations ' + f'{args.warmup}..{args.warmup + args.steps - 1}',
                        'global_batch': args.batch_gpu * world, 'parallelism': f'dp{world}' + (' (RCCL all-reduce)' if world > 1 else '')},
         }
         fam = meter.summary()
