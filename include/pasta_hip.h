@@ -93,7 +93,17 @@ typedef struct pasta_conv_desc {
     int32_t groups;               /* 1 (training) or N-style grouped (eval modconv)   */
     int32_t transposed;           /* 0 = conv2d, 1 = conv_transpose2d                 */
     int32_t flip;                 /* 1 = true convolution (flip taps), 0 = correlation */
+    int32_t math;                 /* PASTA_MATH_*: arithmetic of the matrix-core products (see below)  */
 } pasta_conv_desc;
+
+/* Arithmetic of the convolution products.  Accumulation is fp32 in every mode.
+ *   PASTA_MATH_F32    v_mfma_f32_32x32x2_f32: every product and sum is an fp32 FMA (bit-exact fp32 chains).
+ *   PASTA_MATH_BF16X6 each fp32 operand is split into three bf16 pieces (24 significand bits) and a*b is formed
+ *                     from six exact bf16 x bf16 products on v_mfma_f32_32x32x16_bf16: fp32-equivalent accuracy
+ *                     (dropped terms < 2^-22 |ab|) at 2.67x the fp32 matrix-core rate.  Used by the 128x128-tile
+ *                     forward / input-gradient launches; all other launches run PASTA_MATH_F32.
+ *   PASTA_MATH_DEFAULT = PASTA_MATH_BF16X6. */
+enum { PASTA_MATH_DEFAULT = 0, PASTA_MATH_F32 = 1, PASTA_MATH_BF16X6 = 2 };
 
 /* Bytes of scratch the forward / weight-gradient launches need (caller allocs). */
 int64_t pasta_conv2d_workspace(const pasta_conv_desc* d);

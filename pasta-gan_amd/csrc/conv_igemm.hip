@@ -21,6 +21,7 @@
 // C/D fragment map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace pasta {
 
@@ -72,6 +73,7 @@ struct ConvFwdParams {
     int ksplit;                           // > 1: K is cut into slices, partial sums go to `partial`
     float* partial;                       // [ksplit][N*Cout*OH*OW] when ksplit > 1
     int o_tiles;                          // output-channel tiles (blockIdx.y = ks * o_tiles + tile)
+    int bf16x6;                           // weights packed as split-bf16 pieces, run conv_fwd_bf16x6_kernel
     short tap_dy[MAX_TAPS], tap_dx[MAX_TAPS], tap_slab[MAX_TAPS];
 };
 
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_kernel(ConvFwdParams p) {
 
     float  breg[BPT];
     float4 areg[APT];
+    unsigned bmask = 0;         // bit j: breg[j] is a real element (inside the image, channel < Ig)
 
     // Loader state: tap index and channel offset of the NEXT chunk to fetch, plus the per-tap
     // quantities derived from them (recomputed only when the tap changes: T times, not per chunk).
@@ -130,20 +133,32 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_kernel(ConvFwdParams p) {
     auto set_tap = [&](int t) {
         const int iy = iy_base + p.tap_dy[t], ix = ix_base + p.tap_dx[t];
         ld_ok = pix_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        ld_xp = xb + iy * p.W + ix;
+        ld_xp = ld_ok ? xb + iy * p.W + ix : xb;       // always readable; out-of-image taps are zeroed by the select below
         ld_wt = wb + (int64_t)p.tap_slab[t] * p.Ig_pad * p.Og_pad;
     };
     if (ld_t < p.T) set_tap(ld_t);
+    // Unconditional loads from a clamped channel index: no branch and no wait sits between a load and the MFMAs that
+    // cover its latency.
     auto load_chunk = [&]() {
+        const int last = p.Ig - 1;
+        bmask = 0;
 #pragma unroll
         for (int j = 0; j < BPT; j++) {
             const int c = ld_c0 + brow0 + j * RSTEP;
-            float v = 0.f;
-            if (ld_ok && c < p.Ig) {
-                v = ld_xp[(int64_t)c * HW];
-                if (isb) v *= isb[c];
+            if (ld_ok && c < p.Ig) bmask |= 1u << j;         // validity is known now; the select waits until the store
+        }
+        if (isb) {
+#pragma unroll
+            for (int j = 0; j < BPT; j++) {
+                const int c = ld_c0 + brow0 + j * RSTEP, cs = c < last ? c : last;
+                breg[j] = ld_xp[(int64_t)cs * HW] * isb[cs];
             }
-            breg[j] = v;
+        } else {
+#pragma unroll
+            for (int j = 0; j < BPT; j++) {
+                const int c = ld_c0 + brow0 + j * RSTEP, cs = c < last ? c : last;
+                breg[j] = ld_xp[(int64_t)cs * HW];
+            }
         }
         const float* wt = ld_wt + (int64_t)ld_c0 * p.Og_pad;
 #pragma unroll
@@ -159,7 +174,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_kernel(ConvFwdParams p) {
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < BPT; j++) Bs[buf][brow0 + j * RSTEP][bcol] = breg[j];
+        for (int j = 0; j < BPT; j++) Bs[buf][brow0 + j * RSTEP][bcol] = (bmask >> j & 1u) ? breg[j] : 0.f;
 #pragma unroll
         for (int j = 0; j < APT; j++) {
             const int e = tid + j * 256, row = e / A4_PER_ROW, c4 = e - row * A4_PER_ROW;
@@ -254,6 +269,240 @@ static FwdTile choose_fwd_tile(int Og, int64_t npix) {
 }
 static int fwd_tile_bm(FwdTile t) { return t == T128x128 ? 128 : t == T32x256 ? 32 : 64; }
 
+//------------------------------------------------------------------------------------
+// Forward-type implicit GEMM on the bf16 matrix cores with fp32-equivalent products ("split-bf16").
+//
+// Every fp32 operand v is written as v = v1 + v2 + v3 with v1 = bf16(v), v2 = bf16(v - v1), v3 = bf16(v - v1 - v2):
+// three bf16 pieces of 8 significand bits each carry the 24 bits of an fp32 significand, and a product of two bf16
+// values is exact in fp32.  a*b is evaluated as a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1 (the three dropped terms are
+// below 2^-24 |ab|), accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Six bf16 MFMAs replace eight fp32 MFMAs of a
+// quarter of the rate each: 2.67x the fp32-MFMA throughput at fp32 accuracy.
+// Tile 128 x 128, K chunks of 16 channels of one tap; weights are split once by the packing kernel, activations by
+// the staging code (after the optional modulation scale).  Layouts in LDS (per piece and per k-half of 8):
+// [piece][half][row or pixel][8 bf16] so that a fragment is one conflict-free 16-byte read.
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3(float v, __bf16& a, __bf16& b, __bf16& c) {
+    a = (__bf16)v;
+    float r = v - (float)a;
+    b = (__bf16)r;
+    r -= (float)b;
+    c = (__bf16)r;
+}
+
+// [g][tap][chunk of 16 channels][piece 3][half 2][O_pad][8]
+__global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int G, int Ig,
+                                                                int Og, int Ig_pad, int Og_pad, int kh, int kw, int transposed,
+                                                                int flip) {
+    const int64_t total = (int64_t)G * kh * kw * Ig_pad * Og_pad;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int j = (int)(idx & 7);
+        int64_t r = idx >> 3;
+        const int o = (int)(r % Og_pad); r /= Og_pad;
+        const int half = (int)(r & 1); r >>= 1;
+        const int cc = (int)(r % (Ig_pad / 16)); r /= (Ig_pad / 16);
+        const int t = (int)(r % (kh * kw));
+        const int g = (int)(r / (kh * kw));
+        const int i = cc * 16 + half * 8 + j;
+        float v = 0.f;
+        if (i < Ig && o < Og) {
+            int ty = t / kw, tx = t - ty * kw;
+            if (flip) { ty = kh - 1 - ty; tx = kw - 1 - tx; }
+            const int64_t src = transposed ? (((int64_t)(g * Ig + i) * Og + o) * kh + ty) * kw + tx
+                                           : (((int64_t)(g * Og + o) * Ig + i) * kh + ty) * kw + tx;
+            v = w[src];
+        }
+        __bf16 p1, p2, p3;
+        split3(v, p1, p2, p3);
+        const int64_t chunk = (((int64_t)g * kh * kw + t) * (Ig_pad / 16) + cc) * 6 * Og_pad * 8;
+        const int64_t within = ((int64_t)half * Og_pad + o) * 8 + j;
+        wp[chunk + within] = p1;
+        wp[chunk + 2 * Og_pad * 8 + within] = p2;
+        wp[chunk + 4 * Og_pad * 8 + within] = p3;
+    }
+}
+
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams p) {
+    constexpr int BM = 128, BN = 128, WMT = 2, WNT = 2, KC = 16;
+    constexpr int SEG = BM * 8;                         // bf16 elements of one (piece, half) segment
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][6 * SEG];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][6 * SEG];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = blockIdx.z;
+    const int ks = blockIdx.y / p.o_tiles;
+    const int o_blk = (blockIdx.y - ks * p.o_tiles) * BM;
+    const int64_t npix = (int64_t)p.N * p.P * p.Q;
+    const int64_t pix_blk = (int64_t)blockIdx.x * BN;
+    const int HW = p.H * p.W;
+    const int NC = p.Ig_pad / KC;
+    const int chunks_all = p.T * NC;
+    const int c_first = (int)((int64_t)chunks_all * ks / p.ksplit);
+    const int nchunks = (int)((int64_t)chunks_all * (ks + 1) / p.ksplit) - c_first;
+
+    // B staging: pixel column and k-half of this thread, fixed for the whole K loop.
+    const int bcol = tid & (BN - 1), bhalf = tid >> 7;
+    const int64_t mypix = pix_blk + bcol;
+    const bool pix_ok = mypix < npix;
+    int n_in = 0, py = 0, px = 0;
+    if (pix_ok) {
+        n_in = (int)(mypix / (p.P * p.Q));
+        const int rem = (int)(mypix - (int64_t)n_in * p.P * p.Q);
+        py = rem / p.Q; px = rem - py * p.Q;
+    }
+    const float* xb = p.x + ((int64_t)n_in * p.Cin + (int64_t)g * p.Ig) * HW;
+    const int iy_base = py * p.isy, ix_base = px * p.isx;
+    const __bf16* wb = (const __bf16*)p.wp + (int64_t)g * p.KK * NC * 6 * p.Og_pad * 8;
+
+    // Two register sets: while chunk c is multiplied out of LDS, chunk c+1 (already in registers) is split into bf16
+    // pieces and written to the other LDS buffer between the MFMAs, and chunk c+2 is being fetched.
+    struct Stage { float b[8]; float4 a0, a1, a2; int nvalid; };
+    Stage st0, st1;
+    int ld_t = c_first / NC, ld_cc = c_first - ld_t * NC;
+    bool ld_ok = false;
+    const float* ld_xp = xb;           // always a readable address: the tap's pixel when it is inside the image, else xb
+    const __bf16* ld_wt = wb;
+    auto set_tap = [&](int t) {
+        const int iy = iy_base + p.tap_dy[t], ix = ix_base + p.tap_dx[t];
+        ld_ok = pix_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        ld_xp = ld_ok ? xb + iy * p.W + ix : xb;
+        ld_wt = wb + (int64_t)p.tap_slab[t] * NC * 6 * p.Og_pad * 8;
+    };
+    if (ld_t < p.T) set_tap(ld_t);
+    // Loads are unconditional (clamped channel index, always-valid base) so that nothing waits on them before their
+    // first use one iteration later; invalid elements are zeroed when they are split.
+    auto load_chunk = [&](Stage& st) {
+        const int c0 = ld_cc * KC + bhalf * 8;
+        const int last = p.Ig - 1;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int c = c0 + j < last ? c0 + j : last;
+            st.b[j] = ld_xp[(int64_t)c * HW];
+        }
+        st.nvalid = ld_ok ? p.Ig - c0 : 0;       // elements j < nvalid are real
+        const __bf16* wt = ld_wt + (int64_t)ld_cc * 6 * p.Og_pad * 8;
+        // 6 (piece, half) segments of 128 sixteen-byte units: this thread copies units tid, tid+256, tid+512
+        const int within = tid & 127, seg0 = tid >> 7;
+        st.a0 = *(const float4*)(wt + ((int64_t)(seg0) * p.Og_pad + o_blk + within) * 8);
+        st.a1 = *(const float4*)(wt + ((int64_t)(seg0 + 2) * p.Og_pad + o_blk + within) * 8);
+        st.a2 = *(const float4*)(wt + ((int64_t)(seg0 + 4) * p.Og_pad + o_blk + within) * 8);
+        if (++ld_cc >= NC) {
+            ld_cc = 0;
+            if (++ld_t < p.T) set_tap(ld_t);
+        }
+    };
+    uint32_t q1[4], q2[4], q3[4];          // 8 bf16 per piece, packed two per dword
+    auto split_pair = [&](const Stage& st, int j) {
+        __bf16 a0, b0, c0, a1, b1, c1;
+        split3(2 * j < st.nvalid ? st.b[2 * j] : 0.f, a0, b0, c0);
+        split3(2 * j + 1 < st.nvalid ? st.b[2 * j + 1] : 0.f, a1, b1, c1);
+        q1[j] = (uint32_t)__builtin_bit_cast(unsigned short, a0) | ((uint32_t)__builtin_bit_cast(unsigned short, a1) << 16);
+        q2[j] = (uint32_t)__builtin_bit_cast(unsigned short, b0) | ((uint32_t)__builtin_bit_cast(unsigned short, b1) << 16);
+        q3[j] = (uint32_t)__builtin_bit_cast(unsigned short, c0) | ((uint32_t)__builtin_bit_cast(unsigned short, c1) << 16);
+    };
+    auto store_b = [&](int buf) {
+        __bf16* bd = &Bs[buf][(bhalf * BN + bcol) * 8];
+        *(uint4*)(bd) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+        *(uint4*)(bd + 2 * SEG) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+        *(uint4*)(bd + 4 * SEG) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+    };
+    auto store_a = [&](const Stage& st, int buf) {
+        *(float4*)&As[buf][(tid) * 8] = st.a0;
+        *(float4*)&As[buf][(tid + 256) * 8] = st.a1;
+        *(float4*)&As[buf][(tid + 512) * 8] = st.a2;
+    };
+
+    f32x16 acc[WMT][WNT];
+#pragma unroll
+    for (int a = 0; a < WMT; a++)
+#pragma unroll
+        for (int b = 0; b < WNT; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    const int hl = lane >> 5, jl = lane & 31;
+    // One K chunk: 24 MFMAs in six groups of four; the staging work for the next chunk is slotted between the groups.
+    auto step = [&](int ch, Stage& cur_next, Stage& fetch_into) {
+        const int buf = ch & 1;
+        const bool have_next = ch + 1 < nchunks;
+        if (ch + 2 < nchunks) load_chunk(fetch_into);
+        bf16x8 af[WMT][3], bf[WNT][3];
+#pragma unroll
+        for (int pc = 0; pc < 3; pc++) {
+#pragma unroll
+            for (int a = 0; a < WMT; a++) af[a][pc] = *(const bf16x8*)&As[buf][((pc * 2 + hl) * BM + (wm * WMT + a) * 32 + jl) * 8];
+#pragma unroll
+            for (int b = 0; b < WNT; b++) bf[b][pc] = *(const bf16x8*)&Bs[buf][((pc * 2 + hl) * BN + (wn * WNT + b) * 32 + jl) * 8];
+        }
+#define PASTA_MM(PA, PB)                                                                                       \
+        _Pragma("unroll") for (int a = 0; a < WMT; a++) _Pragma("unroll") for (int b = 0; b < WNT; b++)          \
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA], bf[b][PB], acc[a][b], 0, 0, 0);
+        // smallest terms first: a3b1, a1b3, a2b2, a2b1, a1b2, a1b1
+        PASTA_MM(2, 0)
+        if (have_next) split_pair(cur_next, 0);
+        PASTA_MM(0, 2)
+        if (have_next) split_pair(cur_next, 1);
+        PASTA_MM(1, 1)
+        if (have_next) split_pair(cur_next, 2);
+        PASTA_MM(1, 0)
+        if (have_next) split_pair(cur_next, 3);
+        PASTA_MM(0, 1)
+        if (have_next) { store_b(buf ^ 1); store_a(cur_next, buf ^ 1); }
+        PASTA_MM(0, 0)
+#undef PASTA_MM
+        __syncthreads();
+    };
+
+    if (nchunks > 0) {
+        load_chunk(st0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) split_pair(st0, j);
+        store_b(0); store_a(st0, 0);
+        if (nchunks > 1) load_chunk(st0);       // chunk 1 waits in registers
+    }
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ch += 2) {
+        step(ch, st0, st1);                     // st0 holds chunk ch+1, chunk ch+2 is fetched into st1
+        if (ch + 1 < nchunks) step(ch + 1, st1, st0);
+    }
+
+    const int OHW = p.OH * p.OW;
+#pragma unroll
+    for (int b = 0; b < WNT; b++) {
+        const int64_t pix = pix_blk + (wn * WNT + b) * 32 + jl;
+        if (pix >= npix) continue;
+        const int n = (int)(pix / (p.P * p.Q));
+        const int rem = (int)(pix - (int64_t)n * p.P * p.Q);
+        const int pp = rem / p.Q, qq = rem - pp * p.Q;
+        float* yb = (p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW : p.y) +
+                    ((int64_t)n * p.Cout + (int64_t)g * p.Og) * OHW + (p.oy0 + pp * p.osy) * p.OW + p.ox0 + qq * p.osx;
+        const float* osb = (p.oscale && p.ksplit == 1) ? p.oscale + (int64_t)n * p.Cout + (int64_t)g * p.Og : nullptr;
+#pragma unroll
+        for (int a = 0; a < WMT; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
+                if (o < p.Og) {
+                    float v = acc[a][b][r];
+                    if (osb) v *= osb[o];
+                    yb[(int64_t)o * OHW] = v;
+                }
+            }
+    }
+}
+
+static void launch_fwd_bf16x6(const ConvFwdParams& p, hipStream_t s) {
+    const int64_t npix = (int64_t)p.N * p.P * p.Q;
+    ConvFwdParams q = p;
+    q.o_tiles = (p.Og + 127) / 128;
+    dim3 grid((unsigned)ceil_div64(npix, 128), q.o_tiles * q.ksplit, p.G);
+    if (fwd_variant() == 5) hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<3>), grid, dim3(256), 0, s, q);
+    else hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<2>), grid, dim3(256), 0, s, q);
+}
+
 constexpr int FWD_KC = 8;
 // Packed input-channel padding: a multiple of the KC of the kernel instance that will run.
 static int fwd_ipad(int Ig, FwdTile t) { return (Ig <= 4 && t == T64x256) ? 4 : Ig <= 8 ? 8 : 16; }
@@ -261,6 +510,7 @@ static int fwd_ipad(int Ig, FwdTile t) { return (Ig <= 4 && t == T64x256) ? 4 : 
 static void dispatch_fwd(FwdTile t, const ConvFwdParams& p, hipStream_t s) {
     switch (t) {
         case T128x128:
+            if (p.bf16x6) { launch_fwd_bf16x6(p, s); break; }
             switch (fwd_variant()) {
                 case 1:  launch_fwd<128, 128, 2, 2, 8, 1>(p, s); break;
                 case 2:  launch_fwd<128, 256, 2, 4, 8>(p, s); break;
@@ -746,6 +996,7 @@ static int check_desc(const pasta_conv_desc* d, const char* who) {
     PASTA_CHECK(d->kh >= 1 && d->kw >= 1 && d->kh * d->kw <= MAX_TAPS, "%s: kernel %dx%d unsupported (max %d taps)", who, d->kh, d->kw, MAX_TAPS);
     PASTA_CHECK(d->stride >= 1 && d->stride <= 4, "%s: stride %d unsupported", who, d->stride);
     PASTA_CHECK(d->pad_h >= 0 && d->pad_w >= 0, "%s: negative padding", who);
+    PASTA_CHECK(d->math >= PASTA_MATH_DEFAULT && d->math <= PASTA_MATH_BF16X6, "%s: unknown math mode %d", who, d->math);
     PASTA_CHECK(d->groups >= 1 && d->C_in % d->groups == 0 && d->C_out % d->groups == 0, "%s: channels not divisible by groups=%d", who, d->groups);
     if (!d->transposed) {
         const int oh = (d->H + 2 * d->pad_h - d->kh) / d->stride + 1, ow = (d->W + 2 * d->pad_w - d->kw) / d->stride + 1;
@@ -777,7 +1028,8 @@ extern "C" int64_t pasta_conv2d_workspace(const pasta_conv_desc* d) {
     const int Ig = d->C_in / d->groups, Og = d->C_out / d->groups;
     const FwdTile t = choose_fwd_tile(Og, fwd_lattice_pixels(d));
     const int ks = choose_ksplit(d, t);
-    const int64_t pack = (int64_t)d->groups * d->kh * d->kw * round_up(Ig, fwd_ipad(Ig, t)) * round_up(Og, fwd_tile_bm(t));
+    // packed weights: fp32 (4 B) or three bf16 pieces (6 B) per element; sized for the larger, in floats
+    const int64_t pack = ((int64_t)d->groups * d->kh * d->kw * round_up(Ig, fwd_ipad(Ig, t)) * round_up(Og, fwd_tile_bm(t)) * 3 + 1) / 2;
     const int64_t partial = ks > 1 ? (int64_t)ks * d->N * d->C_out * d->OH * d->OW : 0;
     return (round_up((int)pack, 4) + partial) * (int64_t)sizeof(float);
 }
@@ -808,14 +1060,19 @@ extern "C" int pasta_conv2d(const float* x, const float* w, float* y, const floa
     p.KK = d->kh * d->kw;
     p.ksplit = choose_ksplit(d, tile);
     p.o_tiles = 1;
-    p.partial = (float*)workspace + round_up(p.G * p.KK * p.Ig_pad * p.Og_pad, 4);
+    p.partial = (float*)workspace + round_up((int)(((int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad * 3 + 1) / 2), 4);
+    p.bf16x6 = (d->math != PASTA_MATH_F32 && tile == T128x128 && p.Ig >= 16 && !iscale) ? 1 : 0;
 
     {   // pack weights
         const int64_t total = (int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad;
         int64_t blocks = ceil_div64(total, 256);
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, (float*)workspace, p.G, p.Ig, p.Og,
-                           p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip);
+        if (p.bf16x6)
+            hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, (__bf16*)workspace, p.G, p.Ig, p.Og,
+                               p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip);
+        else
+            hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, (float*)workspace, p.G, p.Ig, p.Og,
+                               p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip);
     }
 
     if (!d->transposed) {

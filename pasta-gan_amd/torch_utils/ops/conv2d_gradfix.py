@@ -20,6 +20,12 @@ from .. import custom_ops
 #----------------------------------------------------------------------------
 
 enabled = True                      # Kept for API compatibility; the HIP path is always used for GPU tensors.
+# Matrix-core arithmetic of the convolutions (include/pasta_hip.h PASTA_MATH_*): 'bf16x6' (default; split-bf16 with
+# fp32-equivalent products) or 'f32' (fp32 MFMA, bit-exact fp32 FMA chains). Overridable with PASTA_CONV_MATH.
+import os as _os
+MATH_CODES = {'default': 0, 'f32': 1, 'bf16x6': 2}
+conv_math = _os.environ.get('PASTA_CONV_MATH', 'default')
+assert conv_math in MATH_CODES, f'PASTA_CONV_MATH must be one of {sorted(MATH_CODES)}'
 weight_gradients_disabled = False   # Forcefully disable computation of gradients with respect to the weights.
 
 @contextlib.contextmanager
@@ -56,7 +62,8 @@ def _out_hw(cfg, h, w, kh, kw):
 def _desc(cfg, x_shape, c_out, oh, ow, kh, kw):
     n, c_in, h, w = x_shape
     return custom_ops.ConvDesc(N=n, C_in=c_in, H=h, W=w, C_out=c_out, OH=oh, OW=ow, kh=kh, kw=kw, stride=cfg.stride,
-                               pad_h=cfg.pad_h, pad_w=cfg.pad_w, groups=cfg.groups, transposed=int(cfg.transposed), flip=0)
+                               pad_h=cfg.pad_h, pad_w=cfg.pad_w, groups=cfg.groups, transposed=int(cfg.transposed), flip=0,
+                               math=MATH_CODES[conv_math])
 
 # Optional measurement hook (bench.py): when set, called as hook(kind, desc, launch) around every native
 # convolution launch; ``launch()`` performs it. None = no overhead.

@@ -1,0 +1,50 @@
+"""Accuracy of the two matrix-core arithmetics of the convolution against an fp64 reference: the split-bf16 mode
+(PASTA_MATH_BF16X6) must be as accurate as fp32 FMA chains, not merely inside the 1e-3 parity bar."""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _errs(mode, x, w, ref64):
+    from torch_utils.ops import conv2d_gradfix as cg
+    old = cg.conv_math
+    cg.conv_math = mode
+    try:
+        y = cg.conv2d(x, w, padding=1)
+    finally:
+        cg.conv_math = old
+    d = (y.double().cpu() - ref64).abs()
+    return float(d.max() / ref64.abs().max()), float(d.pow(2).mean().sqrt() / ref64.pow(2).mean().sqrt())
+
+
+@pytest.mark.parametrize('scale', [1.0, 1e-3, 300.0])
+def test_split_bf16_matches_fp32_accuracy(scale):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn([8, 256, 40, 40], generator=g) * scale       # 12800 pixels x 128 channels -> the 128x128 tile
+    w = torch.randn([128, 256, 3, 3], generator=g) / 48
+    ref64 = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    e32 = _errs('f32', x.cuda(), w.cuda(), ref64)
+    e16 = _errs('bf16x6', x.cuda(), w.cuda(), ref64)
+    cpu = torch.nn.functional.conv2d(x, w, padding=1).double()
+    ecpu = float((cpu - ref64).abs().max() / ref64.abs().max())
+    print(f'scale {scale}: max-rel err fp32-MFMA {e32[0]:.3e}, split-bf16 {e16[0]:.3e}, torch CPU fp32 {ecpu:.3e}; rms {e32[1]:.3e} vs {e16[1]:.3e}')
+    assert e32[0] < 5e-6 and e16[0] < 5e-6          # K = 2304 products per output
+    assert e16[1] < 3 * e32[1] + 1e-9          # same error class as fp32 arithmetic
+
+
+def test_math_modes_reach_their_kernels_and_agree():
+    from torch_utils.ops import conv2d_gradfix as cg
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn([16, 128, 32, 32], generator=g).cuda()       # 16384 pixels, 128 output channels -> 128x128 tile
+    w = (torch.randn([128, 128, 3, 3], generator=g) / 34).cuda()
+    out = {}
+    for mode in ['f32', 'bf16x6', 'default']:
+        cg.conv_math = mode
+        out[mode] = cg.conv2d(x, w, padding=1)
+    cg.conv_math = 'default'
+    assert torch.equal(out['default'], out['bf16x6'])
+    assert not torch.equal(out['f32'], out['bf16x6'])             # different arithmetic really ran
+    assert float((out['f32'] - out['bf16x6']).abs().max() / out['f32'].abs().max()) < 2e-6
