@@ -353,9 +353,13 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
         const int rem = (int)(mypix - (int64_t)n_in * p.P * p.Q);
         py = rem / p.Q; px = rem - py * p.Q;
     }
-    const float* xb = p.x + ((int64_t)n_in * p.Cin + (int64_t)g * p.Ig) * HW;
+    // Activation addressing: byte offset = (per-thread pixel part, VGPR) + (per-wave channel part, SGPR); the host only
+    // selects this kernel for tensors below 2^30 elements, so 32-bit byte offsets suffice.
+    const unsigned xb_off = (unsigned)(((int64_t)n_in * p.Cin + (int64_t)g * p.Ig) * HW) * 4u;
+    const char* const xbytes = (const char*)p.x;
     const int iy_base = py * p.isy, ix_base = px * p.isx;
     const __bf16* wb = (const __bf16*)p.wp + (int64_t)g * p.KK * NC * 6 * p.Og_pad * 8;
+    const int bhalf_u = __builtin_amdgcn_readfirstlane(bhalf);      // uniform per wave (128 pixels = 2 waves per half)
 
     // Two register sets: while chunk c is multiplied out of LDS, chunk c+1 (already in registers) is split into bf16
     // pieces and written to the other LDS buffer between the MFMAs, and chunk c+2 is being fetched.
@@ -363,24 +367,25 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     Stage st0, st1;
     int ld_t = c_first / NC, ld_cc = c_first - ld_t * NC;
     bool ld_ok = false;
-    const float* ld_xp = xb;           // always a readable address: the tap's pixel when it is inside the image, else xb
+    unsigned ld_pix = xb_off;          // byte offset of this thread's tap pixel in channel 0 (a readable address also when the tap is outside)
     const __bf16* ld_wt = wb;
-    auto set_tap = [&](int t) {
+    auto set_tap = [&](int t_in) {
+        const int t = __builtin_amdgcn_readfirstlane(t_in);          // the tap tables are read with scalar loads
         const int iy = iy_base + p.tap_dy[t], ix = ix_base + p.tap_dx[t];
         ld_ok = pix_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        ld_xp = ld_ok ? xb + iy * p.W + ix : xb;
+        ld_pix = ld_ok ? xb_off + (unsigned)(iy * p.W + ix) * 4u : xb_off;
         ld_wt = wb + (int64_t)p.tap_slab[t] * NC * 6 * p.Og_pad * 8;
     };
     if (ld_t < p.T) set_tap(ld_t);
     // Loads are unconditional (clamped channel index, always-valid base) so that nothing waits on them before their
     // first use one iteration later; invalid elements are zeroed when they are split.
     auto load_chunk = [&](Stage& st) {
-        const int c0 = ld_cc * KC + bhalf * 8;
+        const int c0 = __builtin_amdgcn_readfirstlane(ld_cc) * KC + bhalf_u * 8;
         const int last = p.Ig - 1;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const int c = c0 + j < last ? c0 + j : last;
-            st.b[j] = ld_xp[(int64_t)c * HW];
+            const unsigned coff = (unsigned)(c0 + j < last ? c0 + j : last) * (unsigned)HW * 4u;    // scalar
+            st.b[j] = *(const float*)(xbytes + (ld_pix + coff));
         }
         st.nvalid = ld_ok ? p.Ig - c0 : 0;       // elements j < nvalid are real
         const __bf16* wt = ld_wt + (int64_t)ld_cc * 6 * p.Og_pad * 8;
@@ -395,13 +400,25 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
         }
     };
     uint32_t q1[4], q2[4], q3[4];          // 8 bf16 per piece, packed two per dword
+    // Two elements at a time: v_cvt_pk_bf16_f32 yields the packed pair, the residuals come from its halves.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     auto split_pair = [&](const Stage& st, int j) {
-        __bf16 a0, b0, c0, a1, b1, c1;
-        split3(2 * j < st.nvalid ? st.b[2 * j] : 0.f, a0, b0, c0);
-        split3(2 * j + 1 < st.nvalid ? st.b[2 * j + 1] : 0.f, a1, b1, c1);
-        q1[j] = (uint32_t)__builtin_bit_cast(unsigned short, a0) | ((uint32_t)__builtin_bit_cast(unsigned short, a1) << 16);
-        q2[j] = (uint32_t)__builtin_bit_cast(unsigned short, b0) | ((uint32_t)__builtin_bit_cast(unsigned short, b1) << 16);
-        q3[j] = (uint32_t)__builtin_bit_cast(unsigned short, c0) | ((uint32_t)__builtin_bit_cast(unsigned short, c1) << 16);
+        float v0 = st.b[2 * j], v1 = st.b[2 * j + 1];
+        if (st.nvalid < 8) {                     // border pixel or channel tail
+            v0 = 2 * j < st.nvalid ? v0 : 0.f;
+            v1 = 2 * j + 1 < st.nvalid ? v1 : 0.f;
+        }
+        f32x2 v = {v0, v1};
+        uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        q1[j] = w;
+        v[0] -= __builtin_bit_cast(float, w << 16);
+        v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
+        w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        q2[j] = w;
+        v[0] -= __builtin_bit_cast(float, w << 16);
+        v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
+        q3[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
     };
     auto store_b = [&](int buf) {
         __bf16* bd = &Bs[buf][(bhalf * BN + bcol) * 8];
@@ -1061,7 +1078,8 @@ extern "C" int pasta_conv2d(const float* x, const float* w, float* y, const floa
     p.ksplit = choose_ksplit(d, tile);
     p.o_tiles = 1;
     p.partial = (float*)workspace + round_up((int)(((int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad * 3 + 1) / 2), 4);
-    p.bf16x6 = (d->math != PASTA_MATH_F32 && tile == T128x128 && p.Ig >= 16 && !iscale) ? 1 : 0;
+    p.bf16x6 = (d->math != PASTA_MATH_F32 && tile == T128x128 && p.Ig >= 16 && !iscale &&
+                (int64_t)d->N * d->C_in * d->H * d->W < (1ll << 30)) ? 1 : 0;
 
     {   // pack weights
         const int64_t total = (int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad;
