@@ -30,6 +30,7 @@ def main():
     ap.add_argument('tag')
     ap.add_argument('--stats')
     ap.add_argument('--pmc')
+    ap.add_argument('--pmc-prefix', default='pmc_')
     ap.add_argument('--steps', type=int, default=5, help='steps (warm-up included) the stats run executed')
     a = ap.parse_args()
     out = os.path.join(ROOT, 'profiles')
@@ -49,7 +50,7 @@ def main():
                             f"{float(r['MaxNs']) / 1e3:.1f}", f'{100 * t / total:.2f}', f'{t / 1e6 / a.steps:.2f}'])
         print('kernel time total %.1f ms over %d steps' % (total / 1e6, a.steps))
     if a.pmc:
-        g = lambda name: glob.glob(os.path.join(a.pmc, name, '*', '*_counter_collection.csv'))[0]
+        g = lambda name: glob.glob(os.path.join(a.pmc, name.replace('pmc_', a.pmc_prefix, 1), '*', '*_counter_collection.csv'))[0]
         fetch = agg(g('pmc_FETCH_SIZE'), 'FETCH_SIZE')
         write = agg(g('pmc_WRITE_SIZE'), 'WRITE_SIZE')
         busy = agg(g('pmc_SQ_VALU_MFMA_BUSY_CYCLES'), 'SQ_VALU_MFMA_BUSY_CYCLES')
