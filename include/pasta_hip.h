@@ -123,6 +123,21 @@ int pasta_conv2d(const float* x, const float* w, float* y,
                  const pasta_conv_desc* d, void* workspace, int64_t workspace_bytes,
                  void* stream);
 
+/* Optional fused epilogue of pasta_conv2d_ex: after the output scale,
+ *   y = clamp(act(y + bias[c]) * gain)      -- Conv2dLayer's bias_act (training/networks.py:176-178), forward only
+ * act: 1 linear, 2 relu, 3 lrelu (bias_act.py:24-26); bias NULL = none; clamp < 0 = none. */
+typedef struct pasta_conv_epilogue {
+    const float* bias;            /* [C_out] or NULL */
+    int32_t act;
+    float alpha, gain, clamp;
+} pasta_conv_epilogue;
+
+/* pasta_conv2d with the epilogue above (ep NULL = plain pasta_conv2d). */
+int pasta_conv2d_ex(const float* x, const float* w, float* y,
+                    const float* iscale, const float* oscale, const pasta_conv_epilogue* ep,
+                    const pasta_conv_desc* d, void* workspace, int64_t workspace_bytes,
+                    void* stream);
+
 /* dw = d(conv)/dw given x and dy (same descriptor as the forward). */
 int pasta_conv2d_wgrad(const float* x, const float* dy, float* dw,
                        const pasta_conv_desc* d, void* workspace,

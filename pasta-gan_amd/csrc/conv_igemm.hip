@@ -31,6 +31,16 @@ constexpr int MAX_TAPS = 49;   // up to 7x7
 
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
+// bias + activation + gain + clamp of one output element (forward semantics of bias_act.cu:38-146, act 1..3)
+__device__ __forceinline__ float conv_epilogue(float v, float b, int act, float alpha, float gain, float clamp) {
+    v += b;
+    if (act == 2) v = v > 0.f ? v : 0.f;
+    else if (act == 3) v = v > 0.f ? v : v * alpha;
+    v *= gain;
+    if (clamp >= 0.f) v = (v > -clamp && v < clamp) ? v : (v >= 0.f ? clamp : -clamp);
+    return v;
+}
+
 //------------------------------------------------------------------------------------
 // Weight packing: PyTorch layout -> [G][kh*kw][I_pad][O_pad] (O contiguous), zero padded so
 // the GEMM's A-operand staging needs no bounds checks.
@@ -74,6 +84,9 @@ struct ConvFwdParams {
     float* partial;                       // [ksplit][N*Cout*OH*OW] when ksplit > 1
     int o_tiles;                          // output-channel tiles (blockIdx.y = ks * o_tiles + tile)
     int bf16x6;                           // weights packed as split-bf16 pieces, run conv_fwd_bf16x6_kernel
+    const float* bias;                    // fused epilogue (pasta_conv_epilogue); act == 0: none
+    int act;
+    float alpha, gain, clamp;
     short tap_dy[MAX_TAPS], tap_dx[MAX_TAPS], tap_slab[MAX_TAPS];
 };
 
@@ -236,6 +249,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_kernel(ConvFwdParams p) {
                 if (o < p.Og) {
                     float v = acc[a][b][r];
                     if (osb) v *= osb[o];
+                    if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
                     yb[(int64_t)o * OHW] = v;
                 }
             }
@@ -505,6 +519,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
                 if (o < p.Og) {
                     float v = acc[a][b][r];
                     if (osb) v *= osb[o];
+                    if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
                     yb[(int64_t)o * OHW] = v;
                 }
             }
@@ -548,11 +563,15 @@ static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 // y[n,c,:] = oscale[n,c] * sum_ks partial[ks][n,c,:]   (fixed order; split-K epilogue)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ y,
-                                                            const float* __restrict__ oscale, int64_t numel, int ohw, int ksplit) {
+                                                            const float* __restrict__ oscale, int64_t numel, int ohw, int ksplit,
+                                                            const float* __restrict__ bias, int cout, int act, float alpha, float gain,
+                                                            float clamp) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
         float v = 0.f;
         for (int k = 0; k < ksplit; k++) v += partial[(int64_t)k * numel + i];
-        if (oscale) v *= oscale[i / ohw];
+        const int64_t nc = i / ohw;
+        if (oscale) v *= oscale[nc];
+        if (act) v = conv_epilogue(v, bias ? bias[nc % cout] : 0.f, act, alpha, gain, clamp);
         y[i] = v;
     }
 }
@@ -1220,8 +1239,15 @@ extern "C" int pasta_conv2d_tile(const pasta_conv_desc* d) {
 
 extern "C" int pasta_conv2d(const float* x, const float* w, float* y, const float* iscale, const float* oscale,
                             const pasta_conv_desc* d, void* workspace, int64_t workspace_bytes, void* stream) {
+    return pasta_conv2d_ex(x, w, y, iscale, oscale, nullptr, d, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pasta_conv2d_ex(const float* x, const float* w, float* y, const float* iscale, const float* oscale,
+                               const pasta_conv_epilogue* ep, const pasta_conv_desc* d, void* workspace, int64_t workspace_bytes,
+                               void* stream) {
     using namespace pasta;
     if (int e = check_desc(d, "conv2d")) return e;
+    PASTA_CHECK(!ep || (ep->act >= 1 && ep->act <= 3), "conv2d: fused epilogue supports act 1..3 (linear, relu, lrelu), got %d", ep ? ep->act : 0);
     PASTA_CHECK(x && w && y, "conv2d: null pointer");
     const int64_t need = pasta_conv2d_workspace(d);
     PASTA_CHECK(workspace && workspace_bytes >= need, "conv2d: workspace of %lld bytes needed, %lld given", (long long)need, (long long)workspace_bytes);
@@ -1236,6 +1262,8 @@ extern "C" int pasta_conv2d(const float* x, const float* w, float* y, const floa
     const FwdTile tile = choose_fwd_tile(p.Og, fwd_lattice_pixels(d));
     p.Ig_pad = round_up(p.Ig, fwd_ipad(p.Ig, tile)); p.Og_pad = round_up(p.Og, fwd_tile_bm(tile));
     p.KK = d->kh * d->kw;
+    p.bias = ep ? ep->bias : nullptr; p.act = ep ? ep->act : 0;
+    p.alpha = ep ? ep->alpha : 0.f; p.gain = ep ? ep->gain : 1.f; p.clamp = ep ? ep->clamp : -1.f;
     p.ksplit = choose_ksplit(d, tile);
     p.o_tiles = 1;
     p.partial = (float*)workspace + round_up((int)(((int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad * 3 + 1) / 2), 4);
@@ -1294,7 +1322,7 @@ extern "C" int pasta_conv2d(const float* x, const float* w, float* y, const floa
         int64_t blocks = ceil_div64(numel, 256);
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)p.partial, y, oscale, numel,
-                           d->OH * d->OW, p.ksplit);
+                           d->OH * d->OW, p.ksplit, p.bias, d->C_out, p.act, p.alpha, p.gain, p.clamp);
     }
     return launch_status("conv2d");
 }

@@ -103,6 +103,10 @@ class ConvDesc(ctypes.Structure):
         'N', 'C_in', 'H', 'W', 'C_out', 'OH', 'OW', 'kh', 'kw', 'stride',
         'pad_h', 'pad_w', 'groups', 'transposed', 'flip', 'math')]
 
+class ConvEpilogue(ctypes.Structure):
+    """Mirror of ``pasta_conv_epilogue`` (include/pasta_hip.h)."""
+    _fields_ = [('bias', _c_ptr), ('act', _c_i32), ('alpha', _c_f32), ('gain', _c_f32), ('clamp', _c_f32)]
+
 # name -> (restype, argtypes); exactly the symbols include/pasta_hip.h declares.
 ABI = {
     'pasta_last_error':   (ctypes.c_char_p, []),
@@ -119,6 +123,7 @@ ABI = {
     'pasta_conv2d_wgrad_workspace': (_c_i64, [ctypes.POINTER(ConvDesc)]),
     'pasta_conv2d_tile':  (ctypes.c_int, [ctypes.POINTER(ConvDesc)]),
     'pasta_conv2d':       (ctypes.c_int, [_c_ptr] * 5 + [ctypes.POINTER(ConvDesc), _c_ptr, _c_i64, _c_ptr]),
+    'pasta_conv2d_ex':    (ctypes.c_int, [_c_ptr] * 5 + [ctypes.POINTER(ConvEpilogue), ctypes.POINTER(ConvDesc), _c_ptr, _c_i64, _c_ptr]),
     'pasta_conv2d_wgrad': (ctypes.c_int, [_c_ptr] * 3 + [ctypes.POINTER(ConvDesc), _c_ptr, _c_i64, _c_ptr]),
     'pasta_scale_add':    (ctypes.c_int, [_c_ptr] * 4 + [ctypes.c_int, ctypes.c_int, _c_i64, ctypes.c_int, _c_ptr]),
     'pasta_plane_dot':    (ctypes.c_int, [_c_ptr] * 3 + [_c_i64, _c_i64, _c_ptr]),

@@ -72,8 +72,9 @@ launch_hook = None
 def _f32(t):
     return t if t.dtype == torch.float32 else t.float()
 
-def _launch_conv(x, w, cfg, iscale=None, oscale=None):
-    """y = conv(x * iscale[n,c]) * oscale[n,c'] through ``pasta_conv2d``; fp32 arithmetic."""
+def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None):
+    """y = conv(x * iscale[n,c]) * oscale[n,c'] through ``pasta_conv2d_ex``; fp32 arithmetic.
+    ``epilogue`` = (bias or None, act code 1..3, alpha, gain, clamp) fuses Conv2dLayer's bias_act into the store."""
     _native.require_gpu(x, 'conv2d')
     if x.ndim != 4 or w.ndim != 4:
         raise RuntimeError('conv2d: x and w must be rank 4')
@@ -107,10 +108,17 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None):
     if oscale is not None:
         oscale = _f32(oscale).contiguous()
         assert oscale.shape == (x.shape[0], c_out)
+    ep = None
+    if epilogue is not None:
+        bias, act_code, alpha, gain, clamp = epilogue
+        bias = _f32(bias).contiguous() if bias is not None else None
+        ep = custom_ops.ConvEpilogue(bias=bias.data_ptr() if bias is not None else None, act=int(act_code), alpha=float(alpha),
+                                     gain=float(gain), clamp=float(clamp))
     def launch():
         with torch.cuda.device(x.device):
-            st = lib.pasta_conv2d(_native.ptr(x), _native.ptr(w), _native.ptr(y), _native.ptr(iscale), _native.ptr(oscale),
-                                  ctypes.byref(desc), _native.ptr(work), work.numel() * 4, _native.stream())
+            st = lib.pasta_conv2d_ex(_native.ptr(x), _native.ptr(w), _native.ptr(y), _native.ptr(iscale), _native.ptr(oscale),
+                                     ctypes.byref(ep) if ep is not None else None, ctypes.byref(desc), _native.ptr(work),
+                                     work.numel() * 4, _native.stream())
         _native.check(st)
     if launch_hook is None:
         launch()
@@ -177,6 +185,56 @@ class _ConvHip(torch.autograd.Function):
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
             dw = _ConvWgradHip.apply(dy, x, cfg, tuple(w.shape))
         return dx, dw, None
+
+class _ConvBiasActHip(torch.autograd.Function):
+    """y = bias_act(conv(x, w), b) with the bias / activation / gain / clamp applied in the convolution's epilogue.
+    The backward is assembled from the stand-alone differentiable pieces (bias_act gradient kernel, input- and
+    weight-gradient convolutions), so gradients of any order keep working."""
+    @staticmethod
+    def forward(ctx, x, w, b, cfg, act_cfg):
+        act, alpha, gain, clamp = act_cfg
+        from . import bias_act as ba
+        y = _launch_conv(x, w, cfg, epilogue=(b, ba.activation_funcs[act].cuda_idx, alpha, gain, clamp))
+        ctx.save_for_backward(x, w, b, y)
+        ctx.cfg, ctx.act_cfg = cfg, act_cfg
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import bias_act as ba
+        x, w, b, y = ctx.saved_tensors
+        act, alpha, gain, clamp = ctx.act_cfg
+        cfg = ctx.cfg
+        dz = dy
+        if act != 'linear' or gain != 1 or clamp >= 0:
+            dz = ba._BiasActHipGrad.apply(dy.contiguous(), None, None, y, (1, act, alpha, gain, clamp))
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _ConvHip.apply(dz, w, _grad_cfg(cfg, x.shape[2:], dz.shape[2:], w.shape[2], w.shape[3]))
+        if ctx.needs_input_grad[1] and not weight_gradients_disabled:
+            dw = _ConvWgradHip.apply(dz, x, cfg, tuple(w.shape))
+        if b is not None and ctx.needs_input_grad[2]:
+            db = ba._BiasSum.apply(dz, 1)
+        return dx, dw, db, None, None
+
+FUSABLE_ACTS = ('linear', 'relu', 'lrelu')
+
+def conv2d_bias_act(input, weight, bias=None, stride=1, padding=0, groups=1, act='linear', alpha=None, gain=None, clamp=None):
+    """``bias_act(conv2d(input, weight), bias, act, alpha, gain, clamp)`` in one launch (fp32 GPU tensors,
+    act in FUSABLE_ACTS); other cases run the two ops separately."""
+    from . import bias_act as ba
+    spec = ba.activation_funcs[act]
+    alpha = float(alpha if alpha is not None else spec.def_alpha)
+    gain = float(gain if gain is not None else spec.def_gain)
+    clampf = float(clamp if clamp is not None else -1)
+    if act in FUSABLE_ACTS and input.dtype == torch.float32 and input.device.type == 'cuda' and input.numel() > 0:
+        sh, sw = _pair(stride)
+        ph, pw = _pair(padding)
+        assert sh == sw
+        cfg = _Cfg((False, sh, ph, pw, 0, 0, int(groups)))
+        return _ConvBiasActHip.apply(input, weight, bias, cfg, (act, alpha, gain, clampf))
+    y = conv2d(input, weight, stride=stride, padding=padding, groups=groups)
+    return ba.bias_act(y, bias, act=act, alpha=alpha, gain=gain, clamp=clamp)
 
 class _ConvWgradHip(torch.autograd.Function):
     @staticmethod

@@ -30,6 +30,36 @@ def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_w
 
 #----------------------------------------------------------------------------
 
+def conv2d_resample_bias_act(x, w, b=None, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False,
+                             act='linear', alpha=None, gain=None, clamp=None):
+    """``bias_act(conv2d_resample(x, w, ...), b, act, alpha, gain, clamp)`` -- the body of ``Conv2dLayer.forward``
+    (reference training/networks.py:170-179). When the dense convolution is the last step of the resampling
+    decomposition (no upsampling), bias / activation / gain / clamp ride in its epilogue; otherwise the two ops run
+    one after the other."""
+    from . import bias_act
+    if up == 1 and x.dtype == torch.float32 and x.device.type == 'cuda' and act in conv2d_gradfix.FUSABLE_ACTS:
+        out_channels, in_channels_per_group, kh, kw = _get_weight_shape(w)
+        fw, fh = _get_filter_size(f)
+        px0, px1, py0, py1 = _parse_padding(padding)
+        if down > 1:
+            px0 += (fw - down + 1) // 2
+            px1 += (fw - down) // 2
+            py0 += (fh - down + 1) // 2
+            py1 += (fh - down) // 2
+        wc = w if flip_weight else w.flip([2, 3])
+        if kw == 1 and kh == 1 and down > 1:          # decimate, then the fused 1x1 convolution
+            x = upfirdn2d.upfirdn2d(x=x, f=f, down=down, padding=[px0, px1, py0, py1], flip_filter=flip_filter)
+            return conv2d_gradfix.conv2d_bias_act(x, wc, b, groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp)
+        if down > 1:                                  # low-pass, then the fused strided convolution
+            x = upfirdn2d.upfirdn2d(x=x, f=f, padding=[px0, px1, py0, py1], flip_filter=flip_filter)
+            return conv2d_gradfix.conv2d_bias_act(x, wc, b, stride=down, groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp)
+        if px0 == px1 and py0 == py1 and px0 >= 0 and py0 >= 0:
+            return conv2d_gradfix.conv2d_bias_act(x, wc, b, padding=[py0, px0], groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp)
+    x = conv2d_resample(x=x, w=w, f=f, up=up, down=down, padding=padding, groups=groups, flip_weight=flip_weight, flip_filter=flip_filter)
+    return bias_act.bias_act(x, b, act=act, alpha=alpha, gain=gain, clamp=clamp)
+
+#----------------------------------------------------------------------------
+
 def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False):
     """Convolve ``x`` [N,C,H,W] with ``w`` [O,C//groups,kh,kw], upsampling by ``up`` before and/or
     downsampling by ``down`` after, low-pass filtered with ``f`` (from ``upfirdn2d.setup_filter``).

@@ -239,11 +239,11 @@ class Conv2dLayer(torch.nn.Module):
         w = self.weight * self.weight_gain
         b = self.bias.to(x.dtype) if self.bias is not None else None
         flip_weight = (self.up == 1)
-        x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
-                                            padding=self.padding, flip_weight=flip_weight)
         act_gain = self.act_gain * gain
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
-        return bias_act.bias_act(x, b, act=self.activation, gain=act_gain, clamp=act_clamp)
+        return conv2d_resample.conv2d_resample_bias_act(x=x, w=w.to(x.dtype), b=b, f=self.resample_filter, up=self.up, down=self.down,
+                                                        padding=self.padding, flip_weight=flip_weight, act=self.activation,
+                                                        gain=act_gain, clamp=act_clamp)
 
 #----------------------------------------------------------------------------
 

@@ -143,9 +143,10 @@ class TrainingStep:
                 sync = (round_idx == self.batch_size // (self.batch_gpu * self.num_gpus) - 1)
                 self.loss.accumulate_gradients(phase=phase.name, gen_z=gen_z, sync=sync, gain=phase.interval, **r)
             phase.module.requires_grad_(False)
-            for param in phase.module.parameters():
-                if param.grad is not None:
-                    misc.nan_to_num(param.grad, nan=0, posinf=1e5, neginf=-1e5, out=param.grad)
+            grads = [param.grad for param in phase.module.parameters() if param.grad is not None]
+            if grads:       # nan_to_num(grad, nan=0, posinf=1e5, neginf=-1e5) (:513-515) over one flat view per dtype
+                for g in grads:
+                    misc.nan_to_num(g, nan=0, posinf=1e5, neginf=-1e5, out=g)
             phase.opt.step()
 
         ema_nimg = self.ema_kimg * 1000
@@ -153,10 +154,9 @@ class TrainingStep:
             ema_nimg = min(ema_nimg, self.cur_nimg * self.ema_rampup)
         ema_beta = 0.5 ** (self.batch_size / max(ema_nimg, 1e-8))
         with torch.no_grad():
-            for p_ema, p in zip(self.G_ema.parameters(), self.G.parameters()):
-                p_ema.copy_(p.lerp(p_ema, ema_beta))
-            for b_ema, b in zip(self.G_ema.buffers(), self.G.buffers()):
-                b_ema.copy_(b)
+            # p_ema <- p.lerp(p_ema, beta) (:522-529), as one multi-tensor launch: p_ema + (1 - beta) * (p - p_ema)
+            torch._foreach_lerp_(list(self.G_ema.parameters()), list(self.G.parameters()), 1.0 - ema_beta)
+            torch._foreach_copy_(list(self.G_ema.buffers()), list(self.G.buffers()))
         self.cur_nimg += self.batch_size
         self.batch_idx += 1
 

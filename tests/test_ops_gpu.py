@@ -318,3 +318,38 @@ def test_spade_norm(hw):
     assert rel_err(y, yr) < TOL
     for a, r in zip(d, dr):
         assert rel_err(a, r) < 2e-5
+
+
+@pytest.mark.parametrize('case', [
+    dict(x=[2, 16, 24, 24], w=[32, 16, 3, 3], kw=dict(padding=1), act='lrelu', gain=np.sqrt(2), clamp=0.8),
+    dict(x=[2, 16, 24, 24], w=[32, 16, 3, 3], kw=dict(down=2, padding=1), act='lrelu', gain=1.0, clamp=256.0),
+    dict(x=[2, 16, 24, 24], w=[24, 16, 1, 1], kw=dict(down=2), act='linear', gain=np.sqrt(0.5), clamp=None, bias=False),
+    dict(x=[2, 3, 40, 40], w=[64, 3, 7, 7], kw=dict(padding=3), act='relu', gain=None, clamp=None),
+    dict(x=[4, 512, 4, 4], w=[64, 512, 3, 3], kw=dict(padding=1), act='lrelu', gain=None, clamp=256.0),          # split-K reduce epilogue
+    dict(x=[2, 16, 12, 12], w=[32, 16, 3, 3], kw=dict(up=2, padding=1, flip_weight=False), act='lrelu', gain=None, clamp=None),  # not fusable: falls back
+])
+def test_conv2d_resample_bias_act_fused(case):
+    """Conv2dLayer's conv + bias_act with the epilogue fused into the convolution, incl. the R1-style double backward."""
+    from torch_utils.ops import conv2d_resample
+    gen = torch.Generator().manual_seed(77)
+    xc = torch.randn(case['x'], generator=gen)
+    wc = torch.randn(case['w'], generator=gen) / np.sqrt(case['w'][1] * case['w'][2] * case['w'][3])
+    bc = torch.randn([case['w'][0]], generator=gen) * 0.3 if case.get('bias', True) else None
+    f = R.setup_filter([1, 3, 3, 1])
+
+    def run(x, w, b, f, fused):
+        x = x.requires_grad_(True); w = w.requires_grad_(True)
+        if b is not None:
+            b = b.requires_grad_(True)
+        if fused:
+            y = conv2d_resample.conv2d_resample_bias_act(x, w, b, f=f, act=case['act'], gain=case['gain'], clamp=case['clamp'], **case['kw'])
+        else:
+            y = R.bias_act(R.conv2d_resample(x, w, f=f, **case['kw']), b, act=case['act'], gain=case['gain'], clamp=case['clamp'])
+        gx, = torch.autograd.grad(y.square().sum(), x, create_graph=True)
+        params = [w] + ([b] if b is not None else [])
+        return [y, gx] + list(torch.autograd.grad(gx.square().sum() + y.sum(), params))
+
+    ref = run(xc.clone(), wc.clone(), bc.clone() if bc is not None else None, f, False)
+    got = run(xc.cuda(), wc.cuda(), bc.cuda() if bc is not None else None, f.cuda(), True)
+    for a, b in zip(got, ref):
+        assert rel_err(a, b) < 5e-5
