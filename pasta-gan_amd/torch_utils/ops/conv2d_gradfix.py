@@ -195,7 +195,10 @@ class _ConvBiasActHip(torch.autograd.Function):
         act, alpha, gain, clamp = act_cfg
         from . import bias_act as ba
         y = _launch_conv(x, w, cfg, epilogue=(b, ba.activation_funcs[act].cuda_idx, alpha, gain, clamp))
-        ctx.save_for_backward(x, w, b, y)
+        # y is needed by the backward only as the activation / clamp mask; a linear, unclamped layer (the residual
+        # skips, whose output the blocks then update in place) must not pin it
+        keep_y = act != 'linear' or clamp >= 0
+        ctx.save_for_backward(x, w, b, y if keep_y else None)
         ctx.cfg, ctx.act_cfg = cfg, act_cfg
         return y
 
