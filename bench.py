@@ -31,6 +31,7 @@ BF16X6 = 'conv_fwd_bf16x6_kernel'
 
 TILE_NAMES = {0: 'conv_fwd_kernel<128,128,2,2,8,4>', 1: 'conv_fwd_kernel<64,256,2,2,8,4>',
               2: 'conv_fwd_kernel<32,256,1,2,8>', 3: 'conv_fwd_kernel<64,64,1,1,8>'}
+WGRAD_NAMES = {0: 'conv_wgrad_kernel', 1: 'conv_wgrad_smallcin_kernel', 2: 'conv_wgrad3x3_bf16x6_kernel'}
 
 
 class ConvMeter:
@@ -50,13 +51,14 @@ class ConvMeter:
         macs = desc.N * desc.C_out * (desc.C_in // g) * desc.kh * desc.kw
         macs *= (desc.H * desc.W) if desc.transposed else (desc.OH * desc.OW)
         if kind == 'conv':
-            tile = self.lib.pasta_conv2d_tile(ctypes.byref(desc))
-            family = TILE_NAMES[tile]
-            if tile == 0 and desc.math != 1 and desc.C_in // g >= 16:
-                family = BF16X6
+            tile, ksplit, math = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            self.lib.pasta_conv2d_plan(ctypes.byref(desc), 0, ctypes.byref(tile), ctypes.byref(ksplit), ctypes.byref(math))
+            family = BF16X6 if math.value == 2 else TILE_NAMES[tile.value]      # the networks never pass iscale
             kernels = desc.stride * desc.stride if desc.transposed else 1
         else:
-            family = 'conv_wgrad_kernel'
+            which = ctypes.c_int()
+            self.lib.pasta_conv2d_wgrad_plan(ctypes.byref(desc), ctypes.byref(which))
+            family = WGRAD_NAMES[which.value]
             kernels = 1
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
@@ -239,7 +241,7 @@ def main():
             name, f = dom
             achieved = f['flops'] / (f['ms'] * 1e-3) / 1e12
             traffic, src = pmc_traffic(name)
-            if name == BF16X6:
+            if name in (BF16X6, WGRAD_NAMES[2]):
                 # six bf16 MFMA products per fp32-equivalent multiply-add: the matrix pipes execute 6x the algorithmic FLOPs
                 peak = PEAK_BF16_MFMA_TFLOPS / 6
                 note = ('split-bf16: fp32-equivalent products from 6 x v_mfma_f32_32x32x16_bf16, fp32 accumulate; peak = 2500 TFLOP/s '

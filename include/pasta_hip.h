@@ -100,8 +100,9 @@ typedef struct pasta_conv_desc {
  *   PASTA_MATH_F32    v_mfma_f32_32x32x2_f32: every product and sum is an fp32 FMA (bit-exact fp32 chains).
  *   PASTA_MATH_BF16X6 each fp32 operand is split into three bf16 pieces (24 significand bits) and a*b is formed
  *                     from six exact bf16 x bf16 products on v_mfma_f32_32x32x16_bf16: fp32-equivalent accuracy
- *                     (dropped terms < 2^-22 |ab|) at 2.67x the fp32 matrix-core rate.  Used by the 128x128-tile
- *                     forward / input-gradient launches; all other launches run PASTA_MATH_F32.
+ *                     (dropped terms < 2^-22 |ab|) at 2.67x the fp32 matrix-core rate.  Used by the 128x128- and
+ *                     64x256-tile forward / input-gradient launches with >= 16 input channels per group and
+ *                     by the 3x3 stride-1 weight gradient; all other launches run PASTA_MATH_F32.
  *   PASTA_MATH_DEFAULT = PASTA_MATH_BF16X6. */
 enum { PASTA_MATH_DEFAULT = 0, PASTA_MATH_F32 = 1, PASTA_MATH_BF16X6 = 2 };
 
@@ -112,6 +113,17 @@ int64_t pasta_conv2d_wgrad_workspace(const pasta_conv_desc* d);
 /* Which forward-type kernel instance the launch will use: 0 = 128x128 tile, 1 = 64x256,
  * 2 = 32x256, 3 = 64x64 (rows = output channels, columns = pixels).  Reporting only. */
 int pasta_conv2d_tile(const pasta_conv_desc* d);
+
+/* The full launch plan of pasta_conv2d(_ex) for d, for reporting (bench.py attributes time and FLOPs to kernel
+ * families with it): *tile as pasta_conv2d_tile, *ksplit = number of K slices (> 1: partial sums in the workspace,
+ * reduced by a second kernel), *math = PASTA_MATH_F32 or PASTA_MATH_BF16X6 actually used (has_iscale != 0 says the
+ * launch passes an iscale vector, which the split-bf16 kernel does not take).  Any out pointer may be NULL. */
+int pasta_conv2d_plan(const pasta_conv_desc* d, int has_iscale, int* tile, int* ksplit, int* math);
+
+/* Same for pasta_conv2d_wgrad: *kernel = 0 conv_wgrad_kernel (fp32 MFMA, taps x 64 x 64 tiles), 1
+ * conv_wgrad_smallcin_kernel (<= 8 input channels: (channel, tap) pairs as GEMM columns), 2
+ * conv_wgrad3x3_bf16x6_kernel (split-bf16; 3x3, stride 1, pad 1, row length a multiple of 32). */
+int pasta_conv2d_wgrad_plan(const pasta_conv_desc* d, int* kernel);
 
 /* y = conv(x, w).  w is the PyTorch-layout weight ([C_out, C_in/g, kh, kw], or
  * [C_in, C_out/g, kh, kw] when transposed).  Optional fused epilogue:

@@ -275,12 +275,6 @@ static int fwd_variant() {
     return v;
 }
 
-static FwdTile choose_fwd_tile(int Og, int64_t npix) {
-    if (Og <= 32) return T32x256;        // ToRGB / parsing heads: HBM-bound, few rows
-    if (npix <= 8192) return T64x64;     // 4..16 pixel layers: more, smaller workgroups
-    if (Og <= 64) return T64x256;
-    return T128x128;
-}
 static int fwd_tile_bm(FwdTile t) { return t == T128x128 ? 128 : t == T32x256 ? 32 : 64; }
 
 //------------------------------------------------------------------------------------
@@ -337,15 +331,20 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __r
     }
 }
 
-template <int OCC>
+template <int BM, int BN, int OCC>      // (128, 128): waves 2 x 2;  (64, 256): waves 1 x 4; each wave 64 rows x 64 pixels
 __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams p) {
-    constexpr int BM = 128, BN = 128, WMT = 2, WNT = 2, KC = 16;
-    constexpr int SEG = BM * 8;                         // bf16 elements of one (piece, half) segment
-    __shared__ __attribute__((aligned(16))) __bf16 As[2][6 * SEG];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][6 * SEG];
+    constexpr int WMT = 2, WNT = 2, KC = 16;
+    constexpr int WAVES_N = BN / 64;
+    static_assert((BM / 64) * WAVES_N == 4, "four waves per workgroup");
+    constexpr int ASEG = BM * 8, BSEG = BN * 8;         // bf16 elements of one (piece, half) segment
+    constexpr int AUNITS = 6 * BM;                      // sixteen-byte units of the A chunk
+    constexpr int APT = (AUNITS + 255) / 256;           // per thread: 3 (BM 128) or 2 (BM 64, second one guarded)
+    constexpr int BPT = BN * 2 / 256;                   // (pixel, k-half) pairs per thread: 1 or 2
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][6 * ASEG];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][6 * BSEG];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int g = blockIdx.z;
     const int ks = blockIdx.y / p.o_tiles;
     const int o_blk = (blockIdx.y - ks * p.o_tiles) * BM;
@@ -357,8 +356,9 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     const int c_first = (int)((int64_t)chunks_all * ks / p.ksplit);
     const int nchunks = (int)((int64_t)chunks_all * (ks + 1) / p.ksplit) - c_first;
 
-    // B staging: pixel column and k-half of this thread, fixed for the whole K loop.
-    const int bcol = tid & (BN - 1), bhalf = tid >> 7;
+    // B staging: this thread's pixel column (fixed for the whole K loop) and its k-halves:
+    //   BN 128: one half, tid >> 7 (uniform per wave);  BN 256: both halves of pixel tid.
+    const int bcol = tid & (BN - 1);
     const int64_t mypix = pix_blk + bcol;
     const bool pix_ok = mypix < npix;
     int n_in = 0, py = 0, px = 0;
@@ -373,11 +373,11 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     const char* const xbytes = (const char*)p.x;
     const int iy_base = py * p.isy, ix_base = px * p.isx;
     const __bf16* wb = (const __bf16*)p.wp + (int64_t)g * p.KK * NC * 6 * p.Og_pad * 8;
-    const int bhalf_u = __builtin_amdgcn_readfirstlane(bhalf);      // uniform per wave (128 pixels = 2 waves per half)
+    const int half0 = BPT == 1 ? __builtin_amdgcn_readfirstlane(tid >> 7) : 0;
 
     // Two register sets: while chunk c is multiplied out of LDS, chunk c+1 (already in registers) is split into bf16
     // pieces and written to the other LDS buffer between the MFMAs, and chunk c+2 is being fetched.
-    struct Stage { float b[8]; float4 a0, a1, a2; int nvalid; };
+    struct Stage { float b[8 * BPT]; float4 a[APT]; int nvalid[BPT]; };
     Stage st0, st1;
     int ld_t = c_first / NC, ld_cc = c_first - ld_t * NC;
     bool ld_ok = false;
@@ -394,56 +394,64 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     // Loads are unconditional (clamped channel index, always-valid base) so that nothing waits on them before their
     // first use one iteration later; invalid elements are zeroed when they are split.
     auto load_chunk = [&](Stage& st) {
-        const int c0 = __builtin_amdgcn_readfirstlane(ld_cc) * KC + bhalf_u * 8;
+        const int cc = __builtin_amdgcn_readfirstlane(ld_cc);
         const int last = p.Ig - 1;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const unsigned coff = (unsigned)(c0 + j < last ? c0 + j : last) * (unsigned)HW * 4u;    // scalar
-            st.b[j] = *(const float*)(xbytes + (ld_pix + coff));
+        for (int i = 0; i < BPT; i++) {
+            const int c0 = cc * KC + (half0 + i) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const unsigned coff = (unsigned)(c0 + j < last ? c0 + j : last) * (unsigned)HW * 4u;    // scalar
+                st.b[8 * i + j] = *(const float*)(xbytes + (ld_pix + coff));
+            }
+            st.nvalid[i] = ld_ok ? p.Ig - c0 : 0;     // elements j < nvalid are real
         }
-        st.nvalid = ld_ok ? p.Ig - c0 : 0;       // elements j < nvalid are real
         const __bf16* wt = ld_wt + (int64_t)ld_cc * 6 * p.Og_pad * 8;
-        // 6 (piece, half) segments of 128 sixteen-byte units: this thread copies units tid, tid+256, tid+512
-        const int within = tid & 127, seg0 = tid >> 7;
-        st.a0 = *(const float4*)(wt + ((int64_t)(seg0) * p.Og_pad + o_blk + within) * 8);
-        st.a1 = *(const float4*)(wt + ((int64_t)(seg0 + 2) * p.Og_pad + o_blk + within) * 8);
-        st.a2 = *(const float4*)(wt + ((int64_t)(seg0 + 4) * p.Og_pad + o_blk + within) * 8);
+        // 6 (piece, half) segments of BM sixteen-byte units each; this thread copies units tid, tid + 256, ...
+#pragma unroll
+        for (int j = 0; j < APT; j++) {
+            const int e = tid + 256 * j, seg = e / BM, within = e - seg * BM;
+            if (e < AUNITS) st.a[j] = *(const float4*)(wt + ((int64_t)seg * p.Og_pad + o_blk + within) * 8);
+        }
         if (++ld_cc >= NC) {
             ld_cc = 0;
             if (++ld_t < p.T) set_tap(ld_t);
         }
     };
-    uint32_t q1[4], q2[4], q3[4];          // 8 bf16 per piece, packed two per dword
+    uint32_t q1[BPT][4], q2[BPT][4], q3[BPT][4];          // 8 bf16 per piece, packed two per dword
     // Two elements at a time: v_cvt_pk_bf16_f32 yields the packed pair, the residuals come from its halves.
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    auto split_pair = [&](const Stage& st, int j) {
-        float v0 = st.b[2 * j], v1 = st.b[2 * j + 1];
-        if (st.nvalid < 8) {                     // border pixel or channel tail
-            v0 = 2 * j < st.nvalid ? v0 : 0.f;
-            v1 = 2 * j + 1 < st.nvalid ? v1 : 0.f;
+    auto split_pair = [&](const Stage& st, int i, int j) {
+        float v0 = st.b[8 * i + 2 * j], v1 = st.b[8 * i + 2 * j + 1];
+        if (st.nvalid[i] < 8) {                  // border pixel or channel tail
+            v0 = 2 * j < st.nvalid[i] ? v0 : 0.f;
+            v1 = 2 * j + 1 < st.nvalid[i] ? v1 : 0.f;
         }
         f32x2 v = {v0, v1};
         uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-        q1[j] = w;
+        q1[i][j] = w;
         v[0] -= __builtin_bit_cast(float, w << 16);
         v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
         w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-        q2[j] = w;
+        q2[i][j] = w;
         v[0] -= __builtin_bit_cast(float, w << 16);
         v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
-        q3[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        q3[i][j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
     };
     auto store_b = [&](int buf) {
-        __bf16* bd = &Bs[buf][(bhalf * BN + bcol) * 8];
-        *(uint4*)(bd) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
-        *(uint4*)(bd + 2 * SEG) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
-        *(uint4*)(bd + 4 * SEG) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+#pragma unroll
+        for (int i = 0; i < BPT; i++) {
+            __bf16* bd = &Bs[buf][((half0 + i) * BN + bcol) * 8];
+            *(uint4*)(bd) = make_uint4(q1[i][0], q1[i][1], q1[i][2], q1[i][3]);
+            *(uint4*)(bd + 2 * BSEG) = make_uint4(q2[i][0], q2[i][1], q2[i][2], q2[i][3]);
+            *(uint4*)(bd + 4 * BSEG) = make_uint4(q3[i][0], q3[i][1], q3[i][2], q3[i][3]);
+        }
     };
     auto store_a = [&](const Stage& st, int buf) {
-        *(float4*)&As[buf][(tid) * 8] = st.a0;
-        *(float4*)&As[buf][(tid + 256) * 8] = st.a1;
-        *(float4*)&As[buf][(tid + 512) * 8] = st.a2;
+#pragma unroll
+        for (int j = 0; j < APT; j++)
+            if (tid + 256 * j < AUNITS) *(float4*)&As[buf][(tid + 256 * j) * 8] = st.a[j];
     };
 
     f32x16 acc[WMT][WNT];
@@ -471,26 +479,31 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
 #define PASTA_MM(PA, PB)                                                                                       \
         _Pragma("unroll") for (int a = 0; a < WMT; a++) _Pragma("unroll") for (int b = 0; b < WNT; b++)          \
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA], bf[b][PB], acc[a][b], 0, 0, 0);
+#define PASTA_SPLIT(J)                                                                                         \
+        if (have_next) { _Pragma("unroll") for (int i = 0; i < BPT; i++) split_pair(cur_next, i, J); }
         // smallest terms first: a3b1, a1b3, a2b2, a2b1, a1b2, a1b1
         PASTA_MM(2, 0)
-        if (have_next) split_pair(cur_next, 0);
+        PASTA_SPLIT(0)
         PASTA_MM(0, 2)
-        if (have_next) split_pair(cur_next, 1);
+        PASTA_SPLIT(1)
         PASTA_MM(1, 1)
-        if (have_next) split_pair(cur_next, 2);
+        PASTA_SPLIT(2)
         PASTA_MM(1, 0)
-        if (have_next) split_pair(cur_next, 3);
+        PASTA_SPLIT(3)
         PASTA_MM(0, 1)
         if (have_next) { store_b(buf ^ 1); store_a(cur_next, buf ^ 1); }
         PASTA_MM(0, 0)
 #undef PASTA_MM
+#undef PASTA_SPLIT
         __syncthreads();
     };
 
     if (nchunks > 0) {
         load_chunk(st0);
 #pragma unroll
-        for (int j = 0; j < 4; j++) split_pair(st0, j);
+        for (int i = 0; i < BPT; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) split_pair(st0, i, j);
         store_b(0); store_a(st0, 0);
         if (nchunks > 1) load_chunk(st0);       // chunk 1 waits in registers
     }
@@ -526,13 +539,13 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     }
 }
 
+template <int BM, int BN>
 static void launch_fwd_bf16x6(const ConvFwdParams& p, hipStream_t s) {
     const int64_t npix = (int64_t)p.N * p.P * p.Q;
     ConvFwdParams q = p;
-    q.o_tiles = (p.Og + 127) / 128;
-    dim3 grid((unsigned)ceil_div64(npix, 128), q.o_tiles * q.ksplit, p.G);
-    if (fwd_variant() == 5) hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<3>), grid, dim3(256), 0, s, q);
-    else hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<2>), grid, dim3(256), 0, s, q);
+    q.o_tiles = (p.Og + BM - 1) / BM;
+    dim3 grid((unsigned)ceil_div64(npix, BN), q.o_tiles * q.ksplit, p.G);
+    hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<BM, BN, 2>), grid, dim3(256), 0, s, q);
 }
 
 constexpr int FWD_KC = 8;
@@ -542,7 +555,7 @@ static int fwd_ipad(int Ig, FwdTile t) { return (Ig <= 4 && t == T64x256) ? 4 : 
 static void dispatch_fwd(FwdTile t, const ConvFwdParams& p, hipStream_t s) {
     switch (t) {
         case T128x128:
-            if (p.bf16x6) { launch_fwd_bf16x6(p, s); break; }
+            if (p.bf16x6) { launch_fwd_bf16x6<128, 128>(p, s); break; }
             switch (fwd_variant()) {
                 case 1:  launch_fwd<128, 128, 2, 2, 8, 1>(p, s); break;
                 case 2:  launch_fwd<128, 256, 2, 4, 8>(p, s); break;
@@ -551,6 +564,7 @@ static void dispatch_fwd(FwdTile t, const ConvFwdParams& p, hipStream_t s) {
             }
             break;
         case T64x256:
+            if (p.bf16x6) { launch_fwd_bf16x6<64, 256>(p, s); break; }
             if (p.Ig_pad == 4) launch_fwd<64, 256, 2, 2, 4>(p, s);      // RGB stems: 4-channel K chunks
             else launch_fwd<64, 256, 2, 2, FWD_KC, 4>(p, s);
             break;
@@ -577,18 +591,37 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 // K slices for launches that would leave most CUs idle (the 4..17 pixel layers: K = 9*512 against <= 4624 pixels).
-static int choose_ksplit(const pasta_conv_desc* d, FwdTile tile) {
-    if (tile != T64x64) return 1;
+static int64_t fwd_lattice_pixels(const pasta_conv_desc* d) {
+    if (!d->transposed) return (int64_t)d->N * d->OH * d->OW;
+    return (int64_t)d->N * ((d->OH + d->stride - 1) / d->stride) * ((d->OW + d->stride - 1) / d->stride);
+}
+
+// Which kernel a forward-type launch uses: the tile, the number of K slices, and whether the split-bf16 kernel may
+// run (it also needs iscale == nullptr, known only at launch).
+struct FwdPlan { FwdTile tile; int ksplit; int bf16x6; };
+
+static FwdPlan plan_fwd(const pasta_conv_desc* d) {
     const int Og = d->C_out / d->groups, Ig = d->C_in / d->groups;
-    const int64_t npix = d->transposed ? (int64_t)d->N * ((d->OH + d->stride - 1) / d->stride) * ((d->OW + d->stride - 1) / d->stride)
-                                        : (int64_t)d->N * d->OH * d->OW;
-    const int64_t blocks = ceil_div64(npix, 64) * ((Og + 63) / 64) * d->groups;
-    const int taps = d->transposed ? (d->kh * d->kw + d->stride * d->stride - 1) / (d->stride * d->stride) : d->kh * d->kw;
-    const int64_t chunks = (int64_t)taps * round_up(Ig, 16) / 8;
-    int64_t ks = 768 / (blocks > 0 ? blocks : 1);
-    if (ks > chunks / 8) ks = chunks / 8;
-    if (ks > 32) ks = 32;
-    return ks < 2 ? 1 : (int)ks;
+    const int64_t npix = fwd_lattice_pixels(d);
+    const bool sb = d->math != PASTA_MATH_F32 && Ig >= 16 && (int64_t)d->N * d->C_in * d->H * d->W < (1ll << 30);
+    FwdPlan f;
+    if (Og <= 32) f.tile = T32x256;                                   // ToRGB / parsing heads: HBM-bound, few rows
+    else if (npix <= 8192) f.tile = (sb && Og > 64) ? T128x128 : T64x64;     // 4..16 pixel layers: K is sliced to fill the chip
+    else if (Og <= 64) f.tile = T64x256;
+    else f.tile = T128x128;
+    f.bf16x6 = sb && (f.tile == T128x128 || f.tile == T64x256);
+    f.ksplit = 1;
+    if (npix <= 8192 && f.tile != T32x256) {
+        const int bm = fwd_tile_bm(f.tile), bn = f.tile == T64x64 ? 64 : 128;
+        const int64_t blocks = ceil_div64(npix, bn) * ((Og + bm - 1) / bm) * d->groups;
+        const int taps = d->transposed ? (d->kh * d->kw + d->stride * d->stride - 1) / (d->stride * d->stride) : d->kh * d->kw;
+        const int64_t k_total = (int64_t)taps * round_up(Ig, 16);
+        int64_t ks = (f.tile == T64x64 ? 768 : 512) / (blocks > 0 ? blocks : 1);
+        if (ks > k_total / 64) ks = k_total / 64;                     // at least 64 channel-taps per slice
+        if (ks > 32) ks = 32;
+        f.ksplit = ks < 2 ? 1 : (int)ks;
+    }
+    return f;
 }
 
 //------------------------------------------------------------------------------------
@@ -1209,11 +1242,6 @@ static int check_desc(const pasta_conv_desc* d, const char* who) {
     return 0;
 }
 
-static int64_t fwd_lattice_pixels(const pasta_conv_desc* d) {
-    if (!d->transposed) return (int64_t)d->N * d->OH * d->OW;
-    return (int64_t)d->N * ((d->OH + d->stride - 1) / d->stride) * ((d->OW + d->stride - 1) / d->stride);
-}
-
 }  // namespace pasta
 
 //------------------------------------------------------------------------------------
@@ -1223,8 +1251,9 @@ extern "C" int64_t pasta_conv2d_workspace(const pasta_conv_desc* d) {
     using namespace pasta;
     if (check_desc(d, "conv2d_workspace")) return -1;
     const int Ig = d->C_in / d->groups, Og = d->C_out / d->groups;
-    const FwdTile t = choose_fwd_tile(Og, fwd_lattice_pixels(d));
-    const int ks = choose_ksplit(d, t);
+    const FwdPlan f = plan_fwd(d);
+    const FwdTile t = f.tile;
+    const int ks = f.ksplit;
     // packed weights: fp32 (4 B) or three bf16 pieces (6 B) per element; sized for the larger, in floats
     const int64_t pack = ((int64_t)d->groups * d->kh * d->kw * round_up(Ig, fwd_ipad(Ig, t)) * round_up(Og, fwd_tile_bm(t)) * 3 + 1) / 2;
     const int64_t partial = ks > 1 ? (int64_t)ks * d->N * d->C_out * d->OH * d->OW : 0;
@@ -1234,7 +1263,17 @@ extern "C" int64_t pasta_conv2d_workspace(const pasta_conv_desc* d) {
 extern "C" int pasta_conv2d_tile(const pasta_conv_desc* d) {
     using namespace pasta;
     if (check_desc(d, "conv2d_tile")) return -1;
-    return (int)choose_fwd_tile(d->C_out / d->groups, fwd_lattice_pixels(d));
+    return (int)plan_fwd(d).tile;
+}
+
+extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int has_iscale, int* tile, int* ksplit, int* math) {
+    using namespace pasta;
+    if (int e = check_desc(d, "conv2d_plan")) return e;
+    const FwdPlan f = plan_fwd(d);
+    if (tile) *tile = (int)f.tile;
+    if (ksplit) *ksplit = f.ksplit;
+    if (math) *math = (f.bf16x6 && !has_iscale) ? PASTA_MATH_BF16X6 : PASTA_MATH_F32;
+    return 0;
 }
 
 extern "C" int pasta_conv2d(const float* x, const float* w, float* y, const float* iscale, const float* oscale,
@@ -1259,16 +1298,16 @@ extern "C" int pasta_conv2d_ex(const float* x, const float* w, float* y, const f
     p.N = d->N; p.Cin = d->C_in; p.H = d->H; p.W = d->W;
     p.Cout = d->C_out; p.OH = d->OH; p.OW = d->OW;
     p.G = d->groups; p.Ig = d->C_in / d->groups; p.Og = d->C_out / d->groups;
-    const FwdTile tile = choose_fwd_tile(p.Og, fwd_lattice_pixels(d));
+    const FwdPlan plan = plan_fwd(d);
+    const FwdTile tile = plan.tile;
     p.Ig_pad = round_up(p.Ig, fwd_ipad(p.Ig, tile)); p.Og_pad = round_up(p.Og, fwd_tile_bm(tile));
     p.KK = d->kh * d->kw;
     p.bias = ep ? ep->bias : nullptr; p.act = ep ? ep->act : 0;
     p.alpha = ep ? ep->alpha : 0.f; p.gain = ep ? ep->gain : 1.f; p.clamp = ep ? ep->clamp : -1.f;
-    p.ksplit = choose_ksplit(d, tile);
+    p.ksplit = plan.ksplit;
     p.o_tiles = 1;
     p.partial = (float*)workspace + round_up((int)(((int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad * 3 + 1) / 2), 4);
-    p.bf16x6 = (d->math != PASTA_MATH_F32 && tile == T128x128 && p.Ig >= 16 && !iscale &&
-                (int64_t)d->N * d->C_in * d->H * d->W < (1ll << 30)) ? 1 : 0;
+    p.bf16x6 = (plan.bf16x6 && !iscale) ? 1 : 0;
 
     {   // pack weights
         const int64_t total = (int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad;
@@ -1325,6 +1364,31 @@ extern "C" int pasta_conv2d_ex(const float* x, const float* w, float* y, const f
                            d->OH * d->OW, p.ksplit, p.bias, d->C_out, p.act, p.alpha, p.gain, p.clamp);
     }
     return launch_status("conv2d");
+}
+
+namespace pasta {
+// The split-bf16 weight-gradient kernel covers 3x3, stride 1, pad 1, rows of a multiple of 32 pixels.
+static bool wgrad_bf16x6(const pasta_conv_desc* d, const WgradPlan& w) {
+    const int P = d->transposed ? d->H : d->OH, Q = d->transposed ? d->W : d->OW;
+    const int LH = d->transposed ? d->OH : d->H, LW = d->transposed ? d->OW : d->W;
+    return d->math != PASTA_MATH_F32 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 &&
+           Q % 32 == 0 && LH == P && LW == Q && w.kp == 32 && w.cw_log2 == 5;
+}
+}  // namespace pasta
+
+extern "C" int pasta_conv2d_wgrad_plan(const pasta_conv_desc* d, int* kernel) {
+    using namespace pasta;
+    if (int e = check_desc(d, "conv2d_wgrad_plan")) return e;
+    const int Ig = d->C_in / d->groups, Og = d->C_out / d->groups;
+    int k = 0;
+    if (plan_wgrad_small(d).use) k = 1;
+    else {
+        const WgradPlan w = d->transposed ? plan_wgrad(d->N, d->H, d->W, d->groups, Ig, Og, d->kh, d->kw, d->stride)
+                                          : plan_wgrad(d->N, d->OH, d->OW, d->groups, Og, Ig, d->kh, d->kw, d->stride);
+        if (wgrad_bf16x6(d, w)) k = 2;
+    }
+    if (kernel) *kernel = k;
+    return 0;
 }
 
 extern "C" int64_t pasta_conv2d_wgrad_workspace(const pasta_conv_desc* d) {
@@ -1394,9 +1458,7 @@ extern "C" int pasta_conv2d_wgrad(const float* x, const float* dy, float* dw, co
         if (w.kp == 16) { if (w.pipe) PASTA_WGRAD1(TR_, TS_, WA_, WB_, 1, 16); else PASTA_WGRAD1(TR_, TS_, WA_, WB_, 0, 16); } \
         else            { if (w.pipe) PASTA_WGRAD1(TR_, TS_, WA_, WB_, 1, 32); else PASTA_WGRAD1(TR_, TS_, WA_, WB_, 0, 32); } \
     } while (0)
-    const bool bf16x6 = d->math != PASTA_MATH_F32 && p.kh == 3 && p.kw == 3 && p.st == 1 && p.pad_h == 1 && p.pad_w == 1 &&
-                        p.Q % 32 == 0 && p.LH == p.P && p.LW == p.Q && w.kp == 32 && w.cw_log2 == 5;
-    if (bf16x6) {
+    if (wgrad_bf16x6(d, w)) {
         const size_t lds = (size_t)(3 * 64 * 40 + 3 * 64 * 3 * 40) * 2;
         hipLaunchKernelGGL(conv_wgrad3x3_bf16x6_kernel, dim3((unsigned)blocks), dim3(256), lds, s, p);
     }
