@@ -87,7 +87,7 @@ struct ConvFwdParams {
     const float* bias;                    // fused epilogue (pasta_conv_epilogue); act == 0: none
     int act;
     float alpha, gain, clamp;
-    short tap_dy[MAX_TAPS], tap_dx[MAX_TAPS], tap_slab[MAX_TAPS];
+    int tap_dy[MAX_TAPS], tap_dx[MAX_TAPS], tap_slab[MAX_TAPS];     // int so that a wave-uniform index reads them with s_load_dword
 };
 
 template <int BM, int BN, int WMT, int WNT, int KC, int OCC = 1>   // OCC = minimum waves per SIMD asked of the register allocator
@@ -340,7 +340,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     constexpr int AUNITS = 6 * BM;                      // sixteen-byte units of the A chunk
     constexpr int APT = (AUNITS + 255) / 256;           // per thread: 3 (BM 128) or 2 (BM 64, second one guarded)
     constexpr int BPT = BN * 2 / 256;                   // (pixel, k-half) pairs per thread: 1 or 2
-    __shared__ __attribute__((aligned(16))) __bf16 As[2][6 * ASEG];
+    // A buffers are rounded up to APT * 256 units: every thread copies APT units without a guard (see load_chunk)
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][APT * 256 * 8];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[2][6 * BSEG];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -377,9 +378,12 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
 
     // Two register sets: while chunk c is multiplied out of LDS, chunk c+1 (already in registers) is split into bf16
     // pieces and written to the other LDS buffer between the MFMAs, and chunk c+2 is being fetched.
+    // The loop body is free of data-dependent control flow around its memory operations: every step issues the same
+    // loads and stores (past the end of the K range they re-read valid addresses and the activations are zeroed), so
+    // that the s_waitcnt counters the compiler derives let a fetch stay in flight for a whole step.
     struct Stage { float b[8 * BPT]; float4 a[APT]; int nvalid[BPT]; };
     Stage st0, st1;
-    int ld_t = c_first / NC, ld_cc = c_first - ld_t * NC;
+    int ld_t = c_first / NC, ld_cc = c_first - ld_t * NC, ld_left = nchunks;
     bool ld_ok = false;
     unsigned ld_pix = xb_off;          // byte offset of this thread's tap pixel in channel 0 (a readable address also when the tap is outside)
     const __bf16* ld_wt = wb;
@@ -390,12 +394,12 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
         ld_pix = ld_ok ? xb_off + (unsigned)(iy * p.W + ix) * 4u : xb_off;
         ld_wt = wb + (int64_t)p.tap_slab[t] * NC * 6 * p.Og_pad * 8;
     };
-    if (ld_t < p.T) set_tap(ld_t);
-    // Loads are unconditional (clamped channel index, always-valid base) so that nothing waits on them before their
-    // first use one iteration later; invalid elements are zeroed when they are split.
+    if (ld_t >= p.T) { ld_t = p.T - 1; ld_cc = 0; }      // empty K slice: nothing is accumulated, addresses stay valid
+    set_tap(ld_t);
     auto load_chunk = [&](Stage& st) {
         const int cc = __builtin_amdgcn_readfirstlane(ld_cc);
         const int last = p.Ig - 1;
+        const bool real = ld_left > 0;              // chunks past the end of this K slice contribute zeros
 #pragma unroll
         for (int i = 0; i < BPT; i++) {
             const int c0 = cc * KC + (half0 + i) * 8;
@@ -404,18 +408,22 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
                 const unsigned coff = (unsigned)(c0 + j < last ? c0 + j : last) * (unsigned)HW * 4u;    // scalar
                 st.b[8 * i + j] = *(const float*)(xbytes + (ld_pix + coff));
             }
-            st.nvalid[i] = ld_ok ? p.Ig - c0 : 0;     // elements j < nvalid are real
+            st.nvalid[i] = (ld_ok && real) ? p.Ig - c0 : 0;     // elements j < nvalid are real
         }
         const __bf16* wt = ld_wt + (int64_t)ld_cc * 6 * p.Og_pad * 8;
         // 6 (piece, half) segments of BM sixteen-byte units each; this thread copies units tid, tid + 256, ...
+        // (BM 64: the last 128 threads repeat unit AUNITS - 1 into the padding of the LDS buffer)
 #pragma unroll
         for (int j = 0; j < APT; j++) {
-            const int e = tid + 256 * j, seg = e / BM, within = e - seg * BM;
-            if (e < AUNITS) st.a[j] = *(const float4*)(wt + ((int64_t)seg * p.Og_pad + o_blk + within) * 8);
+            int e = tid + 256 * j;
+            if (256 * (j + 1) > AUNITS) e = e < AUNITS ? e : AUNITS - 1;
+            const int seg = e / BM, within = e - seg * BM;
+            st.a[j] = *(const float4*)(wt + ((int64_t)seg * p.Og_pad + o_blk + within) * 8);
         }
+        --ld_left;
         if (++ld_cc >= NC) {
             ld_cc = 0;
-            if (++ld_t < p.T) set_tap(ld_t);
+            if (ld_t + 1 < p.T) set_tap(++ld_t);
         }
     };
     uint32_t q1[BPT][4], q2[BPT][4], q3[BPT][4];          // 8 bf16 per piece, packed two per dword
@@ -450,8 +458,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     };
     auto store_a = [&](const Stage& st, int buf) {
 #pragma unroll
-        for (int j = 0; j < APT; j++)
-            if (tid + 256 * j < AUNITS) *(float4*)&As[buf][(tid + 256 * j) * 8] = st.a[j];
+        for (int j = 0; j < APT; j++) *(float4*)&As[buf][(tid + 256 * j) * 8] = st.a[j];
     };
 
     f32x16 acc[WMT][WNT];
@@ -463,24 +470,24 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
     const int hl = lane >> 5, jl = lane & 31;
+    // Fragments of one chunk: [tile][piece], read in the order the MFMA groups consume them.
+    struct Frag { bf16x8 a[WMT][3], b[WNT][3]; };
+    auto read_frag = [&](Frag& f, int buf) {
+#define PASTA_LDA(PC) _Pragma("unroll") for (int a = 0; a < WMT; a++) f.a[a][PC] = *(const bf16x8*)&As[buf][(((PC) * 2 + hl) * BM + (wm * WMT + a) * 32 + jl) * 8];
+#define PASTA_LDB(PC) _Pragma("unroll") for (int b = 0; b < WNT; b++) f.b[b][PC] = *(const bf16x8*)&Bs[buf][(((PC) * 2 + hl) * BN + (wn * WNT + b) * 32 + jl) * 8];
+        PASTA_LDA(2) PASTA_LDB(0) PASTA_LDA(0) PASTA_LDB(2) PASTA_LDA(1) PASTA_LDB(1)
+#undef PASTA_LDA
+#undef PASTA_LDB
+    };
     // One K chunk: 24 MFMAs in six groups of four; the staging work for the next chunk is slotted between the groups.
-    auto step = [&](int ch, Stage& cur_next, Stage& fetch_into) {
-        const int buf = ch & 1;
-        const bool have_next = ch + 1 < nchunks;
-        if (ch + 2 < nchunks) load_chunk(fetch_into);
-        bf16x8 af[WMT][3], bf[WNT][3];
-#pragma unroll
-        for (int pc = 0; pc < 3; pc++) {
-#pragma unroll
-            for (int a = 0; a < WMT; a++) af[a][pc] = *(const bf16x8*)&As[buf][((pc * 2 + hl) * BM + (wm * WMT + a) * 32 + jl) * 8];
-#pragma unroll
-            for (int b = 0; b < WNT; b++) bf[b][pc] = *(const bf16x8*)&Bs[buf][((pc * 2 + hl) * BN + (wn * WNT + b) * 32 + jl) * 8];
-        }
+    // The last two groups run after the barrier, behind the fragment reads of the next chunk, so that the matrix
+    // pipe has work while those reads are in flight.
+    auto step = [&](int buf, Stage& cur_next, Stage& fetch_into, Frag& f, Frag& fnext) {
+        load_chunk(fetch_into);
 #define PASTA_MM(PA, PB)                                                                                       \
         _Pragma("unroll") for (int a = 0; a < WMT; a++) _Pragma("unroll") for (int b = 0; b < WNT; b++)          \
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA], bf[b][PB], acc[a][b], 0, 0, 0);
-#define PASTA_SPLIT(J)                                                                                         \
-        if (have_next) { _Pragma("unroll") for (int i = 0; i < BPT; i++) split_pair(cur_next, i, J); }
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][PA], f.b[b][PB], acc[a][b], 0, 0, 0);
+#define PASTA_SPLIT(J) _Pragma("unroll") for (int i = 0; i < BPT; i++) split_pair(cur_next, i, J);
         // smallest terms first: a3b1, a1b3, a2b2, a2b1, a1b2, a1b1
         PASTA_MM(2, 0)
         PASTA_SPLIT(0)
@@ -490,27 +497,29 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
         PASTA_SPLIT(2)
         PASTA_MM(1, 0)
         PASTA_SPLIT(3)
+        store_b(buf ^ 1); store_a(cur_next, buf ^ 1);
+        __syncthreads();
+        read_frag(fnext, buf ^ 1);
         PASTA_MM(0, 1)
-        if (have_next) { store_b(buf ^ 1); store_a(cur_next, buf ^ 1); }
         PASTA_MM(0, 0)
 #undef PASTA_MM
 #undef PASTA_SPLIT
-        __syncthreads();
     };
 
-    if (nchunks > 0) {
-        load_chunk(st0);
+    load_chunk(st0);
 #pragma unroll
-        for (int i = 0; i < BPT; i++)
+    for (int i = 0; i < BPT; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) split_pair(st0, i, j);
-        store_b(0); store_a(st0, 0);
-        if (nchunks > 1) load_chunk(st0);       // chunk 1 waits in registers
-    }
+        for (int j = 0; j < 4; j++) split_pair(st0, i, j);
+    store_b(0); store_a(st0, 0);
+    load_chunk(st0);                            // chunk 1 waits in registers
     __syncthreads();
+    Frag f0, f1;
+    read_frag(f0, 0);
+    // two chunks per trip so that the register sets swap roles without copies; an odd count runs one all-zero chunk
     for (int ch = 0; ch < nchunks; ch += 2) {
-        step(ch, st0, st1);                     // st0 holds chunk ch+1, chunk ch+2 is fetched into st1
-        if (ch + 1 < nchunks) step(ch + 1, st1, st0);
+        step(0, st0, st1, f0, f1);              // st0 holds chunk ch+1, chunk ch+2 is fetched into st1
+        step(1, st1, st0, f1, f0);
     }
 
     const int OHW = p.OH * p.OW;
