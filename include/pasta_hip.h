@@ -117,8 +117,9 @@ int pasta_conv2d_tile(const pasta_conv_desc* d);
 /* The full launch plan of pasta_conv2d(_ex) for d, for reporting (bench.py attributes time and FLOPs to kernel
  * families with it): *tile as pasta_conv2d_tile, *ksplit = number of K slices (> 1: partial sums in the workspace,
  * reduced by a second kernel), *math = PASTA_MATH_F32 or PASTA_MATH_BF16X6 actually used (has_iscale != 0 says the
- * launch passes an iscale vector, which the split-bf16 kernel does not take).  Any out pointer may be NULL. */
-int pasta_conv2d_plan(const pasta_conv_desc* d, int has_iscale, int* tile, int* ksplit, int* math);
+ * launch passes an iscale vector, which the split-bf16 kernel does not take), *launches = launches of the main
+ * kernel (conv_transpose2d: one per output parity class unless the classes share a grid).  Any out pointer may be NULL. */
+int pasta_conv2d_plan(const pasta_conv_desc* d, int has_iscale, int* tile, int* ksplit, int* math, int* launches);
 
 /* Same for pasta_conv2d_wgrad: *kernel = 0 conv_wgrad_kernel (fp32 MFMA, taps x 64 x 64 tiles), 1
  * conv_wgrad_smallcin_kernel (<= 8 input channels: (channel, tap) pairs as GEMM columns), 2

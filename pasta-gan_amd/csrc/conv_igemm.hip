@@ -652,6 +652,12 @@ static FwdPlan plan_fwd(const pasta_conv_desc* d) {
     return f;
 }
 
+// Large lattices: one grid for the four classes of a stride-2 conv_transpose2d on the split-bf16 kernel (measured
+// 0.475 -> 0.431 ms on 128->64 @128^2; on the 16^2 layers separate launches are faster, 0.241 vs 0.264 ms).
+static bool merged_classes(const pasta_conv_desc* d, bool bf16x6) {
+    return d->transposed && bf16x6 && d->stride == 2 && d->OH >= 2 && d->OW >= 2 && fwd_lattice_pixels(d) >= 65536;
+}
+
 //------------------------------------------------------------------------------------
 // Weight gradient.
 //   dW[g*Ag + a][b][r][s] = sum_{n,p,q} S[n, g*Ag + a, p, q] * L[n, g*Bg + b, p*st + r - pad_h, q*st + s - pad_w]
@@ -1294,13 +1300,15 @@ extern "C" int pasta_conv2d_tile(const pasta_conv_desc* d) {
     return (int)plan_fwd(d).tile;
 }
 
-extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int has_iscale, int* tile, int* ksplit, int* math) {
+extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int has_iscale, int* tile, int* ksplit, int* math, int* launches) {
     using namespace pasta;
     if (int e = check_desc(d, "conv2d_plan")) return e;
     const FwdPlan f = plan_fwd(d);
+    const bool sb = f.bf16x6 && !has_iscale;
     if (tile) *tile = (int)f.tile;
     if (ksplit) *ksplit = f.ksplit;
-    if (math) *math = (f.bf16x6 && !has_iscale) ? PASTA_MATH_BF16X6 : PASTA_MATH_F32;
+    if (math) *math = sb ? PASTA_MATH_BF16X6 : PASTA_MATH_F32;
+    if (launches) *launches = !d->transposed ? 1 : merged_classes(d, sb) ? 1 : (d->stride < d->OH ? d->stride : d->OH) * (d->stride < d->OW ? d->stride : d->OW);
     return 0;
 }
 
@@ -1364,9 +1372,7 @@ extern "C" int pasta_conv2d_ex(const float* x, const float* w, float* y, const f
         // input row = pp + (a + pad - r)/u.
         const int u = d->stride;
         p.osy = u; p.osx = u; p.isy = 1; p.isx = 1;
-        // Large lattices: one grid for the four classes of a stride-2 layer (measured 0.475 -> 0.431 ms on 128->64 @128^2;
-        // on the 16^2 layers separate launches are faster, 0.241 vs 0.264 ms).
-        const bool merged = p.bf16x6 && u == 2 && d->OH >= 2 && d->OW >= 2 && fwd_lattice_pixels(d) >= 65536;
+        const bool merged = merged_classes(d, p.bf16x6 != 0);
         int ntap = 0;
         p.ncls = 0;
         for (int a = 0; a < u && a < d->OH; a++)

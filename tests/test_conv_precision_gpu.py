@@ -48,3 +48,37 @@ def test_math_modes_reach_their_kernels_and_agree():
     assert torch.equal(out['default'], out['bf16x6'])
     assert not torch.equal(out['f32'], out['bf16x6'])             # different arithmetic really ran
     assert float((out['f32'] - out['bf16x6']).abs().max() / out['f32'].abs().max()) < 2e-6
+
+
+def _grads(mode, x, w, dy):
+    from torch_utils.ops import conv2d_gradfix as cg
+    old = cg.conv_math
+    cg.conv_math = mode
+    try:
+        x = x.clone().requires_grad_(True)
+        w = w.clone().requires_grad_(True)
+        gx, gw = torch.autograd.grad(cg.conv2d(x, w, padding=1), [x, w], dy)
+    finally:
+        cg.conv_math = old
+    return gx.double().cpu(), gw.double().cpu()
+
+
+def test_split_bf16_gradients_match_fp32_accuracy():
+    """Input gradient (split-bf16 forward kernel on the flipped weights) and weight gradient
+    (conv_wgrad3x3_bf16x6_kernel, K = 8192 pixels per output) against fp64 autograd."""
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn([8, 128, 32, 32], generator=g)
+    w = torch.randn([128, 128, 3, 3], generator=g) / 34
+    dy = torch.randn([8, 128, 32, 32], generator=g)
+    x64 = x.double().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    rx, rw = torch.autograd.grad(torch.nn.functional.conv2d(x64, w64, padding=1), [x64, w64], dy.double())
+    res = {}
+    for mode in ['f32', 'bf16x6']:
+        gx, gw = _grads(mode, x.cuda(), w.cuda(), dy.cuda())
+        res[mode] = (float((gx - rx).abs().max() / rx.abs().max()), float((gw - rw).abs().max() / rw.abs().max()),
+                     float((gx - rx).pow(2).mean().sqrt() / rx.pow(2).mean().sqrt()), float((gw - rw).pow(2).mean().sqrt() / rw.pow(2).mean().sqrt()))
+    print('max-rel (dx, dw), rms (dx, dw):', res)
+    for mode in res:
+        assert res[mode][0] < 5e-6 and res[mode][1] < 1e-5
+    assert res['bf16x6'][2] < 3 * res['f32'][2] + 1e-9 and res['bf16x6'][3] < 3 * res['f32'][3] + 1e-9
