@@ -75,6 +75,16 @@ int64_t pasta_bias_grad_workspace(int64_t n, int size_b, int64_t step_b);
 int pasta_bias_grad(const void* dx, void* db, float* work, int dtype, int64_t n,
                     int size_b, int64_t step_b, void* stream);
 
+/* First derivative and bias gradient in one pass over HBM (the pair bias_act.py:162-173 `dx = plugin.bias_act(dy, ...,
+ * grad=1, ...)` + `db = dx.sum(...)`):  dx = dy * act'(yref / gain) * gain, zero where |yref| >= clamp >= 0, and
+ * db[c] = sum of dx over its (n, c) planes (fp32 accumulate, fixed order).  act 1..3 (linear, relu, lrelu), fp32 or
+ * fp16, tensors viewed as [outer, size_b, step_b] with step_b a multiple of 16 bytes and >= 256 packs of 16 bytes.
+ * pasta_bias_act_grad_db_workspace returns the bytes of `work`, or 0 when the case is not covered (then call
+ * pasta_bias_act(grad=1) followed by pasta_bias_grad).  yref may be NULL only for act 1 without clamp. */
+int64_t pasta_bias_act_grad_db_workspace(int dtype, int64_t n, int size_b, int64_t step_b, int act);
+int pasta_bias_act_grad_db(const void* dy, const void* yref, void* dx, void* db, float* work, int dtype, int64_t n,
+                           int size_b, int64_t step_b, int act, float alpha, float gain, float clamp, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Dense convolution family on fp32 matrix cores (v_mfma_f32_32x32x2_f32).
  * Replaces the ATen/cuDNN calls behind torch_utils/ops/conv2d_gradfix.py:38,43

@@ -184,7 +184,92 @@ static int bias_grad_nsplit(int64_t n, int size_b, int64_t step_b) {
     return (int)want;
 }
 
+//------------------------------------------------------------------------------------
+// grad 1 with the bias gradient folded in (linear / relu / lrelu on [outer, size_b, step_b] tensors with long
+// step_b runs): dx = dy * act'(yref) * gain under the clamp mask, and per workgroup the sum of its dx values, so that
+// db needs no second pass over dx.  Workgroup (plane, chunk) covers up to 1024 packs of one (n, c) plane; partial sums
+// are laid out [c][n][chunk] and summed per c in a fixed order by bias_grad_final_kernel.
+constexpr int DB_CHUNK_PACKS = 1024;
+
+template <class T, int A, int V>
+__global__ __launch_bounds__(256) void bias_act_grad_db_kernel(BiasActParams p, float* work, int outer, int chunks) {
+    typedef typename acc_of<T>::type S;
+    const S alpha = (S)p.alpha, gain = (S)p.gain, clamp = (S)p.clamp;
+    const int plane = blockIdx.x, chunk = blockIdx.y;
+    const int plane_packs = (int)(p.step_b / V);
+    const Pack<T, V>* dys = (const Pack<T, V>*)p.x + (int64_t)plane * plane_packs;
+    const Pack<T, V>* yr = p.yref ? (const Pack<T, V>*)p.yref + (int64_t)plane * plane_packs : nullptr;
+    Pack<T, V>* dxs = (Pack<T, V>*)p.y + (int64_t)plane * plane_packs;
+    const int j1 = min(plane_packs, (chunk + 1) * DB_CHUNK_PACKS);
+    float acc = 0.f;
+    for (int j = chunk * DB_CHUNK_PACKS + threadIdx.x; j < j1; j += 256) {
+        Pack<T, V> vdy = dys[j], vyr, out;
+        if (yr) vyr = yr[j];
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            const S r = bias_act_point<A, 1, S>(ld<T>(&vdy.v[k]), (S)0, (S)0, yr ? ld<T>(&vyr.v[k]) : (S)0, (S)1, alpha, gain, clamp);
+            st<T>(&out.v[k], r);
+            acc += (float)ld<T>(&out.v[k]);          // the stored (rounded) value, as a sum over dx would see it
+        }
+        dxs[j] = out;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int n = plane / p.size_b, c = plane - n * p.size_b;
+        work[((int64_t)c * outer + n) * chunks + chunk] = part[0] + part[1] + part[2] + part[3];
+    }
+}
+
+// Shapes the fused kernel takes; 0 chunks = not supported (callers use pasta_bias_act + pasta_bias_grad).
+static int grad_db_chunks(int dtype, int64_t n, int size_b, int64_t step_b, int act) {
+    if (dtype != PASTA_F32 && dtype != PASTA_F16) return 0;
+    const int V = dtype == PASTA_F32 ? 4 : 8;
+    if (act < 1 || act > 3 || n <= 0 || size_b <= 0 || step_b <= 0 || n % ((int64_t)size_b * step_b) != 0) return 0;
+    if (step_b % V != 0 || step_b / V < 256 || step_b / V > INT32_MAX / 2 || n / step_b > INT32_MAX) return 0;
+    const int64_t chunks = (step_b / V + DB_CHUNK_PACKS - 1) / DB_CHUNK_PACKS;
+    return chunks <= 65535 ? (int)chunks : 0;
+}
+
+template <class T, int V>
+static int launch_grad_db(const BiasActParams& p, float* work, void* db, int act, int outer, int chunks, hipStream_t s) {
+    dim3 grid((unsigned)(outer * p.size_b), (unsigned)chunks);
+    switch (act) {
+        case 1: hipLaunchKernelGGL((bias_act_grad_db_kernel<T, 1, V>), grid, dim3(256), 0, s, p, work, outer, chunks); break;
+        case 2: hipLaunchKernelGGL((bias_act_grad_db_kernel<T, 2, V>), grid, dim3(256), 0, s, p, work, outer, chunks); break;
+        default: hipLaunchKernelGGL((bias_act_grad_db_kernel<T, 3, V>), grid, dim3(256), 0, s, p, work, outer, chunks); break;
+    }
+    hipLaunchKernelGGL((bias_grad_final_kernel<T>), dim3(p.size_b), dim3(64), 0, s, work, (T*)db, outer * chunks);
+    return launch_status("bias_act_grad_db");
+}
+
 }  // namespace pasta
+
+extern "C" int64_t pasta_bias_act_grad_db_workspace(int dtype, int64_t n, int size_b, int64_t step_b, int act) {
+    const int chunks = pasta::grad_db_chunks(dtype, n, size_b, step_b, act);
+    return chunks ? (n / step_b) * chunks * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int pasta_bias_act_grad_db(const void* dy, const void* yref, void* dx, void* db, float* work, int dtype, int64_t n,
+                                      int size_b, int64_t step_b, int act, float alpha, float gain, float clamp, void* stream) {
+    using namespace pasta;
+    const int chunks = grad_db_chunks(dtype, n, size_b, step_b, act);
+    PASTA_CHECK(chunks > 0, "bias_act_grad_db: unsupported case (dtype %d, n %lld, size_b %d, step_b %lld, act %d)", dtype,
+                (long long)n, size_b, (long long)step_b, act);
+    PASTA_CHECK(dy && dx && db && work, "bias_act_grad_db: null pointer");
+    PASTA_CHECK(yref || (act == 1 && clamp < 0), "bias_act_grad_db: yref is required for this activation / clamp");
+    PASTA_CHECK((((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)yref) & 15) == 0, "bias_act_grad_db: pointers must be 16-byte aligned");
+    BiasActParams p;
+    p.x = dy; p.b = nullptr; p.xref = nullptr; p.yref = yref; p.dy = nullptr; p.y = dx;
+    p.n = n; p.size_b = size_b; p.step_b = step_b;
+    p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    const int outer = (int)(n / ((int64_t)size_b * step_b));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PASTA_F32) return launch_grad_db<float, 4>(p, work, db, act, outer, chunks, s);
+    return launch_grad_db<__half, 8>(p, work, db, act, outer, chunks, s);
+}
 
 extern "C" int pasta_bias_act(const void* x, const void* b, const void* xref, const void* yref, const void* dy, void* y,
                               int dtype, int64_t n, int size_b, int64_t step_b, int grad, int act, float alpha,

@@ -119,6 +119,9 @@ ABI = {
                                                            _c_f32, _c_f32, _c_f32, _c_ptr]),
     'pasta_bias_grad_workspace': (_c_i64, [_c_i64, ctypes.c_int, _c_i64]),
     'pasta_bias_grad':    (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, ctypes.c_int, _c_i64, ctypes.c_int, _c_i64, _c_ptr]),
+    'pasta_bias_act_grad_db_workspace': (_c_i64, [ctypes.c_int, _c_i64, ctypes.c_int, _c_i64, ctypes.c_int]),
+    'pasta_bias_act_grad_db': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, ctypes.c_int, _c_i64, ctypes.c_int, _c_i64, ctypes.c_int,
+                                              ctypes.c_float, ctypes.c_float, ctypes.c_float, _c_ptr]),
     'pasta_conv2d_workspace':       (_c_i64, [ctypes.POINTER(ConvDesc)]),
     'pasta_conv2d_wgrad_workspace': (_c_i64, [ctypes.POINTER(ConvDesc)]),
     'pasta_conv2d_tile':  (ctypes.c_int, [ctypes.POINTER(ConvDesc)]),

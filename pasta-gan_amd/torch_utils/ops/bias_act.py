@@ -83,6 +83,38 @@ def _bias_grad(dx, dim):
     _native.check(st)
     return db
 
+def _grad_db_workspace(dy, dim, act_idx):
+    """Bytes of scratch for the fused (dx, db) launch, 0 when the case is not covered by it."""
+    if dy.device.type != 'cuda' or dy.dtype not in (torch.float32, torch.float16) or not dy.is_contiguous() or dy.numel() == 0:
+        return 0
+    return _native.lib().pasta_bias_act_grad_db_workspace(_native.dtype_code(dy, 'bias_act'), dy.numel(), dy.shape[dim], dy.stride(dim), act_idx)
+
+def _launch_grad_db(dy, y, dim, act_idx, alpha, gain, clamp, nbytes):
+    """dx and db = sum(dx) in one ``pasta_bias_act_grad_db`` launch (dy, y contiguous NCHW)."""
+    if y is not None and (y.shape != dy.shape or y.dtype != dy.dtype or y.stride() != dy.stride()):
+        raise RuntimeError('bias_act: yref must have the same shape, dtype and layout as dy')
+    dx = torch.empty_like(dy)
+    db = torch.empty([dy.shape[dim]], dtype=dy.dtype, device=dy.device)
+    work = torch.empty([nbytes // 4], dtype=torch.float32, device=dy.device)
+    with torch.cuda.device(dy.device):
+        st = _native.lib().pasta_bias_act_grad_db(
+            _native.ptr(dy), _native.ptr(y), _native.ptr(dx), _native.ptr(db), _native.ptr(work), _native.dtype_code(dy, 'bias_act'),
+            dy.numel(), dy.shape[dim], dy.stride(dim), act_idx, float(alpha), float(gain), float(clamp), _native.stream())
+    _native.check(st)
+    return dx, db
+
+def grad_with_bias_grad(dy, y, cfg):
+    """(dx, db) of ``bias_act`` for the piecewise-linear activations whose derivative is expressed in y
+    (``cfg`` = (dim, act, alpha, gain, clamp)); one fused launch when the native kernel covers the case."""
+    dim, act, alpha, gain, clamp = cfg
+    spec = activation_funcs[act]
+    if not spec.has_2nd_grad and 'x' not in spec.ref:
+        nbytes = _grad_db_workspace(dy, dim, spec.cuda_idx)
+        if nbytes > 0:
+            return _BiasActHipGradDb.apply(dy, y, cfg)
+    dx = _BiasActHipGrad.apply(dy, None, None, y, cfg)
+    return dx, _BiasSum.apply(dx, dim)
+
 def _bias_grad_supported(t, dim):
     """The native reduction views t as [outer, size_b, step_b] with long contiguous step_b runs
     (NCHW feature maps); short runs (FC outputs, channels_last) go through ``Tensor.sum``."""
@@ -117,9 +149,13 @@ class _BiasActHip(torch.autograd.Function):
         x, b, y = ctx.saved_tensors
         dy = dy.contiguous(memory_format=ctx.fmt)
         dx = db = None
+        has_kernel = act != 'linear' or gain != 1 or clamp >= 0
+        if ctx.needs_input_grad[1] and has_kernel and x is None and ctx.fmt == torch.contiguous_format:
+            dx, db = grad_with_bias_grad(dy, y, ctx.cfg)
+            return dx, db, None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             dx = dy
-            if act != 'linear' or gain != 1 or clamp >= 0:
+            if has_kernel:
                 dx = _BiasActHipGrad.apply(dy, x, b, y, ctx.cfg)
         if ctx.needs_input_grad[1]:
             db = _BiasSum.apply(dx, dim)
@@ -150,6 +186,33 @@ class _BiasActHipGrad(torch.autograd.Function):
         if spec.has_2nd_grad and ctx.needs_input_grad[2]:
             d_b = d_x.sum([i for i in range(d_x.ndim) if i != dim])
         return d_dy, d_x, d_b, None, None
+
+class _BiasActHipGradDb(torch.autograd.Function):
+    """(dx, db) in one pass for linear / relu / lrelu. Both outputs are linear in dy, so the gradient of a
+    functional of (dx, db) with respect to dy is the same derivative kernel applied to d_dx + broadcast(d_db)."""
+    @staticmethod
+    def forward(ctx, dy, y, cfg):
+        dim, act, alpha, gain, clamp = cfg
+        spec = activation_funcs[act]
+        nbytes = _grad_db_workspace(dy, dim, spec.cuda_idx)
+        dx, db = _launch_grad_db(dy, y, dim, spec.cuda_idx, alpha, gain, clamp, nbytes)
+        ctx.save_for_backward(y)
+        ctx.cfg = cfg
+        ctx.shape = dy.shape
+        ctx.set_materialize_grads(False)
+        return dx, db
+
+    @staticmethod
+    def backward(ctx, d_dx, d_db):
+        dim = ctx.cfg[0]
+        y, = ctx.saved_tensors
+        if not ctx.needs_input_grad[0] or (d_dx is None and d_db is None):
+            return None, None, None
+        g = d_dx
+        if d_db is not None:
+            bc = d_db.reshape([-1 if i == dim else 1 for i in range(len(ctx.shape))]).expand(ctx.shape)
+            g = bc if g is None else g + bc
+        return _BiasActHipGrad.apply(g.contiguous(), None, None, y, ctx.cfg), None, None
 
 class _BiasSum(torch.autograd.Function):
     """db = sum of dx over all dimensions except ``dim`` (differentiable: the transpose is a broadcast)."""

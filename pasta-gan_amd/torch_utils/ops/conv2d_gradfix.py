@@ -209,14 +209,18 @@ class _ConvBiasActHip(torch.autograd.Function):
         act, alpha, gain, clamp = ctx.act_cfg
         cfg = ctx.cfg
         dz = dy
-        if act != 'linear' or gain != 1 or clamp >= 0:
-            dz = ba._BiasActHipGrad.apply(dy.contiguous(), None, None, y, (1, act, alpha, gain, clamp))
         dx = dw = db = None
+        want_db = b is not None and ctx.needs_input_grad[2]
+        if act != 'linear' or gain != 1 or clamp >= 0:
+            if want_db:     # derivative of the epilogue and the bias gradient in one pass
+                dz, db = ba.grad_with_bias_grad(dy.contiguous(), y, (1, act, alpha, gain, clamp))
+            else:
+                dz = ba._BiasActHipGrad.apply(dy.contiguous(), None, None, y, (1, act, alpha, gain, clamp))
         if ctx.needs_input_grad[0]:
             dx = _ConvHip.apply(dz, w, _grad_cfg(cfg, x.shape[2:], dz.shape[2:], w.shape[2], w.shape[3]))
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
             dw = _ConvWgradHip.apply(dz, x, cfg, tuple(w.shape))
-        if b is not None and ctx.needs_input_grad[2]:
+        if want_db and db is None:
             db = ba._BiasSum.apply(dz, 1)
         return dx, dw, db, None, None
 

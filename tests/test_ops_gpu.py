@@ -181,6 +181,28 @@ def test_bias_act_large(shape, dtype):
     assert rel_err(y, yr) < tol and rel_err(dx, dxr) < tol and rel_err(db, dbr) < max(tol, 1e-4)
 
 
+@pytest.mark.parametrize('act,gain,clamp', [('lrelu', np.sqrt(2), 1.0), ('relu', 1.0, None), ('linear', 0.5, None), ('linear', 1.0, 0.8)])
+def test_bias_act_fused_grad_and_bias_grad(act, gain, clamp):
+    """The one-pass (dx, db) kernel: several chunks per plane with a ragged last chunk, and its double backward
+    (d/d dy of a functional of dx and db)."""
+    from torch_utils.ops import bias_act
+    shape = [2, 5, 96, 96]          # 9216 elements per plane = 2304 packs -> chunks of 1024, 1024, 256
+    assert bias_act._grad_db_workspace(torch.empty(shape, device='cuda'), 1, bias_act.activation_funcs[act].cuda_idx) == 2 * 5 * 3 * 4
+    gen = torch.Generator().manual_seed(5)
+    xc, bc, dyc = torch.randn(shape, generator=gen), torch.randn([5], generator=gen), torch.randn(shape, generator=gen)
+    wc, vc = torch.randn(shape, generator=gen), torch.randn([5], generator=gen)
+    def run(bias_act_fn, x, b, dy, w, v):
+        x.requires_grad_(True); b.requires_grad_(True); dy.requires_grad_(True)
+        y = bias_act_fn(x, b, act=act, gain=gain, clamp=clamp)
+        dx, db = torch.autograd.grad(y, [x, b], dy, create_graph=True)
+        g_dy, = torch.autograd.grad((dx * w).sum() + (db * v).sum(), [dy])
+        return y, dx, db, g_dy
+    ref = run(R.bias_act, xc.double(), bc.double(), dyc.double(), wc.double(), vc.double())
+    out = run(bias_act.bias_act, xc.cuda(), bc.cuda(), dyc.cuda(), wc.cuda(), vc.cuda())
+    for name, a, r in zip(['y', 'dx', 'db', 'g_dy'], out, ref):
+        assert rel_err(a, r) < (1e-4 if name == 'db' else TOL), name
+
+
 def test_bias_act_errors():
     from torch_utils.ops import bias_act
     with pytest.raises(RuntimeError):
