@@ -390,26 +390,30 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     const __bf16* wb = (const __bf16*)p.wp + (int64_t)g * p.KK * NC * 6 * p.Og_pad * 8;
     const int half0 = BPT == 1 ? __builtin_amdgcn_readfirstlane(tid >> 7) : 0;
 
-    // Two register sets: while chunk c is multiplied out of LDS, chunk c+1 (already in registers) is split into bf16
-    // pieces and written to the other LDS buffer between the MFMAs, and chunk c+2 is being fetched.
+    // Two register sets for the activations: while chunk c is multiplied out of LDS, chunk c+1 (already in registers)
+    // is split into bf16 pieces and written to the other LDS buffer between the MFMAs, and chunk c+2 is being fetched.
+    // The weights of chunk c+1 (already split, L2-resident: every workgroup reads the same ones) are fetched at the
+    // start of step c and copied to LDS at its end.
     // The loop body is free of data-dependent control flow around its memory operations: every step issues the same
     // loads and stores (past the end of the K range they re-read valid addresses and the activations are zeroed), so
     // that the s_waitcnt counters the compiler derives let a fetch stay in flight for a whole step.
-    struct Stage { float b[8 * BPT]; float4 a[APT]; int nvalid[BPT]; };
+    struct Stage { float b[8 * BPT]; int nvalid[BPT]; };
     Stage st0, st1;
+    float4 areg0, areg1, areg2;         // APT of them are used (scalars: an array here is not kept in registers)
     int ld_t = c_first / NC, ld_cc = c_first - ld_t * NC, ld_left = nchunks;
     bool ld_ok = false;
     unsigned ld_pix = xb_off;          // byte offset of this thread's tap pixel in channel 0 (a readable address also when the tap is outside)
-    const __bf16* ld_wt = wb;
+    const __bf16* a_wt = wb;           // weight fetch position: tap slab and chunk within it
+    int a_t = ld_t, a_cc = ld_cc;
     auto set_tap = [&](int t_in) {
         const int t = __builtin_amdgcn_readfirstlane(tap0 + t_in);   // the tap tables are read with scalar loads
         const int iy = iy_base + p.tap_dy[t], ix = ix_base + p.tap_dx[t];
         ld_ok = pix_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         ld_pix = ld_ok ? xb_off + (unsigned)(iy * p.W + ix) * 4u : xb_off;
-        ld_wt = wb + (int64_t)p.tap_slab[t] * NC * 6 * p.Og_pad * 8;
     };
-    if (ld_t >= T) { ld_t = T - 1; ld_cc = 0; }      // empty K slice: nothing is accumulated, addresses stay valid
+    if (ld_t >= T) { ld_t = T - 1; ld_cc = 0; a_t = ld_t; a_cc = 0; }      // empty K slice: nothing is accumulated, addresses stay valid
     set_tap(ld_t);
+    a_wt = wb + (int64_t)p.tap_slab[tap0 + a_t] * NC * 6 * p.Og_pad * 8;
     auto load_chunk = [&](Stage& st) {
         const int cc = __builtin_amdgcn_readfirstlane(ld_cc);
         const int last = p.Ig - 1;
@@ -424,20 +428,28 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
             }
             st.nvalid[i] = (ld_ok && real) ? p.Ig - c0 : 0;     // elements j < nvalid are real
         }
-        const __bf16* wt = ld_wt + (int64_t)ld_cc * 6 * p.Og_pad * 8;
-        // 6 (piece, half) segments of BM sixteen-byte units each; this thread copies units tid, tid + 256, ...
-        // (BM 64: the last 128 threads repeat unit AUNITS - 1 into the padding of the LDS buffer)
-#pragma unroll
-        for (int j = 0; j < APT; j++) {
-            int e = tid + 256 * j;
-            if (256 * (j + 1) > AUNITS) e = e < AUNITS ? e : AUNITS - 1;
-            const int seg = e / BM, within = e - seg * BM;
-            st.a[j] = *(const float4*)(wt + ((int64_t)seg * p.Og_pad + o_blk + within) * 8);
-        }
         --ld_left;
         if (++ld_cc >= NC) {
             ld_cc = 0;
             if (ld_t + 1 < T) set_tap(++ld_t);
+        }
+    };
+    auto load_a = [&]() {
+        const __bf16* wt = a_wt + (int64_t)a_cc * 6 * p.Og_pad * 8;
+        // 6 (piece, half) segments of BM sixteen-byte units each; this thread copies units tid, tid + 256, ...
+        // (BM 64: the last 128 threads repeat unit AUNITS - 1 into the padding of the LDS buffer)
+        auto unit = [&](int j) {
+            int e = tid + 256 * j;
+            if (256 * (j + 1) > AUNITS) e = e < AUNITS ? e : AUNITS - 1;
+            const int seg = e / BM, within = e - seg * BM;
+            return *(const float4*)(wt + ((int64_t)seg * p.Og_pad + o_blk + within) * 8);
+        };
+        areg0 = unit(0);
+        areg1 = unit(1);
+        if (APT > 2) areg2 = unit(2);
+        if (++a_cc >= NC) {
+            a_cc = 0;
+            if (a_t + 1 < T) a_wt = wb + (int64_t)p.tap_slab[__builtin_amdgcn_readfirstlane(tap0 + ++a_t)] * NC * 6 * p.Og_pad * 8;
         }
     };
     uint32_t q1[BPT][4], q2[BPT][4], q3[BPT][4];          // 8 bf16 per piece, packed two per dword
@@ -470,9 +482,10 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
             *(uint4*)(bd + 4 * BSEG) = make_uint4(q3[i][0], q3[i][1], q3[i][2], q3[i][3]);
         }
     };
-    auto store_a = [&](const Stage& st, int buf) {
-#pragma unroll
-        for (int j = 0; j < APT; j++) *(float4*)&As[buf][(tid + 256 * j) * 8] = st.a[j];
+    auto store_a = [&](int buf) {
+        *(float4*)&As[buf][tid * 8] = areg0;
+        *(float4*)&As[buf][(tid + 256) * 8] = areg1;
+        if (APT > 2) *(float4*)&As[buf][(tid + 512) * 8] = areg2;
     };
 
     f32x16 acc[WMT][WNT];
@@ -494,10 +507,11 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
 #undef PASTA_LDB
     };
     // One K chunk: 24 MFMAs in six groups of four; the staging work for the next chunk is slotted between the groups.
-    // The last two groups run after the barrier, behind the fragment reads of the next chunk, so that the matrix
-    // pipe has work while those reads are in flight.
-    auto step = [&](int buf, Stage& cur_next, Stage& fetch_into, Frag& f, Frag& fnext) {
+    auto step = [&](int buf, Stage& cur_next, Stage& fetch_into) {
+        load_a();                   // weights of the next chunk first: they are waited for with the activation fetch still in flight
         load_chunk(fetch_into);
+        Frag f;
+        read_frag(f, buf);
 #define PASTA_MM(PA, PB)                                                                                       \
         _Pragma("unroll") for (int a = 0; a < WMT; a++) _Pragma("unroll") for (int b = 0; b < WNT; b++)          \
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][PA], f.b[b][PB], acc[a][b], 0, 0, 0);
@@ -511,29 +525,27 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
         PASTA_SPLIT(2)
         PASTA_MM(1, 0)
         PASTA_SPLIT(3)
-        store_b(buf ^ 1); store_a(cur_next, buf ^ 1);
-        __syncthreads();
-        read_frag(fnext, buf ^ 1);
         PASTA_MM(0, 1)
+        store_b(buf ^ 1); store_a(buf ^ 1);
         PASTA_MM(0, 0)
 #undef PASTA_MM
 #undef PASTA_SPLIT
+        __syncthreads();
     };
 
+    load_a();
     load_chunk(st0);
 #pragma unroll
     for (int i = 0; i < BPT; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) split_pair(st0, i, j);
-    store_b(0); store_a(st0, 0);
+    store_b(0); store_a(0);
     load_chunk(st0);                            // chunk 1 waits in registers
     __syncthreads();
-    Frag f0, f1;
-    read_frag(f0, 0);
     // two chunks per trip so that the register sets swap roles without copies; an odd count runs one all-zero chunk
     for (int ch = 0; ch < nchunks; ch += 2) {
-        step(0, st0, st1, f0, f1);              // st0 holds chunk ch+1, chunk ch+2 is fetched into st1
-        step(1, st1, st0, f1, f0);
+        step(0, st0, st1);                      // st0 holds chunk ch+1, chunk ch+2 is fetched into st1
+        step(1, st1, st0);
     }
 
     const int OHW = p.OH * p.OW;
@@ -573,7 +585,7 @@ static void launch_fwd_bf16x6(const ConvFwdParams& p, hipStream_t s) {
     }
     tiles *= p.ncls;
     dim3 grid((unsigned)tiles, q.o_tiles * q.ksplit, p.G);
-    hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<BM, BN, 2>), grid, dim3(256), 0, s, q);
+    hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<BM, BN, 3>), grid, dim3(256), 0, s, q);
 }
 
 constexpr int FWD_KC = 8;
