@@ -272,13 +272,6 @@ static void launch_fwd(const ConvFwdParams& p, hipStream_t s) {
 // Tile choice.  O_pad multiple returned so that the caller can pack weights accordingly.
 enum FwdTile { T128x128 = 0, T64x256 = 1, T32x256 = 2, T64x64 = 3 };
 
-// Experiment knob (tools/bench_conv.py): PASTA_FWD_VARIANT picks among instances of the large tile.
-static int fwd_variant() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("PASTA_FWD_VARIANT"); v = e ? atoi(e) : 0; }
-    return v;
-}
-
 static int fwd_tile_bm(FwdTile t) { return t == T128x128 ? 128 : t == T32x256 ? 32 : 64; }
 
 //------------------------------------------------------------------------------------
@@ -596,12 +589,7 @@ static void dispatch_fwd(FwdTile t, const ConvFwdParams& p, hipStream_t s) {
     switch (t) {
         case T128x128:
             if (p.bf16x6) { launch_fwd_bf16x6<128, 128>(p, s); break; }
-            switch (fwd_variant()) {
-                case 1:  launch_fwd<128, 128, 2, 2, 8, 1>(p, s); break;
-                case 2:  launch_fwd<128, 256, 2, 4, 8>(p, s); break;
-                case 3:  launch_fwd<128, 256, 2, 4, 16>(p, s); break;
-                default: launch_fwd<128, 128, 2, 2, FWD_KC, 4>(p, s); break;   // 4 waves/SIMD: 99-112 TFLOP/s vs 95-104 at 3
-            }
+            launch_fwd<128, 128, 2, 2, FWD_KC, 4>(p, s);        // 4 waves/SIMD: 99-112 TFLOP/s vs 95-104 at 3
             break;
         case T64x256:
             if (p.bf16x6) { launch_fwd_bf16x6<64, 256>(p, s); break; }
