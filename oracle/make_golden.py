@@ -219,6 +219,20 @@ def gen_layers(ref_root):
 
 #----------------------------------------------------------------------------
 
+def gen_primitives(ref_root):
+    """Layer-level cases (oracle/primitive_cases.py) run through the reference's own classes."""
+    rn = import_reference_networks(ref_root)
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle import primitive_cases as PC
+    out = {}
+    for idx, case in enumerate(PC.CASES):
+        for k, v in PC.run_case(rn, case, idx).items():
+            out[case['name'] + '.' + k] = to_np(v)
+    np.savez_compressed(os.path.join(GOLDEN, 'layers_primitives.npz'), **out)
+    print('primitive fixtures written:', len(PC.CASES), 'cases,', len(out), 'arrays')
+
+#----------------------------------------------------------------------------
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
@@ -231,6 +245,11 @@ if __name__ == '__main__':
         gen_ops(args.ref)
     if args.only in ('all', 'layers'):
         gen_layers(args.ref)
+    if args.only in ('all', 'primitives'):
+        gen_primitives(args.ref)
     if args.only in ('all', 'models'):
         from make_golden_models import gen_models
         gen_models(args.ref, import_reference_networks)
+    if args.only in ('all', 'loss'):
+        from make_golden_loss import gen_loss
+        gen_loss(args.ref, import_reference_networks)

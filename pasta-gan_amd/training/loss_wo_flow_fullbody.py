@@ -110,7 +110,12 @@ class StyleGAN2Loss(Loss):
             if self.mask_weight > 0:
                 loss_mask = torch.mean(self.ce_parsing(pred_parsing, gt_parsing.long()[:, 0, ...])) * self.mask_weight
             loss_G = (loss_Gmain + loss_Gmain_finetune) / 2 + (loss_G_L1 + loss_G_finetune_L1) / 2 + loss_mask
+            self.report('Loss/scores/fake_finetune', gen_finetune_logits)
             self.report('Loss/G/loss', loss_Gmain)
+            self.report('Loss/G/loss_finetune', loss_Gmain_finetune)
+            self.report('Loss/G/L1', loss_G_L1)
+            self.report('Loss/G/L1_finetune', loss_G_finetune_L1)
+            self.report('Loss/G/mask_loss', loss_mask)
             loss_G.mul(gain).backward()
 
         # Dmain: minimise logits for generated images (:210-228).
@@ -139,6 +144,7 @@ class StyleGAN2Loss(Loss):
                 r1_penalty = r1_grads.square().sum([1, 2, 3])
                 loss_Dr1 = r1_penalty * (self.r1_gamma / 2)
                 self.report('Loss/r1_penalty', r1_penalty)
+                self.report('Loss/D/reg', loss_Dr1)
             (real_logits * 0 + loss_Dreal + loss_Dr1).mean().mul(gain).backward()
 
 #----------------------------------------------------------------------------

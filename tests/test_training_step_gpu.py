@@ -1,0 +1,116 @@
+"""Training-step semantics on the GPU against tests/golden/training_step.npz (oracle/make_golden_loss.py: the
+reference's own networks driven by a restatement of its loss and hot loop).
+
+(a) StyleGAN2Loss.accumulate_gradients: every reported scalar and the gradient norm of every parameter, per phase.
+(b) TrainingStep.run x 2: parameter updates of G, D and G_ema (phase schedule, lazy-regularisation scaling of lr and
+    betas, gain = interval, nan_to_num, Adam, EMA)."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import param_fill as PF
+from oracle.make_golden_loss import BATCH, DELTA_KEYS_D, DELTA_KEYS_G, prepare
+
+pytestmark = pytest.mark.gpu
+
+TOL_SCALAR = 2e-4       # losses are means over <= 4 x 256 x 256 values of fp32 network outputs
+TOL_GRAD = 1e-3         # BASELINE.json's bar for gradients
+
+
+def _batch():
+    inp = PF.make_inputs(n=BATCH, seed=2)
+    return {k: v.cuda() for k, v in inp.items()}
+
+
+def _kwargs(inp):
+    keys = ['real_img', 'gen_z', 'style_input', 'retain', 'pose', 'denorm_upper_input', 'denorm_lower_input', 'denorm_upper_mask',
+            'denorm_lower_mask', 'gt_parsing']
+    return {k: inp[k] for k in keys}
+
+
+@pytest.mark.parametrize('phase', ['Gmain', 'Dmain', 'Dreg'])
+def test_loss_terms_and_gradients(phase):
+    from training import networks
+    from training.loss_wo_flow_fullbody import StyleGAN2Loss
+    g = load_golden('training_step.npz')
+    G, D = prepare(networks.GeneratorFull(**PF.G_KWARGS).train(), networks.Discriminator(**PF.D_KWARGS).train())
+    G.cuda().requires_grad_(False); D.cuda().requires_grad_(False)
+    log = {}
+    loss = StyleGAN2Loss(torch.device('cuda'), G.mapping, G.synthesis, G.const_encoding, G.style_encoding, D, r1_gamma=10, l1_weight=40,
+                         vgg_weight=0, contextual_weight=0, pl_weight=0, mask_weight=20, report_fn=lambda name, value: log.__setitem__(name, value))
+    module = G if phase == 'Gmain' else D
+    module.requires_grad_(True)
+    loss.accumulate_gradients(phase=phase, sync=True, gain=1.0, **_kwargs(_batch()))
+    rename = {'Dmain': {}, 'Dreg': {'Loss/scores/real': 'Dreg/scores/real'}, 'Gmain': {}}[phase]
+    checked = 0
+    for name, value in log.items():
+        key = f'a.{phase}.{rename.get(name, name)}'
+        if key in g:
+            v = torch.as_tensor(value).detach().double().cpu().numpy()
+            assert np.allclose(v, g[key], rtol=TOL_SCALAR, atol=TOL_SCALAR * float(np.abs(g[key]).max())), (key, v, g[key])
+            checked += 1
+    assert checked >= {'Gmain': 7, 'Dmain': 2, 'Dreg': 3}[phase], sorted(log)
+    norms = np.array([p.grad.norm().item() if p.grad is not None else -1.0 for _, p in sorted(module.named_parameters())])
+    ref = g[f'a.{phase}.gradnorms']
+    assert norms.shape == ref.shape
+    assert ((norms < 0) == (ref < 0)).all()                     # the same parameters receive a gradient
+    names = [n for n, _ in sorted(module.named_parameters())]
+    # not comparable: d/d noise_strength = <dy, noise> with freshly drawn noise (the loss runs G in 'random' noise mode);
+    # the style encoder's pyramid weights, whose gradients are instance-norm cancellation residue
+    skip = np.array([n.endswith('noise_strength') or n.startswith('style_encoding.model.') for n in names])
+    big = (ref > 1e-6 * ref.max()) & ~skip
+    assert big.sum() >= 0.5 * ((ref >= 0) & ~skip).sum()
+    worst = int(np.argmax(np.abs(norms - ref) * big))
+    assert np.abs(norms[big] - ref[big]).max() / ref.max() < TOL_GRAD, (names[worst], norms[worst], ref[worst])
+    assert np.abs(norms[big] / ref[big] - 1).max() < 5 * TOL_GRAD, names[int(np.argmax(np.abs(norms / np.maximum(ref, 1e-30) - 1) * big))]
+    assert np.median(np.abs(norms[big] / ref[big] - 1)) < 1e-4
+
+
+def test_two_iterations_of_the_loop():
+    from training.training_loop_wo_flow_fullbody import TrainingStep, fashion_config
+
+    class Batch:                                   # TrainingStep only needs split()
+        def __init__(self, inp):
+            self.inp = inp
+        def split(self, n):
+            keys = [k for k in self.inp if k != 'gen_z']
+            return [{k: self.inp[k][i:i + n] for k in keys} for i in range(0, BATCH, n)]
+
+    g = load_golden('training_step.npz')
+    step = TrainingStep(torch.device('cuda'), cfg=fashion_config(channel_base=2048), num_gpus=1, rank=0, batch_size=BATCH, batch_gpu=BATCH)
+    prepare(step.G, step.D)
+    step.G_ema.load_state_dict(step.G.state_dict())
+    init_G = {k: v.detach().clone() for k, v in step.G.named_parameters()}
+    init_D = {k: v.detach().clone() for k, v in step.D.named_parameters()}
+    data = Batch(_batch())
+    step.run(data)
+    step.run(data)
+    assert step.batch_idx == 2 and step.cur_nimg == 2 * BATCH
+
+    def check(tag, params, init, keys):
+        for k in keys:
+            ours = PF.summarize(params[k].detach() - init[k])['sample'].astype(np.float64)
+            ref = g[f'{tag}.delta.{k}'].astype(np.float64)
+            # Adam's first steps move every element by about lr whatever the gradient's size, so elements whose gradient
+            # is rounding noise may step the other way: compare direction and size of the update, not element values.
+            if np.linalg.norm(ref) == 0:             # a parameter the step leaves alone (zero gradient): same here
+                assert np.linalg.norm(ours) == 0, (tag, k)
+                continue
+            cos = float((ours * ref).sum() / (np.linalg.norm(ours) * np.linalg.norm(ref)))
+            assert cos > 0.98, (tag, k, cos)
+            assert abs(np.abs(ours).mean() / np.abs(ref).mean() - 1) < 0.02, (tag, k)
+
+    check('b.G', dict(step.G.named_parameters()), init_G, DELTA_KEYS_G)
+    check('b.D', dict(step.D.named_parameters()), init_D, DELTA_KEYS_D)
+    check('b.G_ema', dict(step.G_ema.named_parameters()), init_G, DELTA_KEYS_G)
+    # w_avg: four EMA updates per iteration pair, through mapping weights that already took Adam steps (see above)
+    assert rel_err(step.G.mapping.w_avg, g['b.G.w_avg']) < 2e-3
+    assert rel_err(step.G_ema.mapping.w_avg, g['b.G_ema.w_avg']) < 2e-3
+    # EMA is a fixed fraction of the live update: p_ema - p0 = (1 - beta)(1 + beta) / 2 ... of two different steps; at least
+    # it must be much smaller than the live update and non-zero
+    k = DELTA_KEYS_G[0]
+    d_live = (dict(step.G.named_parameters())[k] - init_G[k]).abs().mean().item()
+    d_ema = (dict(step.G_ema.named_parameters())[k] - init_G[k]).abs().mean().item()
+    assert 0 < d_ema < 0.01 * d_live
