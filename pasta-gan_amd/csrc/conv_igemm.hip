@@ -92,6 +92,9 @@ struct ConvFwdParams {
     // conv_transpose2d, else one) share a grid; class c owns taps [tap0, tap0 + T) of the tables above.
     int ncls;
     struct Lattice { int P, Q, oy0, ox0, T, tap0; } cls[4];
+    // conv_fwd_rows_bf16x6_kernel (3-wide stride-1 lattices): smallest horizontal tap offset, and whether the three
+    // taps of a kernel row are stored with descending offsets (input-gradient launches)
+    int rows, rows_d0, rows_rev;
 };
 
 template <int BM, int BN, int WMT, int WNT, int KC, int OCC = 1>   // OCC = minimum waves per SIMD asked of the register allocator
@@ -567,6 +570,302 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     }
 }
 
+
+//------------------------------------------------------------------------------------
+// Row-reuse variant of conv_fwd_bf16x6_kernel for stride-1 lattices whose taps form kh rows of three horizontally
+// adjacent offsets (every 3x3 stride-1 convolution and its input gradient: 85 % of the forward-type FLOPs of the step).
+// A pixel tile is R = BN / SEG row segments of SEG = min(Q, BN) consecutive pixels.  The activations of one input row
+// (kernel row dy) and one 16-channel chunk are fetched, split into bf16 pieces and stored to LDS ONCE, with one halo
+// pixel on either side of every segment ([piece][k-half][slot][8 bf16], slot = pixel + 2 * segment + 1), and the three
+// horizontal taps read their B fragments from that image at slot offsets 0, 1, 2: per 72 MFMAs one activation fetch
+// and split instead of three.  The weights are fetched per tap as in the base kernel.
+// K loop: "stages" (dy, chunk) of three steps (the taps of the row).  Step 0 of a stage issues the loads of the next
+// stage (halo pixels first: one wave, the waves take turns), step 1 splits and stores its main pixels, step 2 its halo
+// pixels; the B
+// image is double-buffered per stage, the A image per step.  Control flow around memory operations is static as in
+// the base kernel.
+template <int BM, int BN, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdParams p) {
+    constexpr int WMT = 2, WNT = 2, KC = 16;
+    constexpr int WAVES_N = BN / 64;
+    static_assert((BM / 64) * WAVES_N == 4, "four waves per workgroup");
+    constexpr int AUNITS = 6 * BM;
+    constexpr int APT = (AUNITS + 255) / 256;
+    constexpr int BPT = BN * 2 / 256;                   // (pixel, k-half) pairs per thread: 1 or 2
+    constexpr int SLOTS = BN + 16;                      // up to 8 segments with two halo slots each
+    constexpr int ABUF = APT * 256 * 8, BSEG = SLOTS * 8, BBUF = 6 * BSEG;      // bf16 elements
+    extern __shared__ __attribute__((aligned(16))) __bf16 rows_smem[];
+    __bf16* const As = rows_smem;                       // [2][ABUF]
+    __bf16* const Bs = rows_smem + 2 * ABUF;            // [2][BBUF]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int g = blockIdx.z;
+    const int ks = blockIdx.y / p.o_tiles;
+    const int o_blk = (blockIdx.y - ks * p.o_tiles) * BM;
+    const int P = p.cls[0].P, Q = p.cls[0].Q, oy0 = p.cls[0].oy0, ox0 = p.cls[0].ox0, T = p.cls[0].T;
+    const int KH = T / 3;
+    const int64_t pix_blk = (int64_t)blockIdx.x * BN;   // the host guarantees full tiles inside one image
+    const int HW = p.H * p.W;
+    const int NC = p.Ig_pad / KC;
+    const int stages_all = KH * NC;
+    const int s_first = (int)((int64_t)stages_all * ks / p.ksplit);
+    const int nstages = (int)((int64_t)stages_all * (ks + 1) / p.ksplit) - s_first;
+    const int seg_log2 = 31 - __builtin_clz(Q < BN ? Q : BN);
+    const int SEG = 1 << seg_log2, R = BN >> seg_log2;
+    const int d0 = p.rows_d0;
+
+    // main pixel of this thread (fixed): tile pixel bcol -> image (n, py, px); its slot keeps one halo slot per segment free
+    const int bcol = tid & (BN - 1);
+    const int n_in = (int)((pix_blk + bcol) / (P * Q));
+    const int rem_in = (int)(pix_blk + bcol - (int64_t)n_in * P * Q);
+    const int py = rem_in / Q, px = rem_in - py * Q;
+    const int m_slot = bcol + 2 * (bcol >> seg_log2) + 1;
+    const int m_cx = px + d0 + 1;
+    const unsigned xb_off = (unsigned)(((int64_t)n_in * p.Cin + (int64_t)g * p.Ig) * HW) * 4u;
+    // halo pixels (one wave per stage, in turn): BN 128: lane = segment * 4 + side * 2 + k-half; BN 256: lane = segment * 2 + side, both halves.
+    // Lanes beyond the last segment repeat it (identical data to the identical slot).
+    int h_r = BPT == 1 ? lane >> 2 : lane >> 1;
+    h_r = h_r < R ? h_r : R - 1;
+    const int h_side = BPT == 1 ? (lane >> 1) & 1 : lane & 1;
+    const int h_half = BPT == 1 ? lane & 1 : 0;
+    const int64_t h_pixel = pix_blk + ((int64_t)h_r << seg_log2);
+    const int h_n = (int)(h_pixel / (P * Q));
+    const int h_rem = (int)(h_pixel - (int64_t)h_n * P * Q);
+    const int h_py = h_rem / Q, h_qs = h_rem - h_py * Q;
+    const int h_slot = h_r * (SEG + 2) + (h_side ? SEG + 1 : 0);
+    const int h_cx = h_side ? h_qs + SEG + d0 + 1 : h_qs + d0;
+    const unsigned hb_off = (unsigned)(((int64_t)h_n * p.Cin + (int64_t)g * p.Ig) * HW) * 4u;
+
+    const char* const xbytes = (const char*)p.x;
+    const __bf16* wb = (const __bf16*)p.wp + (int64_t)g * p.KK * NC * 6 * p.Og_pad * 8;
+    const int half0 = BPT == 1 ? __builtin_amdgcn_readfirstlane(tid >> 7) : 0;
+    const int64_t a_chunk = (int64_t)6 * p.Og_pad * 8;             // bf16 elements of one packed 16-channel chunk
+
+    // ---- fetch state of the activations: the stage (kernel row b_dy, chunk b_cc) that the next load_b() fetches
+    int b_dy = s_first / NC, b_cc = s_first - b_dy * NC, b_left = nstages;
+    if (b_dy >= KH) { b_dy = KH - 1; b_cc = 0; }
+    bool m_ok = false, h_ok = false;
+    unsigned m_pix = xb_off, h_pix = hb_off;
+    auto set_row = [&](int dyi) {
+        const int dy = p.tap_dy[__builtin_amdgcn_readfirstlane(3 * dyi)];
+        const int iy = py + dy, hy = h_py + dy;
+        m_ok = (unsigned)iy < (unsigned)p.H && (unsigned)m_cx < (unsigned)p.W;
+        m_pix = m_ok ? xb_off + (unsigned)(iy * p.W + m_cx) * 4u : xb_off;
+        h_ok = (unsigned)hy < (unsigned)p.H && (unsigned)h_cx < (unsigned)p.W;
+        h_pix = h_ok ? hb_off + (unsigned)(hy * p.W + h_cx) * 4u : hb_off;
+    };
+    set_row(b_dy);
+    float mb[8 * BPT], hb[8 * BPT];
+    int m_nvalid[BPT], h_nvalid[BPT];
+    int h_owner = 0;                                 // the wave that stages the halo pixels of the stage in flight
+    auto load_b = [&]() {
+        const int cc = __builtin_amdgcn_readfirstlane(b_cc);
+        const int last = p.Ig - 1;
+        const bool real = b_left > 0;
+        h_owner = b_left & 3;
+        if (wave == h_owner) {                       // oldest loads of the step: every later wait covers them
+#pragma unroll
+            for (int i = 0; i < BPT; i++) {
+                const int c0 = cc * KC + (h_half + i) * 8;
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    hb[8 * i + j] = *(const float*)(xbytes + (h_pix + (unsigned)(c0 + j < last ? c0 + j : last) * (unsigned)HW * 4u));
+                h_nvalid[i] = (h_ok && real) ? p.Ig - c0 : 0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BPT; i++) {
+            const int c0 = cc * KC + (half0 + i) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const unsigned coff = (unsigned)(c0 + j < last ? c0 + j : last) * (unsigned)HW * 4u;    // scalar
+                mb[8 * i + j] = *(const float*)(xbytes + (m_pix + coff));
+            }
+            m_nvalid[i] = (m_ok && real) ? p.Ig - c0 : 0;
+        }
+        --b_left;
+        if (++b_cc >= NC) {
+            b_cc = 0;
+            if (b_dy + 1 < KH) set_row(++b_dy);
+        }
+    };
+    // ---- fetch state of the weights: one step ahead of the multiplication
+    int a_dy = b_dy, a_cc = b_cc;
+    const __bf16* a_w0 = wb; const __bf16* a_w1 = wb; const __bf16* a_w2 = wb;
+    auto set_a_row = [&](int dyi) {
+        const int t = __builtin_amdgcn_readfirstlane(3 * dyi);
+        a_w0 = wb + (int64_t)p.tap_slab[t] * NC * a_chunk;
+        a_w1 = wb + (int64_t)p.tap_slab[t + 1] * NC * a_chunk;
+        a_w2 = wb + (int64_t)p.tap_slab[t + 2] * NC * a_chunk;
+    };
+    set_a_row(a_dy);
+    float4 areg0, areg1, areg2;
+    auto load_a = [&](int tap_i) {                   // tap_i is a compile-time constant at every call
+        const __bf16* wt = (tap_i == 0 ? a_w0 : tap_i == 1 ? a_w1 : a_w2) + (int64_t)a_cc * a_chunk;
+        auto unit = [&](int j) {
+            int e = tid + 256 * j;
+            if (256 * (j + 1) > AUNITS) e = e < AUNITS ? e : AUNITS - 1;
+            const int seg = e / BM, within = e - seg * BM;
+            return *(const float4*)(wt + ((int64_t)seg * p.Og_pad + o_blk + within) * 8);
+        };
+        areg0 = unit(0);
+        areg1 = unit(1);
+        if (APT > 2) areg2 = unit(2);
+    };
+    auto next_a_stage = [&]() {
+        if (++a_cc >= NC) {
+            a_cc = 0;
+            if (a_dy + 1 < KH) set_a_row(++a_dy);
+        }
+    };
+    auto store_a = [&](int buf) {
+        __bf16* d = As + buf * ABUF;
+        *(float4*)&d[tid * 8] = areg0;
+        *(float4*)&d[(tid + 256) * 8] = areg1;
+        if (APT > 2) *(float4*)&d[(tid + 512) * 8] = areg2;
+    };
+
+    uint32_t q1[BPT][4], q2[BPT][4], q3[BPT][4];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    auto split_pair = [&](const float* b, const int* nvalid, int i, int j) {
+        float v0 = b[8 * i + 2 * j], v1 = b[8 * i + 2 * j + 1];
+        if (nvalid[i] < 8) {
+            v0 = 2 * j < nvalid[i] ? v0 : 0.f;
+            v1 = 2 * j + 1 < nvalid[i] ? v1 : 0.f;
+        }
+        f32x2 v = {v0, v1};
+        uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        q1[i][j] = w;
+        v[0] -= __builtin_bit_cast(float, w << 16);
+        v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
+        w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        q2[i][j] = w;
+        v[0] -= __builtin_bit_cast(float, w << 16);
+        v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
+        q3[i][j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    };
+    auto store_q = [&](int buf, int slot, int hbase) {
+#pragma unroll
+        for (int i = 0; i < BPT; i++) {
+            __bf16* bd = Bs + buf * BBUF + ((hbase + i) * SLOTS + slot) * 8;
+            *(uint4*)(bd) = make_uint4(q1[i][0], q1[i][1], q1[i][2], q1[i][3]);
+            *(uint4*)(bd + 2 * BSEG) = make_uint4(q2[i][0], q2[i][1], q2[i][2], q2[i][3]);
+            *(uint4*)(bd + 4 * BSEG) = make_uint4(q3[i][0], q3[i][1], q3[i][2], q3[i][3]);
+        }
+    };
+
+    f32x16 acc[WMT][WNT];
+#pragma unroll
+    for (int a = 0; a < WMT; a++)
+#pragma unroll
+        for (int b = 0; b < WNT; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    const int hl = lane >> 5, jl = lane & 31;
+    int fslot[WNT];                                  // slot of this lane's pixel of B fragment b, for tap offset 0
+#pragma unroll
+    for (int b = 0; b < WNT; b++) {
+        const int t = (wn * WNT + b) * 32 + jl;
+        fslot[b] = t + 2 * (t >> seg_log2);
+    }
+    struct Frag { bf16x8 a[WMT][3], b[WNT][3]; };
+    auto read_frag = [&](Frag& f, int abuf, int bbuf, int off) {
+        const __bf16* A_ = As + abuf * ABUF;
+        const __bf16* B_ = Bs + bbuf * BBUF;
+#define PASTA_LDA(PC) _Pragma("unroll") for (int a = 0; a < WMT; a++) f.a[a][PC] = *(const bf16x8*)&A_[(((PC) * 2 + hl) * BM + (wm * WMT + a) * 32 + jl) * 8];
+#define PASTA_LDB(PC) _Pragma("unroll") for (int b = 0; b < WNT; b++) f.b[b][PC] = *(const bf16x8*)&B_[(((PC) * 2 + hl) * SLOTS + fslot[b] + off) * 8];
+        PASTA_LDA(2) PASTA_LDB(0) PASTA_LDA(0) PASTA_LDB(2) PASTA_LDA(1) PASTA_LDB(1)
+#undef PASTA_LDA
+#undef PASTA_LDB
+    };
+    // One tap = one step: 24 MFMAs in six groups; TAP (0, 1, 2: position in the kernel row), ABUF_ and BBUF_ are literals.
+    auto step = [&](const int TAP, const int abuf, const int bbuf) {
+        if (TAP == 2) next_a_stage();
+        if (TAP == 0) {
+            // halo loads (wave 0) are issued inside load_b ahead of everything else of this step
+            load_b();
+            load_a(1);
+        } else {
+            load_a(TAP == 1 ? 2 : 0);
+        }
+        Frag f;
+        read_frag(f, abuf, bbuf, p.rows_rev ? 2 - TAP : TAP);
+#define PASTA_MM(PA, PB)                                                                                       \
+        _Pragma("unroll") for (int a = 0; a < WMT; a++) _Pragma("unroll") for (int b = 0; b < WNT; b++)          \
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][PA], f.b[b][PB], acc[a][b], 0, 0, 0);
+#define PASTA_SPLIT(J)                                                                                         \
+        if (TAP == 1) { _Pragma("unroll") for (int i = 0; i < BPT; i++) split_pair(mb, m_nvalid, i, J); }        \
+        if (TAP == 2 && wave == h_owner) { _Pragma("unroll") for (int i = 0; i < BPT; i++) split_pair(hb, h_nvalid, i, J); }
+        PASTA_MM(2, 0)
+        PASTA_SPLIT(0)
+        PASTA_MM(0, 2)
+        PASTA_SPLIT(1)
+        PASTA_MM(1, 1)
+        PASTA_SPLIT(2)
+        PASTA_MM(1, 0)
+        PASTA_SPLIT(3)
+        PASTA_MM(0, 1)
+        if (TAP == 1) store_q(bbuf ^ 1, m_slot, half0);
+        if (TAP == 2 && wave == h_owner) store_q(bbuf ^ 1, h_slot, h_half);
+        store_a(abuf ^ 1);
+        PASTA_MM(0, 0)
+#undef PASTA_MM
+#undef PASTA_SPLIT
+        __syncthreads();
+    };
+
+    // prologue: stage 0 of this K slice entirely, and the weights of its first tap
+    load_b();
+    load_a(0);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < BPT; i++) split_pair(mb, m_nvalid, i, j);
+    store_q(0, m_slot, half0);
+    if (wave == h_owner) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int i = 0; i < BPT; i++) split_pair(hb, h_nvalid, i, j);
+        store_q(0, h_slot, h_half);
+    }
+    store_a(0);
+    __syncthreads();
+    // two stages (six steps) per trip: the B image alternates per stage, the A image per step; an odd stage count runs
+    // one all-zero stage
+    for (int s = 0; s < nstages; s += 2) {
+        step(0, 0, 0); step(1, 1, 0); step(2, 0, 0);
+        step(0, 1, 1); step(1, 0, 1); step(2, 1, 1);
+    }
+
+    const int OHW = p.OH * p.OW;
+#pragma unroll
+    for (int b = 0; b < WNT; b++) {
+        const int64_t pix = pix_blk + (wn * WNT + b) * 32 + jl;
+        const int n = (int)(pix / (P * Q));
+        const int rem = (int)(pix - (int64_t)n * P * Q);
+        const int pp = rem / Q, qq = rem - pp * Q;
+        float* yb = (p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW : p.y) +
+                    ((int64_t)n * p.Cout + (int64_t)g * p.Og) * OHW + (oy0 + pp * p.osy) * p.OW + ox0 + qq * p.osx;
+        const float* osb = (p.oscale && p.ksplit == 1) ? p.oscale + (int64_t)n * p.Cout + (int64_t)g * p.Og : nullptr;
+#pragma unroll
+        for (int a = 0; a < WMT; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
+                if (o < p.Og) {
+                    float v = acc[a][b][r];
+                    if (osb) v *= osb[o];
+                    if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
+                    yb[(int64_t)o * OHW] = v;
+                }
+            }
+    }
+}
+
 template <int BM, int BN>
 static void launch_fwd_bf16x6(const ConvFwdParams& p, hipStream_t s) {
     ConvFwdParams q = p;
@@ -578,7 +877,38 @@ static void launch_fwd_bf16x6(const ConvFwdParams& p, hipStream_t s) {
     }
     tiles *= p.ncls;
     dim3 grid((unsigned)tiles, q.o_tiles * q.ksplit, p.G);
+    if (p.rows && p.ncls == 1) {
+        // row-reuse kernel: full tiles made of whole row segments inside one image
+        const int P = p.cls[0].P, Q = p.cls[0].Q;
+        const int seg = Q < BN ? Q : BN;
+        const bool ok = Q % 32 == 0 && (seg & (seg - 1)) == 0 && BN % seg == 0 && Q % seg == 0 && ((int64_t)P * Q) % BN == 0;
+        if (ok) {
+            constexpr int APT = (6 * BM + 255) / 256;
+            constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 6 * (BN + 16) * 8) * sizeof(__bf16);
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2>), grid, dim3(256), lds, s, q);
+            return;
+        }
+    }
     hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<BM, BN, 3>), grid, dim3(256), 0, s, q);
+}
+
+// Do the T taps at table positions [0, T) form rows of three horizontally adjacent offsets (ascending or descending)?
+static bool detect_tap_rows(ConvFwdParams& p, int T) {
+    p.rows = 0;
+    if (T % 3 != 0 || p.isx != 1 || p.isy != 1 || p.osx != 1 || p.osy != 1) return false;
+    const int step = p.tap_dx[1] - p.tap_dx[0];
+    if (step != 1 && step != -1) return false;
+    const int d0 = step == 1 ? p.tap_dx[0] : p.tap_dx[2];
+    for (int j = 0; j < T; j += 3)
+        for (int i = 0; i < 3; i++)
+            if (p.tap_dy[j + i] != p.tap_dy[j] || p.tap_dx[j + i] != p.tap_dx[0] + i * step) return false;
+    p.rows = 1; p.rows_d0 = d0; p.rows_rev = step == -1 ? 1 : 0;
+    return true;
 }
 
 constexpr int FWD_KC = 8;
@@ -1344,6 +1674,7 @@ extern "C" int pasta_conv2d_ex(const float* x, const float* w, float* y, const f
     p.o_tiles = 1;
     p.partial = (float*)workspace + round_up((int)(((int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad * 3 + 1) / 2), 4);
     p.bf16x6 = (plan.bf16x6 && !iscale) ? 1 : 0;
+    p.rows = 0; p.rows_d0 = 0; p.rows_rev = 0;
 
     {   // pack weights
         const int64_t total = (int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad;
@@ -1366,6 +1697,7 @@ extern "C" int pasta_conv2d_ex(const float* x, const float* w, float* y, const f
                 p.tap_dy[t] = r - d->pad_h; p.tap_dx[t] = c - d->pad_w; p.tap_slab[t] = t;
             }
         p.ncls = 1; p.cls[0] = {p.P, p.Q, 0, 0, p.T, 0};
+        detect_tap_rows(p, p.T);
         dispatch_fwd(tile, p, s);
     } else {
         // output row oy = iy*u - pad + r.  For parity class a (oy = a + u*pp): taps r with (a + pad - r) % u == 0,
@@ -1398,6 +1730,7 @@ extern "C" int pasta_conv2d_ex(const float* x, const float* w, float* y, const f
                     p.cls[p.ncls++] = {p.P, p.Q, a, b, p.T, tap0};
                 } else {
                     p.ncls = 1; p.cls[0] = {p.P, p.Q, a, b, p.T, 0};
+                    detect_tap_rows(p, p.T);
                     dispatch_fwd(tile, p, s);
                 }
             }
