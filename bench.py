@@ -28,6 +28,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X dense fp32 matrix peak (MI355X_MICROAR
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 matrix peak
 PEAK_HBM_GBS = 8000.0
 BF16X6 = {0: 'conv_fwd_bf16x6_kernel<128,128,3>', 1: 'conv_fwd_bf16x6_kernel<64,256,3>'}
+BF16X6_ROWS = {0: 'conv_fwd_rows_bf16x6_kernel<128,128,2>', 1: 'conv_fwd_rows_bf16x6_kernel<64,256,2>'}
 
 TILE_NAMES = {0: 'conv_fwd_kernel<128,128,2,2,8,4>', 1: 'conv_fwd_kernel<64,256,2,2,8,4>',
               2: 'conv_fwd_kernel<32,256,1,2,8>', 3: 'conv_fwd_kernel<64,64,1,1,8>'}
@@ -51,9 +52,10 @@ class ConvMeter:
         macs = desc.N * desc.C_out * (desc.C_in // g) * desc.kh * desc.kw
         macs *= (desc.H * desc.W) if desc.transposed else (desc.OH * desc.OW)
         if kind == 'conv':
-            tile, ksplit, math, launches = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-            self.lib.pasta_conv2d_plan(ctypes.byref(desc), 0, ctypes.byref(tile), ctypes.byref(ksplit), ctypes.byref(math), ctypes.byref(launches))
-            family = BF16X6[tile.value] if math.value == 2 else TILE_NAMES[tile.value]      # the networks never pass iscale
+            tile, ksplit, math, launches, kernel = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            self.lib.pasta_conv2d_plan(ctypes.byref(desc), 0, ctypes.byref(tile), ctypes.byref(ksplit), ctypes.byref(math), ctypes.byref(launches),
+                                       ctypes.byref(kernel))      # has_iscale = 0: the networks never pass iscale
+            family = {0: TILE_NAMES, 1: BF16X6, 2: BF16X6_ROWS}[kernel.value][tile.value]
             kernels = launches.value
         else:
             which = ctypes.c_int()
@@ -242,7 +244,7 @@ def main():
             name, f = dom
             achieved = f['flops'] / (f['ms'] * 1e-3) / 1e12
             traffic, src = pmc_traffic(name)
-            if name in (BF16X6[0], BF16X6[1], WGRAD_NAMES[2]):
+            if name in (BF16X6[0], BF16X6[1], BF16X6_ROWS[0], BF16X6_ROWS[1], WGRAD_NAMES[2]):
                 # six bf16 MFMA products per fp32-equivalent multiply-add: the matrix pipes execute 6x the algorithmic FLOPs
                 peak = PEAK_BF16_MFMA_TFLOPS / 6
                 note = ('split-bf16: fp32-equivalent products from 6 x v_mfma_f32_32x32x16_bf16, fp32 accumulate; peak = 2500 TFLOP/s '

@@ -866,6 +866,12 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     }
 }
 
+// Pixel tiles of the row-reuse kernel: full tiles of BN pixels made of whole row segments inside one image.
+static bool rows_tile_ok(int P, int Q, int BN) {
+    const int seg = Q < BN ? Q : BN;
+    return Q % 32 == 0 && (seg & (seg - 1)) == 0 && BN % seg == 0 && Q % seg == 0 && ((int64_t)P * Q) % BN == 0;
+}
+
 template <int BM, int BN>
 static void launch_fwd_bf16x6(const ConvFwdParams& p, hipStream_t s) {
     ConvFwdParams q = p;
@@ -879,10 +885,7 @@ static void launch_fwd_bf16x6(const ConvFwdParams& p, hipStream_t s) {
     dim3 grid((unsigned)tiles, q.o_tiles * q.ksplit, p.G);
     if (p.rows && p.ncls == 1) {
         // row-reuse kernel: full tiles made of whole row segments inside one image
-        const int P = p.cls[0].P, Q = p.cls[0].Q;
-        const int seg = Q < BN ? Q : BN;
-        const bool ok = Q % 32 == 0 && (seg & (seg - 1)) == 0 && BN % seg == 0 && Q % seg == 0 && ((int64_t)P * Q) % BN == 0;
-        if (ok) {
+        if (rows_tile_ok(p.cls[0].P, p.cls[0].Q, BN)) {
             constexpr int APT = (6 * BM + 255) / 256;
             constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 6 * (BN + 16) * 8) * sizeof(__bf16);
             static bool attr_set = false;
@@ -1630,7 +1633,7 @@ extern "C" int pasta_conv2d_tile(const pasta_conv_desc* d) {
     return (int)plan_fwd(d).tile;
 }
 
-extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int has_iscale, int* tile, int* ksplit, int* math, int* launches) {
+extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int has_iscale, int* tile, int* ksplit, int* math, int* launches, int* kernel) {
     using namespace pasta;
     if (int e = check_desc(d, "conv2d_plan")) return e;
     const FwdPlan f = plan_fwd(d);
@@ -1639,6 +1642,11 @@ extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int has_iscale, int* 
     if (ksplit) *ksplit = f.ksplit;
     if (math) *math = sb ? PASTA_MATH_BF16X6 : PASTA_MATH_F32;
     if (launches) *launches = !d->transposed ? 1 : merged_classes(d, sb) ? 1 : (d->stride < d->OH ? d->stride : d->OH) * (d->stride < d->OW ? d->stride : d->OW);
+    if (kernel) {
+        // the lattice of a stride-1 launch is the output plane itself, its taps kh rows of kw adjacent offsets
+        const bool rows = sb && d->stride == 1 && d->kw == 3 && rows_tile_ok(d->OH, d->OW, f.tile == T128x128 ? 128 : 256);
+        *kernel = !sb ? 0 : rows ? 2 : 1;
+    }
     return 0;
 }
 

@@ -125,7 +125,7 @@ ABI = {
     'pasta_conv2d_workspace':       (_c_i64, [ctypes.POINTER(ConvDesc)]),
     'pasta_conv2d_wgrad_workspace': (_c_i64, [ctypes.POINTER(ConvDesc)]),
     'pasta_conv2d_tile':  (ctypes.c_int, [ctypes.POINTER(ConvDesc)]),
-    'pasta_conv2d_plan':  (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 4),
+    'pasta_conv2d_plan':  (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 5),
     'pasta_conv2d_wgrad_plan': (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ctypes.c_int)]),
     'pasta_conv2d':       (ctypes.c_int, [_c_ptr] * 5 + [ctypes.POINTER(ConvDesc), _c_ptr, _c_i64, _c_ptr]),
     'pasta_conv2d_ex':    (ctypes.c_int, [_c_ptr] * 5 + [ctypes.POINTER(ConvEpilogue), ctypes.POINTER(ConvDesc), _c_ptr, _c_i64, _c_ptr]),

@@ -82,3 +82,32 @@ def test_split_bf16_gradients_match_fp32_accuracy():
     for mode in res:
         assert res[mode][0] < 5e-6 and res[mode][1] < 1e-5
     assert res['bf16x6'][2] < 3 * res['f32'][2] + 1e-9 and res['bf16x6'][3] < 3 * res['f32'][3] + 1e-9
+
+
+@pytest.mark.parametrize('n,cin,cout,hw', [(9, 32, 48, 32), (2, 16, 136, 64), (1, 24, 40, 128), (1, 16, 64, 256), (3, 48, 64, 64), (2, 32, 130, 128),
+                                           (4, 64, 128, 32), (2, 20, 200, 96)])
+def test_row_reuse_kernel_every_tiling(n, cin, cout, hw):
+    """conv_fwd_rows_bf16x6_kernel on every (tile, row-segment) combination: 128- and 256-pixel tiles made of 1, 2, 4
+    or 8 row segments, image borders on all sides, channel tails; forward (ascending taps) and input gradient
+    (descending taps) against torch's CPU convolution.  The last case (96-pixel rows) must fall back to the base kernel."""
+    import ctypes
+    from torch_utils.ops import conv2d_gradfix as cg
+    from torch_utils import custom_ops
+    g = torch.Generator().manual_seed(hw + cout)
+    x = torch.randn([n, cin, hw, hw], generator=g)
+    w = torch.randn([cout, cin, 3, 3], generator=g) / (3 * cin ** 0.5)
+    dy = torch.randn([n, cout, hw, hw], generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, w, padding=1)
+    gxr, = torch.autograd.grad(yr, xr, dy)
+    xc = x.cuda().requires_grad_(True)
+    y = cg.conv2d(xc, w.cuda(), padding=1)
+    gx, = torch.autograd.grad(y, xc, dy.cuda())
+    assert float((y.detach().cpu() - yr.detach()).abs().max() / yr.detach().abs().max()) < 1e-5
+    assert float((gx.cpu() - gxr).abs().max() / gxr.abs().max()) < 1e-5
+    # which kernel ran
+    desc = custom_ops.ConvDesc(N=n, C_in=cin, H=hw, W=hw, C_out=cout, OH=hw, OW=hw, kh=3, kw=3, stride=1, pad_h=1, pad_w=1, groups=1,
+                               transposed=0, flip=0, math=0)
+    kernel = ctypes.c_int()
+    custom_ops.get_plugin().pasta_conv2d_plan(ctypes.byref(desc), 0, None, None, None, None, ctypes.byref(kernel))
+    assert kernel.value == (1 if hw == 96 else 2)
