@@ -943,7 +943,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             float clamp) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
         float v = 0.f;
-        for (int k = 0; k < ksplit; k++) v += partial[(int64_t)k * numel + i];
+        int k = 0;
+        for (; k + 4 <= ksplit; k += 4) {                       // four slices in flight, summed in slice order
+            const float r0 = partial[(int64_t)k * numel + i], r1 = partial[(int64_t)(k + 1) * numel + i];
+            const float r2 = partial[(int64_t)(k + 2) * numel + i], r3 = partial[(int64_t)(k + 3) * numel + i];
+            v += r0; v += r1; v += r2; v += r3;
+        }
+        for (; k < ksplit; k++) v += partial[(int64_t)k * numel + i];
         const int64_t nc = i / ohw;
         if (oscale) v *= oscale[nc];
         if (act) v = conv_epilogue(v, bias ? bias[nc % cout] : 0.f, act, alpha, gain, clamp);
@@ -1216,8 +1222,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         const int t = (int)(r % KK);
         const int g = (int)(r / KK);
         const float* src = slab + (((int64_t)g * KK + t) * Ag_pad + a) * Bg_pad + b;
-        float v = 0.f;
-        for (int k = 0; k < ksplit; k++) v += src[k * slab_stride];
+        // sixteen slabs in flight per thread; four partial sums combined in a fixed order (bitwise reproducible)
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        int k = 0;
+        for (; k + 16 <= ksplit; k += 16) {
+            float r[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) r[j] = src[(int64_t)(k + j) * slab_stride];
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) { v0 += r[j]; v1 += r[j + 1]; v2 += r[j + 2]; v3 += r[j + 3]; }
+        }
+        for (; k < ksplit; k++) v0 += src[(int64_t)k * slab_stride];
+        const float v = (v0 + v1) + (v2 + v3);
         int ty = t / kw, tx = t - ty * kw;
         if (flip) { ty = kh - 1 - ty; tx = kw - 1 - tx; }
         dw[(((int64_t)(g * Ag + a) * Bg + b) * kh + ty) * kw + tx] = v;
@@ -1346,9 +1362,18 @@ __global__ __launch_bounds__(256) void wgrad_smallcin_reduce_kernel(const float*
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
         const int a = idx / bprime, b = idx - a * bprime;
         const float* src = slab + (int64_t)a * bpad + b;
-        float v = 0.f;
-        for (int k = 0; k < ksplit; k++) v += src[(int64_t)k * a_pad * bpad];
-        dw[idx] = v;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;          // as wgrad_reduce_kernel: sixteen slabs in flight, fixed order
+        const int64_t stride = (int64_t)a_pad * bpad;
+        int k = 0;
+        for (; k + 16 <= ksplit; k += 16) {
+            float r[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) r[j] = src[(k + j) * stride];
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) { v0 += r[j]; v1 += r[j + 1]; v2 += r[j + 2]; v3 += r[j + 3]; }
+        }
+        for (; k < ksplit; k++) v0 += src[k * stride];
+        dw[idx] = (v0 + v1) + (v2 + v3);
     }
 }
 
