@@ -291,6 +291,9 @@ static int fwd_tile_bm(FwdTile t) { return t == T128x128 ? 128 : t == T32x256 ? 
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// An empty asm that makes a VGPR value opaque to the SLP vectoriser (no instruction is emitted).
+#define PASTA_KEEP_SCALAR(x) asm("" : "+v"(x))
+
 __device__ __forceinline__ void split3(float v, __bf16& a, __bf16& b, __bf16& c) {
     a = (__bf16)v;
     float r = v - (float)a;
@@ -461,12 +464,18 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
         f32x2 v = {v0, v1};
         uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
         q1[i][j] = w;
-        v[0] -= __builtin_bit_cast(float, w << 16);
-        v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
+        // the two residual subtractions stay scalar: packed f32 VALU next to MFMAs costs more than it saves
+        // (MI355X_MICROARCH.md, cycle table), and the empty asm keeps the SLP vectoriser from pairing them
+        v0 -= __builtin_bit_cast(float, w << 16);
+        v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
+        PASTA_KEEP_SCALAR(v0);
+        v = f32x2{v0, v1};
         w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
         q2[i][j] = w;
-        v[0] -= __builtin_bit_cast(float, w << 16);
-        v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
+        v0 -= __builtin_bit_cast(float, w << 16);
+        v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
+        PASTA_KEEP_SCALAR(v0);
+        v = f32x2{v0, v1};
         q3[i][j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
     };
     auto store_b = [&](int buf) {
@@ -738,12 +747,18 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
         f32x2 v = {v0, v1};
         uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
         q1[i][j] = w;
-        v[0] -= __builtin_bit_cast(float, w << 16);
-        v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
+        // the two residual subtractions stay scalar: packed f32 VALU next to MFMAs costs more than it saves
+        // (MI355X_MICROARCH.md, cycle table), and the empty asm keeps the SLP vectoriser from pairing them
+        v0 -= __builtin_bit_cast(float, w << 16);
+        v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
+        PASTA_KEEP_SCALAR(v0);
+        v = f32x2{v0, v1};
         w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
         q2[i][j] = w;
-        v[0] -= __builtin_bit_cast(float, w << 16);
-        v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
+        v0 -= __builtin_bit_cast(float, w << 16);
+        v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
+        PASTA_KEEP_SCALAR(v0);
+        v = f32x2{v0, v1};
         q3[i][j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
     };
     auto store_q = [&](int buf, int slot, int hbase) {
