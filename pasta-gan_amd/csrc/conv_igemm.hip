@@ -1006,10 +1006,10 @@ static FwdPlan plan_fwd(const pasta_conv_desc* d) {
     return f;
 }
 
-// Large lattices: one grid for the four classes of a stride-2 conv_transpose2d on the split-bf16 kernel (measured
-// 0.475 -> 0.431 ms on 128->64 @128^2; on the 16^2 layers separate launches are faster, 0.241 vs 0.264 ms).
+// The four output parity classes of a stride-2 conv_transpose2d share one class-major grid on the split-bf16 kernel:
+// four times the workgroups per launch (measured 0.410 -> 0.266 ms on 512->256 @32^2, 0.262 -> 0.239 ms on 512->512 @16^2).
 static bool merged_classes(const pasta_conv_desc* d, bool bf16x6) {
-    return d->transposed && bf16x6 && d->stride == 2 && d->OH >= 2 && d->OW >= 2 && fwd_lattice_pixels(d) >= 65536;
+    return d->transposed && bf16x6 && d->stride == 2 && d->OH >= 2 && d->OW >= 2;
 }
 
 //------------------------------------------------------------------------------------

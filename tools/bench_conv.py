@@ -23,6 +23,8 @@ SHAPES = [  # name, N, Cin, H, Cout, k, stride, transposed
     ('b4 512->512 3x3 @4', 16, 512, 4, 512, 3, 1, False),
     ('up 128->64 3x3 T2 @128', 16, 128, 128, 64, 3, 2, True),
     ('up 512->512 3x3 T2 @16', 16, 512, 16, 512, 3, 2, True),
+    ('up 256->128 3x3 T2 @64', 16, 256, 64, 128, 3, 2, True),
+    ('up 512->256 3x3 T2 @32', 16, 512, 32, 256, 3, 2, True),
     ('merge 192->128 1x1 @128', 16, 192, 128, 128, 1, 1, False),
     ('skip 64->128 1x1 @128', 16, 64, 128, 128, 1, 1, False),
     ('torgb 64->3 1x1 @256', 16, 64, 256, 3, 1, 1, False),
