@@ -1310,10 +1310,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_smallcin_kernel(WgradSmallPara
     const int c_begin = (int)((int64_t)p.chunks_total * ks / p.ksplit);
     const int c_end = (int)((int64_t)p.chunks_total * (ks + 1) / p.ksplit);
 
-    for (int ch = c_begin; ch < c_end; ch++) {
+    // Register prefetch: chunk ch+1 is fetched while chunk ch is multiplied out of LDS.  Every thread owns the same 8 S
+    // elements (channel s_a0 + 8j, pixel s_k) and up to 4 halo slots of every chunk; the slot -> (channel, kernel row,
+    // chunk row, halo column) decomposition is fixed, only the chunk origin moves.
+    constexpr int HSLOTS = 4;                          // halo_elems <= 1024 (checked by the host)
+    int h_off[HSLOTS], h_r[HSLOTS], h_cr[HSLOTS], h_hx[HSLOTS], h_i[HSLOTS];
+#pragma unroll
+    for (int j = 0; j < HSLOTS; j++) {
+        int rem = tid + 256 * j;
+        h_off[j] = rem < halo_elems ? rem : -1;
+        h_hx[j] = rem % HW_; rem /= HW_;
+        h_r[j] = rem % p.kh; rem /= p.kh;
+        h_cr[j] = rem % CHH; h_i[j] = rem / CHH;
+    }
+    float sreg[8], hreg[HSLOTS];
+    auto fetch = [&](int ch) {
         const int rb = ch / p.qblocks, qb = ch - rb * p.qblocks;
         const int row0 = rb * CHH, q0 = qb * CW;
-        __syncthreads();
         {   // S: 64 channels x 32 pixels
             const int row = row0 + s_dr, q = q0 + s_dq;
             const bool ok = row < p.rows_total && q < p.Q;
@@ -1322,26 +1335,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_smallcin_kernel(WgradSmallPara
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int a = s_a0 + 8 * j;
-                Ss[a * SPITCH + s_k] = (ok && a_blk + a < p.Ag) ? sp[(int64_t)a * PQ] : 0.f;
+                sreg[j] = (ok && a_blk + a < p.Ag) ? sp[(int64_t)a * PQ] : 0.f;
             }
         }
-        for (int e = tid; e < halo_elems; e += 256) {   // L halo, [i][cr*kh + r][hx]
-            int rem = e;
-            const int hx = rem % HW_; rem /= HW_;
-            const int r = rem % p.kh; rem /= p.kh;
-            const int cr = rem % CHH, i = rem / CHH;
-            const int row = row0 + cr;
+#pragma unroll
+        for (int j = 0; j < HSLOTS; j++) {              // L halo, [i][cr*kh + r][hx]
             float v = 0.f;
-            if (row < p.rows_total) {
+            const int row = row0 + h_cr[j];
+            if (h_off[j] >= 0 && row < p.rows_total) {
                 const int n = row / p.P, pp = row - n * p.P;
-                const int ly = pp + r - p.pad_h, lx = q0 + hx - p.pad_w;
+                const int ly = pp + h_r[j] - p.pad_h, lx = q0 + h_hx[j] - p.pad_w;
                 if ((unsigned)ly < (unsigned)p.LH && (unsigned)lx < (unsigned)p.LW)
-                    v = p.L[((int64_t)n * p.Bg + i) * LHW + ly * p.LW + lx];
+                    v = p.L[((int64_t)n * p.Bg + h_i[j]) * LHW + ly * p.LW + lx];
             }
-            Ls[e] = v;
+            hreg[j] = v;
         }
+    };
+    if (c_begin < c_end) fetch(c_begin);
+    for (int ch = c_begin; ch < c_end; ch++) {
+        __syncthreads();                                // the previous chunk's LDS reads are done
+#pragma unroll
+        for (int j = 0; j < 8; j++) Ss[(s_a0 + 8 * j) * SPITCH + s_k] = sreg[j];
+#pragma unroll
+        for (int j = 0; j < HSLOTS; j++)
+            if (h_off[j] >= 0) Ls[h_off[j]] = hreg[j];
         if (tid == 0) Ls[halo_elems] = 0.f;
         __syncthreads();
+        if (ch + 1 < c_end) fetch(ch + 1);
 #pragma unroll 4
         for (int kk = 0; kk < KP / 2; kk++) {
             const int k = kk * 2 + kl;
@@ -1407,12 +1427,13 @@ static WgradSmallPlan plan_wgrad_small(const pasta_conv_desc* d) {
     w.qblocks = (d->OW + cw - 1) / cw;
     w.chunks_total = ((w.rows_total + chh - 1) / chh) * w.qblocks;
     w.a_tiles = (d->C_out + 63) / 64;
-    int64_t ks = (512 + w.a_tiles - 1) / w.a_tiles;
+    int64_t ks = (1024 + w.a_tiles - 1) / w.a_tiles;        // four workgroups per CU: one chunk in flight each
     if (ks > w.chunks_total / 8) ks = w.chunks_total / 8;
     if (ks < 1) ks = 1;
     w.ksplit = (int)ks;
     w.slab_floats = (int64_t)w.ksplit * w.a_tiles * 64 * w.nb * 32;
     w.lds_bytes = (size_t)(64 * 33 + Ig * chh * d->kh * (cw + d->kw - 1) + 4) * sizeof(float);
+    if (Ig * chh * d->kh * (cw + d->kw - 1) > 1024) w.use = false;      // four halo slots per thread in the kernel
     return w;
 }
 
