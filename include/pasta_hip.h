@@ -104,6 +104,9 @@ typedef struct pasta_conv_desc {
     int32_t transposed;           /* 0 = conv2d, 1 = conv_transpose2d                 */
     int32_t flip;                 /* 1 = true convolution (flip taps), 0 = correlation */
     int32_t math;                 /* PASTA_MATH_*: arithmetic of the matrix-core products (see below)  */
+    float   wscale;               /* the weights are used as w * wscale (0 = 1): Conv2dLayer's `self.weight *
+                                     self.weight_gain` (networks.py:171) folded into the weight packing; the weight
+                                     gradient is returned with respect to the unscaled w (i.e. times wscale)        */
 } pasta_conv_desc;
 
 /* Arithmetic of the convolution products.  Accumulation is fp32 in every mode.

@@ -47,7 +47,7 @@ __device__ __forceinline__ float conv_epilogue(float v, float b, int act, float 
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int G, int Ig,
                                                            int Og, int Ig_pad, int Og_pad, int kh, int kw, int transposed,
-                                                           int flip) {
+                                                           int flip, float wscale) {
     const int64_t total = (int64_t)G * kh * kw * Ig_pad * Og_pad;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         int o = (int)(idx % Og_pad);
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
             if (flip) { ty = kh - 1 - ty; tx = kw - 1 - tx; }
             int64_t src = transposed ? (((int64_t)(g * Ig + i) * Og + o) * kh + ty) * kw + tx
                                      : (((int64_t)(g * Og + o) * Ig + i) * kh + ty) * kw + tx;
-            v = w[src];
+            v = w[src] * wscale;
         }
         wp[idx] = v;
     }
@@ -305,7 +305,7 @@ __device__ __forceinline__ void split3(float v, __bf16& a, __bf16& b, __bf16& c)
 // [g][tap][chunk of 16 channels][piece 3][half 2][O_pad][8]
 __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int G, int Ig,
                                                                 int Og, int Ig_pad, int Og_pad, int kh, int kw, int transposed,
-                                                                int flip) {
+                                                                int flip, float wscale) {
     const int64_t total = (int64_t)G * kh * kw * Ig_pad * Og_pad;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int j = (int)(idx & 7);
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __r
             if (flip) { ty = kh - 1 - ty; tx = kw - 1 - tx; }
             const int64_t src = transposed ? (((int64_t)(g * Ig + i) * Og + o) * kh + ty) * kw + tx
                                            : (((int64_t)(g * Og + o) * Ig + i) * kh + ty) * kw + tx;
-            v = w[src];
+            v = w[src] * wscale;
         }
         __bf16 p1, p2, p3;
         split3(v, p1, p2, p3);
@@ -1226,7 +1226,7 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 1) void conv_wgrad_kernel(WgradPara
 // dW[(g*Ag + a)][b][ty][tx] = sum_ks slab[ks][g][t][a][b]   (tap index optionally mirrored)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int ksplit,
                                                            int G, int Ag, int Bg, int Ag_pad, int Bg_pad, int kh, int kw,
-                                                           int flip) {
+                                                           int flip, float wscale) {
     const int KK = kh * kw;
     const int64_t total = (int64_t)G * KK * Ag * Bg;
     const int64_t slab_stride = (int64_t)G * KK * Ag_pad * Bg_pad;
@@ -1248,7 +1248,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
             for (int j = 0; j < 16; j += 4) { v0 += r[j]; v1 += r[j + 1]; v2 += r[j + 2]; v3 += r[j + 3]; }
         }
         for (; k < ksplit; k++) v0 += src[(int64_t)k * slab_stride];
-        const float v = (v0 + v1) + (v2 + v3);
+        const float v = ((v0 + v1) + (v2 + v3)) * wscale;
         int ty = t / kw, tx = t - ty * kw;
         if (flip) { ty = kh - 1 - ty; tx = kw - 1 - tx; }
         dw[(((int64_t)(g * Ag + a) * Bg + b) * kh + ty) * kw + tx] = v;
@@ -1392,7 +1392,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_smallcin_kernel(WgradSmallPara
 
 // dw[o][b'] = sum_ks slab[ks][o][b']   (b' already in PyTorch's [i][r][s] order)
 __global__ __launch_bounds__(256) void wgrad_smallcin_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int ksplit,
-                                                                    int Ag, int bprime, int a_pad, int bpad) {
+                                                                    int Ag, int bprime, int a_pad, int bpad, float wscale) {
     const int total = Ag * bprime;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
         const int a = idx / bprime, b = idx - a * bprime;
@@ -1408,7 +1408,7 @@ __global__ __launch_bounds__(256) void wgrad_smallcin_reduce_kernel(const float*
             for (int j = 0; j < 16; j += 4) { v0 += r[j]; v1 += r[j + 1]; v2 += r[j + 2]; v3 += r[j + 3]; }
         }
         for (; k < ksplit; k++) v0 += src[k * stride];
-        dw[idx] = (v0 + v1) + (v2 + v3);
+        dw[idx] = ((v0 + v1) + (v2 + v3)) * wscale;
     }
 }
 
@@ -1745,16 +1745,17 @@ extern "C" int pasta_conv2d_ex(const float* x, const float* w, float* y, const f
     p.bf16x6 = (plan.bf16x6 && !iscale) ? 1 : 0;
     p.rows = 0; p.rows_d0 = 0; p.rows_rev = 0;
 
-    {   // pack weights
+    const float wscale = d->wscale == 0.f ? 1.f : d->wscale;
+    {   // pack weights (times wscale)
         const int64_t total = (int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad;
         int64_t blocks = ceil_div64(total, 256);
         if (blocks > 4096) blocks = 4096;
         if (p.bf16x6)
             hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, (__bf16*)workspace, p.G, p.Ig, p.Og,
-                               p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip);
+                               p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip, wscale);
         else
             hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, (float*)workspace, p.G, p.Ig, p.Og,
-                               p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip);
+                               p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip, wscale);
     }
 
     if (!d->transposed) {
@@ -1873,7 +1874,7 @@ extern "C" int pasta_conv2d_wgrad(const float* x, const float* dy, float* dw, co
         hipLaunchKernelGGL(conv_wgrad_smallcin_kernel, dim3((unsigned)(ws.a_tiles * ws.ksplit)), dim3(256), ws.lds_bytes, s, q);
         const int total = d->C_out * ws.bprime;
         hipLaunchKernelGGL(wgrad_smallcin_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)workspace, dw,
-                           ws.ksplit, d->C_out, ws.bprime, ws.a_tiles * 64, ws.nb * 32);
+                           ws.ksplit, d->C_out, ws.bprime, ws.a_tiles * 64, ws.nb * 32, d->wscale == 0.f ? 1.f : d->wscale);
         return launch_status("conv2d_wgrad(small-cin)");
     }
 
@@ -1923,7 +1924,7 @@ extern "C" int pasta_conv2d_wgrad(const float* x, const float* dy, float* dw, co
         int64_t rb = ceil_div64(total, 256);
         if (rb > 8192) rb = 8192;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, s, (const float*)workspace, dw, w.ksplit, p.G,
-                           p.Ag, p.Bg, w.a_tiles * 64 * w.WA, w.b_tiles * 64 * w.WB, p.kh, p.kw, d->flip);
+                           p.Ag, p.Bg, w.a_tiles * 64 * w.WA, w.b_tiles * 64 * w.WB, p.kh, p.kw, d->flip, d->wscale == 0.f ? 1.f : d->wscale);
     }
     return launch_status("conv2d_wgrad");
 }

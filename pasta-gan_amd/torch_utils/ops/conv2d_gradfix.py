@@ -47,8 +47,11 @@ def _pair(v):
     return v
 
 class _Cfg(tuple):
-    """(transposed, stride, pad_h, pad_w, outpad_h, outpad_w, groups) -- hashable op configuration."""
+    """(transposed, stride, pad_h, pad_w, outpad_h, outpad_w, groups[, wgain]) -- hashable op configuration.
+    ``wgain``: the weights enter every launch of the family as ``w * wgain`` (folded into the weight packing, and
+    into the weight gradient's reduction), so a layer's ``self.weight * self.weight_gain`` needs no kernel of its own."""
     __slots__ = ()
+    wgain = property(lambda s: s[7] if len(s) > 7 else 1.0)
     transposed = property(lambda s: s[0]); stride = property(lambda s: s[1])
     pad_h = property(lambda s: s[2]); pad_w = property(lambda s: s[3])
     outpad_h = property(lambda s: s[4]); outpad_w = property(lambda s: s[5]); groups = property(lambda s: s[6])
@@ -63,7 +66,7 @@ def _desc(cfg, x_shape, c_out, oh, ow, kh, kw):
     n, c_in, h, w = x_shape
     return custom_ops.ConvDesc(N=n, C_in=c_in, H=h, W=w, C_out=c_out, OH=oh, OW=ow, kh=kh, kw=kw, stride=cfg.stride,
                                pad_h=cfg.pad_h, pad_w=cfg.pad_w, groups=cfg.groups, transposed=int(cfg.transposed), flip=0,
-                               math=MATH_CODES[conv_math])
+                               math=MATH_CODES[conv_math], wscale=float(cfg.wgain))
 
 # Optional measurement hook (bench.py): when set, called as hook(kind, desc, launch) around every native
 # convolution launch; ``launch()`` performs it. None = no overhead.
@@ -160,10 +163,10 @@ def _launch_wgrad(x, dy, cfg, w_shape):
 def _grad_cfg(cfg, x_hw, y_hw, kh, kw):
     """Configuration of the operator that maps dy back to dx (reference :95-104, :125-128)."""
     if cfg.transposed:
-        return _Cfg((False, cfg.stride, cfg.pad_h, cfg.pad_w, 0, 0, cfg.groups))
+        return _Cfg((False, cfg.stride, cfg.pad_h, cfg.pad_w, 0, 0, cfg.groups, cfg.wgain))
     oph = x_hw[0] - ((y_hw[0] - 1) * cfg.stride - 2 * cfg.pad_h + kh)
     opw = x_hw[1] - ((y_hw[1] - 1) * cfg.stride - 2 * cfg.pad_w + kw)
-    return _Cfg((True, cfg.stride, cfg.pad_h, cfg.pad_w, oph, opw, cfg.groups))
+    return _Cfg((True, cfg.stride, cfg.pad_h, cfg.pad_w, oph, opw, cfg.groups, cfg.wgain))
 
 class _ConvHip(torch.autograd.Function):
     @staticmethod
@@ -226,7 +229,7 @@ class _ConvBiasActHip(torch.autograd.Function):
 
 FUSABLE_ACTS = ('linear', 'relu', 'lrelu')
 
-def conv2d_bias_act(input, weight, bias=None, stride=1, padding=0, groups=1, act='linear', alpha=None, gain=None, clamp=None):
+def conv2d_bias_act(input, weight, bias=None, stride=1, padding=0, groups=1, act='linear', alpha=None, gain=None, clamp=None, wgain=1.0):
     """``bias_act(conv2d(input, weight), bias, act, alpha, gain, clamp)`` in one launch (fp32 GPU tensors,
     act in FUSABLE_ACTS); other cases run the two ops separately."""
     from . import bias_act as ba
@@ -238,9 +241,9 @@ def conv2d_bias_act(input, weight, bias=None, stride=1, padding=0, groups=1, act
         sh, sw = _pair(stride)
         ph, pw = _pair(padding)
         assert sh == sw
-        cfg = _Cfg((False, sh, ph, pw, 0, 0, int(groups)))
+        cfg = _Cfg((False, sh, ph, pw, 0, 0, int(groups), float(wgain)))
         return _ConvBiasActHip.apply(input, weight, bias, cfg, (act, alpha, gain, clampf))
-    y = conv2d(input, weight, stride=stride, padding=padding, groups=groups)
+    y = conv2d(input, weight, stride=stride, padding=padding, groups=groups, wgain=wgain)
     return ba.bias_act(y, bias, act=act, alpha=alpha, gain=gain, clamp=clamp)
 
 class _ConvWgradHip(torch.autograd.Function):
@@ -275,17 +278,18 @@ def _check_common(input, weight, dilation):
 def _add_bias(y, bias):
     return y if bias is None else y + bias.to(y.dtype).reshape(1, -1, 1, 1)
 
-def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
-    """Same contract as ``torch.nn.functional.conv2d`` (reference :35-38); equal strides in x and y."""
+def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, wgain=1.0):
+    """Same contract as ``torch.nn.functional.conv2d`` (reference :35-38); equal strides in x and y.
+    ``wgain`` (extension): convolve with ``weight * wgain`` without materialising the product."""
     _check_common(input, weight, dilation)
     sh, sw = _pair(stride)
     if sh != sw:
         raise NotImplementedError('conv2d_gradfix: anisotropic stride is not implemented')
     ph, pw = _pair(padding)
-    cfg = _Cfg((False, sh, ph, pw, 0, 0, int(groups)))
+    cfg = _Cfg((False, sh, ph, pw, 0, 0, int(groups), float(wgain)))
     return _add_bias(_ConvHip.apply(input, weight, cfg), bias)
 
-def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
+def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1, wgain=1.0):
     """Same contract as ``torch.nn.functional.conv_transpose2d`` (reference :40-43)."""
     _check_common(input, weight, dilation)
     sh, sw = _pair(stride)
@@ -293,7 +297,7 @@ def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_paddi
         raise NotImplementedError('conv2d_gradfix: anisotropic stride is not implemented')
     ph, pw = _pair(padding)
     oph, opw = _pair(output_padding)
-    cfg = _Cfg((True, sh, ph, pw, oph, opw, int(groups)))
+    cfg = _Cfg((True, sh, ph, pw, oph, opw, int(groups), float(wgain)))
     return _add_bias(_ConvHip.apply(input, weight, cfg), bias)
 
 #----------------------------------------------------------------------------

@@ -19,23 +19,24 @@ from .upfirdn2d import _get_filter_size
 def _get_weight_shape(w):
     return [int(sz) for sz in w.shape]
 
-def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True):
+def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True, wgain=1.0):
     """Dispatch to ``conv2d`` / ``conv_transpose2d``. Both are correlations, so a true convolution
     (``flip_weight=False``) mirrors the taps first."""
     if not flip_weight:
         w = w.flip([2, 3])
     if transpose:
-        return conv2d_gradfix.conv_transpose2d(x, w, stride=stride, padding=padding, groups=groups)
-    return conv2d_gradfix.conv2d(x, w, stride=stride, padding=padding, groups=groups)
+        return conv2d_gradfix.conv_transpose2d(x, w, stride=stride, padding=padding, groups=groups, wgain=wgain)
+    return conv2d_gradfix.conv2d(x, w, stride=stride, padding=padding, groups=groups, wgain=wgain)
 
 #----------------------------------------------------------------------------
 
 def conv2d_resample_bias_act(x, w, b=None, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False,
-                             act='linear', alpha=None, gain=None, clamp=None):
+                             act='linear', alpha=None, gain=None, clamp=None, wgain=1.0):
     """``bias_act(conv2d_resample(x, w, ...), b, act, alpha, gain, clamp)`` -- the body of ``Conv2dLayer.forward``
     (reference training/networks.py:170-179). When the dense convolution is the last step of the resampling
     decomposition (no upsampling), bias / activation / gain / clamp ride in its epilogue; otherwise the two ops run
-    one after the other."""
+    one after the other. ``wgain``: the convolution uses ``w * wgain`` (``Conv2dLayer``'s weight gain) without a
+    multiplication kernel of its own."""
     from . import bias_act
     if up == 1 and x.dtype == torch.float32 and x.device.type == 'cuda' and act in conv2d_gradfix.FUSABLE_ACTS:
         out_channels, in_channels_per_group, kh, kw = _get_weight_shape(w)
@@ -49,18 +50,19 @@ def conv2d_resample_bias_act(x, w, b=None, f=None, up=1, down=1, padding=0, grou
         wc = w if flip_weight else w.flip([2, 3])
         if kw == 1 and kh == 1 and down > 1:          # decimate, then the fused 1x1 convolution
             x = upfirdn2d.upfirdn2d(x=x, f=f, down=down, padding=[px0, px1, py0, py1], flip_filter=flip_filter)
-            return conv2d_gradfix.conv2d_bias_act(x, wc, b, groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp)
+            return conv2d_gradfix.conv2d_bias_act(x, wc, b, groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp, wgain=wgain)
         if down > 1:                                  # low-pass, then the fused strided convolution
             x = upfirdn2d.upfirdn2d(x=x, f=f, padding=[px0, px1, py0, py1], flip_filter=flip_filter)
-            return conv2d_gradfix.conv2d_bias_act(x, wc, b, stride=down, groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp)
+            return conv2d_gradfix.conv2d_bias_act(x, wc, b, stride=down, groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp, wgain=wgain)
         if px0 == px1 and py0 == py1 and px0 >= 0 and py0 >= 0:
-            return conv2d_gradfix.conv2d_bias_act(x, wc, b, padding=[py0, px0], groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp)
-    x = conv2d_resample(x=x, w=w, f=f, up=up, down=down, padding=padding, groups=groups, flip_weight=flip_weight, flip_filter=flip_filter)
+            return conv2d_gradfix.conv2d_bias_act(x, wc, b, padding=[py0, px0], groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp, wgain=wgain)
+    x = conv2d_resample(x=x, w=w, f=f, up=up, down=down, padding=padding, groups=groups, flip_weight=flip_weight, flip_filter=flip_filter,
+                        wgain=wgain)
     return bias_act.bias_act(x, b, act=act, alpha=alpha, gain=gain, clamp=clamp)
 
 #----------------------------------------------------------------------------
 
-def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False):
+def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False, wgain=1.0):
     """Convolve ``x`` [N,C,H,W] with ``w`` [O,C//groups,kh,kw], upsampling by ``up`` before and/or
     downsampling by ``down`` after, low-pass filtered with ``f`` (from ``upfirdn2d.setup_filter``).
 
@@ -93,17 +95,17 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
     # 1x1 kernel, downsampling: decimate first, then mix channels on the small image.
     if pointwise and down > 1 and up == 1:
         x = upfirdn2d.upfirdn2d(x=x, f=f, down=down, padding=pad, flip_filter=flip_filter)
-        return _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight)
+        return _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight, wgain=wgain)
 
     # 1x1 kernel, upsampling: mix channels on the small image, then interpolate.
     if pointwise and up > 1 and down == 1:
-        x = _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight)
+        x = _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight, wgain=wgain)
         return upfirdn2d.upfirdn2d(x=x, f=f, up=up, padding=pad, gain=up ** 2, flip_filter=flip_filter)
 
     # Downsampling only: low-pass at full resolution, strided convolution.
     if down > 1 and up == 1:
         x = upfirdn2d.upfirdn2d(x=x, f=f, padding=pad, flip_filter=flip_filter)
-        return _conv2d_wrapper(x=x, w=w, stride=down, groups=groups, flip_weight=flip_weight)
+        return _conv2d_wrapper(x=x, w=w, stride=down, groups=groups, flip_weight=flip_weight, wgain=wgain)
 
     # Upsampling (optionally followed by downsampling): transposed strided convolution, then low-pass.
     if up > 1:
@@ -119,7 +121,7 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
         py1 -= kh - up
         pxt = max(min(-px0, -px1), 0)
         pyt = max(min(-py0, -py1), 0)
-        x = _conv2d_wrapper(x=x, w=w, stride=up, padding=[pyt, pxt], groups=groups, transpose=True, flip_weight=(not flip_weight))
+        x = _conv2d_wrapper(x=x, w=w, stride=up, padding=[pyt, pxt], groups=groups, transpose=True, flip_weight=(not flip_weight), wgain=wgain)
         x = upfirdn2d.upfirdn2d(x=x, f=f, padding=[px0 + pxt, px1 + pxt, py0 + pyt, py1 + pyt], gain=up ** 2, flip_filter=flip_filter)
         if down > 1:
             x = upfirdn2d.upfirdn2d(x=x, f=f, down=down, flip_filter=flip_filter)
@@ -127,11 +129,11 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
 
     # No resampling and symmetric non-negative padding: a plain convolution.
     if up == 1 and down == 1 and px0 == px1 and py0 == py1 and px0 >= 0 and py0 >= 0:
-        return _conv2d_wrapper(x=x, w=w, padding=[py0, px0], groups=groups, flip_weight=flip_weight)
+        return _conv2d_wrapper(x=x, w=w, padding=[py0, px0], groups=groups, flip_weight=flip_weight, wgain=wgain)
 
     # Anything else: pad/upsample, convolve, downsample as three separate steps.
     x = upfirdn2d.upfirdn2d(x=x, f=(f if up > 1 else None), up=up, padding=pad, gain=up ** 2, flip_filter=flip_filter)
-    x = _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight)
+    x = _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight, wgain=wgain)
     if down > 1:
         x = upfirdn2d.upfirdn2d(x=x, f=f, down=down, flip_filter=flip_filter)
     return x

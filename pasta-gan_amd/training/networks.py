@@ -180,16 +180,14 @@ class FullyConnectedLayer(torch.nn.Module):
         self.bias_gain = lr_multiplier
 
     def forward(self, x):
-        w = self.weight.to(x.dtype) * self.weight_gain
+        # networks.py:115-128.  The weight and bias gains ride in the GEMM's alpha / beta instead of two scaling kernels.
+        w = self.weight.to(x.dtype)
         b = self.bias
         if b is not None:
-            b = b.to(x.dtype)
-            if self.bias_gain != 1:
-                b = b * self.bias_gain
-        if self.activation == 'linear' and b is not None:
-            return torch.addmm(b.unsqueeze(0), x, w.t())
-        x = x.matmul(w.t())
-        return bias_act.bias_act(x, b, act=self.activation)
+            y = torch.addmm(b.to(x.dtype).unsqueeze(0), x, w.t(), beta=float(self.bias_gain), alpha=float(self.weight_gain))
+            return y if self.activation == 'linear' else bias_act.bias_act(y, None, act=self.activation)
+        x = x.matmul((w * self.weight_gain).t())
+        return bias_act.bias_act(x, None, act=self.activation)
 
 #----------------------------------------------------------------------------
 
@@ -236,14 +234,14 @@ class Conv2dLayer(torch.nn.Module):
         _make_conv_params(self, in_channels, out_channels, kernel_size, bias, channels_last, trainable)
 
     def forward(self, x, gain=1):
-        w = self.weight * self.weight_gain
+        # `w = self.weight * self.weight_gain` (networks.py:171) is folded into the convolution's weight packing (wgain)
         b = self.bias.to(x.dtype) if self.bias is not None else None
         flip_weight = (self.up == 1)
         act_gain = self.act_gain * gain
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
-        return conv2d_resample.conv2d_resample_bias_act(x=x, w=w.to(x.dtype), b=b, f=self.resample_filter, up=self.up, down=self.down,
-                                                        padding=self.padding, flip_weight=flip_weight, act=self.activation,
-                                                        gain=act_gain, clamp=act_clamp)
+        return conv2d_resample.conv2d_resample_bias_act(x=x, w=self.weight.to(x.dtype), b=b, f=self.resample_filter, up=self.up,
+                                                        down=self.down, padding=self.padding, flip_weight=flip_weight,
+                                                        act=self.activation, gain=act_gain, clamp=act_clamp, wgain=self.weight_gain)
 
 #----------------------------------------------------------------------------
 
@@ -533,15 +531,14 @@ class Spade_Conv2dLayer(torch.nn.Module):
         _make_conv_params(self, in_channels, out_channels, kernel_size, bias, channels_last, trainable)
 
     def forward(self, x, gain=1, no_act=False):
-        w = self.weight * self.weight_gain
         b = self.bias.to(x.dtype) if self.bias is not None else None
         if not no_act:
             act_gain = self.act_gain * gain
             act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
             x = bias_act.bias_act(x, b, act=self.activation, gain=act_gain, clamp=act_clamp)
         flip_weight = (self.up == 1)
-        return conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
-                                               padding=self.padding, flip_weight=flip_weight)
+        return conv2d_resample.conv2d_resample(x=x, w=self.weight.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
+                                               padding=self.padding, flip_weight=flip_weight, wgain=self.weight_gain)
 
 @persistence.persistent_class
 class Spade_Norm_Block(torch.nn.Module):
