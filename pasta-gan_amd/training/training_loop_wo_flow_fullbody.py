@@ -126,6 +126,7 @@ class TrainingStep:
                 self.phases += [dnnlib.EasyDict(name=name + 'reg', module=module, opt=opt, interval=reg_interval)]
         self.batch_idx = 0
         self.cur_nimg = 0
+        self._buf_versions = {}         # G buffer index -> version counter at its last copy into G_ema
 
     def run(self, data):
         """One iteration: every due phase accumulates gradients over the local rounds, then steps its optimiser;
@@ -156,7 +157,15 @@ class TrainingStep:
         with torch.no_grad():
             # p_ema <- p.lerp(p_ema, beta) (:522-529), as one multi-tensor launch: p_ema + (1 - beta) * (p - p_ema)
             torch._foreach_lerp_(list(self.G_ema.parameters()), list(self.G.parameters()), 1.0 - ema_beta)
-            torch._foreach_copy_(list(self.G_ema.buffers()), list(self.G.buffers()))
+            # b_ema.copy_(b) for every buffer (:528-529).  Only w_avg ever changes; a buffer whose version counter has not
+            # moved since its last copy still equals its copy, so it is skipped (~75 tiny device copies per iteration).
+            src, dst = [], []
+            for i, (b_ema, b) in enumerate(zip(self.G_ema.buffers(), self.G.buffers())):
+                if self._buf_versions.get(i) != b._version:
+                    src.append(b); dst.append(b_ema)
+                    self._buf_versions[i] = b._version
+            if src:
+                torch._foreach_copy_(dst, src)
         self.cur_nimg += self.batch_size
         self.batch_idx += 1
 
