@@ -1598,6 +1598,177 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
     }
 }
 
+//------------------------------------------------------------------------------------
+// Stride-2 sibling of conv_wgrad3x3_bf16x6_kernel (3x3, stride 2, pad 0 or 1 on both axes; conv2d and, with the
+// operand roles swapped, conv_transpose2d): dW[tap r,s][a][b] = sum_pix S[a][p][q] * L[b][2p + r - pad][2q + s - pad].
+// K chunk = 16 consecutive S pixels of one row = one K step.  The L halo is three rows of 40 columns starting at
+// column 2*q0 - 4, split once and stored as [piece][b][3 rows][40] like the stride-1 kernel; the operand of tap column
+// s is every second halo element from 4 - pad + s on, gathered from three aligned 16-byte LDS reads with v_perm_b32
+// (the bf16 pairs of a dword are halo columns 2i, 2i + 1: a window of even or of odd columns is the low or the high
+// halves of eight consecutive dwords).  L rows are not 16-byte aligned in general (257-pixel planes), so the halo is
+// fetched with dword loads.
+template <int PW>
+__global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradParams p) {
+    constexpr int SP = 16, LP = 40;                 // row pitches in bf16 elements
+    constexpr int S_PIECE = 64 * SP;
+    constexpr int L_PIECE = 64 * 3 * LP;
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+    __bf16* Ss = smem16;                            // [3][64][SP]
+    __bf16* Ls = smem16 + 3 * S_PIECE;              // [3][64][3][LP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave >> 1, wb = wave & 1;
+    const int hl = lane >> 5, jl = lane & 31;
+
+    int bid = blockIdx.x;
+    const int ks = bid % p.ksplit; bid /= p.ksplit;
+    const int bt = bid % p.b_tiles; bid /= p.b_tiles;
+    const int at = bid % p.a_tiles; bid /= p.a_tiles;
+    const int g = bid;
+    const int a_blk = at * 64, b_blk = bt * 64;
+    const int PQ = p.P * p.Q, LHW = p.LH * p.LW;
+    const float* const Sg = p.S + ((int64_t)g * p.Ag + a_blk) * PQ;
+    const float* const Lg = p.L + ((int64_t)g * p.Bg + b_blk) * LHW;
+
+    // staging roles (fixed): S unit = (channel a, group of 8 pixels), threads 0..127; L units = (channel b, halo row,
+    // group of 8 columns), 960 of them
+    const int s_a = tid >> 1, s_grp = tid & 1;
+    const bool s_on = tid < 128 && a_blk + s_a < p.Ag;
+    int l_b[4], l_row[4], l_grp[4];
+    bool l_ch_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int v = tid + 256 * j;
+        l_b[j] = v / 15;
+        const int rg = v - l_b[j] * 15;
+        l_row[j] = rg / 5; l_grp[j] = rg - l_row[j] * 5;
+        l_ch_ok[j] = v < 960 && b_blk + l_b[j] < p.Bg;
+    }
+
+    float4 sreg[2];
+    float lreg[4][8];
+    unsigned lmask = 0;                              // validity bit of each of the 32 halo elements held in registers
+    bool s_ok = false;
+    auto fetch = [&](int ch) {
+        const int row = ch / p.qblocks, qb = ch - row * p.qblocks;
+        const int n = row / p.P, pp = row - n * p.P, q0 = qb * 16;
+        s_ok = s_on;
+        if (s_on) {
+            const float* sp = Sg + (int64_t)n * p.SC * PQ + (int64_t)s_a * PQ + pp * p.Q + q0 + 8 * s_grp;
+            sreg[0] = *(const float4*)sp; sreg[1] = *(const float4*)(sp + 4);
+        }
+        lmask = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int ly = 2 * pp + l_row[j] - p.pad_h, lx = 2 * q0 - 4 + 8 * l_grp[j];
+            const bool rok = l_ch_ok[j] && (unsigned)ly < (unsigned)p.LH;
+            const float* lp = Lg + (int64_t)n * p.LC * LHW + (int64_t)l_b[j] * LHW + ly * p.LW + lx;
+            int first = lx < 0 ? -lx : 0, last = p.LW - lx < 8 ? p.LW - lx : 8;
+            if (!rok || last < 0) last = 0;
+            if (first > last) first = last;
+            const unsigned m = ((1u << last) - 1u) & ~((1u << first) - 1u);
+            if (m == 0xffu) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) lreg[j][e] = lp[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    if ((m >> e) & 1u) lreg[j][e] = lp[e];
+            }
+            lmask |= m << (8 * j);
+        }
+    };
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    auto split_store = [&](const float* vals, __bf16* dst, int piece_stride) {
+        uint32_t q1[4], q2[4], q3[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            f32x2 v = {vals[2 * j], vals[2 * j + 1]};
+            uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+            q1[j] = w;
+            v[0] -= __builtin_bit_cast(float, w << 16);
+            v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
+            w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+            q2[j] = w;
+            v[0] -= __builtin_bit_cast(float, w << 16);
+            v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
+            q3[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        }
+        *(uint4*)(dst) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+        *(uint4*)(dst + piece_stride) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+        *(uint4*)(dst + 2 * piece_stride) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+    };
+    auto stash = [&]() {
+        if (tid < 128) {
+            const float sv[8] = {s_ok ? sreg[0].x : 0.f, s_ok ? sreg[0].y : 0.f, s_ok ? sreg[0].z : 0.f, s_ok ? sreg[0].w : 0.f,
+                                 s_ok ? sreg[1].x : 0.f, s_ok ? sreg[1].y : 0.f, s_ok ? sreg[1].z : 0.f, s_ok ? sreg[1].w : 0.f};
+            split_store(sv, Ss + s_a * SP + 8 * s_grp, S_PIECE);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (tid + 256 * j < 960) {
+                float lv[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) lv[e] = ((lmask >> (8 * j + e)) & 1u) ? lreg[j][e] : 0.f;
+                split_store(lv, Ls + (l_b[j] * 3 + l_row[j]) * LP + 8 * l_grp[j], L_PIECE);
+            }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+
+    const int c_begin = (int)((int64_t)p.chunks_total * ks / p.ksplit);
+    const int c_end = (int)((int64_t)p.chunks_total * (ks + 1) / p.ksplit);
+    if (c_begin < c_end) fetch(c_begin);
+    for (int ch = c_begin; ch < c_end; ch++) {
+        __syncthreads();                  // the previous chunk's fragment reads are done
+        stash();
+        __syncthreads();
+        if (ch + 1 < c_end) fetch(ch + 1);
+        bf16x8 af[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; pc++) af[pc] = *(const bf16x8*)&Ss[pc * S_PIECE + (wa * 32 + jl) * SP + 8 * hl];
+#pragma unroll
+        for (int pb = 2; pb >= 0; pb--) {           // B pieces from the smallest to the largest
+#pragma unroll
+            for (int row = 0; row < 3; row++) {
+                const __bf16* lb = &Ls[pb * L_PIECE + ((wb * 32 + jl) * 3 + row) * LP + 16 * hl];
+                const uint4 b0 = *(const uint4*)lb, b1 = *(const uint4*)(lb + 8), b2 = *(const uint4*)(lb + 16);
+                const uint32_t d[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+                for (int ts = 0; ts < 3; ts++) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int c0 = 4 - PW + ts, d0 = c0 >> 1;
+                    const uint32_t sel = (c0 & 1) ? 0x07060302u : 0x05040100u;
+                    const uint4 w = make_uint4(__builtin_amdgcn_perm(d[d0 + 1], d[d0], sel), __builtin_amdgcn_perm(d[d0 + 3], d[d0 + 2], sel),
+                                               __builtin_amdgcn_perm(d[d0 + 5], d[d0 + 4], sel), __builtin_amdgcn_perm(d[d0 + 7], d[d0 + 6], sel));
+                    const bf16x8 bw = __builtin_bit_cast(bf16x8, w);
+                    const int tap = row * 3 + ts;
+#pragma unroll
+                    for (int pa = 2 - pb; pa >= 0; pa--)
+                        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa], bw, acc[tap], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const int Ag_pad = p.a_tiles * 64, Bg_pad = p.b_tiles * 64;
+    float* out = p.slab + ((int64_t)ks * p.G + g) * 9 * Ag_pad * Bg_pad;
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        float* ot = out + (int64_t)t * Ag_pad * Bg_pad;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int a = a_blk + wa * 32 + acc_row(r, lane), b = b_blk + wb * 32 + jl;
+            ot[(int64_t)a * Bg_pad + b] = acc[t][r];
+        }
+    }
+}
+
 struct WgradPlan {
     int TR, TS, WA, WB, pipe, npos, kp, bf16x6, tgr, tgs, a_tiles, b_tiles, cw_log2, qblocks, chunks_total, ksplit, rows_total;
     int64_t slab_floats; size_t lds_bytes;
@@ -1824,6 +1995,12 @@ static bool wgrad_bf16x6(const pasta_conv_desc* d, const WgradPlan& w) {
     return d->math != PASTA_MATH_F32 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 &&
            Q % 32 == 0 && LH == P && LW == Q && w.kp == 32 && w.cw_log2 == 5;
 }
+// ... and its stride-2 sibling: 3x3, stride 2, equal pads of 0 or 1, rows of a multiple of 16 pixels.
+static bool wgrad_s2_bf16x6(const pasta_conv_desc* d, const WgradPlan& w) {
+    const int Q = d->transposed ? d->W : d->OW;
+    return d->math != PASTA_MATH_F32 && d->kh == 3 && d->kw == 3 && d->stride == 2 && d->pad_h == d->pad_w && d->pad_h <= 1 &&
+           Q % 16 == 0 && w.kp == 16 && w.cw_log2 == 4;
+}
 }  // namespace pasta
 
 extern "C" int pasta_conv2d_wgrad_plan(const pasta_conv_desc* d, int* kernel) {
@@ -1836,6 +2013,7 @@ extern "C" int pasta_conv2d_wgrad_plan(const pasta_conv_desc* d, int* kernel) {
         const WgradPlan w = d->transposed ? plan_wgrad(d->N, d->H, d->W, d->groups, Ig, Og, d->kh, d->kw, d->stride)
                                           : plan_wgrad(d->N, d->OH, d->OW, d->groups, Og, Ig, d->kh, d->kw, d->stride);
         if (wgrad_bf16x6(d, w)) k = 2;
+        else if (wgrad_s2_bf16x6(d, w)) k = 3;
     }
     if (kernel) *kernel = k;
     return 0;
@@ -1911,6 +2089,11 @@ extern "C" int pasta_conv2d_wgrad(const float* x, const float* dy, float* dw, co
     if (wgrad_bf16x6(d, w)) {
         const size_t lds = (size_t)(3 * 64 * 40 + 3 * 64 * 3 * 40) * 2;
         hipLaunchKernelGGL(conv_wgrad3x3_bf16x6_kernel, dim3((unsigned)blocks), dim3(256), lds, s, p);
+    }
+    else if (wgrad_s2_bf16x6(d, w)) {
+        const size_t lds = (size_t)(3 * 64 * 16 + 3 * 64 * 3 * 40) * 2;
+        if (d->pad_w == 1) hipLaunchKernelGGL(conv_wgrad3x3s2_bf16x6_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, s, p);
+        else               hipLaunchKernelGGL(conv_wgrad3x3s2_bf16x6_kernel<0>, dim3((unsigned)blocks), dim3(256), lds, s, p);
     }
     else if (w.TR == 3 && w.TS == 3) PASTA_WGRAD(3, 3, 1, 1);
     else if (w.TS == 7) PASTA_WGRAD(1, 7, 1, 1);

@@ -111,3 +111,45 @@ def test_row_reuse_kernel_every_tiling(n, cin, cout, hw):
     kernel = ctypes.c_int()
     custom_ops.get_plugin().pasta_conv2d_plan(ctypes.byref(desc), 0, None, None, None, None, ctypes.byref(kernel))
     assert kernel.value == (1 if hw == 96 else 2)
+
+
+@pytest.mark.parametrize('transposed,n,cin,cout,hw,pad', [(False, 2, 40, 72, 65, 0), (False, 2, 64, 64, 64, 1), (False, 1, 24, 130, 129, 0),
+                                                        (True, 2, 72, 40, 32, 0), (True, 1, 130, 24, 64, 0), (False, 2, 32, 64, 33, 0)])
+def test_stride2_weight_gradient_split_bf16(transposed, n, cin, cout, hw, pad):
+    """conv_wgrad3x3s2_bf16x6_kernel: stride-2 3x3 weight gradients of conv2d (pad 0 on odd planes as in the
+    discriminator's down blocks, pad 1 on even planes as in the encoders) and of conv_transpose2d (operand roles
+    swapped), channel tails, against fp64 autograd; the last case (16-pixel rows... 33 -> 16) exercises K slicing."""
+    import ctypes
+    from torch_utils.ops import conv2d_gradfix as cg
+    from torch_utils import custom_ops
+    g = torch.Generator().manual_seed(hw * 7 + cout)
+    x = torch.randn([n, cin, hw, hw], generator=g)
+    if transposed:
+        w = torch.randn([cin, cout, 3, 3], generator=g) / (3 * cin ** 0.5)
+        ref_fn = lambda a, b: torch.nn.functional.conv_transpose2d(a, b, stride=2, padding=pad)
+        our_fn = lambda a, b: cg.conv_transpose2d(a, b, stride=2, padding=pad)
+    else:
+        w = torch.randn([cout, cin, 3, 3], generator=g) / (3 * cin ** 0.5)
+        ref_fn = lambda a, b: torch.nn.functional.conv2d(a, b, stride=2, padding=pad)
+        our_fn = lambda a, b: cg.conv2d(a, b, stride=2, padding=pad)
+    w64 = w.double().requires_grad_(True)
+    y64 = ref_fn(x.double(), w64)
+    dy = torch.randn(list(y64.shape), generator=g)
+    rw, = torch.autograd.grad(y64, w64, dy.double())
+    res = {}
+    for mode in ['f32', 'bf16x6']:
+        old = cg.conv_math
+        cg.conv_math = mode
+        try:
+            wc = w.cuda().requires_grad_(True)
+            gw, = torch.autograd.grad(our_fn(x.cuda(), wc), wc, dy.cuda())
+        finally:
+            cg.conv_math = old
+        res[mode] = float((gw.double().cpu() - rw).abs().max() / rw.abs().max())
+    assert res['f32'] < 1e-5 and res['bf16x6'] < 1e-5, res
+    oh = y64.shape[2]
+    desc = custom_ops.ConvDesc(N=n, C_in=cin, H=hw, W=hw, C_out=cout, OH=oh, OW=oh, kh=3, kw=3, stride=2, pad_h=pad, pad_w=pad, groups=1,
+                               transposed=int(transposed), flip=0, math=0, wscale=1.0)
+    kernel = ctypes.c_int()
+    custom_ops.get_plugin().pasta_conv2d_wgrad_plan(ctypes.byref(desc), ctypes.byref(kernel))
+    assert kernel.value == 3

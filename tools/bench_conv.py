@@ -15,7 +15,8 @@ SHAPES = [  # name, N, Cin, H, Cout, k, stride, transposed
     ('spade 128->128 3x3 @128', 16, 128, 128, 128, 3, 1, False),
     ('spade 256->128 3x3 @128', 16, 256, 128, 128, 3, 1, False),
     ('b256 64->64 3x3 @256', 16, 64, 256, 64, 3, 1, False),
-    ('enc 64->128 3x3 s2 @257', 16, 64, 257, 128, 3, 2, False),
+    ('down 64->128 3x3 s2 @257 p0', 16, 64, 257, 128, 3, 2, False, 0),      # discriminator: blur to 257, then stride 2 without padding
+    ('enc 64->128 3x3 s2 @256 p1', 16, 64, 256, 128, 3, 2, False),
     ('b64 256->256 3x3 @64', 16, 256, 64, 256, 3, 1, False),
     ('b32 512->512 3x3 @32', 16, 512, 32, 512, 3, 1, False),
     ('b16 512->512 3x3 @16', 16, 512, 16, 512, 3, 1, False),
@@ -54,10 +55,10 @@ def main():
     only = args.only.split(',')
     dev = torch.device('cuda')
     print(f"{'shape':28s} {'pass':6s} {'ms':>8s} {'TFLOP/s':>8s}" + (f" {'miopen ms':>10s} {'TF/s':>7s}" if args.miopen else ''))
-    for name, n, ci, h, co, k, st, tr in SHAPES:
+    for name, n, ci, h, co, k, st, tr, *rest in SHAPES:
         if args.match and args.match not in name:
             continue
-        pad = k // 2 if not tr else 0
+        pad = rest[0] if rest else (k // 2 if not tr else 0)
         x = torch.randn([n, ci, h, h], device=dev)
         w = torch.randn([ci, co, k, k] if tr else [co, ci, k, k], device=dev) * 0.05
         cfg = cg._Cfg((tr, st, pad, pad, 0, 0, 1))
