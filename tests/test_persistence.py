@@ -116,9 +116,9 @@ def test_load_network_pkl():
 def test_loaded_generator_runs_on_the_hip_path():
     """test.py's flow: load the snapshot, move G_ema to the GPU, run the inference call sequence."""
     import legacy
-    G = _tiny_generator()
-    buf = io.BytesIO()
     from training import networks
+    G = PF.fill_module(networks.GeneratorV18(**PF.G_KWARGS)).eval().requires_grad_(False)      # a configuration that can run
+    buf = io.BytesIO()
     D = networks.Discriminator(c_dim=512, img_resolution=256, img_channels=3, channel_base=512, channel_max=32)
     pickle.dump(dict(G=G, D=D, G_ema=G), buf)
     buf.seek(0)
