@@ -174,6 +174,8 @@ def main():
     ap.add_argument('--steps', type=int, default=16, help='timed iterations; 16 = one full lazy-regularisation period (Dreg runs every 16th)')
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch-gpu', type=int, default=16)
+    ap.add_argument('--vgg-weight', type=float, default=0.0, help='> 0: add the VGG-19 perceptual term with random-init weights '
+                    '(train.sh uses 40; the pretrained checkpoint cannot be obtained here). Not the headline configuration.')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-meter', action='store_true', help='do not bracket convolution launches with events')
     ap.add_argument('--by-shape', action='store_true', help='also print a per-shape convolution table to stderr')
@@ -206,6 +208,9 @@ def main():
 
     lib = _native.lib()       # raises if libpasta_hip.so is missing
     cfg = fashion_config()
+    if args.vgg_weight > 0:
+        cfg.loss_kwargs.vgg_weight = args.vgg_weight
+        cfg.loss_kwargs.vgg_random_init = True
     step = TrainingStep(device, cfg=cfg, num_gpus=world, rank=rank, batch_size=args.batch_gpu * world, batch_gpu=args.batch_gpu)
     data = SyntheticFullBodyBatch(args.batch_gpu, device, seed=rank)
     meter = ConvMeter(lib)
@@ -254,8 +259,8 @@ def main():
             'ms_per_step': round(1000 * dt / args.steps, 2), 'host_issue_ms_per_step': round(1000 * host_dt / args.steps, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'conv_math': conv2d_gradfix.conv_math, 'data': 'synthetic', 'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
             'config': {'workload': 'BASELINE config 2: full training_loop step (Gmain+Dmain every iter, Dreg/16, Greg/4, Adam, EMA), '
-                                   'GeneratorFull+Discriminator cfg=fashion 256x256, batch 16/GPU, G and D in fp32, '
-                                   'vgg_weight=0 (weights unavailable), no ADA, random-init weights; timed iterations ' + f'{args.warmup}..{args.warmup + args.steps - 1}',
+                                   'GeneratorFull+Discriminator cfg=fashion 256x256, batch 16/GPU, G and D in fp32, ' +
+                                   ('vgg_weight=0 (weights unavailable)' if args.vgg_weight <= 0 else f'vgg_weight={args.vgg_weight:g} with random-init VGG-19') + ', no ADA, random-init weights; timed iterations ' + f'{args.warmup}..{args.warmup + args.steps - 1}',
                        'global_batch': args.batch_gpu * world, 'parallelism': f'dp{world}' + (' (RCCL all-reduce)' if world > 1 else '')},
         }
         fam = meter.summary()

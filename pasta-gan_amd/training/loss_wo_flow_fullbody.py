@@ -4,16 +4,84 @@ Mirrors ``StyleGAN2Loss`` of the reference's training/loss_wo_flow_fullbody.py (
 ``run_G`` :74-94, ``run_D`` :96-102, ``accumulate_gradients`` :106-254): non-saturating GAN terms on
 both generator outputs, L1, 6-class parsing cross-entropy and lazy R1, with DistributedDataParallel
 synchronisation gated exactly as there. Differences, all outside the G/D kernels:
-the VGG19 perceptual and contextual terms need weights that are not distributable
-(``./checkpoints/vgg19-dcbb9e9d.pth``) and are rejected unless their weight is 0; statistics
-reporting is a no-op hook; style mixing picks its cutoff without a host synchronisation.
+the VGG19 perceptual term (``VGGLoss`` :259-273 over ``VGG19_Feature`` :275-310) runs on this package's convolution
+when ``vgg_weight > 0``; its pretrained weights (``./checkpoints/vgg19-dcbb9e9d.pth``) cannot be obtained here, so the
+file is loaded when present and otherwise ``vgg_random_init=True`` must be passed (random weights: the arithmetic and
+its cost are the reference's, the loss value is not meaningful).  The contextual term needs a second unobtainable
+checkpoint and is rejected unless its weight is 0; statistics reporting is a no-op hook; style mixing picks its cutoff
+without a host synchronisation.
 """
+
+import os
 
 import numpy as np
 import torch
 
 from torch_utils import misc
 from torch_utils.ops import conv2d_gradfix
+
+#----------------------------------------------------------------------------
+
+# torchvision's configuration 'E' (VGG-19 without batch norm), as listed in the reference (:385); 'M' = 2x2 max pooling.
+VGG19_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M']
+# Feature taps of VGG19_Feature (:293-302): outputs of layers 1, 6, 11, 20, 29 of ``features`` = relu1_1, relu2_1, relu3_1,
+# relu4_1, relu5_1, i.e. after convolution number 1, 3, 5, 9, 13 (1-based).
+VGG19_TAPS = (1, 3, 5, 9, 13)
+
+class VGG19_Feature(torch.nn.Module):
+    """relu{1..5}_1 activations of VGG-19 (:275-310).  Weights are frozen buffers named as torchvision's
+    ``features.<index>.weight / .bias`` so that the reference's checkpoint loads unchanged."""
+    def __init__(self, device, ckpt_path='./checkpoints/vgg19-dcbb9e9d.pth', random_init=False, seed=0):
+        super().__init__()
+        self.layers = []                                    # ('conv', features-index) / ('pool', None), up to relu5_1
+        idx, cin, convs = 0, 3, 0
+        gen = torch.Generator().manual_seed(seed)
+        state = None
+        if os.path.isfile(ckpt_path):
+            state = torch.load(ckpt_path, map_location='cpu')
+        elif not random_init:
+            raise FileNotFoundError(f'{ckpt_path} not found: pass vgg_random_init=True to run the perceptual term with random weights')
+        for v in VGG19_CFG:
+            if v == 'M':
+                self.layers.append(('pool', None)); idx += 1
+                continue
+            if state is not None:
+                w, b = state[f'features.{idx}.weight'], state[f'features.{idx}.bias']
+            else:       # He-normal, like torchvision's initialisation of an untrained VGG
+                w = torch.randn([v, cin, 3, 3], generator=gen) * (2.0 / (9 * v)) ** 0.5
+                b = torch.zeros([v])
+            self.register_buffer(f'features_{idx}_weight', w.float().to(device))
+            self.register_buffer(f'features_{idx}_bias', b.float().to(device))
+            self.layers.append(('conv', idx)); idx += 2; cin = v; convs += 1
+            if convs == VGG19_TAPS[-1]:
+                break
+
+    def forward(self, x):
+        feats, convs = [], 0
+        for kind, idx in self.layers:
+            if kind == 'pool':
+                x = torch.nn.functional.max_pool2d(x, kernel_size=2, stride=2)
+                continue
+            x = conv2d_gradfix.conv2d_bias_act(x, getattr(self, f'features_{idx}_weight'), getattr(self, f'features_{idx}_bias'),
+                                               padding=1, act='relu', gain=1)
+            convs += 1
+            if convs in VGG19_TAPS:
+                feats.append(x)
+        return feats
+
+class VGGLoss(torch.nn.Module):
+    """sum_i w_i * L1(vgg_i(x), vgg_i(y).detach()) with w = 1/32, 1/16, 1/8, 1/4, 1 (:259-273)."""
+    def __init__(self, device, random_init=False, weights=(1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0)):
+        super().__init__()
+        self.vgg = VGG19_Feature(device, random_init=random_init)
+        self.weights = weights
+
+    def forward(self, x, y):
+        x_vgg, y_vgg = self.vgg(x), self.vgg(y)
+        loss = 0
+        for w, fx, fy in zip(self.weights, x_vgg, y_vgg):
+            loss = loss + w * torch.nn.functional.l1_loss(fx, fy.detach())
+        return loss
 
 #----------------------------------------------------------------------------
 
@@ -27,11 +95,11 @@ class Loss:
 class StyleGAN2Loss(Loss):
     def __init__(self, device, G_mapping, G_synthesis, G_const_encoding, G_style_encoding, D, augment_pipe=None,
                  style_mixing_prob=0.9, r1_gamma=10, pl_batch_shrink=2, pl_decay=0.01, pl_weight=0, l1_weight=50,
-                 vgg_weight=50, contextual_weight=1.0, mask_weight=1.0, report_fn=None):
+                 vgg_weight=50, contextual_weight=1.0, mask_weight=1.0, report_fn=None, vgg_random_init=False):
         super().__init__()
-        if vgg_weight > 0 or contextual_weight > 0:
-            raise NotImplementedError('VGG19 perceptual / contextual terms need ./checkpoints/vgg19*.pth, which cannot be '
-                                      'obtained here; pass vgg_weight=0, contextual_weight=0 (SURVEY.md 8f-2)')
+        if contextual_weight > 0:
+            raise NotImplementedError('the contextual term needs ./checkpoints/vgg19_conv.pth, which cannot be obtained here; '
+                                      'pass contextual_weight=0 (accumulate_gradients never uses it: :106-254)')
         if pl_weight != 0:
             raise NotImplementedError('path-length regularisation is unreachable in the reference (wrong arity at '
                                       'loss_wo_flow_fullbody.py:185-205; train.sh sets --pl_weight 0)')
@@ -49,6 +117,8 @@ class StyleGAN2Loss(Loss):
         self.vgg_weight = vgg_weight
         self.mask_weight = mask_weight
         self.report = report_fn if report_fn is not None else (lambda name, value: None)
+        if vgg_weight > 0:
+            self.criterionVGG = VGGLoss(device, random_init=vgg_random_init)
         class_weight = torch.tensor([1, 2, 2, 3, 3, 3], dtype=torch.float32, device=device)
         self.ce_parsing = torch.nn.CrossEntropyLoss(ignore_index=255, weight=class_weight)
 
@@ -109,7 +179,14 @@ class StyleGAN2Loss(Loss):
             loss_mask = 0
             if self.mask_weight > 0:
                 loss_mask = torch.mean(self.ce_parsing(pred_parsing, gt_parsing.long()[:, 0, ...])) * self.mask_weight
-            loss_G = (loss_Gmain + loss_Gmain_finetune) / 2 + (loss_G_L1 + loss_G_finetune_L1) / 2 + loss_mask
+            loss_G_VGG = loss_G_finetune_VGG = 0
+            if self.vgg_weight > 0:       # :162-171
+                loss_G_VGG = self.criterionVGG(gen_img, real_img) * self.vgg_weight
+                loss_G_finetune_VGG = self.criterionVGG(gen_finetune_img, real_img) * self.vgg_weight
+            self.report('Loss/G/vgg', loss_G_VGG)
+            self.report('Loss/G/vgg_finetune', loss_G_finetune_VGG)
+            loss_G = (loss_Gmain + loss_Gmain_finetune) / 2 + (loss_G_L1 + loss_G_finetune_L1) / 2 + \
+                     (loss_G_VGG + loss_G_finetune_VGG) / 2 + loss_mask
             self.report('Loss/scores/fake_finetune', gen_finetune_logits)
             self.report('Loss/G/loss', loss_Gmain)
             self.report('Loss/G/loss_finetune', loss_Gmain_finetune)

@@ -144,4 +144,6 @@ def test_loss_rejects_terms_outside_the_path():
         StyleGAN2Loss(**kw)                       # defaults ask for VGG19 weights
     with pytest.raises(NotImplementedError):
         StyleGAN2Loss(vgg_weight=0, contextual_weight=0, pl_weight=2, **kw)
+    with pytest.raises(FileNotFoundError):
+        StyleGAN2Loss(vgg_weight=40, contextual_weight=0, **kw)      # no checkpoint and random weights not asked for
     StyleGAN2Loss(vgg_weight=0, contextual_weight=0, **kw)

@@ -120,3 +120,41 @@ def test_generator_v18_inference_golden():
                  inp['denorm_upper_mask'], inp['denorm_lower_mask'], noise_mode='const')
     for name, t in zip(['img', 'finetune_img', 'upper_mask', 'lower_mask'], outs):
         _summary_ok(g, 'G18.' + name, t, TOL_FWD)
+
+
+def test_vgg19_perceptual_term_matches_the_cpu_restatement():
+    """Row f2: VGG19_Feature / VGGLoss on the HIP convolution against oracle/ref_vgg.py with the same (seeded random)
+    weights: the five feature maps, the loss value and its gradient with respect to the image."""
+    from oracle import ref_vgg
+    from training.loss_wo_flow_fullbody import VGGLoss
+    crit = VGGLoss(torch.device('cuda'), random_init=True)
+    state = {}
+    for name, buf in crit.vgg.named_buffers():
+        _, idx, kind = name.split('_')
+        state[f'features.{idx}.{kind}'] = buf.detach().cpu()
+    assert len(state) == 26 and state['features.28.weight'].shape == (512, 512, 3, 3)      # 13 convolutions up to relu5_1
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand([2, 3, 64, 64], generator=g) * 2 - 1
+    y = torch.rand([2, 3, 64, 64], generator=g) * 2 - 1
+    xr = x.clone().requires_grad_(True)
+    ref = ref_vgg.vgg_loss(xr, y, state)
+    gref, = torch.autograd.grad(ref, xr)
+    feats = crit.vgg(x.cuda())
+    for a, b in zip(feats, ref_vgg.features(x, state)):
+        assert a.shape == b.shape and rel_err(a, b) < 1e-5
+    xc = x.cuda().requires_grad_(True)
+    ours = crit(xc, y.cuda())
+    gours, = torch.autograd.grad(ours, xc)
+    assert abs(float(ours) - float(ref)) < 1e-5 * abs(float(ref))
+    # d|a - b| is a sign: elements whose difference is rounding noise may flip it, so the gradient of the loss is compared
+    # in direction and norm, and the backward path itself through a smooth (linear) functional of the features
+    cos = float((gours.cpu() * gref).sum() / (gours.norm().cpu() * gref.norm()))
+    assert cos > 0.9999 and abs(float(gours.norm()) / float(gref.norm()) - 1) < 1e-3
+    probes = [torch.randn(list(f.shape), generator=g) for f in feats]
+    xr2 = x.clone().requires_grad_(True)
+    lin_ref = sum((f * r).sum() for f, r in zip(ref_vgg.features(xr2, state), probes))
+    g_ref, = torch.autograd.grad(lin_ref, xr2)
+    xc2 = x.cuda().requires_grad_(True)
+    lin = sum((f * r.cuda()).sum() for f, r in zip(crit.vgg(xc2), probes))
+    g_ours, = torch.autograd.grad(lin, xc2)
+    assert rel_err(g_ours, g_ref) < 1e-3
