@@ -1,0 +1,657 @@
+// Split-bf16 forward-type kernels (v_mfma_f32_32x32x16_bf16, fp32-equivalent products): weight packing, conv_fwd_bf16x6_kernel, conv_fwd_rows_bf16x6_kernel and their launcher.  Included by conv_igemm.hip.
+#pragma once
+#include "conv_common.h"
+
+namespace pasta {
+
+//------------------------------------------------------------------------------------
+// Forward-type implicit GEMM on the bf16 matrix cores with fp32-equivalent products ("split-bf16").
+//
+// Every fp32 operand v is written as v = v1 + v2 + v3 with v1 = bf16(v), v2 = bf16(v - v1), v3 = bf16(v - v1 - v2):
+// three bf16 pieces of 8 significand bits each carry the 24 bits of an fp32 significand, and a product of two bf16
+// values is exact in fp32.  a*b is evaluated as a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1 (the three dropped terms are
+// below 2^-24 |ab|), accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Six bf16 MFMAs replace eight fp32 MFMAs of a
+// quarter of the rate each: 2.67x the fp32-MFMA throughput at fp32 accuracy.
+// Tile 128 x 128, K chunks of 16 channels of one tap; weights are split once by the packing kernel, activations by
+// the staging code (after the optional modulation scale).  Layouts in LDS (per piece and per k-half of 8):
+// [piece][half][row or pixel][8 bf16] so that a fragment is one conflict-free 16-byte read.
+
+
+
+__device__ __forceinline__ void split3(float v, __bf16& a, __bf16& b, __bf16& c) {
+    a = (__bf16)v;
+    float r = v - (float)a;
+    b = (__bf16)r;
+    r -= (float)b;
+    c = (__bf16)r;
+}
+
+// [g][tap][chunk of 16 channels][piece 3][half 2][O_pad][8]
+__global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int G, int Ig,
+                                                                int Og, int Ig_pad, int Og_pad, int kh, int kw, int transposed,
+                                                                int flip, float wscale) {
+    const int64_t total = (int64_t)G * kh * kw * Ig_pad * Og_pad;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int j = (int)(idx & 7);
+        int64_t r = idx >> 3;
+        const int o = (int)(r % Og_pad); r /= Og_pad;
+        const int half = (int)(r & 1); r >>= 1;
+        const int cc = (int)(r % (Ig_pad / 16)); r /= (Ig_pad / 16);
+        const int t = (int)(r % (kh * kw));
+        const int g = (int)(r / (kh * kw));
+        const int i = cc * 16 + half * 8 + j;
+        float v = 0.f;
+        if (i < Ig && o < Og) {
+            int ty = t / kw, tx = t - ty * kw;
+            if (flip) { ty = kh - 1 - ty; tx = kw - 1 - tx; }
+            const int64_t src = transposed ? (((int64_t)(g * Ig + i) * Og + o) * kh + ty) * kw + tx
+                                           : (((int64_t)(g * Og + o) * Ig + i) * kh + ty) * kw + tx;
+            v = w[src] * wscale;
+        }
+        __bf16 p1, p2, p3;
+        split3(v, p1, p2, p3);
+        const int64_t chunk = (((int64_t)g * kh * kw + t) * (Ig_pad / 16) + cc) * 6 * Og_pad * 8;
+        const int64_t within = ((int64_t)half * Og_pad + o) * 8 + j;
+        wp[chunk + within] = p1;
+        wp[chunk + 2 * Og_pad * 8 + within] = p2;
+        wp[chunk + 4 * Og_pad * 8 + within] = p3;
+    }
+}
+
+template <int BM, int BN, int OCC>      // (128, 128): waves 2 x 2;  (64, 256): waves 1 x 4; each wave 64 rows x 64 pixels
+__global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams p) {
+    constexpr int WMT = 2, WNT = 2, KC = 16;
+    constexpr int WAVES_N = BN / 64;
+    static_assert((BM / 64) * WAVES_N == 4, "four waves per workgroup");
+    constexpr int ASEG = BM * 8, BSEG = BN * 8;         // bf16 elements of one (piece, half) segment
+    constexpr int AUNITS = 6 * BM;                      // sixteen-byte units of the A chunk
+    constexpr int APT = (AUNITS + 255) / 256;           // per thread: 3 (BM 128) or 2 (BM 64, second one guarded)
+    constexpr int BPT = BN * 2 / 256;                   // (pixel, k-half) pairs per thread: 1 or 2
+    // A buffers are rounded up to APT * 256 units: every thread copies APT units without a guard (see load_chunk)
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][APT * 256 * 8];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][6 * BSEG];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int g = blockIdx.z;
+    const int ks = blockIdx.y / p.o_tiles;
+    const int o_blk = (blockIdx.y - ks * p.o_tiles) * BM;
+    // Workgroup -> (lattice class, pixel tile), class-major: the grid holds gridDim.x / ncls tiles for every class.
+    int cls = 0;
+    unsigned tile_x = blockIdx.x;
+    if (p.ncls > 1) {
+        const unsigned per = gridDim.x / (unsigned)p.ncls;
+        cls = (int)(blockIdx.x / per);
+        tile_x = blockIdx.x - (unsigned)cls * per;
+    }
+    const int P = p.cls[cls].P, Q = p.cls[cls].Q, oy0 = p.cls[cls].oy0, ox0 = p.cls[cls].ox0, T = p.cls[cls].T, tap0 = p.cls[cls].tap0;
+    const int64_t npix = (int64_t)p.N * P * Q;
+    const int64_t pix_blk = (int64_t)tile_x * BN;
+    if (pix_blk >= npix) return;                   // grid is sized for the largest class
+    const int HW = p.H * p.W;
+    const int NC = p.Ig_pad / KC;
+    const int chunks_all = T * NC;
+    const int c_first = (int)((int64_t)chunks_all * ks / p.ksplit);
+    const int nchunks = (int)((int64_t)chunks_all * (ks + 1) / p.ksplit) - c_first;
+
+    // B staging: this thread's pixel column (fixed for the whole K loop) and its k-halves:
+    //   BN 128: one half, tid >> 7 (uniform per wave);  BN 256: both halves of pixel tid.
+    const int bcol = tid & (BN - 1);
+    const int64_t mypix = pix_blk + bcol;
+    const bool pix_ok = mypix < npix;
+    int n_in = 0, py = 0, px = 0;
+    if (pix_ok) {
+        n_in = (int)(mypix / (P * Q));
+        const int rem = (int)(mypix - (int64_t)n_in * P * Q);
+        py = rem / Q; px = rem - py * Q;
+    }
+    // Activation addressing: byte offset = (per-thread pixel part, VGPR) + (per-wave channel part, SGPR); the host only
+    // selects this kernel for tensors below 2^30 elements, so 32-bit byte offsets suffice.
+    const unsigned xb_off = (unsigned)(((int64_t)n_in * p.Cin + (int64_t)g * p.Ig) * HW) * 4u;
+    const char* const xbytes = (const char*)p.x;
+    const int iy_base = py * p.isy, ix_base = px * p.isx;
+    const __bf16* wb = (const __bf16*)p.wp + (int64_t)g * p.KK * NC * 6 * p.Og_pad * 8;
+    const int half0 = BPT == 1 ? __builtin_amdgcn_readfirstlane(tid >> 7) : 0;
+
+    // Two register sets for the activations: while chunk c is multiplied out of LDS, chunk c+1 (already in registers)
+    // is split into bf16 pieces and written to the other LDS buffer between the MFMAs, and chunk c+2 is being fetched.
+    // The weights of chunk c+1 (already split, L2-resident: every workgroup reads the same ones) are fetched at the
+    // start of step c and copied to LDS at its end.
+    // The loop body is free of data-dependent control flow around its memory operations: every step issues the same
+    // loads and stores (past the end of the K range they re-read valid addresses and the activations are zeroed), so
+    // that the s_waitcnt counters the compiler derives let a fetch stay in flight for a whole step.
+    struct Stage { float b[8 * BPT]; int nvalid[BPT]; };
+    Stage st0, st1;
+    float4 areg0, areg1, areg2;         // APT of them are used (scalars: an array here is not kept in registers)
+    int ld_t = c_first / NC, ld_cc = c_first - ld_t * NC, ld_left = nchunks;
+    bool ld_ok = false;
+    unsigned ld_pix = xb_off;          // byte offset of this thread's tap pixel in channel 0 (a readable address also when the tap is outside)
+    const __bf16* a_wt = wb;           // weight fetch position: tap slab and chunk within it
+    int a_t = ld_t, a_cc = ld_cc;
+    auto set_tap = [&](int t_in) {
+        const int t = __builtin_amdgcn_readfirstlane(tap0 + t_in);   // the tap tables are read with scalar loads
+        const int iy = iy_base + p.tap_dy[t], ix = ix_base + p.tap_dx[t];
+        ld_ok = pix_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        ld_pix = ld_ok ? xb_off + (unsigned)(iy * p.W + ix) * 4u : xb_off;
+    };
+    if (ld_t >= T) { ld_t = T - 1; ld_cc = 0; a_t = ld_t; a_cc = 0; }      // empty K slice: nothing is accumulated, addresses stay valid
+    set_tap(ld_t);
+    a_wt = wb + (int64_t)p.tap_slab[tap0 + a_t] * NC * 6 * p.Og_pad * 8;
+    auto load_chunk = [&](Stage& st) {
+        const int cc = __builtin_amdgcn_readfirstlane(ld_cc);
+        const int last = p.Ig - 1;
+        const bool real = ld_left > 0;              // chunks past the end of this K slice contribute zeros
+#pragma unroll
+        for (int i = 0; i < BPT; i++) {
+            const int c0 = cc * KC + (half0 + i) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const unsigned coff = (unsigned)(c0 + j < last ? c0 + j : last) * (unsigned)HW * 4u;    // scalar
+                st.b[8 * i + j] = *(const float*)(xbytes + (ld_pix + coff));
+            }
+            st.nvalid[i] = (ld_ok && real) ? p.Ig - c0 : 0;     // elements j < nvalid are real
+        }
+        --ld_left;
+        if (++ld_cc >= NC) {
+            ld_cc = 0;
+            if (ld_t + 1 < T) set_tap(++ld_t);
+        }
+    };
+    auto load_a = [&]() {
+        const __bf16* wt = a_wt + (int64_t)a_cc * 6 * p.Og_pad * 8;
+        // 6 (piece, half) segments of BM sixteen-byte units each; this thread copies units tid, tid + 256, ...
+        // (BM 64: the last 128 threads repeat unit AUNITS - 1 into the padding of the LDS buffer)
+        auto unit = [&](int j) {
+            int e = tid + 256 * j;
+            if (256 * (j + 1) > AUNITS) e = e < AUNITS ? e : AUNITS - 1;
+            const int seg = e / BM, within = e - seg * BM;
+            return *(const float4*)(wt + ((int64_t)seg * p.Og_pad + o_blk + within) * 8);
+        };
+        areg0 = unit(0);
+        areg1 = unit(1);
+        if (APT > 2) areg2 = unit(2);
+        if (++a_cc >= NC) {
+            a_cc = 0;
+            if (a_t + 1 < T) a_wt = wb + (int64_t)p.tap_slab[__builtin_amdgcn_readfirstlane(tap0 + ++a_t)] * NC * 6 * p.Og_pad * 8;
+        }
+    };
+    uint32_t q1[BPT][4], q2[BPT][4], q3[BPT][4];          // 8 bf16 per piece, packed two per dword
+    // Two elements at a time: v_cvt_pk_bf16_f32 yields the packed pair, the residuals come from its halves.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    auto split_pair = [&](const Stage& st, int i, int j) {
+        float v0 = st.b[8 * i + 2 * j], v1 = st.b[8 * i + 2 * j + 1];
+        if (st.nvalid[i] < 8) {                  // border pixel or channel tail
+            v0 = 2 * j < st.nvalid[i] ? v0 : 0.f;
+            v1 = 2 * j + 1 < st.nvalid[i] ? v1 : 0.f;
+        }
+        f32x2 v = {v0, v1};
+        uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        q1[i][j] = w;
+        // the two residual subtractions stay scalar: packed f32 VALU next to MFMAs costs more than it saves
+        // (MI355X_MICROARCH.md, cycle table), and the empty asm keeps the SLP vectoriser from pairing them
+        v0 -= __builtin_bit_cast(float, w << 16);
+        v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
+        PASTA_KEEP_SCALAR(v0);
+        v = f32x2{v0, v1};
+        w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        q2[i][j] = w;
+        v0 -= __builtin_bit_cast(float, w << 16);
+        v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
+        PASTA_KEEP_SCALAR(v0);
+        v = f32x2{v0, v1};
+        q3[i][j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < BPT; i++) {
+            __bf16* bd = &Bs[buf][((half0 + i) * BN + bcol) * 8];
+            *(uint4*)(bd) = make_uint4(q1[i][0], q1[i][1], q1[i][2], q1[i][3]);
+            *(uint4*)(bd + 2 * BSEG) = make_uint4(q2[i][0], q2[i][1], q2[i][2], q2[i][3]);
+            *(uint4*)(bd + 4 * BSEG) = make_uint4(q3[i][0], q3[i][1], q3[i][2], q3[i][3]);
+        }
+    };
+    auto store_a = [&](int buf) {
+        *(float4*)&As[buf][tid * 8] = areg0;
+        *(float4*)&As[buf][(tid + 256) * 8] = areg1;
+        if (APT > 2) *(float4*)&As[buf][(tid + 512) * 8] = areg2;
+    };
+
+    f32x16 acc[WMT][WNT];
+#pragma unroll
+    for (int a = 0; a < WMT; a++)
+#pragma unroll
+        for (int b = 0; b < WNT; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    const int hl = lane >> 5, jl = lane & 31;
+    // Fragments of one chunk: [tile][piece], read in the order the MFMA groups consume them.
+    struct Frag { bf16x8 a[WMT][3], b[WNT][3]; };
+    auto read_frag = [&](Frag& f, int buf) {
+#define PASTA_LDA(PC) _Pragma("unroll") for (int a = 0; a < WMT; a++) f.a[a][PC] = *(const bf16x8*)&As[buf][(((PC) * 2 + hl) * BM + (wm * WMT + a) * 32 + jl) * 8];
+#define PASTA_LDB(PC) _Pragma("unroll") for (int b = 0; b < WNT; b++) f.b[b][PC] = *(const bf16x8*)&Bs[buf][(((PC) * 2 + hl) * BN + (wn * WNT + b) * 32 + jl) * 8];
+        PASTA_LDA(2) PASTA_LDB(0) PASTA_LDA(0) PASTA_LDB(2) PASTA_LDA(1) PASTA_LDB(1)
+#undef PASTA_LDA
+#undef PASTA_LDB
+    };
+    // One K chunk: 24 MFMAs in six groups of four; the staging work for the next chunk is slotted between the groups.
+    auto step = [&](int buf, Stage& cur_next, Stage& fetch_into) {
+        load_a();                   // weights of the next chunk first: they are waited for with the activation fetch still in flight
+        load_chunk(fetch_into);
+        Frag f;
+        read_frag(f, buf);
+#define PASTA_MM(PA, PB)                                                                                       \
+        _Pragma("unroll") for (int a = 0; a < WMT; a++) _Pragma("unroll") for (int b = 0; b < WNT; b++)          \
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][PA], f.b[b][PB], acc[a][b], 0, 0, 0);
+#define PASTA_SPLIT(J) _Pragma("unroll") for (int i = 0; i < BPT; i++) split_pair(cur_next, i, J);
+        // smallest terms first: a3b1, a1b3, a2b2, a2b1, a1b2, a1b1
+        PASTA_MM(2, 0)
+        PASTA_SPLIT(0)
+        PASTA_MM(0, 2)
+        PASTA_SPLIT(1)
+        PASTA_MM(1, 1)
+        PASTA_SPLIT(2)
+        PASTA_MM(1, 0)
+        PASTA_SPLIT(3)
+        PASTA_MM(0, 1)
+        store_b(buf ^ 1); store_a(buf ^ 1);
+        PASTA_MM(0, 0)
+#undef PASTA_MM
+#undef PASTA_SPLIT
+        __syncthreads();
+    };
+
+    load_a();
+    load_chunk(st0);
+#pragma unroll
+    for (int i = 0; i < BPT; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) split_pair(st0, i, j);
+    store_b(0); store_a(0);
+    load_chunk(st0);                            // chunk 1 waits in registers
+    __syncthreads();
+    // two chunks per trip so that the register sets swap roles without copies; an odd count runs one all-zero chunk
+    for (int ch = 0; ch < nchunks; ch += 2) {
+        step(0, st0, st1);                      // st0 holds chunk ch+1, chunk ch+2 is fetched into st1
+        step(1, st1, st0);
+    }
+
+    const int OHW = p.OH * p.OW;
+#pragma unroll
+    for (int b = 0; b < WNT; b++) {
+        const int64_t pix = pix_blk + (wn * WNT + b) * 32 + jl;
+        if (pix >= npix) continue;
+        const int n = (int)(pix / (P * Q));
+        const int rem = (int)(pix - (int64_t)n * P * Q);
+        const int pp = rem / Q, qq = rem - pp * Q;
+        float* yb = (p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW : p.y) +
+                    ((int64_t)n * p.Cout + (int64_t)g * p.Og) * OHW + (oy0 + pp * p.osy) * p.OW + ox0 + qq * p.osx;
+        const float* osb = (p.oscale && p.ksplit == 1) ? p.oscale + (int64_t)n * p.Cout + (int64_t)g * p.Og : nullptr;
+#pragma unroll
+        for (int a = 0; a < WMT; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
+                if (o < p.Og) {
+                    float v = acc[a][b][r];
+                    if (osb) v *= osb[o];
+                    if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
+                    yb[(int64_t)o * OHW] = v;
+                }
+            }
+    }
+}
+
+
+//------------------------------------------------------------------------------------
+// Row-reuse variant of conv_fwd_bf16x6_kernel for stride-1 lattices whose taps form kh rows of three horizontally
+// adjacent offsets (every 3x3 stride-1 convolution and its input gradient: 85 % of the forward-type FLOPs of the step).
+// A pixel tile is R = BN / SEG row segments of SEG = min(Q, BN) consecutive pixels.  The activations of one input row
+// (kernel row dy) and one 16-channel chunk are fetched, split into bf16 pieces and stored to LDS ONCE, with one halo
+// pixel on either side of every segment ([piece][k-half][slot][8 bf16], slot = pixel + 2 * segment + 1), and the three
+// horizontal taps read their B fragments from that image at slot offsets 0, 1, 2: per 72 MFMAs one activation fetch
+// and split instead of three.  The weights are fetched per tap as in the base kernel.
+// K loop: "stages" (dy, chunk) of three steps (the taps of the row).  Step 0 of a stage issues the loads of the next
+// stage (halo pixels first: one wave, the waves take turns), step 1 splits and stores its main pixels, step 2 its halo
+// pixels; the B
+// image is double-buffered per stage, the A image per step.  Control flow around memory operations is static as in
+// the base kernel.
+template <int BM, int BN, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdParams p) {
+    constexpr int WMT = 2, WNT = 2, KC = 16;
+    constexpr int WAVES_N = BN / 64;
+    static_assert((BM / 64) * WAVES_N == 4, "four waves per workgroup");
+    constexpr int AUNITS = 6 * BM;
+    constexpr int APT = (AUNITS + 255) / 256;
+    constexpr int BPT = BN * 2 / 256;                   // (pixel, k-half) pairs per thread: 1 or 2
+    constexpr int SLOTS = BN + 16;                      // up to 8 segments with two halo slots each
+    constexpr int ABUF = APT * 256 * 8, BSEG = SLOTS * 8, BBUF = 6 * BSEG;      // bf16 elements
+    extern __shared__ __attribute__((aligned(16))) __bf16 rows_smem[];
+    __bf16* const As = rows_smem;                       // [2][ABUF]
+    __bf16* const Bs = rows_smem + 2 * ABUF;            // [2][BBUF]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int g = blockIdx.z;
+    const int ks = blockIdx.y / p.o_tiles;
+    const int o_blk = (blockIdx.y - ks * p.o_tiles) * BM;
+    const int P = p.cls[0].P, Q = p.cls[0].Q, oy0 = p.cls[0].oy0, ox0 = p.cls[0].ox0, T = p.cls[0].T;
+    const int KH = T / 3;
+    const int64_t pix_blk = (int64_t)blockIdx.x * BN;   // the host guarantees full tiles inside one image
+    const int HW = p.H * p.W;
+    const int NC = p.Ig_pad / KC;
+    const int stages_all = KH * NC;
+    const int s_first = (int)((int64_t)stages_all * ks / p.ksplit);
+    const int nstages = (int)((int64_t)stages_all * (ks + 1) / p.ksplit) - s_first;
+    const int seg_log2 = 31 - __builtin_clz(Q < BN ? Q : BN);
+    const int SEG = 1 << seg_log2, R = BN >> seg_log2;
+    const int d0 = p.rows_d0;
+
+    // main pixel of this thread (fixed): tile pixel bcol -> image (n, py, px); its slot keeps one halo slot per segment free
+    const int bcol = tid & (BN - 1);
+    const int n_in = (int)((pix_blk + bcol) / (P * Q));
+    const int rem_in = (int)(pix_blk + bcol - (int64_t)n_in * P * Q);
+    const int py = rem_in / Q, px = rem_in - py * Q;
+    const int m_slot = bcol + 2 * (bcol >> seg_log2) + 1;
+    const int m_cx = px + d0 + 1;
+    const unsigned xb_off = (unsigned)(((int64_t)n_in * p.Cin + (int64_t)g * p.Ig) * HW) * 4u;
+    // halo pixels (one wave per stage, in turn): BN 128: lane = segment * 4 + side * 2 + k-half; BN 256: lane = segment * 2 + side, both halves.
+    // Lanes beyond the last segment repeat it (identical data to the identical slot).
+    int h_r = BPT == 1 ? lane >> 2 : lane >> 1;
+    h_r = h_r < R ? h_r : R - 1;
+    const int h_side = BPT == 1 ? (lane >> 1) & 1 : lane & 1;
+    const int h_half = BPT == 1 ? lane & 1 : 0;
+    const int64_t h_pixel = pix_blk + ((int64_t)h_r << seg_log2);
+    const int h_n = (int)(h_pixel / (P * Q));
+    const int h_rem = (int)(h_pixel - (int64_t)h_n * P * Q);
+    const int h_py = h_rem / Q, h_qs = h_rem - h_py * Q;
+    const int h_slot = h_r * (SEG + 2) + (h_side ? SEG + 1 : 0);
+    const int h_cx = h_side ? h_qs + SEG + d0 + 1 : h_qs + d0;
+    const unsigned hb_off = (unsigned)(((int64_t)h_n * p.Cin + (int64_t)g * p.Ig) * HW) * 4u;
+
+    const char* const xbytes = (const char*)p.x;
+    const __bf16* wb = (const __bf16*)p.wp + (int64_t)g * p.KK * NC * 6 * p.Og_pad * 8;
+    const int half0 = BPT == 1 ? __builtin_amdgcn_readfirstlane(tid >> 7) : 0;
+    const int64_t a_chunk = (int64_t)6 * p.Og_pad * 8;             // bf16 elements of one packed 16-channel chunk
+
+    // ---- fetch state of the activations: the stage (kernel row b_dy, chunk b_cc) that the next load_b() fetches
+    int b_dy = s_first / NC, b_cc = s_first - b_dy * NC, b_left = nstages;
+    if (b_dy >= KH) { b_dy = KH - 1; b_cc = 0; }
+    bool m_ok = false, h_ok = false;
+    unsigned m_pix = xb_off, h_pix = hb_off;
+    auto set_row = [&](int dyi) {
+        const int dy = p.tap_dy[__builtin_amdgcn_readfirstlane(3 * dyi)];
+        const int iy = py + dy, hy = h_py + dy;
+        m_ok = (unsigned)iy < (unsigned)p.H && (unsigned)m_cx < (unsigned)p.W;
+        m_pix = m_ok ? xb_off + (unsigned)(iy * p.W + m_cx) * 4u : xb_off;
+        h_ok = (unsigned)hy < (unsigned)p.H && (unsigned)h_cx < (unsigned)p.W;
+        h_pix = h_ok ? hb_off + (unsigned)(hy * p.W + h_cx) * 4u : hb_off;
+    };
+    set_row(b_dy);
+    float mb[8 * BPT], hb[8 * BPT];
+    int m_nvalid[BPT], h_nvalid[BPT];
+    int h_owner = 0;                                 // the wave that stages the halo pixels of the stage in flight
+    auto load_b = [&]() {
+        const int cc = __builtin_amdgcn_readfirstlane(b_cc);
+        const int last = p.Ig - 1;
+        const bool real = b_left > 0;
+        h_owner = b_left & 3;
+        if (wave == h_owner) {                       // oldest loads of the step: every later wait covers them
+#pragma unroll
+            for (int i = 0; i < BPT; i++) {
+                const int c0 = cc * KC + (h_half + i) * 8;
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    hb[8 * i + j] = *(const float*)(xbytes + (h_pix + (unsigned)(c0 + j < last ? c0 + j : last) * (unsigned)HW * 4u));
+                h_nvalid[i] = (h_ok && real) ? p.Ig - c0 : 0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BPT; i++) {
+            const int c0 = cc * KC + (half0 + i) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const unsigned coff = (unsigned)(c0 + j < last ? c0 + j : last) * (unsigned)HW * 4u;    // scalar
+                mb[8 * i + j] = *(const float*)(xbytes + (m_pix + coff));
+            }
+            m_nvalid[i] = (m_ok && real) ? p.Ig - c0 : 0;
+        }
+        --b_left;
+        if (++b_cc >= NC) {
+            b_cc = 0;
+            if (b_dy + 1 < KH) set_row(++b_dy);
+        }
+    };
+    // ---- fetch state of the weights: one step ahead of the multiplication
+    int a_dy = b_dy, a_cc = b_cc;
+    const __bf16* a_w0 = wb; const __bf16* a_w1 = wb; const __bf16* a_w2 = wb;
+    auto set_a_row = [&](int dyi) {
+        const int t = __builtin_amdgcn_readfirstlane(3 * dyi);
+        a_w0 = wb + (int64_t)p.tap_slab[t] * NC * a_chunk;
+        a_w1 = wb + (int64_t)p.tap_slab[t + 1] * NC * a_chunk;
+        a_w2 = wb + (int64_t)p.tap_slab[t + 2] * NC * a_chunk;
+    };
+    set_a_row(a_dy);
+    float4 areg0, areg1, areg2;
+    auto load_a = [&](int tap_i) {                   // tap_i is a compile-time constant at every call
+        const __bf16* wt = (tap_i == 0 ? a_w0 : tap_i == 1 ? a_w1 : a_w2) + (int64_t)a_cc * a_chunk;
+        auto unit = [&](int j) {
+            int e = tid + 256 * j;
+            if (256 * (j + 1) > AUNITS) e = e < AUNITS ? e : AUNITS - 1;
+            const int seg = e / BM, within = e - seg * BM;
+            return *(const float4*)(wt + ((int64_t)seg * p.Og_pad + o_blk + within) * 8);
+        };
+        areg0 = unit(0);
+        areg1 = unit(1);
+        if (APT > 2) areg2 = unit(2);
+    };
+    auto next_a_stage = [&]() {
+        if (++a_cc >= NC) {
+            a_cc = 0;
+            if (a_dy + 1 < KH) set_a_row(++a_dy);
+        }
+    };
+    auto store_a = [&](int buf) {
+        __bf16* d = As + buf * ABUF;
+        *(float4*)&d[tid * 8] = areg0;
+        *(float4*)&d[(tid + 256) * 8] = areg1;
+        if (APT > 2) *(float4*)&d[(tid + 512) * 8] = areg2;
+    };
+
+    uint32_t q1[BPT][4], q2[BPT][4], q3[BPT][4];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    auto split_pair = [&](const float* b, const int* nvalid, int i, int j) {
+        float v0 = b[8 * i + 2 * j], v1 = b[8 * i + 2 * j + 1];
+        if (nvalid[i] < 8) {
+            v0 = 2 * j < nvalid[i] ? v0 : 0.f;
+            v1 = 2 * j + 1 < nvalid[i] ? v1 : 0.f;
+        }
+        f32x2 v = {v0, v1};
+        uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        q1[i][j] = w;
+        // the two residual subtractions stay scalar: packed f32 VALU next to MFMAs costs more than it saves
+        // (MI355X_MICROARCH.md, cycle table), and the empty asm keeps the SLP vectoriser from pairing them
+        v0 -= __builtin_bit_cast(float, w << 16);
+        v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
+        PASTA_KEEP_SCALAR(v0);
+        v = f32x2{v0, v1};
+        w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        q2[i][j] = w;
+        v0 -= __builtin_bit_cast(float, w << 16);
+        v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
+        PASTA_KEEP_SCALAR(v0);
+        v = f32x2{v0, v1};
+        q3[i][j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    };
+    auto store_q = [&](int buf, int slot, int hbase) {
+#pragma unroll
+        for (int i = 0; i < BPT; i++) {
+            __bf16* bd = Bs + buf * BBUF + ((hbase + i) * SLOTS + slot) * 8;
+            *(uint4*)(bd) = make_uint4(q1[i][0], q1[i][1], q1[i][2], q1[i][3]);
+            *(uint4*)(bd + 2 * BSEG) = make_uint4(q2[i][0], q2[i][1], q2[i][2], q2[i][3]);
+            *(uint4*)(bd + 4 * BSEG) = make_uint4(q3[i][0], q3[i][1], q3[i][2], q3[i][3]);
+        }
+    };
+
+    f32x16 acc[WMT][WNT];
+#pragma unroll
+    for (int a = 0; a < WMT; a++)
+#pragma unroll
+        for (int b = 0; b < WNT; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    const int hl = lane >> 5, jl = lane & 31;
+    int fslot[WNT];                                  // slot of this lane's pixel of B fragment b, for tap offset 0
+#pragma unroll
+    for (int b = 0; b < WNT; b++) {
+        const int t = (wn * WNT + b) * 32 + jl;
+        fslot[b] = t + 2 * (t >> seg_log2);
+    }
+    struct Frag { bf16x8 a[WMT][3], b[WNT][3]; };
+    auto read_frag = [&](Frag& f, int abuf, int bbuf, int off) {
+        const __bf16* A_ = As + abuf * ABUF;
+        const __bf16* B_ = Bs + bbuf * BBUF;
+#define PASTA_LDA(PC) _Pragma("unroll") for (int a = 0; a < WMT; a++) f.a[a][PC] = *(const bf16x8*)&A_[(((PC) * 2 + hl) * BM + (wm * WMT + a) * 32 + jl) * 8];
+#define PASTA_LDB(PC) _Pragma("unroll") for (int b = 0; b < WNT; b++) f.b[b][PC] = *(const bf16x8*)&B_[(((PC) * 2 + hl) * SLOTS + fslot[b] + off) * 8];
+        PASTA_LDA(2) PASTA_LDB(0) PASTA_LDA(0) PASTA_LDB(2) PASTA_LDA(1) PASTA_LDB(1)
+#undef PASTA_LDA
+#undef PASTA_LDB
+    };
+    // One tap = one step: 24 MFMAs in six groups; TAP (0, 1, 2: position in the kernel row), ABUF_ and BBUF_ are literals.
+    auto step = [&](const int TAP, const int abuf, const int bbuf) {
+        if (TAP == 2) next_a_stage();
+        if (TAP == 0) {
+            // halo loads (wave 0) are issued inside load_b ahead of everything else of this step
+            load_b();
+            load_a(1);
+        } else {
+            load_a(TAP == 1 ? 2 : 0);
+        }
+        Frag f;
+        read_frag(f, abuf, bbuf, p.rows_rev ? 2 - TAP : TAP);
+#define PASTA_MM(PA, PB)                                                                                       \
+        _Pragma("unroll") for (int a = 0; a < WMT; a++) _Pragma("unroll") for (int b = 0; b < WNT; b++)          \
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][PA], f.b[b][PB], acc[a][b], 0, 0, 0);
+#define PASTA_SPLIT(J)                                                                                         \
+        if (TAP == 1) { _Pragma("unroll") for (int i = 0; i < BPT; i++) split_pair(mb, m_nvalid, i, J); }        \
+        if (TAP == 2 && wave == h_owner) { _Pragma("unroll") for (int i = 0; i < BPT; i++) split_pair(hb, h_nvalid, i, J); }
+        PASTA_MM(2, 0)
+        PASTA_SPLIT(0)
+        PASTA_MM(0, 2)
+        PASTA_SPLIT(1)
+        PASTA_MM(1, 1)
+        PASTA_SPLIT(2)
+        PASTA_MM(1, 0)
+        PASTA_SPLIT(3)
+        PASTA_MM(0, 1)
+        if (TAP == 1) store_q(bbuf ^ 1, m_slot, half0);
+        if (TAP == 2 && wave == h_owner) store_q(bbuf ^ 1, h_slot, h_half);
+        store_a(abuf ^ 1);
+        PASTA_MM(0, 0)
+#undef PASTA_MM
+#undef PASTA_SPLIT
+        __syncthreads();
+    };
+
+    // prologue: stage 0 of this K slice entirely, and the weights of its first tap
+    load_b();
+    load_a(0);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < BPT; i++) split_pair(mb, m_nvalid, i, j);
+    store_q(0, m_slot, half0);
+    if (wave == h_owner) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int i = 0; i < BPT; i++) split_pair(hb, h_nvalid, i, j);
+        store_q(0, h_slot, h_half);
+    }
+    store_a(0);
+    __syncthreads();
+    // two stages (six steps) per trip: the B image alternates per stage, the A image per step; an odd stage count runs
+    // one all-zero stage
+    for (int s = 0; s < nstages; s += 2) {
+        step(0, 0, 0); step(1, 1, 0); step(2, 0, 0);
+        step(0, 1, 1); step(1, 0, 1); step(2, 1, 1);
+    }
+
+    const int OHW = p.OH * p.OW;
+#pragma unroll
+    for (int b = 0; b < WNT; b++) {
+        const int64_t pix = pix_blk + (wn * WNT + b) * 32 + jl;
+        const int n = (int)(pix / (P * Q));
+        const int rem = (int)(pix - (int64_t)n * P * Q);
+        const int pp = rem / Q, qq = rem - pp * Q;
+        float* yb = (p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW : p.y) +
+                    ((int64_t)n * p.Cout + (int64_t)g * p.Og) * OHW + (oy0 + pp * p.osy) * p.OW + ox0 + qq * p.osx;
+        const float* osb = (p.oscale && p.ksplit == 1) ? p.oscale + (int64_t)n * p.Cout + (int64_t)g * p.Og : nullptr;
+#pragma unroll
+        for (int a = 0; a < WMT; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
+                if (o < p.Og) {
+                    float v = acc[a][b][r];
+                    if (osb) v *= osb[o];
+                    if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
+                    yb[(int64_t)o * OHW] = v;
+                }
+            }
+    }
+}
+
+// Pixel tiles of the row-reuse kernel: full tiles of BN pixels made of whole row segments inside one image.
+static bool rows_tile_ok(int P, int Q, int BN) {
+    const int seg = Q < BN ? Q : BN;
+    return Q % 32 == 0 && (seg & (seg - 1)) == 0 && BN % seg == 0 && Q % seg == 0 && ((int64_t)P * Q) % BN == 0;
+}
+
+template <int BM, int BN>
+static void launch_fwd_bf16x6(const ConvFwdParams& p, hipStream_t s) {
+    ConvFwdParams q = p;
+    q.o_tiles = (p.Og + BM - 1) / BM;
+    int64_t tiles = 0;
+    for (int c = 0; c < p.ncls; c++) {
+        const int64_t t = ceil_div64((int64_t)p.N * p.cls[c].P * p.cls[c].Q, BN);
+        if (t > tiles) tiles = t;
+    }
+    tiles *= p.ncls;
+    dim3 grid((unsigned)tiles, q.o_tiles * q.ksplit, p.G);
+    if (p.rows && p.ncls == 1) {
+        // row-reuse kernel: full tiles made of whole row segments inside one image
+        if (rows_tile_ok(p.cls[0].P, p.cls[0].Q, BN)) {
+            constexpr int APT = (6 * BM + 255) / 256;
+            constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 6 * (BN + 16) * 8) * sizeof(__bf16);
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2>), grid, dim3(256), lds, s, q);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<BM, BN, (BN == 256 ? 2 : 3)>), grid, dim3(256), 0, s, q);     // 64 KB of LDS: two workgroups per CU
+}
+
+// Do the T taps at table positions [0, T) form rows of three horizontally adjacent offsets (ascending or descending)?
+static bool detect_tap_rows(ConvFwdParams& p, int T) {
+    p.rows = 0;
+    if (T % 3 != 0 || p.isx != 1 || p.isy != 1 || p.osx != 1 || p.osy != 1) return false;
+    const int step = p.tap_dx[1] - p.tap_dx[0];
+    if (step != 1 && step != -1) return false;
+    const int d0 = step == 1 ? p.tap_dx[0] : p.tap_dx[2];
+    for (int j = 0; j < T; j += 3)
+        for (int i = 0; i < 3; i++)
+            if (p.tap_dy[j + i] != p.tap_dy[j] || p.tap_dx[j + i] != p.tap_dx[0] + i * step) return false;
+    p.rows = 1; p.rows_d0 = d0; p.rows_rev = step == -1 ? 1 : 0;
+    return true;
+}
+
+
+}  // namespace pasta

@@ -1,0 +1,340 @@
+// Split-bf16 weight-gradient kernels for 3x3 convolutions: stride 1 (conv_wgrad3x3_bf16x6_kernel) and stride 2 (conv_wgrad3x3s2_bf16x6_kernel).  Included by conv_igemm.hip.
+#pragma once
+#include "conv_common.h"
+
+namespace pasta {
+
+//------------------------------------------------------------------------------------
+// Weight gradient of 3x3 / stride-1 / pad-1 convolutions on the bf16 matrix cores with split-bf16 products
+// (same arithmetic as conv_fwd_bf16x6_kernel: three bf16 pieces per fp32 operand, six exact products, fp32
+// accumulate).  K = pixels: a chunk is 32 consecutive pixels of one image row (Q % 32 == 0), two K steps of 16.
+//   A operand: S pieces in LDS as [piece][a][32 px] (row pitch 40 bf16 = 80 B: conflict-free 16-byte reads)
+//   B operand: L halo pieces as [piece][b][3 rows][40 px], halo column 0 = image column q0 - 4, so every global and
+//              LDS access is 16-byte aligned; the window of tap column ts starts at halo column 3 + ts: it is cut out
+//              of two aligned 16-byte blocks with v_alignbit (ts = 0, 2) or by register renaming (ts = 1).
+// One wave owns a 32 x 32 (a, b) tile for all 9 taps (144 accumulator registers): 54 MFMAs per K step.
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParams p) {
+    constexpr int SP = 40, LP = 40;                 // row pitches in bf16 elements (80 B)
+    constexpr int S_PIECE = 64 * SP;                // one piece of the S tile
+    constexpr int L_PIECE = 64 * 3 * LP;            // one piece of the L halo tile
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+    __bf16* Ss = smem16;                            // [3][64][SP]
+    __bf16* Ls = smem16 + 3 * S_PIECE;              // [3][64][3][LP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave >> 1, wb = wave & 1;
+    const int hl = lane >> 5, jl = lane & 31;
+
+    int bid = blockIdx.x;
+    const int ks = bid % p.ksplit; bid /= p.ksplit;
+    const int bt = bid % p.b_tiles; bid /= p.b_tiles;
+    const int at = bid % p.a_tiles; bid /= p.a_tiles;
+    const int g = bid;
+    const int a_blk = at * 64, b_blk = bt * 64;
+    const int PQ = p.P * p.Q;
+    const float* const Sg = p.S + ((int64_t)g * p.Ag + a_blk) * PQ;
+    const float* const Lg = p.L + ((int64_t)g * p.Bg + b_blk) * PQ;       // LH == P, LW == Q for this kernel
+
+    // staging roles (fixed): S unit = (channel a, group of 8 pixels); L units = (channel b, halo row, group of 8 columns)
+    const int s_a = tid >> 2, s_grp = tid & 3;
+    const bool s_ch_ok = a_blk + s_a < p.Ag;
+    int l_b[4], l_row[4], l_grp[4];
+    bool l_ch_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int v = tid + 256 * j;                // 960 units
+        l_b[j] = v / 15;
+        const int rg = v - l_b[j] * 15;
+        l_row[j] = rg / 5; l_grp[j] = rg - l_row[j] * 5;
+        l_ch_ok[j] = v < 960 && b_blk + l_b[j] < p.Bg;
+    }
+
+    float4 sreg[2], lreg[4][2];
+    unsigned vmask = 0;                              // validity of the 10 sixteen-byte halves held in registers
+    auto fetch = [&](int ch) {
+        const int row = ch / p.qblocks, qb = ch - row * p.qblocks;
+        const int n = row / p.P, pp = row - n * p.P, q0 = qb * 32;
+        vmask = 0;
+        {
+            const float* sp = Sg + (int64_t)n * p.SC * PQ + (int64_t)s_a * PQ + pp * p.Q + q0 + 8 * s_grp;
+            if (s_ch_ok) {
+                sreg[0] = *(const float4*)sp; sreg[1] = *(const float4*)(sp + 4);
+                vmask |= 3u;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int ly = pp + l_row[j] - 1, lx = q0 - 4 + 8 * l_grp[j];
+            const bool rok = l_ch_ok[j] && (unsigned)ly < (unsigned)p.P;
+            const float* lp = Lg + (int64_t)n * p.LC * PQ + (int64_t)l_b[j] * PQ + ly * p.Q + lx;
+            if (rok && lx >= 0 && lx + 4 <= p.Q) { lreg[j][0] = *(const float4*)lp; vmask |= 4u << (2 * j); }
+            if (rok && lx + 4 >= 0 && lx + 8 <= p.Q) { lreg[j][1] = *(const float4*)(lp + 4); vmask |= 8u << (2 * j); }
+        }
+    };
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    // split 8 floats (two float4 halves, each possibly invalid -> 0) into three packed bf16x8 pieces and store them
+    auto split_store = [&](float4 h0, float4 h1, bool ok0, bool ok1, __bf16* dst, int piece_stride) {
+        const float vals[8] = {ok0 ? h0.x : 0.f, ok0 ? h0.y : 0.f, ok0 ? h0.z : 0.f, ok0 ? h0.w : 0.f,
+                               ok1 ? h1.x : 0.f, ok1 ? h1.y : 0.f, ok1 ? h1.z : 0.f, ok1 ? h1.w : 0.f};
+        uint32_t q1[4], q2[4], q3[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            f32x2 v = {vals[2 * j], vals[2 * j + 1]};
+            uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+            q1[j] = w;
+            v[0] -= __builtin_bit_cast(float, w << 16);
+            v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
+            w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+            q2[j] = w;
+            v[0] -= __builtin_bit_cast(float, w << 16);
+            v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
+            q3[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        }
+        *(uint4*)(dst) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+        *(uint4*)(dst + piece_stride) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+        *(uint4*)(dst + 2 * piece_stride) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+    };
+    auto stash = [&]() {
+        split_store(sreg[0], sreg[1], vmask & 1u, vmask & 2u, Ss + s_a * SP + 8 * s_grp, S_PIECE);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (tid + 256 * j < 960)
+                split_store(lreg[j][0], lreg[j][1], vmask & (4u << (2 * j)), vmask & (8u << (2 * j)),
+                            Ls + (l_b[j] * 3 + l_row[j]) * LP + 8 * l_grp[j], L_PIECE);
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+
+    const int c_begin = (int)((int64_t)p.chunks_total * ks / p.ksplit);
+    const int c_end = (int)((int64_t)p.chunks_total * (ks + 1) / p.ksplit);
+    if (c_begin < c_end) fetch(c_begin);
+    for (int ch = c_begin; ch < c_end; ch++) {
+        __syncthreads();                  // the previous chunk's fragment reads are done
+        stash();
+        __syncthreads();
+        if (ch + 1 < c_end) fetch(ch + 1);
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            bf16x8 af[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; pc++) af[pc] = *(const bf16x8*)&Ss[pc * S_PIECE + (wa * 32 + jl) * SP + 16 * s + 8 * hl];
+#pragma unroll
+            for (int pb = 2; pb >= 0; pb--) {       // B pieces from the smallest to the largest
+#pragma unroll
+                for (int row = 0; row < 3; row++) {
+                    const __bf16* lb = &Ls[pb * L_PIECE + ((wb * 32 + jl) * 3 + row) * LP + 16 * s + 8 * hl];
+                    const uint4 b0 = *(const uint4*)lb, b1 = *(const uint4*)(lb + 8);
+                    const uint32_t d[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                    uint4 w[3];
+                    w[0] = make_uint4(__builtin_amdgcn_alignbit(d[2], d[1], 16), __builtin_amdgcn_alignbit(d[3], d[2], 16),
+                                      __builtin_amdgcn_alignbit(d[4], d[3], 16), __builtin_amdgcn_alignbit(d[5], d[4], 16));   // halo col 3
+                    w[1] = make_uint4(d[2], d[3], d[4], d[5]);                                                                 // halo col 4
+                    w[2] = make_uint4(__builtin_amdgcn_alignbit(d[3], d[2], 16), __builtin_amdgcn_alignbit(d[4], d[3], 16),
+                                      __builtin_amdgcn_alignbit(d[5], d[4], 16), __builtin_amdgcn_alignbit(d[6], d[5], 16));   // halo col 5
+#pragma unroll
+                    for (int ts = 0; ts < 3; ts++) {
+                        const bf16x8 bw = __builtin_bit_cast(bf16x8, w[ts]);
+                        const int tap = row * 3 + ts;
+                        // a_pa * b_pb with pa + pb <= 2, smallest A piece first
+#pragma unroll
+                        for (int pa = 2 - pb; pa >= 0; pa--)
+                            acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa], bw, acc[tap], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // partial slab: [ksplit][G][9][Ag_pad][Bg_pad], b contiguous (same layout as conv_wgrad_kernel)
+    const int Ag_pad = p.a_tiles * 64, Bg_pad = p.b_tiles * 64;
+    float* out = p.slab + ((int64_t)ks * p.G + g) * 9 * Ag_pad * Bg_pad;
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        float* ot = out + (int64_t)t * Ag_pad * Bg_pad;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int a = a_blk + wa * 32 + acc_row(r, lane), b = b_blk + wb * 32 + jl;
+            ot[(int64_t)a * Bg_pad + b] = acc[t][r];
+        }
+    }
+}
+
+//------------------------------------------------------------------------------------
+// Stride-2 sibling of conv_wgrad3x3_bf16x6_kernel (3x3, stride 2, pad 0 or 1 on both axes; conv2d and, with the
+// operand roles swapped, conv_transpose2d): dW[tap r,s][a][b] = sum_pix S[a][p][q] * L[b][2p + r - pad][2q + s - pad].
+// K chunk = 16 consecutive S pixels of one row = one K step.  The L halo is three rows of 40 columns starting at
+// column 2*q0 - 4, split once and stored as [piece][b][3 rows][40] like the stride-1 kernel; the operand of tap column
+// s is every second halo element from 4 - pad + s on, gathered from three aligned 16-byte LDS reads with v_perm_b32
+// (the bf16 pairs of a dword are halo columns 2i, 2i + 1: a window of even or of odd columns is the low or the high
+// halves of eight consecutive dwords).  L rows are not 16-byte aligned in general (257-pixel planes), so the halo is
+// fetched with dword loads.
+template <int PW>
+__global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradParams p) {
+    constexpr int SP = 16, LP = 40;                 // row pitches in bf16 elements
+    constexpr int S_PIECE = 64 * SP;
+    constexpr int L_PIECE = 64 * 3 * LP;
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+    __bf16* Ss = smem16;                            // [3][64][SP]
+    __bf16* Ls = smem16 + 3 * S_PIECE;              // [3][64][3][LP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave >> 1, wb = wave & 1;
+    const int hl = lane >> 5, jl = lane & 31;
+
+    int bid = blockIdx.x;
+    const int ks = bid % p.ksplit; bid /= p.ksplit;
+    const int bt = bid % p.b_tiles; bid /= p.b_tiles;
+    const int at = bid % p.a_tiles; bid /= p.a_tiles;
+    const int g = bid;
+    const int a_blk = at * 64, b_blk = bt * 64;
+    const int PQ = p.P * p.Q, LHW = p.LH * p.LW;
+    const float* const Sg = p.S + ((int64_t)g * p.Ag + a_blk) * PQ;
+    const float* const Lg = p.L + ((int64_t)g * p.Bg + b_blk) * LHW;
+
+    // staging roles (fixed): S unit = (channel a, group of 8 pixels), threads 0..127; L units = (channel b, halo row,
+    // group of 8 columns), 960 of them
+    const int s_a = tid >> 1, s_grp = tid & 1;
+    const bool s_on = tid < 128 && a_blk + s_a < p.Ag;
+    int l_b[4], l_row[4], l_grp[4];
+    bool l_ch_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int v = tid + 256 * j;
+        l_b[j] = v / 15;
+        const int rg = v - l_b[j] * 15;
+        l_row[j] = rg / 5; l_grp[j] = rg - l_row[j] * 5;
+        l_ch_ok[j] = v < 960 && b_blk + l_b[j] < p.Bg;
+    }
+
+    float4 sreg[2];
+    float lreg[4][8];
+    unsigned lmask = 0;                              // validity bit of each of the 32 halo elements held in registers
+    bool s_ok = false;
+    auto fetch = [&](int ch) {
+        const int row = ch / p.qblocks, qb = ch - row * p.qblocks;
+        const int n = row / p.P, pp = row - n * p.P, q0 = qb * 16;
+        s_ok = s_on;
+        if (s_on) {
+            const float* sp = Sg + (int64_t)n * p.SC * PQ + (int64_t)s_a * PQ + pp * p.Q + q0 + 8 * s_grp;
+            sreg[0] = *(const float4*)sp; sreg[1] = *(const float4*)(sp + 4);
+        }
+        lmask = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int ly = 2 * pp + l_row[j] - p.pad_h, lx = 2 * q0 - 4 + 8 * l_grp[j];
+            const bool rok = l_ch_ok[j] && (unsigned)ly < (unsigned)p.LH;
+            const float* lp = Lg + (int64_t)n * p.LC * LHW + (int64_t)l_b[j] * LHW + ly * p.LW + lx;
+            int first = lx < 0 ? -lx : 0, last = p.LW - lx < 8 ? p.LW - lx : 8;
+            if (!rok || last < 0) last = 0;
+            if (first > last) first = last;
+            const unsigned m = ((1u << last) - 1u) & ~((1u << first) - 1u);
+            if (m == 0xffu) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) lreg[j][e] = lp[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    if ((m >> e) & 1u) lreg[j][e] = lp[e];
+            }
+            lmask |= m << (8 * j);
+        }
+    };
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    auto split_store = [&](const float* vals, __bf16* dst, int piece_stride) {
+        uint32_t q1[4], q2[4], q3[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            f32x2 v = {vals[2 * j], vals[2 * j + 1]};
+            uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+            q1[j] = w;
+            v[0] -= __builtin_bit_cast(float, w << 16);
+            v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
+            w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+            q2[j] = w;
+            v[0] -= __builtin_bit_cast(float, w << 16);
+            v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
+            q3[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        }
+        *(uint4*)(dst) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+        *(uint4*)(dst + piece_stride) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+        *(uint4*)(dst + 2 * piece_stride) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+    };
+    auto stash = [&]() {
+        if (tid < 128) {
+            const float sv[8] = {s_ok ? sreg[0].x : 0.f, s_ok ? sreg[0].y : 0.f, s_ok ? sreg[0].z : 0.f, s_ok ? sreg[0].w : 0.f,
+                                 s_ok ? sreg[1].x : 0.f, s_ok ? sreg[1].y : 0.f, s_ok ? sreg[1].z : 0.f, s_ok ? sreg[1].w : 0.f};
+            split_store(sv, Ss + s_a * SP + 8 * s_grp, S_PIECE);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (tid + 256 * j < 960) {
+                float lv[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) lv[e] = ((lmask >> (8 * j + e)) & 1u) ? lreg[j][e] : 0.f;
+                split_store(lv, Ls + (l_b[j] * 3 + l_row[j]) * LP + 8 * l_grp[j], L_PIECE);
+            }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+
+    const int c_begin = (int)((int64_t)p.chunks_total * ks / p.ksplit);
+    const int c_end = (int)((int64_t)p.chunks_total * (ks + 1) / p.ksplit);
+    if (c_begin < c_end) fetch(c_begin);
+    for (int ch = c_begin; ch < c_end; ch++) {
+        __syncthreads();                  // the previous chunk's fragment reads are done
+        stash();
+        __syncthreads();
+        if (ch + 1 < c_end) fetch(ch + 1);
+        bf16x8 af[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; pc++) af[pc] = *(const bf16x8*)&Ss[pc * S_PIECE + (wa * 32 + jl) * SP + 8 * hl];
+#pragma unroll
+        for (int pb = 2; pb >= 0; pb--) {           // B pieces from the smallest to the largest
+#pragma unroll
+            for (int row = 0; row < 3; row++) {
+                const __bf16* lb = &Ls[pb * L_PIECE + ((wb * 32 + jl) * 3 + row) * LP + 16 * hl];
+                const uint4 b0 = *(const uint4*)lb, b1 = *(const uint4*)(lb + 8), b2 = *(const uint4*)(lb + 16);
+                const uint32_t d[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+                for (int ts = 0; ts < 3; ts++) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int c0 = 4 - PW + ts, d0 = c0 >> 1;
+                    const uint32_t sel = (c0 & 1) ? 0x07060302u : 0x05040100u;
+                    const uint4 w = make_uint4(__builtin_amdgcn_perm(d[d0 + 1], d[d0], sel), __builtin_amdgcn_perm(d[d0 + 3], d[d0 + 2], sel),
+                                               __builtin_amdgcn_perm(d[d0 + 5], d[d0 + 4], sel), __builtin_amdgcn_perm(d[d0 + 7], d[d0 + 6], sel));
+                    const bf16x8 bw = __builtin_bit_cast(bf16x8, w);
+                    const int tap = row * 3 + ts;
+#pragma unroll
+                    for (int pa = 2 - pb; pa >= 0; pa--)
+                        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa], bw, acc[tap], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const int Ag_pad = p.a_tiles * 64, Bg_pad = p.b_tiles * 64;
+    float* out = p.slab + ((int64_t)ks * p.G + g) * 9 * Ag_pad * Bg_pad;
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        float* ot = out + (int64_t)t * Ag_pad * Bg_pad;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int a = a_blk + wa * 32 + acc_row(r, lane), b = b_blk + wb * 32 + jl;
+            ot[(int64_t)a * Bg_pad + b] = acc[t][r];
+        }
+    }
+}
+
+
+}  // namespace pasta

@@ -1,0 +1,420 @@
+// fp32-MFMA weight-gradient kernels: conv_wgrad_kernel, the small-Cin variant, their slab reductions and the small-Cin plan.  Included by conv_igemm.hip.
+#pragma once
+#include "conv_common.h"
+
+namespace pasta {
+
+//------------------------------------------------------------------------------------
+// Weight gradient.
+//   dW[g*Ag + a][b][r][s] = sum_{n,p,q} S[n, g*Ag + a, p, q] * L[n, g*Bg + b, p*st + r - pad_h, q*st + s - pad_w]
+// Workgroup: 64 (a) x 64 (b) x TR*TS taps, over a slice of K = pixels.  K is walked in chunks of
+// CHH x CW = 32 lattice pixels (CW a power of two <= 32 chosen from Q).
+
+
+// TR x TS taps per workgroup; each wave owns WA x WB 32x32 tiles per tap; PIPE = prefetch the next chunk into
+// registers behind the MFMAs (needs a halo of at most 128 positions)
+template <int TR, int TS, int WA, int WB, int PIPE, int KP>   // PIPE: 0 = none, 1 = halo <= 128 positions; KP pixels per chunk
+__global__ __launch_bounds__(256, PIPE ? 2 : 1) void conv_wgrad_kernel(WgradParams p) {
+    constexpr int NT = TR * TS;
+    constexpr int BA = 64 * WA, BB = 64 * WB;  // workgroup tile: 2 x 2 waves
+    constexpr int SPITCH = KP + 1;             // odd pitch: column-of-channels reads hit 32 banks
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave >> 1, wb = wave & 1;
+    const int CW = 1 << p.cw_log2, CHH = KP >> p.cw_log2;
+    const int LWID = (CW - 1) * p.st + TS;     // halo width per chunk row
+    const int LPITCH = LWID | 1;
+    const int LROWS = CHH * TR;                // halo rows per channel: one set of TR rows per chunk row
+    const int LCH = (LROWS * LPITCH) | 1;      // odd per-channel pitch
+    float* Ss = smem;                          // [BA][SPITCH]
+    float* Ls = smem + BA * SPITCH;            // [BB][LCH]
+
+    // block coordinates
+    int bid = blockIdx.x;
+    const int ks = bid % p.ksplit; bid /= p.ksplit;
+    const int tgs = bid % p.tap_groups_s; bid /= p.tap_groups_s;
+    const int tgr = bid % p.tap_groups_r; bid /= p.tap_groups_r;
+    const int bt = bid % p.b_tiles; bid /= p.b_tiles;
+    const int at = bid % p.a_tiles; bid /= p.a_tiles;
+    const int g = bid;
+    const int r0 = tgr * TR, s0 = tgs * TS;
+    const int a_blk = at * BA, b_blk = bt * BB;
+    const int PQ = p.P * p.Q, LHW = p.LH * p.LW;
+
+    // ---- staging roles, fixed for the whole K loop.
+    // S: this thread's pixel of the chunk and every 8th channel.
+    constexpr int SROWS = 256 / KP;                        // channels covered by one pass of the workgroup
+    constexpr int SPT = BA / SROWS;
+    const int s_k = tid & (KP - 1), s_a0 = tid / KP;
+    const int s_dr = s_k >> p.cw_log2, s_dq = s_k & (CW - 1);
+    // L: one halo position and every `lgroups`-th channel (the host guarantees NPOS <= 256).
+    const int NPOS = LROWS * LWID;
+    int npos_pad = 64;
+    while (npos_pad < NPOS) npos_pad <<= 1;
+    const int lgroups = 256 / npos_pad;                    // 4, 2 or 1 channel groups
+    const int l_pos = tid & (npos_pad - 1), l_cg = tid / npos_pad;
+    const bool l_act = l_pos < NPOS;
+    const int l_lr = l_act ? l_pos / LWID : 0, l_lc = l_pos - l_lr * LWID;
+    const int l_cr = l_lr / TR, l_tr = l_lr - l_cr * TR;
+    float* const l_dst = Ls + l_lr * LPITCH + l_lc;
+    const bool l_tap_ok = l_act && r0 + l_tr < p.kh;
+    constexpr int LPT = PIPE ? BB / 2 : 1;                 // prefetch registers per thread (PIPE needs lgroups >= 2)
+
+    f32x16 acc[NT][WA][WB];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int i = 0; i < WA; i++)
+#pragma unroll
+            for (int j = 0; j < WB; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[t][i][j][r] = 0.f;
+
+    const int c_begin = (int)((int64_t)p.chunks_total * ks / p.ksplit);
+    const int c_end = (int)((int64_t)p.chunks_total * (ks + 1) / p.ksplit);
+    const int kl = lane >> 5, jl = lane & 31;
+    const float* const Sg = p.S + ((int64_t)g * p.Ag + a_blk) * PQ;
+    const float* const Lg = p.L + ((int64_t)g * p.Bg + b_blk) * LHW;
+
+    float sreg[SPT];
+    float lreg[LPT];
+
+    // Per-chunk source offsets of this thread's S pixel and L halo position (element offsets fit in 31 bits).
+    auto s_source = [&](int ch, bool& ok) -> unsigned {
+        const int rb = ch / p.qblocks, qb = ch - rb * p.qblocks;
+        const int row = rb * CHH + s_dr, q = qb * CW + s_dq;
+        ok = row < p.rows_total && q < p.Q;
+        const int n = ok ? row / p.P : 0, pp = row - n * p.P;
+        return (unsigned)(n * p.SC) * (unsigned)PQ + (unsigned)(pp * p.Q + q);
+    };
+    auto l_source = [&](int ch, bool& ok) -> unsigned {
+        const int rb = ch / p.qblocks, qb = ch - rb * p.qblocks;
+        const int row = rb * CHH + l_cr;
+        const bool rok = l_tap_ok && row < p.rows_total;
+        const int n = rok ? row / p.P : 0, pp = row - n * p.P;
+        const int ly = pp * p.st + r0 + l_tr - p.pad_h, lx = qb * CW * p.st + s0 + l_lc - p.pad_w;
+        ok = rok && (unsigned)ly < (unsigned)p.LH && (unsigned)lx < (unsigned)p.LW;
+        return ok ? (unsigned)(n * p.LC) * (unsigned)LHW + (unsigned)(ly * p.LW + lx) : 0u;
+    };
+
+    const bool full_a = a_blk + BA <= p.Ag, full_b = b_blk + BB <= p.Bg;   // uniform: no per-channel bound checks
+    auto fetch = [&](int ch) {            // global -> registers (PIPE only)
+        bool ok;
+        const unsigned so = s_source(ch, ok);
+        {
+            const float* sp = Sg + so + (unsigned)s_a0 * (unsigned)PQ;
+            const unsigned step = (unsigned)SROWS * (unsigned)PQ;
+#pragma unroll
+            for (int j = 0; j < SPT; j++) {
+                sreg[j] = (ok && (full_a || a_blk + s_a0 + SROWS * j < p.Ag)) ? *sp : 0.f;
+                sp += step;
+            }
+        }
+        const unsigned lo = l_source(ch, ok);
+        {
+            const float* lp = Lg + lo + (unsigned)l_cg * (unsigned)LHW;
+            const unsigned step = (unsigned)lgroups * (unsigned)LHW;
+#pragma unroll
+            for (int j = 0; j < LPT; j++) {
+                const int b = l_cg + lgroups * j;
+                lreg[j] = (ok && b < BB && (full_b || b_blk + b < p.Bg)) ? *lp : 0.f;
+                lp += step;
+            }
+        }
+    };
+    auto stash = [&]() {                  // registers -> LDS (PIPE only)
+#pragma unroll
+        for (int j = 0; j < SPT; j++) Ss[(s_a0 + SROWS * j) * SPITCH + s_k] = sreg[j];
+        if (l_act) {
+#pragma unroll
+            for (int j = 0; j < LPT; j++) {
+                const int b = l_cg + lgroups * j;
+                if (b < BB) l_dst[b * LCH] = lreg[j];
+            }
+        }
+    };
+    auto stage_direct = [&](int ch) {     // global -> LDS without the register stage (!PIPE)
+        bool ok;
+        const unsigned so = s_source(ch, ok);
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            const int a = s_a0 + SROWS * j;
+            Ss[a * SPITCH + s_k] = (ok && a_blk + a < p.Ag) ? Sg[so + (unsigned)a * (unsigned)PQ] : 0.f;
+        }
+        const unsigned lo = l_source(ch, ok);
+        if (l_act) {
+#pragma unroll 8
+            for (int b = l_cg; b < BB; b += lgroups)
+                l_dst[b * LCH] = (ok && b_blk + b < p.Bg) ? Lg[lo + (unsigned)b * (unsigned)LHW] : 0.f;
+        }
+    };
+
+    if (PIPE && c_begin < c_end) fetch(c_begin);
+    for (int ch = c_begin; ch < c_end; ch++) {
+        __syncthreads();                  // the previous chunk's fragment reads are done
+        if (PIPE) stash(); else stage_direct(ch);
+        __syncthreads();
+        if (PIPE && ch + 1 < c_end) fetch(ch + 1);   // in flight behind the MFMAs below
+        // ---- KP/2 k-steps of 2 pixels; per step WA A-fragments feed NT*WA*WB MFMAs
+#pragma unroll 2
+        for (int kk = 0; kk < KP / 2; kk++) {
+            const int k = kk * 2 + kl;
+            float af[WA];
+#pragma unroll
+            for (int i = 0; i < WA; i++) af[i] = Ss[((wa * WA + i) * 32 + jl) * SPITCH + k];
+            const int cr = k >> p.cw_log2, cc = k & (CW - 1);
+            const float* lb = Ls + cr * TR * LPITCH + cc * p.st;
+#pragma unroll
+            for (int j = 0; j < WB; j++) {
+                const float* lbj = lb + ((wb * WB + j) * 32 + jl) * LCH;
+#pragma unroll
+                for (int tr = 0; tr < TR; tr++)
+#pragma unroll
+                    for (int ts = 0; ts < TS; ts++) {
+                        const float bf = lbj[tr * LPITCH + ts];
+#pragma unroll
+                        for (int i = 0; i < WA; i++)
+                            acc[tr * TS + ts][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf, acc[tr * TS + ts][i][j], 0, 0, 0);
+                    }
+            }
+        }
+    }
+
+    // ---- partial slab: [ksplit][G][kh*kw][Ag_pad][Bg_pad], b contiguous
+    const int Ag_pad = p.a_tiles * BA, Bg_pad = p.b_tiles * BB;
+    float* out = p.slab + ((int64_t)ks * p.G + g) * p.kh * p.kw * Ag_pad * Bg_pad;
+#pragma unroll
+    for (int tr = 0; tr < TR; tr++)
+#pragma unroll
+        for (int ts = 0; ts < TS; ts++) {
+            if (r0 + tr >= p.kh || s0 + ts >= p.kw) continue;
+            float* ot = out + (int64_t)((r0 + tr) * p.kw + s0 + ts) * Ag_pad * Bg_pad;
+#pragma unroll
+            for (int i = 0; i < WA; i++)
+#pragma unroll
+                for (int j = 0; j < WB; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int a = a_blk + (wa * WA + i) * 32 + acc_row(r, lane), b = b_blk + (wb * WB + j) * 32 + jl;
+                        ot[(int64_t)a * Bg_pad + b] = acc[tr * TS + ts][i][j][r];
+                    }
+        }
+}
+
+// dW[(g*Ag + a)][b][ty][tx] = sum_ks slab[ks][g][t][a][b]   (tap index optionally mirrored)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int ksplit,
+                                                           int G, int Ag, int Bg, int Ag_pad, int Bg_pad, int kh, int kw,
+                                                           int flip, float wscale) {
+    const int KK = kh * kw;
+    const int64_t total = (int64_t)G * KK * Ag * Bg;
+    const int64_t slab_stride = (int64_t)G * KK * Ag_pad * Bg_pad;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int b = (int)(idx % Bg);
+        int64_t r = idx / Bg;
+        const int a = (int)(r % Ag); r /= Ag;
+        const int t = (int)(r % KK);
+        const int g = (int)(r / KK);
+        const float* src = slab + (((int64_t)g * KK + t) * Ag_pad + a) * Bg_pad + b;
+        // sixteen slabs in flight per thread; four partial sums combined in a fixed order (bitwise reproducible)
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        int k = 0;
+        for (; k + 16 <= ksplit; k += 16) {
+            float r[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) r[j] = src[(int64_t)(k + j) * slab_stride];
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) { v0 += r[j]; v1 += r[j + 1]; v2 += r[j + 2]; v3 += r[j + 3]; }
+        }
+        for (; k < ksplit; k++) v0 += src[(int64_t)k * slab_stride];
+        const float v = ((v0 + v1) + (v2 + v3)) * wscale;
+        int ty = t / kw, tx = t - ty * kw;
+        if (flip) { ty = kh - 1 - ty; tx = kw - 1 - tx; }
+        dw[(((int64_t)(g * Ag + a) * Bg + b) * kh + ty) * kw + tx] = v;
+    }
+}
+
+//------------------------------------------------------------------------------------
+// Weight gradient when the input has very few channels (RGB / pose stems: 3 or 6 channels, up to 7x7):
+// the (channel, tap) pairs become the GEMM's column index b' = (i*kh + r)*kw + s, so a 7x7x3 kernel fills
+// 147 of 160 MFMA columns instead of 3 of 64.  conv2d, stride 1, groups 1 only.
+//   dW[o][b'] = sum_{n,p,q} dy[n,o,p,q] * x[n, i, p + r - pad_h, q + s - pad_w]
+
+struct WgradSmallParams {
+    const float* S; const float* L; float* slab;
+    int N, Ag, P, Q;        // S = dy: [N, Ag, P, Q]
+    int Bg, LH, LW;         // L = x : [N, Bg, LH, LW]
+    int kh, kw, pad_h, pad_w;
+    int bprime, nb;         // Bg*kh*kw and its number of 32-column tiles (<= 5)
+    int cw_log2, rows_total, qblocks, chunks_total, ksplit, a_tiles;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_smallcin_kernel(WgradSmallParams p) {
+    constexpr int KP = 32, SPITCH = KP + 1, MAXT = 3;     // each wave owns column tiles wb, wb+2, wb+4
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave >> 1, wb = wave & 1;
+    const int CW = 1 << p.cw_log2, CHH = KP >> p.cw_log2;
+    const int HW_ = CW + p.kw - 1;           // halo width
+    const int RH = CHH * p.kh;               // halo rows per channel: kh rows for each chunk row (rows may straddle images)
+    float* Ss = smem;                        // [64][SPITCH]
+    float* Ls = smem + 64 * SPITCH;          // [Bg][RH][HW_], then one zero word
+    const int halo_elems = p.Bg * RH * HW_;
+
+    int bid = blockIdx.x;
+    const int ks = bid % p.ksplit; bid /= p.ksplit;
+    const int a_blk = bid * 64;
+    const int PQ = p.P * p.Q, LHW = p.LH * p.LW;
+    const int kl = lane >> 5, jl = lane & 31;
+
+    // this lane's (channel, tap) column in each of its tiles -> LDS offset of its halo element for chunk pixel (0,0);
+    // columns beyond Bg*kh*kw read the zero word
+    int boff[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+        const int bp = (wb + 2 * t) * 32 + jl;
+        if (bp < p.bprime) {
+            const int i = bp / (p.kh * p.kw), rs = bp - i * p.kh * p.kw, r = rs / p.kw, sx = rs - r * p.kw;
+            boff[t] = (i * RH + r) * HW_ + sx;
+        } else boff[t] = -1;
+    }
+    f32x16 acc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+
+    const int s_k = tid & 31, s_a0 = tid >> 5;
+    const int s_dr = s_k >> p.cw_log2, s_dq = s_k & (CW - 1);
+    const int c_begin = (int)((int64_t)p.chunks_total * ks / p.ksplit);
+    const int c_end = (int)((int64_t)p.chunks_total * (ks + 1) / p.ksplit);
+
+    // Register prefetch: chunk ch+1 is fetched while chunk ch is multiplied out of LDS.  Every thread owns the same 8 S
+    // elements (channel s_a0 + 8j, pixel s_k) and up to 4 halo slots of every chunk; the slot -> (channel, kernel row,
+    // chunk row, halo column) decomposition is fixed, only the chunk origin moves.
+    constexpr int HSLOTS = 4;                          // halo_elems <= 1024 (checked by the host)
+    int h_off[HSLOTS], h_r[HSLOTS], h_cr[HSLOTS], h_hx[HSLOTS], h_i[HSLOTS];
+#pragma unroll
+    for (int j = 0; j < HSLOTS; j++) {
+        int rem = tid + 256 * j;
+        h_off[j] = rem < halo_elems ? rem : -1;
+        h_hx[j] = rem % HW_; rem /= HW_;
+        h_r[j] = rem % p.kh; rem /= p.kh;
+        h_cr[j] = rem % CHH; h_i[j] = rem / CHH;
+    }
+    float sreg[8], hreg[HSLOTS];
+    auto fetch = [&](int ch) {
+        const int rb = ch / p.qblocks, qb = ch - rb * p.qblocks;
+        const int row0 = rb * CHH, q0 = qb * CW;
+        {   // S: 64 channels x 32 pixels
+            const int row = row0 + s_dr, q = q0 + s_dq;
+            const bool ok = row < p.rows_total && q < p.Q;
+            const int n = ok ? row / p.P : 0, pp = row - n * p.P;
+            const float* sp = p.S + ((int64_t)n * p.Ag + a_blk) * PQ + pp * p.Q + q;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int a = s_a0 + 8 * j;
+                sreg[j] = (ok && a_blk + a < p.Ag) ? sp[(int64_t)a * PQ] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < HSLOTS; j++) {              // L halo, [i][cr*kh + r][hx]
+            float v = 0.f;
+            const int row = row0 + h_cr[j];
+            if (h_off[j] >= 0 && row < p.rows_total) {
+                const int n = row / p.P, pp = row - n * p.P;
+                const int ly = pp + h_r[j] - p.pad_h, lx = q0 + h_hx[j] - p.pad_w;
+                if ((unsigned)ly < (unsigned)p.LH && (unsigned)lx < (unsigned)p.LW)
+                    v = p.L[((int64_t)n * p.Bg + h_i[j]) * LHW + ly * p.LW + lx];
+            }
+            hreg[j] = v;
+        }
+    };
+    if (c_begin < c_end) fetch(c_begin);
+    for (int ch = c_begin; ch < c_end; ch++) {
+        __syncthreads();                                // the previous chunk's LDS reads are done
+#pragma unroll
+        for (int j = 0; j < 8; j++) Ss[(s_a0 + 8 * j) * SPITCH + s_k] = sreg[j];
+#pragma unroll
+        for (int j = 0; j < HSLOTS; j++)
+            if (h_off[j] >= 0) Ls[h_off[j]] = hreg[j];
+        if (tid == 0) Ls[halo_elems] = 0.f;
+        __syncthreads();
+        if (ch + 1 < c_end) fetch(ch + 1);
+#pragma unroll 4
+        for (int kk = 0; kk < KP / 2; kk++) {
+            const int k = kk * 2 + kl;
+            const float af = Ss[(wa * 32 + jl) * SPITCH + k];
+            const int koff = (k >> p.cw_log2) * p.kh * HW_ + (k & (CW - 1));
+#pragma unroll
+            for (int t = 0; t < MAXT; t++) {
+                if (wb + 2 * t >= p.nb) continue;      // uniform per wave
+                const float bf = Ls[boff[t] >= 0 ? boff[t] + koff : halo_elems];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // slab [ksplit][a_pad][nb*32]
+    const int bpad = p.nb * 32;
+    float* out = p.slab + (int64_t)ks * p.a_tiles * 64 * bpad;
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+        if (wb + 2 * t >= p.nb) continue;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int a = a_blk + wa * 32 + acc_row(r, lane), b = (wb + 2 * t) * 32 + jl;
+            out[(int64_t)a * bpad + b] = acc[t][r];
+        }
+    }
+}
+
+// dw[o][b'] = sum_ks slab[ks][o][b']   (b' already in PyTorch's [i][r][s] order)
+__global__ __launch_bounds__(256) void wgrad_smallcin_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int ksplit,
+                                                                    int Ag, int bprime, int a_pad, int bpad, float wscale) {
+    const int total = Ag * bprime;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int a = idx / bprime, b = idx - a * bprime;
+        const float* src = slab + (int64_t)a * bpad + b;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;          // as wgrad_reduce_kernel: sixteen slabs in flight, fixed order
+        const int64_t stride = (int64_t)a_pad * bpad;
+        int k = 0;
+        for (; k + 16 <= ksplit; k += 16) {
+            float r[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) r[j] = src[(k + j) * stride];
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) { v0 += r[j]; v1 += r[j + 1]; v2 += r[j + 2]; v3 += r[j + 3]; }
+        }
+        for (; k < ksplit; k++) v0 += src[k * stride];
+        dw[idx] = ((v0 + v1) + (v2 + v3)) * wscale;
+    }
+}
+
+struct WgradSmallPlan { bool use; int nb, bprime, cw_log2, qblocks, chunks_total, ksplit, a_tiles, rows_total; int64_t slab_floats; size_t lds_bytes; };
+
+static WgradSmallPlan plan_wgrad_small(const pasta_conv_desc* d) {
+    WgradSmallPlan w; w.use = false;
+    const int Ig = d->C_in / d->groups;
+    if (d->transposed || d->groups != 1 || d->stride != 1 || d->flip || Ig > 8 || Ig * d->kh * d->kw > 160) return w;
+    w.use = true;
+    w.bprime = Ig * d->kh * d->kw; w.nb = (w.bprime + 31) / 32;
+    int cw = 32, lg = 5;
+    while (cw > 1 && cw / 2 >= d->OW) { cw /= 2; lg--; }
+    const int chh = 32 / cw;
+    w.cw_log2 = lg; w.rows_total = d->N * d->OH;
+    w.qblocks = (d->OW + cw - 1) / cw;
+    w.chunks_total = ((w.rows_total + chh - 1) / chh) * w.qblocks;
+    w.a_tiles = (d->C_out + 63) / 64;
+    int64_t ks = (1024 + w.a_tiles - 1) / w.a_tiles;        // four workgroups per CU: one chunk in flight each
+    if (ks > w.chunks_total / 8) ks = w.chunks_total / 8;
+    if (ks < 1) ks = 1;
+    w.ksplit = (int)ks;
+    w.slab_floats = (int64_t)w.ksplit * w.a_tiles * 64 * w.nb * 32;
+    w.lds_bytes = (size_t)(64 * 33 + Ig * chh * d->kh * (cw + d->kw - 1) + 4) * sizeof(float);
+    if (Ig * chh * d->kh * (cw + d->kw - 1) > 1024) w.use = false;      // four halo slots per thread in the kernel
+    return w;
+}
+
+
+}  // namespace pasta
