@@ -100,8 +100,11 @@ static FwdPlan plan_fwd(const pasta_conv_desc* d) {
     f.ksplit = 1;
     if (npix <= 8192 && f.tile != T32x256) {
         const int bm = fwd_tile_bm(f.tile), bn = f.tile == T64x64 ? 64 : 128;
-        const int64_t blocks = ceil_div64(npix, bn) * ((Og + bm - 1) / bm) * d->groups;
-        const int taps = d->transposed ? (d->kh * d->kw + d->stride * d->stride - 1) / (d->stride * d->stride) : d->kh * d->kw;
+        int64_t blocks = ceil_div64(npix, bn) * ((Og + bm - 1) / bm) * d->groups;
+        // conv_transpose2d: a parity class has between 1 and ceil(k/u)^2 of the taps; the slices are sized for the
+        // smallest class, and on the split-bf16 kernel the u*u classes share the grid (merged_classes)
+        const int taps = d->transposed ? 1 : d->kh * d->kw;
+        if (d->transposed && f.bf16x6 && d->stride == 2) blocks *= 4;
         const int64_t k_total = (int64_t)taps * round_up(Ig, 16);
         int64_t ks = (f.tile == T64x64 ? 768 : 512) / (blocks > 0 ? blocks : 1);
         if (ks > k_total / 64) ks = k_total / 64;                     // at least 64 channel-taps per slice
