@@ -552,8 +552,11 @@ class Spade_Norm_Block(torch.nn.Module):
         self.param_free_norm = nn.InstanceNorm2d(norm_channels, affine=False)
 
     def forward(self, x, denorm_feats):
-        actv = self.conv_mlp(denorm_feats, no_act=True)
-        actv = bias_act.bias_act(actv, act='relu', gain=1)          # == nn.ReLU()
+        # conv_mlp (no activation in front, no bias) followed by nn.ReLU (:4373-4374): the ReLU rides in the convolution's epilogue
+        m = self.conv_mlp
+        actv = conv2d_resample.conv2d_resample_bias_act(x=denorm_feats, w=m.weight.to(denorm_feats.dtype), b=None, f=m.resample_filter,
+                                                        up=m.up, down=m.down, padding=m.padding, flip_weight=(m.up == 1),
+                                                        act='relu', gain=1, wgain=m.weight_gain)
         gamma = self.conv_gamma(actv, no_act=True)
         beta = self.conv_beta(actv, no_act=True)
         return spade_modulate(x, gamma, beta, eps=self.param_free_norm.eps)
