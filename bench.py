@@ -32,7 +32,7 @@ BF16X6_ROWS = {0: 'conv_fwd_rows_bf16x6_kernel<128,128,2>', 1: 'conv_fwd_rows_bf
 
 TILE_NAMES = {0: 'conv_fwd_kernel<128,128,2,2,8,4>', 1: 'conv_fwd_kernel<64,256,2,2,8,4>',
               2: 'conv_fwd_kernel<32,256,1,2,8>', 3: 'conv_fwd_kernel<64,64,1,1,8>'}
-WGRAD_NAMES = {0: 'conv_wgrad_kernel', 1: 'conv_wgrad_smallcin_kernel', 2: 'conv_wgrad3x3_bf16x6_kernel', 3: 'conv_wgrad3x3s2_bf16x6_kernel'}
+WGRAD_NAMES = {0: 'conv_wgrad_kernel', 1: 'conv_wgrad_smallcin_kernel', 2: 'conv_wgrad3x3_bf16x6_kernel', 3: 'conv_wgrad3x3s2_bf16x6_kernel', 4: 'conv_wgrad1x1_bf16x6_kernel'}
 
 
 class ConvMeter:
@@ -269,7 +269,7 @@ def main():
             name, f = dom
             achieved = f['flops'] / (f['ms'] * 1e-3) / 1e12
             traffic, src = pmc_traffic(name)
-            if name in (BF16X6[0], BF16X6[1], BF16X6_ROWS[0], BF16X6_ROWS[1], WGRAD_NAMES[2], WGRAD_NAMES[3]):
+            if name in (BF16X6[0], BF16X6[1], BF16X6_ROWS[0], BF16X6_ROWS[1], WGRAD_NAMES[2], WGRAD_NAMES[3], WGRAD_NAMES[4]):
                 # six bf16 MFMA products per fp32-equivalent multiply-add: the matrix pipes execute 6x the algorithmic FLOPs
                 peak = PEAK_BF16_MFMA_TFLOPS / 6
                 note = ('split-bf16: fp32-equivalent products from 6 x v_mfma_f32_32x32x16_bf16, fp32 accumulate; peak = 2500 TFLOP/s '

@@ -352,6 +352,14 @@ static bool wgrad_s2_bf16x6(const pasta_conv_desc* d, const WgradPlan& w) {
     return d->math != PASTA_MATH_F32 && d->kh == 3 && d->kw == 3 && d->stride == 2 && d->pad_h == d->pad_w && d->pad_h <= 1 &&
            Q % 16 == 0 && w.kp == 16 && w.cw_log2 == 4;
 }
+// ... and the pointwise one: 1x1, stride 1, no padding, planes of a multiple of 32 pixels, >= 16 channels on both sides.
+static bool wgrad_1x1_bf16x6(const pasta_conv_desc* d, const WgradPlan& w) {
+    const int P = d->transposed ? d->H : d->OH, Q = d->transposed ? d->W : d->OW;
+    const int Ig = d->C_in / d->groups, Og = d->C_out / d->groups;
+    return d->math != PASTA_MATH_F32 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 &&
+           ((int64_t)P * Q) % 32 == 0 && Ig >= 16 && Og >= 16 && w.kp == 32 && w.WA == w.WB &&
+           d->H == d->OH && d->W == d->OW && (int64_t)w.chunks_total == (int64_t)d->N * P * Q / 32;
+}
 }  // namespace pasta
 
 extern "C" int pasta_conv2d_wgrad_plan(const pasta_conv_desc* d, int* kernel) {
@@ -365,6 +373,7 @@ extern "C" int pasta_conv2d_wgrad_plan(const pasta_conv_desc* d, int* kernel) {
                                           : plan_wgrad(d->N, d->OH, d->OW, d->groups, Og, Ig, d->kh, d->kw, d->stride);
         if (wgrad_bf16x6(d, w)) k = 2;
         else if (wgrad_s2_bf16x6(d, w)) k = 3;
+        else if (wgrad_1x1_bf16x6(d, w)) k = 4;
     }
     if (kernel) *kernel = k;
     return 0;
@@ -449,6 +458,11 @@ extern "C" int pasta_conv2d_wgrad(const float* x, const float* dy, float* dw, co
     else if (w.TR == 3 && w.TS == 3) PASTA_WGRAD(3, 3, 1, 1);
     else if (w.TS == 7) PASTA_WGRAD(1, 7, 1, 1);
     else if (w.TS == 4) PASTA_WGRAD(1, 4, 1, 1);
+    else if (wgrad_1x1_bf16x6(d, w)) {
+        const size_t lds = (size_t)(3 * 64 * 40) * 2 * 2 * w.WA;          // S and L images of 64 WA (= 64 WB) channels
+        if (w.WA == 2) hipLaunchKernelGGL((conv_wgrad1x1_bf16x6_kernel<2, 2>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+        else           hipLaunchKernelGGL((conv_wgrad1x1_bf16x6_kernel<1, 1>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+    }
     else if (w.WA == 2) PASTA_WGRAD(1, 1, 2, 2);
     else PASTA_WGRAD(1, 1, 1, 1);
 #undef PASTA_WGRAD

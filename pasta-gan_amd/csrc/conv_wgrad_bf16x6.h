@@ -336,5 +336,142 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
     }
 }
 
+//------------------------------------------------------------------------------------
+// 1x1, stride 1, no padding (the residual skips, ToRGB-side merges and the discriminator's fromrgb/skip convolutions):
+// a plain GEMM dW[a][b] = sum_pix S[a][pix] * L[b][pix] over K = all pixels, both operands pixel-contiguous.  Same
+// split-bf16 arithmetic; workgroup tile (64 WA) x (64 WB) channels, every wave WA x WB tiles of 32 x 32; K chunk = 32
+// consecutive pixels of one image (P*Q % 32 == 0).  Both operands are split and stored as [piece][channel][32 px]
+// (row pitch 40 bf16).  The shape is bandwidth-bound: 2 x 64 x (WA + WB) x 32 floats per 32 x (64 WA)(64 WB) MACs.
+template <int WA, int WB>
+__global__ __launch_bounds__(256, 2) void conv_wgrad1x1_bf16x6_kernel(WgradParams p) {
+    constexpr int SP = 40;
+    constexpr int TA = 64 * WA, TB = 64 * WB;
+    constexpr int A_PIECE = TA * SP, B_PIECE = TB * SP;
+    constexpr int UA = TA * 4 / 256, UB = TB * 4 / 256;             // (channel, 8-pixel group) units per thread
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+    __bf16* Ss = smem16;                            // [3][TA][SP]
+    __bf16* Ls = smem16 + 3 * A_PIECE;              // [3][TB][SP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave >> 1, wb = wave & 1;
+    const int hl = lane >> 5, jl = lane & 31;
+
+    int bid = blockIdx.x;
+    const int ks = bid % p.ksplit; bid /= p.ksplit;
+    const int bt = bid % p.b_tiles; bid /= p.b_tiles;
+    const int at = bid % p.a_tiles; bid /= p.a_tiles;
+    const int g = bid;
+    const int a_blk = at * TA, b_blk = bt * TB;
+    const int PQ = p.P * p.Q;
+    const float* const Sg = p.S + ((int64_t)g * p.Ag + a_blk) * PQ;
+    const float* const Lg = p.L + ((int64_t)g * p.Bg + b_blk) * PQ;
+    const int chunks_per_image = PQ / 32;
+
+    float4 sreg[UA][2], lreg[UB][2];
+    auto fetch = [&](int ch) {
+        const int n = ch / chunks_per_image, px0 = (ch - n * chunks_per_image) * 32;
+#pragma unroll
+        for (int j = 0; j < UA; j++) {
+            const int u = tid + 256 * j, c = u >> 2, grp = u & 3;
+            if (a_blk + c < p.Ag) {
+                const float* sp = Sg + (int64_t)n * p.SC * PQ + (int64_t)c * PQ + px0 + 8 * grp;
+                sreg[j][0] = *(const float4*)sp; sreg[j][1] = *(const float4*)(sp + 4);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < UB; j++) {
+            const int u = tid + 256 * j, c = u >> 2, grp = u & 3;
+            if (b_blk + c < p.Bg) {
+                const float* lp = Lg + (int64_t)n * p.LC * PQ + (int64_t)c * PQ + px0 + 8 * grp;
+                lreg[j][0] = *(const float4*)lp; lreg[j][1] = *(const float4*)(lp + 4);
+            }
+        }
+    };
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    auto split_store = [&](float4 h0, float4 h1, bool ok, __bf16* dst, int piece_stride) {
+        const float vals[8] = {ok ? h0.x : 0.f, ok ? h0.y : 0.f, ok ? h0.z : 0.f, ok ? h0.w : 0.f,
+                               ok ? h1.x : 0.f, ok ? h1.y : 0.f, ok ? h1.z : 0.f, ok ? h1.w : 0.f};
+        uint32_t q1[4], q2[4], q3[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            f32x2 v = {vals[2 * j], vals[2 * j + 1]};
+            uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+            q1[j] = w;
+            v[0] -= __builtin_bit_cast(float, w << 16);
+            v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
+            w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+            q2[j] = w;
+            v[0] -= __builtin_bit_cast(float, w << 16);
+            v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
+            q3[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        }
+        *(uint4*)(dst) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+        *(uint4*)(dst + piece_stride) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+        *(uint4*)(dst + 2 * piece_stride) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int j = 0; j < UA; j++) {
+            const int u = tid + 256 * j, c = u >> 2, grp = u & 3;
+            split_store(sreg[j][0], sreg[j][1], a_blk + c < p.Ag, Ss + c * SP + 8 * grp, A_PIECE);
+        }
+#pragma unroll
+        for (int j = 0; j < UB; j++) {
+            const int u = tid + 256 * j, c = u >> 2, grp = u & 3;
+            split_store(lreg[j][0], lreg[j][1], b_blk + c < p.Bg, Ls + c * SP + 8 * grp, B_PIECE);
+        }
+    };
+
+    f32x16 acc[WA][WB];
+#pragma unroll
+    for (int a = 0; a < WA; a++)
+#pragma unroll
+        for (int b = 0; b < WB; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    const int c_begin = (int)((int64_t)p.chunks_total * ks / p.ksplit);
+    const int c_end = (int)((int64_t)p.chunks_total * (ks + 1) / p.ksplit);
+    if (c_begin < c_end) fetch(c_begin);
+    for (int ch = c_begin; ch < c_end; ch++) {
+        __syncthreads();                  // the previous chunk's fragment reads are done
+        stash();
+        __syncthreads();
+        if (ch + 1 < c_end) fetch(ch + 1);
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            bf16x8 af[WA][3], bf[WB][3];
+#pragma unroll
+            for (int pc = 0; pc < 3; pc++) {
+#pragma unroll
+                for (int a = 0; a < WA; a++) af[a][pc] = *(const bf16x8*)&Ss[pc * A_PIECE + ((wa * WA + a) * 32 + jl) * SP + 16 * s + 8 * hl];
+#pragma unroll
+                for (int b = 0; b < WB; b++) bf[b][pc] = *(const bf16x8*)&Ls[pc * B_PIECE + ((wb * WB + b) * 32 + jl) * SP + 16 * s + 8 * hl];
+            }
+#pragma unroll
+            for (int pb = 2; pb >= 0; pb--)             // smallest terms first
+#pragma unroll
+                for (int pa = 2 - pb; pa >= 0; pa--)
+#pragma unroll
+                    for (int a = 0; a < WA; a++)
+#pragma unroll
+                        for (int b = 0; b < WB; b++)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][pa], bf[b][pb], acc[a][b], 0, 0, 0);
+        }
+    }
+
+    const int Ag_pad = p.a_tiles * TA, Bg_pad = p.b_tiles * TB;
+    float* out = p.slab + ((int64_t)ks * p.G + g) * Ag_pad * Bg_pad;
+#pragma unroll
+    for (int a = 0; a < WA; a++)
+#pragma unroll
+        for (int b = 0; b < WB; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int ai = a_blk + (wa * WA + a) * 32 + acc_row(r, lane), bi = b_blk + (wb * WB + b) * 32 + jl;
+                out[(int64_t)ai * Bg_pad + bi] = acc[a][b][r];
+            }
+}
 
 }  // namespace pasta

@@ -153,3 +153,34 @@ def test_stride2_weight_gradient_split_bf16(transposed, n, cin, cout, hw, pad):
     kernel = ctypes.c_int()
     custom_ops.get_plugin().pasta_conv2d_wgrad_plan(ctypes.byref(desc), ctypes.byref(kernel))
     assert kernel.value == 3
+
+
+@pytest.mark.parametrize('n,cin,cout,hw', [(2, 192, 128, 64), (2, 64, 40, 32), (1, 24, 200, 128), (3, 130, 130, 16), (16, 512, 512, 8), (16, 512, 512, 4)])
+def test_pointwise_weight_gradient_split_bf16(n, cin, cout, hw):
+    """conv_wgrad1x1_bf16x6_kernel: 128x128 and 64x64 channel tiles, channel tails, small planes (K slicing over few
+    chunks), against fp64 autograd."""
+    import ctypes
+    from torch_utils.ops import conv2d_gradfix as cg
+    from torch_utils import custom_ops
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn([n, cin, hw, hw], generator=g)
+    w = torch.randn([cout, cin, 1, 1], generator=g) / cin ** 0.5
+    dy = torch.randn([n, cout, hw, hw], generator=g)
+    w64 = w.double().requires_grad_(True)
+    rw, = torch.autograd.grad(torch.nn.functional.conv2d(x.double(), w64), w64, dy.double())
+    res = {}
+    for mode in ['f32', 'bf16x6']:
+        old = cg.conv_math
+        cg.conv_math = mode
+        try:
+            wc = w.cuda().requires_grad_(True)
+            gw, = torch.autograd.grad(cg.conv2d(x.cuda(), wc), wc, dy.cuda())
+        finally:
+            cg.conv_math = old
+        res[mode] = float((gw.double().cpu() - rw).abs().max() / rw.abs().max())
+    assert res['f32'] < 1e-5 and res['bf16x6'] < 1e-5, res
+    desc = custom_ops.ConvDesc(N=n, C_in=cin, H=hw, W=hw, C_out=cout, OH=hw, OW=hw, kh=1, kw=1, stride=1, pad_h=0, pad_w=0, groups=1,
+                               transposed=0, flip=0, math=0, wscale=1.0)
+    kernel = ctypes.c_int()
+    custom_ops.get_plugin().pasta_conv2d_wgrad_plan(ctypes.byref(desc), ctypes.byref(kernel))
+    assert kernel.value == (4 if hw * hw % 32 == 0 else 0)       # 4 x 4 planes stay on the fp32 kernel
