@@ -352,12 +352,13 @@ static bool wgrad_s2_bf16x6(const pasta_conv_desc* d, const WgradPlan& w) {
     return d->math != PASTA_MATH_F32 && d->kh == 3 && d->kw == 3 && d->stride == 2 && d->pad_h == d->pad_w && d->pad_h <= 1 &&
            Q % 16 == 0 && w.kp == 16 && w.cw_log2 == 4;
 }
-// ... and the pointwise one: 1x1, stride 1, no padding, planes of a multiple of 32 pixels, >= 16 channels on both sides.
+// ... and the pointwise one: 1x1, stride 1, no padding, planes of a multiple of 32 pixels (ToRGB heads included: the shape is
+// bandwidth-bound, so a mostly empty 64-channel tile costs nothing).
 static bool wgrad_1x1_bf16x6(const pasta_conv_desc* d, const WgradPlan& w) {
     const int P = d->transposed ? d->H : d->OH, Q = d->transposed ? d->W : d->OW;
     const int Ig = d->C_in / d->groups, Og = d->C_out / d->groups;
     return d->math != PASTA_MATH_F32 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 &&
-           ((int64_t)P * Q) % 32 == 0 && Ig >= 16 && Og >= 16 && w.kp == 32 && w.WA == w.WB &&
+           ((int64_t)P * Q) % 32 == 0 && (Ig >= 16 || Og >= 16) && w.kp == 32 && w.WA == w.WB &&
            d->H == d->OH && d->W == d->OW && (int64_t)w.chunks_total == (int64_t)d->N * P * Q / 32;
 }
 }  // namespace pasta
