@@ -114,3 +114,27 @@ def test_two_iterations_of_the_loop():
     d_live = (dict(step.G.named_parameters())[k] - init_G[k]).abs().mean().item()
     d_ema = (dict(step.G_ema.named_parameters())[k] - init_G[k]).abs().mean().item()
     assert 0 < d_ema < 0.01 * d_live
+
+
+def test_merged_discriminator_pass_equals_separate_passes():
+    """run_D_multi: one discriminator pass over several image batches, stacked so that every minibatch-std group stays
+    inside its own batch, returns the logits (and, through them, the gradients) of the separate passes."""
+    from training import networks
+    from training.loss_wo_flow_fullbody import StyleGAN2Loss
+    G, D = prepare(networks.GeneratorFull(**PF.G_KWARGS).train(), networks.Discriminator(**PF.D_KWARGS).train())
+    D.cuda()
+    loss = StyleGAN2Loss(torch.device('cuda'), G.mapping, G.synthesis, G.const_encoding, G.style_encoding, D, vgg_weight=0, contextual_weight=0)
+    assert loss._mbstd_groups(16) == 4 and loss._mbstd_groups(8) == 2 and loss._mbstd_groups(6) is None
+    g = torch.Generator().manual_seed(9)
+    imgs = [(torch.rand([8, 3, 256, 256], generator=g) * 2 - 1).cuda().requires_grad_(True) for _ in range(3)]
+    cs = [torch.randn([8, 512], generator=g).cuda() for _ in range(3)]
+    sep = [loss.run_D(i, c, sync=True) for i, c in zip(imgs, cs)]
+    mer = loss.run_D_multi(imgs, cs, sync=True)
+    for a, b in zip(sep, mer):
+        assert a.shape == b.shape == (8, 1)
+        assert rel_err(b, a) < 1e-5
+    w = [torch.randn([8, 1], generator=g).cuda() for _ in range(3)]
+    g_sep = torch.autograd.grad(sum((a * x).sum() for a, x in zip(sep, w)), imgs)
+    g_mer = torch.autograd.grad(sum((a * x).sum() for a, x in zip(mer, w)), imgs)
+    for a, b in zip(g_sep, g_mer):
+        assert rel_err(b, a) < 1e-4
