@@ -188,6 +188,21 @@ int pasta_scale_add(const float* x, const float* a, const float* b, float* y,
 int pasta_plane_dot(const float* p, const float* q, float* out, int64_t planes,
                     int64_t HW, void* stream);
 
+/* Tail of SynthesisLayer in one pass (networks.py:72-82 demodulation + noise, :313-314 bias_act):
+ *   y = clamp(act(u * d[n,c] + noise * strength[0] + b[c]) * gain),  act = 1 (linear) or 3 (lrelu),
+ * u: [N,C,HW] convolution output, d: [N,C] demodulation coefficients (NULL = 1), noise: [N,HW] (noise_per_sample)
+ * or [HW] or NULL, strength: device scalar, b: [C] or NULL, clamp < 0 = none.
+ * Backward: du = dz * d with dz = dy * act'(y) * gain (0 where |y| >= clamp), and per (plane, 4096-element chunk)
+ * the triple (sum dz*u, sum dz*noise, sum dz) in `partial` ([N*C][chunks][3] floats, pasta_mod_bias_act_bwd_workspace
+ * bytes), from which the caller forms dd[n,c], dstrength and db[c]. */
+int pasta_mod_bias_act(const float* u, const float* d, const float* noise, const float* strength, const float* b, float* y,
+                       int N, int C, int64_t HW, int noise_per_sample, int act, float alpha, float gain, float clamp,
+                       void* stream);
+int64_t pasta_mod_bias_act_bwd_workspace(int N, int C, int64_t HW);
+int pasta_mod_bias_act_bwd(const float* dy, const float* y, const float* u, const float* d, const float* noise, float* du,
+                           float* partial, int N, int C, int64_t HW, int noise_per_sample, int act, float alpha, float gain,
+                           float clamp, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * SPADE normalisation (training/networks.py:4371-4379):
  *   out = InstanceNorm(x) * (1 + gamma) + beta, eps 1e-5, biased variance.

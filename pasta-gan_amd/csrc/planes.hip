@@ -209,6 +209,97 @@ __global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const float* __res
     }
 }
 
+
+//------------------------------------------------------------------------------------
+// Tail of a modulated convolution layer in one pass (SynthesisLayer, training/networks.py:72-82 + 313-314):
+//   y = clamp(act(u * d[n,c] + noise[n|.,hw] * strength + b[c]) * gain),   act = linear (1) or leaky relu (3)
+// and its backward: with dz = dy * act'(y) * gain (zero where |y| >= clamp)
+//   du = dz * d[n,c],   partial[n,c][chunk] = (sum dz*u, sum dz*noise, sum dz)  -> dd[n,c], dstrength, db[c] on the host.
+// One workgroup per (plane, chunk of 4096 elements); 16-byte accesses when HW % 4 == 0.
+constexpr int MBA_CHUNK = 4096;
+
+__device__ __forceinline__ float mba_fwd(float u, float d, float nz, float b, int act, float alpha, float gain, float clamp) {
+    float v = fmaf(u, d, nz) + b;
+    if (act == 3) v = v > 0.f ? v : v * alpha;
+    v *= gain;
+    if (clamp >= 0.f) v = (v > -clamp && v < clamp) ? v : (v >= 0.f ? clamp : -clamp);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void mod_bias_act_kernel(const float* __restrict__ u, const float* __restrict__ d,
+                                                           const float* __restrict__ noise, const float* __restrict__ strength,
+                                                           const float* __restrict__ b, float* __restrict__ y, int C, int64_t HW,
+                                                           int noise_per_sample, int act, float alpha, float gain, float clamp) {
+    const int64_t plane = blockIdx.x;
+    const int n = (int)(plane / C), c = (int)(plane - (int64_t)n * C);
+    const float dv = d ? d[plane] : 1.f, bv = b ? b[c] : 0.f, ns = noise ? strength[0] : 0.f;
+    const float* up = u + plane * HW;
+    const float* np_ = noise ? noise + (noise_per_sample ? (int64_t)n * HW : 0) : nullptr;
+    float* yp = y + plane * HW;
+    const int64_t i0 = (int64_t)blockIdx.y * MBA_CHUNK, i1 = i0 + MBA_CHUNK < HW ? i0 + MBA_CHUNK : HW;
+    if ((HW & 3) == 0) {
+        for (int64_t i = i0 + 4 * threadIdx.x; i < i1; i += 1024) {
+            const float4 uv = *(const float4*)(up + i);
+            const float4 nv = np_ ? *(const float4*)(np_ + i) : make_float4(0, 0, 0, 0);
+            float4 o;
+            o.x = mba_fwd(uv.x, dv, nv.x * ns, bv, act, alpha, gain, clamp);
+            o.y = mba_fwd(uv.y, dv, nv.y * ns, bv, act, alpha, gain, clamp);
+            o.z = mba_fwd(uv.z, dv, nv.z * ns, bv, act, alpha, gain, clamp);
+            o.w = mba_fwd(uv.w, dv, nv.w * ns, bv, act, alpha, gain, clamp);
+            *(float4*)(yp + i) = o;
+        }
+    } else {
+        for (int64_t i = i0 + threadIdx.x; i < i1; i += 256)
+            yp[i] = mba_fwd(up[i], dv, np_ ? np_[i] * ns : 0.f, bv, act, alpha, gain, clamp);
+    }
+}
+
+__device__ __forceinline__ float mba_dz(float dy, float y, int act, float alpha, float gain, float clamp) {
+    float g = dy * gain;
+    if (act == 3) g = y > 0.f ? g : g * alpha;
+    if (clamp >= 0.f) g = (y > -clamp && y < clamp) ? g : 0.f;
+    return g;
+}
+
+__global__ __launch_bounds__(256) void mod_bias_act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                               const float* __restrict__ u, const float* __restrict__ d,
+                                                               const float* __restrict__ noise, float* __restrict__ du,
+                                                               float* __restrict__ partial, int C, int64_t HW, int chunks,
+                                                               int noise_per_sample, int act, float alpha, float gain, float clamp) {
+    __shared__ float red[4];
+    const int64_t plane = blockIdx.x;
+    const int n = (int)(plane / C);
+    const float dv = d ? d[plane] : 1.f;
+    const float* dyp = dy + plane * HW; const float* yp = y + plane * HW; const float* up = u + plane * HW;
+    const float* np_ = noise ? noise + (noise_per_sample ? (int64_t)n * HW : 0) : nullptr;
+    float* dup = du + plane * HW;
+    const int64_t i0 = (int64_t)blockIdx.y * MBA_CHUNK, i1 = i0 + MBA_CHUNK < HW ? i0 + MBA_CHUNK : HW;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if ((HW & 3) == 0) {
+        for (int64_t i = i0 + 4 * threadIdx.x; i < i1; i += 1024) {
+            const float4 gv = *(const float4*)(dyp + i), yv = *(const float4*)(yp + i), uv = *(const float4*)(up + i);
+            const float4 nv = np_ ? *(const float4*)(np_ + i) : make_float4(0, 0, 0, 0);
+            const float z0 = mba_dz(gv.x, yv.x, act, alpha, gain, clamp), z1 = mba_dz(gv.y, yv.y, act, alpha, gain, clamp);
+            const float z2 = mba_dz(gv.z, yv.z, act, alpha, gain, clamp), z3 = mba_dz(gv.w, yv.w, act, alpha, gain, clamp);
+            s0 += z0 * uv.x + z1 * uv.y + z2 * uv.z + z3 * uv.w;
+            s1 += z0 * nv.x + z1 * nv.y + z2 * nv.z + z3 * nv.w;
+            s2 += z0 + z1 + z2 + z3;
+            *(float4*)(dup + i) = make_float4(z0 * dv, z1 * dv, z2 * dv, z3 * dv);
+        }
+    } else {
+        for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+            const float z = mba_dz(dyp[i], yp[i], act, alpha, gain, clamp);
+            s0 += z * up[i]; s1 += np_ ? z * np_[i] : 0.f; s2 += z;
+            dup[i] = z * dv;
+        }
+    }
+    s0 = block_sum<256>(s0, red); s1 = block_sum<256>(s1, red); s2 = block_sum<256>(s2, red);
+    if (threadIdx.x == 0) {
+        float* o = partial + (plane * chunks + blockIdx.y) * 3;
+        o[0] = s0; o[1] = s1; o[2] = s2;
+    }
+}
+
 }  // namespace pasta
 
 extern "C" int pasta_scale_add(const float* x, const float* a, const float* b, float* y, int N, int C, int64_t HW,
@@ -263,4 +354,41 @@ extern "C" int pasta_spade_norm_bwd(const float* dout, const float* x, const flo
     else if (HW == 4096 && al) hipLaunchKernelGGL((spade_norm_bwd_kernel<4>), dim3(grid), dim3(1024), 0, s, dout, x, gamma, stats, dx, dgamma, dbeta, planes, HW);
     else hipLaunchKernelGGL((spade_norm_bwd_kernel<0>), dim3(grid), dim3(1024), 0, s, dout, x, gamma, stats, dx, dgamma, dbeta, planes, HW);
     return launch_status("spade_norm_bwd");
+}
+
+extern "C" int pasta_mod_bias_act(const float* u, const float* d, const float* noise, const float* strength, const float* b, float* y,
+                                  int N, int C, int64_t HW, int noise_per_sample, int act, float alpha, float gain, float clamp,
+                                  void* stream) {
+    using namespace pasta;
+    PASTA_CHECK(u && y, "mod_bias_act: null pointer");
+    PASTA_CHECK(N >= 1 && C >= 1 && HW >= 1, "mod_bias_act: empty tensor");
+    PASTA_CHECK(act == 1 || act == 3, "mod_bias_act: activation code %d (linear = 1 and lrelu = 3 are supported)", act);
+    PASTA_CHECK(!noise || strength, "mod_bias_act: noise without strength");
+    PASTA_CHECK(((HW & 3) != 0) || ((((uintptr_t)u | (uintptr_t)y | (uintptr_t)noise) & 15) == 0), "mod_bias_act: pointers must be 16-byte aligned");
+    const int64_t chunks = (HW + MBA_CHUNK - 1) / MBA_CHUNK;
+    PASTA_CHECK(chunks <= 65535 && (int64_t)N * C <= INT32_MAX, "mod_bias_act: tensor too large");
+    hipLaunchKernelGGL(mod_bias_act_kernel, dim3((unsigned)(N * C), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, u, d, noise, strength, b, y,
+                       C, HW, noise_per_sample, act, alpha, gain, clamp);
+    return launch_status("mod_bias_act");
+}
+
+extern "C" int64_t pasta_mod_bias_act_bwd_workspace(int N, int C, int64_t HW) {
+    if (N <= 0 || C <= 0 || HW <= 0) return 0;
+    return (int64_t)N * C * ((HW + pasta::MBA_CHUNK - 1) / pasta::MBA_CHUNK) * 3 * (int64_t)sizeof(float);
+}
+
+extern "C" int pasta_mod_bias_act_bwd(const float* dy, const float* y, const float* u, const float* d, const float* noise, float* du,
+                                      float* partial, int N, int C, int64_t HW, int noise_per_sample, int act, float alpha, float gain,
+                                      float clamp, void* stream) {
+    using namespace pasta;
+    PASTA_CHECK(dy && y && u && du && partial, "mod_bias_act_bwd: null pointer");
+    PASTA_CHECK(N >= 1 && C >= 1 && HW >= 1, "mod_bias_act_bwd: empty tensor");
+    PASTA_CHECK(act == 1 || act == 3, "mod_bias_act_bwd: activation code %d (linear = 1 and lrelu = 3 are supported)", act);
+    PASTA_CHECK(((HW & 3) != 0) || ((((uintptr_t)dy | (uintptr_t)y | (uintptr_t)u | (uintptr_t)du | (uintptr_t)noise) & 15) == 0),
+                "mod_bias_act_bwd: pointers must be 16-byte aligned");
+    const int64_t chunks = (HW + MBA_CHUNK - 1) / MBA_CHUNK;
+    PASTA_CHECK(chunks <= 65535 && (int64_t)N * C <= INT32_MAX, "mod_bias_act_bwd: tensor too large");
+    hipLaunchKernelGGL(mod_bias_act_bwd_kernel, dim3((unsigned)(N * C), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, dy, y, u, d, noise, du,
+                       partial, C, HW, (int)chunks, noise_per_sample, act, alpha, gain, clamp);
+    return launch_status("mod_bias_act_bwd");
 }

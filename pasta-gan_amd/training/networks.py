@@ -89,12 +89,83 @@ def spade_modulate(x, gamma, beta, eps=1e-5):
 
 #----------------------------------------------------------------------------
 
+class _ModBiasAct(torch.autograd.Function):
+    """Tail of a modulated-convolution layer in one pass: ``clamp(act(u * d[n,c] + noise * strength + b[c]) * gain)``
+    (the demodulation + noise of modulated_conv2d, networks.py:77-82, and SynthesisLayer's bias_act, :313-314).
+    The backward pass is one kernel as well: du and, per plane, the sums that give dd, dstrength and db."""
+    @staticmethod
+    def forward(ctx, u, d, noise, strength, b, cfg):
+        act_idx, alpha, gain, clamp = cfg
+        n, c, h, w = u.shape
+        u = u.contiguous()
+        d = d.contiguous() if d is not None else None
+        per_sample = 0
+        if noise is not None:
+            per_sample = int(noise.numel() == n * h * w and n > 1)
+            assert noise.numel() in (h * w, n * h * w)
+            noise = noise.contiguous()
+        y = torch.empty_like(u)
+        with torch.cuda.device(u.device):
+            st = _native.lib().pasta_mod_bias_act(_native.ptr(u), _native.ptr(d), _native.ptr(noise), _native.ptr(strength), _native.ptr(b),
+                                                  _native.ptr(y), n, c, h * w, per_sample, act_idx, float(alpha), float(gain), float(clamp),
+                                                  _native.stream())
+        _native.check(st)
+        ctx.save_for_backward(u, d, noise, y)
+        ctx.cfg, ctx.per_sample = cfg, per_sample
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        u, d, noise, y = ctx.saved_tensors
+        act_idx, alpha, gain, clamp = ctx.cfg
+        n, c, h, w = u.shape
+        dy = dy.contiguous()
+        lib = _native.lib()
+        du = torch.empty_like(u)
+        part = torch.empty([lib.pasta_mod_bias_act_bwd_workspace(n, c, h * w) // 4], dtype=torch.float32, device=u.device)
+        with torch.cuda.device(u.device):
+            st = lib.pasta_mod_bias_act_bwd(_native.ptr(dy), _native.ptr(y), _native.ptr(u), _native.ptr(d), _native.ptr(noise), _native.ptr(du),
+                                            _native.ptr(part), n, c, h * w, ctx.per_sample, act_idx, float(alpha), float(gain), float(clamp),
+                                            _native.stream())
+        _native.check(st)
+        sums = part.reshape(n, c, -1, 3).sum(dim=2)                    # [N, C, 3]: sum dz*u, sum dz*noise, sum dz
+        dd = sums[:, :, 0] if d is not None and ctx.needs_input_grad[1] else None
+        dstrength = sums[:, :, 1].sum() if noise is not None and ctx.needs_input_grad[3] else None
+        db = sums[:, :, 2].sum(dim=0) if ctx.needs_input_grad[4] else None
+        return du, dd, None, dstrength, db, None
+
+def mod_bias_act(u, dcoefs, noise, strength, bias, act='lrelu', alpha=None, gain=None, clamp=None):
+    """``bias_act(u * dcoefs[n,c] + noise * strength, bias, act, alpha, gain, clamp)`` in one pass; ``noise`` is the
+    unit noise ([H,W] or [N,1,H,W]) and ``strength`` the 0-dim strength parameter (both None = no noise).
+    First-order differentiable (the generator takes no double backward)."""
+    _native.require_gpu(u, 'mod_bias_act')
+    spec = bias_act.activation_funcs[act]
+    assert act in ('linear', 'lrelu') and u.dtype == torch.float32
+    cfg = (spec.cuda_idx, float(alpha if alpha is not None else spec.def_alpha), float(gain if gain is not None else spec.def_gain),
+           float(clamp if clamp is not None else -1))
+    return _ModBiasAct.apply(u, dcoefs, noise, strength, bias, cfg)
+
+#----------------------------------------------------------------------------
+
 @misc.profiled_function
 def normalize_2nd_moment(x, dim=1, eps=1e-8):
     """networks.py:30-32"""
     return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
 
 #----------------------------------------------------------------------------
+
+def _modulate_and_convolve(x, weight, styles, up, down, padding, resample_filter, demodulate, flip_weight):
+    """Non-fused modulated convolution up to, not including, the demodulation (networks.py:65-76): returns the
+    convolution of the style-scaled activations and the demodulation coefficients ``rsqrt(s^2 @ sum_k w^2 + 1e-8)``."""
+    dcoefs = None
+    if demodulate:
+        wsq = weight.square().sum(dim=[2, 3])                                   # [O, I]
+        dcoefs = (styles.square() @ wsq.t() + 1e-8).rsqrt()                     # [N, O]
+    x = scale_planes(x, styles)
+    x = conv2d_resample.conv2d_resample(x=x, w=weight.to(x.dtype), f=resample_filter, up=up, down=down,
+                                        padding=padding, flip_weight=flip_weight)
+    return x, dcoefs
 
 @misc.profiled_function
 def modulated_conv2d(
@@ -129,13 +200,7 @@ def modulated_conv2d(
         styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)
 
     if not fused_modconv:
-        dcoefs = None
-        if demodulate:
-            wsq = weight.square().sum(dim=[2, 3])                                   # [O, I]
-            dcoefs = (styles.square() @ wsq.t() + 1e-8).rsqrt()                     # [N, O]
-        x = scale_planes(x, styles)
-        x = conv2d_resample.conv2d_resample(x=x, w=weight.to(x.dtype), f=resample_filter, up=up, down=down,
-                                            padding=padding, flip_weight=flip_weight)
+        x, dcoefs = _modulate_and_convolve(x, weight, styles, up, down, padding, resample_filter, demodulate, flip_weight)
         if demodulate and noise is not None:
             x = fma.fma(x, dcoefs.to(x.dtype).reshape(batch_size, -1, 1, 1), noise.to(x.dtype))
         elif demodulate:
@@ -344,16 +409,26 @@ class SynthesisLayer(torch.nn.Module):
         in_resolution = self.resolution // self.up
         misc.assert_shape(x, [None, self.weight.shape[1], in_resolution, in_resolution])
         styles = self.affine(w)
+        flip_weight = (self.up == 1)
+        act_gain = self.act_gain * gain
+        act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        if not fused_modconv and x.dtype == torch.float32 and x.device.type == 'cuda' and self.activation in ('linear', 'lrelu'):
+            # training path: demodulation, noise, bias and activation as one pass over the convolution's output
+            unit = None
+            if self.use_noise and noise_mode == 'random':
+                unit = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device)
+            if self.use_noise and noise_mode == 'const':
+                unit = self.noise_const
+            u, dcoefs = _modulate_and_convolve(x, self.weight, styles, self.up, 1, self.padding, self.resample_filter, True, flip_weight)
+            return mod_bias_act(u, dcoefs, unit, self.noise_strength if unit is not None else None, self.bias, act=self.activation,
+                                gain=act_gain, clamp=act_clamp)
         noise = None
         if self.use_noise and noise_mode == 'random':
             noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
         if self.use_noise and noise_mode == 'const':
             noise = self.noise_const * self.noise_strength
-        flip_weight = (self.up == 1)
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
                              resample_filter=self.resample_filter, flip_weight=flip_weight, fused_modconv=fused_modconv)
-        act_gain = self.act_gain * gain
-        act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         return bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=act_gain, clamp=act_clamp)
 
 #----------------------------------------------------------------------------
