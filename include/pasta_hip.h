@@ -207,13 +207,17 @@ int pasta_mod_bias_act_bwd(const float* dy, const float* y, const float* u, cons
  * SPADE normalisation (training/networks.py:4371-4379):
  *   out = InstanceNorm(x) * (1 + gamma) + beta, eps 1e-5, biased variance.
  * stats: [N*C, 2] (mean, rstd) written by the forward, read by the backward.
+ * Optional fused activation (act = 2): out = min(relu(out) * gain, clamp) -- what the Spade_Conv2dLayer that
+ * consumes the block's output applies in front of its convolution (networks.py:4346-4352); act 0/1 = none,
+ * clamp < 0 = none.  The backward then needs beta (to recompute the activation mask) and a dbeta buffer.
  * ------------------------------------------------------------------------- */
 int pasta_spade_norm(const float* x, const float* gamma, const float* beta,
                      float* out, float* stats, int64_t planes, int64_t HW,
-                     float eps, void* stream);
+                     float eps, int act, float gain, float clamp, void* stream);
 int pasta_spade_norm_bwd(const float* dout, const float* x, const float* gamma,
                          const float* stats, float* dx, float* dgamma,
-                         float* dbeta, int64_t planes, int64_t HW, void* stream);
+                         float* dbeta, int64_t planes, int64_t HW,
+                         const float* beta, int act, float gain, float clamp, void* stream);
 
 #ifdef __cplusplus
 }

@@ -92,8 +92,14 @@ __global__ __launch_bounds__(256) void plane_dot_kernel(const float* __restrict_
 template <int EPT>   // EPT == 0: generic loops
 __global__ __launch_bounds__(1024) void spade_norm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ out,
-                                                          float* __restrict__ stats, int64_t planes, int64_t HW, float eps) {
+                                                          float* __restrict__ stats, int64_t planes, int64_t HW, float eps,
+                                                          int act, float gain, float clamp) {
     __shared__ float red[16];
+    // optional relu * gain with clamp on the way out (the activation Spade_Conv2dLayer applies before its convolution)
+    auto post = [&](float v) {
+        if (act == 2) { v = v > 0.f ? v * gain : 0.f; if (clamp >= 0.f && v > clamp) v = clamp; }
+        return v;
+    };
     const int tid = threadIdx.x;
     for (int64_t plane = blockIdx.x; plane < planes; plane += gridDim.x) {
         const float* xp = x + plane * HW;
@@ -118,10 +124,10 @@ __global__ __launch_bounds__(1024) void spade_norm_kernel(const float* __restric
                 float4 g = gamma ? ((const float4*)(gamma + plane * HW))[i] : make_float4(0, 0, 0, 0);
                 float4 b = beta ? ((const float4*)(beta + plane * HW))[i] : make_float4(0, 0, 0, 0);
                 float4 o;
-                o.x = fmaf((r[k].x - mean) * rstd, 1.f + g.x, b.x);
-                o.y = fmaf((r[k].y - mean) * rstd, 1.f + g.y, b.y);
-                o.z = fmaf((r[k].z - mean) * rstd, 1.f + g.z, b.z);
-                o.w = fmaf((r[k].w - mean) * rstd, 1.f + g.w, b.w);
+                o.x = post(fmaf((r[k].x - mean) * rstd, 1.f + g.x, b.x));
+                o.y = post(fmaf((r[k].y - mean) * rstd, 1.f + g.y, b.y));
+                o.z = post(fmaf((r[k].z - mean) * rstd, 1.f + g.z, b.z));
+                o.w = post(fmaf((r[k].w - mean) * rstd, 1.f + g.w, b.w));
                 ((float4*)(out + plane * HW))[i] = o;
             }
         } else {
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(1024) void spade_norm_kernel(const float* __restric
             rstd = rsqrtf(block_sum<1024>(q, red) * inv + eps);
             for (int64_t i = tid; i < HW; i += 1024) {
                 float g = gamma ? gamma[plane * HW + i] : 0.f, b = beta ? beta[plane * HW + i] : 0.f;
-                out[plane * HW + i] = fmaf((xp[i] - mean) * rstd, 1.f + g, b);
+                out[plane * HW + i] = post(fmaf((xp[i] - mean) * rstd, 1.f + g, b));
             }
         }
         if (tid == 0 && stats) { stats[2 * plane] = mean; stats[2 * plane + 1] = rstd; }
@@ -147,8 +153,17 @@ template <int EPT>
 __global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x,
                                                               const float* __restrict__ gamma, const float* __restrict__ stats,
                                                               float* __restrict__ dx, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, int64_t planes, int64_t HW) {
+                                                              float* __restrict__ dbeta, int64_t planes, int64_t HW,
+                                                              const float* __restrict__ beta, int act, float gain, float clamp) {
     __shared__ float red[16];
+    // gradient through the optional relu * gain / clamp of the forward: v = x_hat * (1 + gamma) + beta is recomputed
+    auto pre = [&](float d, float h, float g, float b) {
+        if (act == 2) {
+            const float v = fmaf(h, 1.f + g, b);
+            d = (v > 0.f && (clamp < 0.f || v * gain < clamp)) ? d * gain : 0.f;
+        }
+        return d;
+    };
     const int tid = threadIdx.x;
     for (int64_t plane = blockIdx.x; plane < planes; plane += gridDim.x) {
         const float mean = stats[2 * plane], rstd = stats[2 * plane + 1];
@@ -163,18 +178,21 @@ __global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const float* __res
                 float4 xv = ((const float4*)(x + base))[i];
                 float4 dv = ((const float4*)(dout + base))[i];
                 float4 gv = gamma ? ((const float4*)(gamma + base))[i] : make_float4(0, 0, 0, 0);
-                const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+                float4 bv = (act == 2 && beta) ? ((const float4*)(beta + base))[i] : make_float4(0, 0, 0, 0);
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w}, bs[4] = {bv.x, bv.y, bv.z, bv.w};
+                float ds[4] = {dv.x, dv.y, dv.z, dv.w};
                 float dg[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     float h = (xs[j] - mean) * rstd;
+                    ds[j] = pre(ds[j], h, gs[j], bs[j]);
                     float tt = ds[j] * (1.f + gs[j]);
                     xh[k * 4 + j] = h; t[k * 4 + j] = tt;
                     dg[j] = ds[j] * h;
                     s1 += tt; s2 += tt * h;
                 }
                 if (dgamma) ((float4*)(dgamma + base))[i] = make_float4(dg[0], dg[1], dg[2], dg[3]);
-                if (dbeta) ((float4*)(dbeta + base))[i] = dv;
+                if (dbeta) ((float4*)(dbeta + base))[i] = make_float4(ds[0], ds[1], ds[2], ds[3]);
             }
             if (dx) {
                 const float m1 = block_sum<1024>(s1, red) * inv, m2 = block_sum<1024>(s2, red) * inv;
@@ -191,7 +209,8 @@ __global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const float* __res
         } else {
             float s1 = 0.f, s2 = 0.f;
             for (int64_t i = tid; i < HW; i += 1024) {
-                float h = (x[base + i] - mean) * rstd, d = dout[base + i];
+                float h = (x[base + i] - mean) * rstd;
+                float d = pre(dout[base + i], h, gamma ? gamma[base + i] : 0.f, (act == 2 && beta) ? beta[base + i] : 0.f);
                 float tt = d * (1.f + (gamma ? gamma[base + i] : 0.f));
                 s1 += tt; s2 += tt * h;
                 if (dgamma) dgamma[base + i] = d * h;
@@ -201,7 +220,8 @@ __global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const float* __res
                 const float m1 = block_sum<1024>(s1, red) * inv, m2 = block_sum<1024>(s2, red) * inv;
                 for (int64_t i = tid; i < HW; i += 1024) {
                     float h = (x[base + i] - mean) * rstd;
-                    float tt = dout[base + i] * (1.f + (gamma ? gamma[base + i] : 0.f));
+                    float d = pre(dout[base + i], h, gamma ? gamma[base + i] : 0.f, (act == 2 && beta) ? beta[base + i] : 0.f);
+                    float tt = d * (1.f + (gamma ? gamma[base + i] : 0.f));
                     dx[base + i] = rstd * (tt - m1 - h * m2);
                 }
             }
@@ -329,30 +349,34 @@ extern "C" int pasta_plane_dot(const float* p, const float* q, float* out, int64
 }
 
 extern "C" int pasta_spade_norm(const float* x, const float* gamma, const float* beta, float* out, float* stats,
-                                int64_t planes, int64_t HW, float eps, void* stream) {
+                                int64_t planes, int64_t HW, float eps, int act, float gain, float clamp, void* stream) {
     using namespace pasta;
     PASTA_CHECK(x && out, "spade_norm: null pointer");
+    PASTA_CHECK(act == 0 || act == 1 || act == 2, "spade_norm: fused activation code %d (0/1 = none, 2 = relu)", act);
     PASTA_CHECK(planes >= 1 && HW >= 1, "spade_norm: empty tensor");
     int grid = (int)(planes < 65535 ? planes : 65535);
     hipStream_t s = (hipStream_t)stream;
     const bool al = (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out) & 15) == 0;
-    if (HW == 16384 && al) hipLaunchKernelGGL((spade_norm_kernel<16>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, stats, planes, HW, eps);
-    else if (HW == 4096 && al) hipLaunchKernelGGL((spade_norm_kernel<4>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, stats, planes, HW, eps);
-    else hipLaunchKernelGGL((spade_norm_kernel<0>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, stats, planes, HW, eps);
+    if (HW == 16384 && al) hipLaunchKernelGGL((spade_norm_kernel<16>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, stats, planes, HW, eps, act, gain, clamp);
+    else if (HW == 4096 && al) hipLaunchKernelGGL((spade_norm_kernel<4>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, stats, planes, HW, eps, act, gain, clamp);
+    else hipLaunchKernelGGL((spade_norm_kernel<0>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, stats, planes, HW, eps, act, gain, clamp);
     return launch_status("spade_norm");
 }
 
 extern "C" int pasta_spade_norm_bwd(const float* dout, const float* x, const float* gamma, const float* stats, float* dx,
-                                    float* dgamma, float* dbeta, int64_t planes, int64_t HW, void* stream) {
+                                    float* dgamma, float* dbeta, int64_t planes, int64_t HW, const float* beta, int act, float gain,
+                                    float clamp, void* stream) {
     using namespace pasta;
     PASTA_CHECK(dout && x && stats, "spade_norm_bwd: null pointer");
+    PASTA_CHECK(act == 0 || act == 1 || act == 2, "spade_norm_bwd: fused activation code %d (0/1 = none, 2 = relu)", act);
+    PASTA_CHECK(act != 2 || dbeta || !dgamma, "spade_norm_bwd: dbeta buffer required with a fused activation");
     PASTA_CHECK(planes >= 1 && HW >= 1, "spade_norm_bwd: empty tensor");
     int grid = (int)(planes < 65535 ? planes : 65535);
     hipStream_t s = (hipStream_t)stream;
-    const bool al = (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dout | (uintptr_t)dx | (uintptr_t)dgamma | (uintptr_t)dbeta) & 15) == 0;
-    if (HW == 16384 && al) hipLaunchKernelGGL((spade_norm_bwd_kernel<16>), dim3(grid), dim3(1024), 0, s, dout, x, gamma, stats, dx, dgamma, dbeta, planes, HW);
-    else if (HW == 4096 && al) hipLaunchKernelGGL((spade_norm_bwd_kernel<4>), dim3(grid), dim3(1024), 0, s, dout, x, gamma, stats, dx, dgamma, dbeta, planes, HW);
-    else hipLaunchKernelGGL((spade_norm_bwd_kernel<0>), dim3(grid), dim3(1024), 0, s, dout, x, gamma, stats, dx, dgamma, dbeta, planes, HW);
+    const bool al = (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dout | (uintptr_t)dx | (uintptr_t)dgamma | (uintptr_t)dbeta | (uintptr_t)beta) & 15) == 0;
+    if (HW == 16384 && al) hipLaunchKernelGGL((spade_norm_bwd_kernel<16>), dim3(grid), dim3(1024), 0, s, dout, x, gamma, stats, dx, dgamma, dbeta, planes, HW, beta, act, gain, clamp);
+    else if (HW == 4096 && al) hipLaunchKernelGGL((spade_norm_bwd_kernel<4>), dim3(grid), dim3(1024), 0, s, dout, x, gamma, stats, dx, dgamma, dbeta, planes, HW, beta, act, gain, clamp);
+    else hipLaunchKernelGGL((spade_norm_bwd_kernel<0>), dim3(grid), dim3(1024), 0, s, dout, x, gamma, stats, dx, dgamma, dbeta, planes, HW, beta, act, gain, clamp);
     return launch_status("spade_norm_bwd");
 }
 

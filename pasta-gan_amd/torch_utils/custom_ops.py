@@ -137,8 +137,8 @@ ABI = {
     'pasta_mod_bias_act_bwd_workspace': (_c_i64, [ctypes.c_int, ctypes.c_int, _c_i64]),
     'pasta_mod_bias_act_bwd': (ctypes.c_int, [_c_ptr] * 7 + [ctypes.c_int, ctypes.c_int, _c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                               ctypes.c_float, ctypes.c_float, _c_ptr]),
-    'pasta_spade_norm':   (ctypes.c_int, [_c_ptr] * 5 + [_c_i64, _c_i64, _c_f32, _c_ptr]),
-    'pasta_spade_norm_bwd': (ctypes.c_int, [_c_ptr] * 7 + [_c_i64, _c_i64, _c_ptr]),
+    'pasta_spade_norm':   (ctypes.c_int, [_c_ptr] * 5 + [_c_i64, _c_i64, _c_f32, ctypes.c_int, _c_f32, _c_f32, _c_ptr]),
+    'pasta_spade_norm_bwd': (ctypes.c_int, [_c_ptr] * 7 + [_c_i64, _c_i64, _c_ptr, ctypes.c_int, _c_f32, _c_f32, _c_ptr]),
 }
 
 def get_plugin(module_name='pasta_hip', sources=None, **build_kwargs):

@@ -53,39 +53,51 @@ class _SpadeModulate(torch.autograd.Function):
     """InstanceNorm(x) * (1 + gamma) + beta with statistics, normalisation and modulation in one
     kernel (networks.py:4371-4379: InstanceNorm2d(affine=False), eps 1e-5, biased variance)."""
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, post):
         n, c, h, w = x.shape
         x, gamma, beta = x.contiguous(), gamma.contiguous(), beta.contiguous()
         out = torch.empty_like(x)
         stats = torch.empty([n * c, 2], dtype=torch.float32, device=x.device)
+        act, gain, clamp = post                     # (2, gain, clamp): relu * gain with clamp on the way out; (0, 1, -1): none
         with torch.cuda.device(x.device):
             st = _native.lib().pasta_spade_norm(_native.ptr(x), _native.ptr(gamma), _native.ptr(beta), _native.ptr(out),
-                                                _native.ptr(stats), n * c, h * w, float(eps), _native.stream())
+                                                _native.ptr(stats), n * c, h * w, float(eps), act, float(gain), float(clamp),
+                                                _native.stream())
         _native.check(st)
-        ctx.save_for_backward(x, gamma, stats)
+        ctx.save_for_backward(x, gamma, stats, beta if act == 2 else None)
+        ctx.post = post
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, gamma, stats = ctx.saved_tensors
+        x, gamma, stats, beta = ctx.saved_tensors
+        act, gain, clamp = ctx.post
         n, c, h, w = x.shape
         dout = dout.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dgamma = torch.empty_like(x) if ctx.needs_input_grad[1] else None
-        dbeta = dout if ctx.needs_input_grad[2] else None
-        if dx is not None or dgamma is not None:
+        # without a fused activation d/dbeta is dout itself; with one it is dout through the activation, written by the kernel
+        dbeta = None
+        if act == 2 and (ctx.needs_input_grad[2] or dgamma is not None or dx is not None):
+            dbeta = torch.empty_like(x)
+        elif ctx.needs_input_grad[2]:
+            dbeta = dout
+        if dx is not None or dgamma is not None or act == 2:
             with torch.cuda.device(x.device):
                 st = _native.lib().pasta_spade_norm_bwd(_native.ptr(dout), _native.ptr(x), _native.ptr(gamma), _native.ptr(stats),
-                                                        _native.ptr(dx), _native.ptr(dgamma), _native.ptr(None), n * c, h * w,
-                                                        _native.stream())
+                                                        _native.ptr(dx), _native.ptr(dgamma), _native.ptr(dbeta if act == 2 else None),
+                                                        n * c, h * w, _native.ptr(beta), act, float(gain), float(clamp), _native.stream())
             _native.check(st)
-        return dx, dgamma, dbeta, None
+        return dx, dgamma, (dbeta if ctx.needs_input_grad[2] else None), None, None
 
-def spade_modulate(x, gamma, beta, eps=1e-5):
+def spade_modulate(x, gamma, beta, eps=1e-5, relu_gain=None, clamp=None):
+    """InstanceNorm(x) * (1 + gamma) + beta; ``relu_gain`` not None additionally applies ``min(relu(.) * relu_gain, clamp)``
+    in the same pass (the activation of the Spade_Conv2dLayer that consumes the result)."""
     _native.require_gpu(x, 'spade_modulate')
     if x.dtype != torch.float32:
         raise RuntimeError('spade_modulate: float32 only (the generator runs in fp32, networks.py:5747-5748)')
-    return _SpadeModulate.apply(x, gamma, beta, eps)
+    post = (0, 1.0, -1.0) if relu_gain is None else (2, float(relu_gain), float(clamp if clamp is not None else -1))
+    return _SpadeModulate.apply(x, gamma, beta, eps, post)
 
 #----------------------------------------------------------------------------
 
@@ -605,6 +617,13 @@ class Spade_Conv2dLayer(torch.nn.Module):
         self.act_gain = bias_act.activation_funcs[activation].def_gain
         _make_conv_params(self, in_channels, out_channels, kernel_size, bias, channels_last, trainable)
 
+    def fusable_activation(self, gain=1):
+        """(relu gain, clamp) of the activation this layer applies in front of its convolution, when the producer of
+        its input can apply it instead (no bias, relu); else None."""
+        if self.bias is not None or self.activation != 'relu':
+            return None
+        return self.act_gain * gain, (self.conv_clamp * gain if self.conv_clamp is not None else None)
+
     def forward(self, x, gain=1, no_act=False):
         b = self.bias.to(x.dtype) if self.bias is not None else None
         if not no_act:
@@ -626,7 +645,7 @@ class Spade_Norm_Block(torch.nn.Module):
         self.conv_beta = Spade_Conv2dLayer(norm_channels, norm_channels, kernel_size=3, bias=False)
         self.param_free_norm = nn.InstanceNorm2d(norm_channels, affine=False)
 
-    def forward(self, x, denorm_feats):
+    def forward(self, x, denorm_feats, post_act=None):
         # conv_mlp (no activation in front, no bias) followed by nn.ReLU (:4373-4374): the ReLU rides in the convolution's epilogue
         m = self.conv_mlp
         actv = conv2d_resample.conv2d_resample_bias_act(x=denorm_feats, w=m.weight.to(denorm_feats.dtype), b=None, f=m.resample_filter,
@@ -634,6 +653,8 @@ class Spade_Norm_Block(torch.nn.Module):
                                                         act='relu', gain=1, wgain=m.weight_gain)
         gamma = self.conv_gamma(actv, no_act=True)
         beta = self.conv_beta(actv, no_act=True)
+        if post_act is not None:        # (relu gain, clamp) of the consuming Spade_Conv2dLayer, applied in the same pass
+            return spade_modulate(x, gamma, beta, eps=self.param_free_norm.eps, relu_gain=post_act[0], clamp=post_act[1])
         return spade_modulate(x, gamma, beta, eps=self.param_free_norm.eps)
 
 @persistence.persistent_class
@@ -655,10 +676,19 @@ class Spade_ResBlockV2(torch.nn.Module):
 
     def forward(self, x, denorm_feat):
         x = self.conv(x, no_act=True)
-        y = self.skip(self.spade_skip(x, denorm_feat), gain=np.sqrt(0.5))
-        x = self.conv0(self.spade0(x, denorm_feat))
-        x = self.conv1(self.spade1(x, denorm_feat), gain=np.sqrt(0.5))
+        y = self._normed_conv(self.spade_skip, self.skip, x, denorm_feat, np.sqrt(0.5))
+        x = self._normed_conv(self.spade0, self.conv0, x, denorm_feat, 1)
+        x = self._normed_conv(self.spade1, self.conv1, x, denorm_feat, np.sqrt(0.5))
         return y.add_(x)
+
+    @staticmethod
+    def _normed_conv(norm, conv, x, denorm_feat, gain):
+        """conv(norm(x, feat), gain): the activation in front of the convolution is applied by the SPADE kernel when
+        the layer allows it."""
+        post = conv.fusable_activation(gain)
+        if post is None:
+            return conv(norm(x, denorm_feat), gain=gain)
+        return conv(norm(x, denorm_feat, post_act=post), no_act=True)
 
 #----------------------------------------------------------------------------
 # Full-body generator.

@@ -342,6 +342,35 @@ def test_spade_norm(hw):
         assert rel_err(a, r) < 2e-5
 
 
+@pytest.mark.parametrize('hw', [(128, 128), (64, 64), (17, 13)])
+@pytest.mark.parametrize('clamp', [None, 0.9])
+def test_spade_norm_with_fused_activation(hw, clamp):
+    """spade_modulate(relu_gain=, clamp=) == bias_act(relu, gain, clamp) applied to the plain result: the activation
+    Spade_Conv2dLayer (networks.py:4346-4352) puts in front of its convolution, done in the normalisation pass."""
+    from training import networks
+    gen = torch.Generator().manual_seed(23)
+    shape = [2, 3, hw[0], hw[1]]
+    xc = torch.randn(shape, generator=gen) * 2 + 0.5
+    gc = torch.randn(shape, generator=gen) * 0.3
+    bc = torch.randn(shape, generator=gen) * 0.3
+    dc = torch.randn(shape, generator=gen)
+    gain = float(np.sqrt(2) * np.sqrt(0.5) * 1.1)
+    xr, gr, br = [t.double().requires_grad_(True) for t in (xc, gc, bc)]
+    yr = torch.relu(torch.nn.functional.instance_norm(xr, eps=1e-5) * (1 + gr) + br) * gain
+    if clamp is not None:
+        yr = yr.clamp(-clamp, clamp)
+    dr = torch.autograd.grad(yr, [xr, gr, br], dc.double())
+    x, g_, b = [t.cuda().requires_grad_(True) for t in (xc, gc, bc)]
+    y = networks.spade_modulate(x, g_, b, relu_gain=gain, clamp=clamp)
+    d = torch.autograd.grad(y, [x, g_, b], dc.cuda())
+    assert rel_err(y, yr) < TOL
+    for a, r in zip(d, dr):
+        assert rel_err(a, r) < 2e-5
+    # beta gradient alone (the kernel still has to run for the activation mask)
+    db, = torch.autograd.grad(networks.spade_modulate(x.detach(), g_.detach(), b, relu_gain=gain, clamp=clamp), [b], dc.cuda())
+    assert rel_err(db, dr[2]) < 2e-5
+
+
 @pytest.mark.parametrize('case', [
     dict(x=[2, 16, 24, 24], w=[32, 16, 3, 3], kw=dict(padding=1), act='lrelu', gain=np.sqrt(2), clamp=0.8),
     dict(x=[2, 16, 24, 24], w=[32, 16, 3, 3], kw=dict(down=2, padding=1), act='lrelu', gain=1.0, clamp=256.0),

@@ -55,7 +55,7 @@ def main():
             ms = timeit(lambda: bias_act._bias_grad(x, 1))
             rows.append(('bias_grad (db)', shape, x.numel() * 4, ms))
         x = torch.randn([16, 128, 128, 128], device=dev); g = torch.randn_like(x); b = torch.randn_like(x)
-        ms = timeit(lambda: networks._SpadeModulate.apply(x, g, b, 1e-5))
+        ms = timeit(lambda: networks.spade_modulate(x, g, b))
         rows.append(('spade_norm fwd', list(x.shape), 4 * x.numel() * 4, ms))
         s = torch.randn([16, 128], device=dev); nz = torch.randn([16, 1, 128, 128], device=dev)
         ms = timeit(lambda: fma.scale_planes(x, s, nz))
