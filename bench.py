@@ -176,6 +176,10 @@ def main():
     ap.add_argument('--batch-gpu', type=int, default=16)
     ap.add_argument('--vgg-weight', type=float, default=0.0, help='> 0: add the VGG-19 perceptual term with random-init weights '
                     '(train.sh uses 40; the pretrained checkpoint cannot be obtained here). Not the headline configuration.')
+    ap.add_argument('--aug', default='noaug', choices=['noaug', 'ada', 'fixed'], help="discriminator augmentation (SURVEY 8d: 'noaug' is the "
+                    "headline; 'ada' = the shipped train.sh default, pipeline 'bgc', target 0.6)")
+    ap.add_argument('--aug-p', type=float, default=0.5, help='initial (ada) or constant (fixed) augmentation probability; the reference starts '
+                    'ADA at 0 and takes ~100 kimg to reach its working point, a benchmark has to start near it')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-meter', action='store_true', help='do not bracket convolution launches with events')
     ap.add_argument('--by-shape', action='store_true', help='also print a per-shape convolution table to stderr')
@@ -208,6 +212,8 @@ def main():
 
     lib = _native.lib()       # raises if libpasta_hip.so is missing
     cfg = fashion_config()
+    from training.training_loop_wo_flow_fullbody import augment_options
+    cfg.update(augment_options(aug=args.aug, augpipe='bgc', p=args.aug_p))
     if args.vgg_weight > 0:
         cfg.loss_kwargs.vgg_weight = args.vgg_weight
         cfg.loss_kwargs.vgg_random_init = True
@@ -260,7 +266,7 @@ def main():
             'dtype': 'f32', 'conv_math': conv2d_gradfix.conv_math, 'data': 'synthetic', 'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
             'config': {'workload': 'BASELINE config 2: full training_loop step (Gmain+Dmain every iter, Dreg/16, Greg/4, Adam, EMA), '
                                    'GeneratorFull+Discriminator cfg=fashion 256x256, batch 16/GPU, G and D in fp32, ' +
-                                   ('vgg_weight=0 (weights unavailable)' if args.vgg_weight <= 0 else f'vgg_weight={args.vgg_weight:g} with random-init VGG-19') + ', no ADA, random-init weights; timed iterations ' + f'{args.warmup}..{args.warmup + args.steps - 1}',
+                                   ('vgg_weight=0 (weights unavailable)' if args.vgg_weight <= 0 else f'vgg_weight={args.vgg_weight:g} with random-init VGG-19') + (', no ADA' if args.aug == 'noaug' else f', ADA pipeline bgc ({args.aug}, p0={args.aug_p:g})') + ', random-init weights; timed iterations ' + f'{args.warmup}..{args.warmup + args.steps - 1}',
                        'global_batch': args.batch_gpu * world, 'parallelism': f'dp{world}' + (' (RCCL all-reduce)' if world > 1 else '')},
         }
         fam = meter.summary()

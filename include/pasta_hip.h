@@ -219,6 +219,28 @@ int pasta_spade_norm_bwd(const float* dout, const float* x, const float* gamma,
                          float* dbeta, int64_t planes, int64_t HW,
                          const float* beta, int act, float gain, float clamp, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * ADA augmentation (training/augment.py:121-431).
+ * pasta_ada_matrices: sample s turns its draws u[s, :] ~ U(0,1), z[s, :] ~ N(0,1) into the inverse geometric
+ *   transform g_inv[s] (3x3 row-major, augment.py:186-263) and the colour transform c[s] (4x4, :306-350); margins[4]
+ *   = the reflect-padding widths (x0, y0, x1, y1) over the whole batch (:272-282).  Column order of u / z = the order
+ *   augment.py draws them (the enum in csrc/augment.hip; training/augment.py DRAWS_U / DRAWS_Z).  p: device scalar,
+ *   the overall probability multiplier (AugmentPipe.p).  debug_percentile < 0 = off (:179-180).
+ * pasta_ada_theta: theta[s] = (a @ g_inv[s] @ b)[:2, :]; a, b are HOST arrays of 9 floats (:285-296).
+ * pasta_color_affine: mode 0: out[n, :, p] = c[n][:3, :3] @ x[n, :, p] + c[n][:3, 3] for [N,3,HW] images (:356-360);
+ *   mode 1: the adjoint (c[n][:3, :3]^T, no offset); mode 2: the linear part alone (for second derivatives).
+ * ------------------------------------------------------------------------- */
+typedef struct pasta_ada_config {
+    float xflip, rotate90, xint, xint_max;
+    float scale, rotate, aniso, xfrac, scale_std, rotate_max, aniso_std, xfrac_std;
+    float brightness, contrast, lumaflip, hue, saturation, brightness_std, contrast_std, hue_max, saturation_std;
+} pasta_ada_config;
+int pasta_ada_matrices(const float* u, const float* z, int64_t n, int u_cols, int z_cols, const float* p,
+                       const pasta_ada_config* cfg, int width, int height, int channels, int hz_pad,
+                       float debug_percentile, float* g_inv, float* c, int32_t* margins, void* stream);
+int pasta_ada_theta(const float* g_inv, int64_t n, const float* a, const float* b, float* theta, void* stream);
+int pasta_color_affine(const float* x, const float* c, float* out, int64_t n, int64_t hw, int mode, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

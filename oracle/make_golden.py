@@ -1,6 +1,6 @@
 """Generate tests/golden/*.npz by running the REFERENCE itself (build container only).
 
-    python oracle/make_golden.py [--ref /root/reference] [--only ops|layers|models]
+    python oracle/make_golden.py [--ref /root/reference] [--only ops|layers|primitives|models|loss|augment]
 
 The reference is imported read-only from ``--ref`` (never copied): op level as is, model level
 with the two harness accommodations SURVEY.md F1/F4 describe (cwd = reference root,
@@ -253,3 +253,6 @@ if __name__ == '__main__':
     if args.only in ('all', 'loss'):
         from make_golden_loss import gen_loss
         gen_loss(args.ref, import_reference_networks)
+    if args.only in ('all', 'augment'):
+        from make_golden_augment import gen_augment
+        gen_augment(args.ref)

@@ -107,6 +107,13 @@ class ConvEpilogue(ctypes.Structure):
     """Mirror of ``pasta_conv_epilogue`` (include/pasta_hip.h)."""
     _fields_ = [('bias', _c_ptr), ('act', _c_i32), ('alpha', _c_f32), ('gain', _c_f32), ('clamp', _c_f32)]
 
+class AdaConfig(ctypes.Structure):
+    """Mirror of ``pasta_ada_config`` (include/pasta_hip.h)."""
+    _fields_ = [(name, _c_f32) for name in (
+        'xflip', 'rotate90', 'xint', 'xint_max', 'scale', 'rotate', 'aniso', 'xfrac', 'scale_std', 'rotate_max', 'aniso_std',
+        'xfrac_std', 'brightness', 'contrast', 'lumaflip', 'hue', 'saturation', 'brightness_std', 'contrast_std', 'hue_max',
+        'saturation_std')]
+
 # name -> (restype, argtypes); exactly the symbols include/pasta_hip.h declares.
 ABI = {
     'pasta_last_error':   (ctypes.c_char_p, []),
@@ -139,6 +146,10 @@ ABI = {
                                               ctypes.c_float, ctypes.c_float, _c_ptr]),
     'pasta_spade_norm':   (ctypes.c_int, [_c_ptr] * 5 + [_c_i64, _c_i64, _c_f32, ctypes.c_int, _c_f32, _c_f32, _c_ptr]),
     'pasta_spade_norm_bwd': (ctypes.c_int, [_c_ptr] * 7 + [_c_i64, _c_i64, _c_ptr, ctypes.c_int, _c_f32, _c_f32, _c_ptr]),
+    'pasta_ada_matrices': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, ctypes.c_int, ctypes.c_int, _c_ptr, ctypes.POINTER(AdaConfig)] +
+                                         [ctypes.c_int] * 4 + [_c_f32, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
+    'pasta_ada_theta':    (ctypes.c_int, [_c_ptr, _c_i64, ctypes.POINTER(_c_f32), ctypes.POINTER(_c_f32), _c_ptr, _c_ptr]),
+    'pasta_color_affine': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, ctypes.c_int, _c_ptr]),
 }
 
 def get_plugin(module_name='pasta_hip', sources=None, **build_kwargs):

@@ -168,8 +168,8 @@ class StyleGAN2Loss(Loss):
         B = self._mbstd_groups(n) if len(imgs) > 1 and all(i.shape == imgs[0].shape for i in imgs) else None
         if B is None:
             return [self.run_D(img, c, sync) for img, c in zip(imgs, cs)]
-        if self.augment_pipe is not None:
-            imgs = [self.augment_pipe(img) for img in imgs]
+        if self.augment_pipe is not None:       # per-sample independent transforms: one call for all k batches
+            imgs = list(self.augment_pipe(torch.cat(imgs)).split(n))
         k, G = len(imgs), n // B
         def merge(ts):
             return torch.stack([t.reshape(G, B, *t.shape[1:]) for t in ts], dim=1).reshape(k * n, *ts[0].shape[1:])
@@ -233,6 +233,7 @@ class StyleGAN2Loss(Loss):
             self.report('Loss/scores/fake', gen_logits)
             self.report('Loss/scores/fake_finetune', gen_finetune_logits)
             self.report('Loss/scores/real', real_logits)
+            self.report('Loss/signs/real', real_logits.sign())
             loss_Dgen, loss_Dgen_finetune, loss_Dreal = softplus(gen_logits), softplus(gen_finetune_logits), softplus(-real_logits)
             self.report('Loss/D/loss', loss_Dgen + loss_Dreal)
             ((loss_Dgen.mean() + loss_Dgen_finetune.mean()) / 2 + loss_Dreal.mean()).mul(gain).backward()
@@ -252,6 +253,7 @@ class StyleGAN2Loss(Loss):
             real_img_tmp = real_img.detach().requires_grad_(do_Dr1)
             real_logits = self.run_D(real_img_tmp, real_c, sync=sync)
             self.report('Loss/scores/real', real_logits)
+            self.report('Loss/signs/real', real_logits.sign())
             loss_Dreal = 0
             if do_Dmain:
                 loss_Dreal = softplus(-real_logits)

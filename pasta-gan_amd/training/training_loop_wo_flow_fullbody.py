@@ -22,8 +22,34 @@ from torch_utils import misc
 
 #----------------------------------------------------------------------------
 
+AUGPIPE_SPECS = {    # train_wo_flow_fullbody.py:297-309: which AugmentPipe multipliers each --augpipe name switches on
+    'blit':   ['xflip', 'rotate90', 'xint'],
+    'geom':   ['scale', 'rotate', 'aniso', 'xfrac'],
+    'color':  ['brightness', 'contrast', 'lumaflip', 'hue', 'saturation'],
+    'filter': ['imgfilter'],
+    'noise':  ['noise'],
+    'cutout': ['cutout'],
+}
+for _name, _parts in [('bg', ['blit', 'geom']), ('bgc', ['blit', 'geom', 'color']), ('bgcf', ['blit', 'geom', 'color', 'filter']),
+                      ('bgcfn', ['blit', 'geom', 'color', 'filter', 'noise']), ('bgcfnc', ['blit', 'geom', 'color', 'filter', 'noise', 'cutout'])]:
+    AUGPIPE_SPECS[_name] = [m for part in _parts for m in AUGPIPE_SPECS[part]]
+
+def augment_options(aug='ada', augpipe='bgc', p=None, target=None):
+    """The --aug / --p / --target / --augpipe options (train_wo_flow_fullbody.py:249-313) as TrainingStep config entries:
+    'ada' adapts p towards ``target`` (default 0.6) from ``p`` (default 0); 'fixed' keeps ``p``; 'noaug' -> {}."""
+    if aug == 'noaug':
+        return dnnlib.EasyDict()
+    assert aug in ('ada', 'fixed') and augpipe in AUGPIPE_SPECS
+    assert aug != 'fixed' or p is not None, '--aug=fixed requires p'
+    opts = dnnlib.EasyDict(augment_kwargs=dnnlib.EasyDict(class_name='training.augment.AugmentPipe', **{m: 1 for m in AUGPIPE_SPECS[augpipe]}),
+                           augment_p=float(p) if p is not None else 0.0)
+    if aug == 'ada':
+        opts.ada_target = 0.6 if target is None else float(target)
+    return opts
+
 def fashion_config(channel_base=16384, d_fp16_res=0, mbstd_group_size=4):
-    """G/D/optimiser/loss options of ``--cfg fashion`` (train_wo_flow_fullbody.py:166-215, train.sh:3-10)."""
+    """G/D/optimiser/loss options of ``--cfg fashion`` (train_wo_flow_fullbody.py:166-215, train.sh:3-10); augmentation
+    off (``cfg.update(augment_options(...))`` turns it on)."""
     G_kwargs = dnnlib.EasyDict(class_name='training.networks.GeneratorFull', z_dim=0, c_dim=512, w_dim=512, img_resolution=256,
                                img_channels=3, mapping_kwargs=dnnlib.EasyDict(num_layers=1),
                                synthesis_kwargs=dnnlib.EasyDict(channel_base=channel_base, channel_max=512, num_fp16_res=3,
@@ -109,7 +135,27 @@ class TrainingStep:
             if name is not None:
                 ddp[name] = module
         self.ddp_modules = ddp
-        self.loss = dnnlib.util.construct_class_by_name(device=device, **ddp, **cfg.loss_kwargs)
+
+        # ADA (training_loop_wo_flow_fullbody.py:301-310): the pipeline, its probability p, and the statistic that steers p
+        self.augment_pipe = None
+        self.ada_target, self.ada_interval, self.ada_kimg = cfg.get('ada_target'), cfg.get('ada_interval', 4), cfg.get('ada_kimg', 500)
+        loss_kwargs = dict(cfg.loss_kwargs)
+        if cfg.get('augment_kwargs') is not None and (cfg.get('augment_p', 0) > 0 or self.ada_target is not None):
+            self.augment_pipe = dnnlib.util.construct_class_by_name(**cfg.augment_kwargs).train().requires_grad_(False).to(device)
+            self.augment_pipe.p.copy_(torch.as_tensor(float(cfg.get('augment_p', 0))))
+            if self.ada_target is not None:
+                # sum and count of sign(D(real)) since the last adjustment, kept on the device (the reference's
+                # training_stats.Collector(regex='Loss/signs/real') reads them back to the host every ada_interval)
+                self._ada_acc = torch.zeros([2], device=device)
+                user_report = loss_kwargs.get('report_fn')
+                def report(name, value):
+                    if name == 'Loss/signs/real':
+                        v = value.detach().float()
+                        self._ada_acc += torch.stack([v.sum(), torch.full([], float(v.numel()), device=v.device)])
+                    if user_report is not None:
+                        user_report(name, value)
+                loss_kwargs['report_fn'] = report
+        self.loss = dnnlib.util.construct_class_by_name(device=device, **ddp, augment_pipe=self.augment_pipe, **loss_kwargs)
 
         self.phases = []
         for name, module, opt_kwargs, reg_interval in [('G', G, cfg.G_opt_kwargs, cfg.G_reg_interval), ('D', D, cfg.D_opt_kwargs, cfg.D_reg_interval)]:
@@ -167,6 +213,18 @@ class TrainingStep:
             if src:
                 torch._foreach_copy_(dst, src)
         self.cur_nimg += self.batch_size
+
+        # ADA adjustment (:536-539): p += sign(E[sign(D(real))] - target) * batch_size * ada_interval / (ada_kimg * 1000), p >= 0;
+        # evaluated on the device, no read-back
+        if self.augment_pipe is not None and self.ada_target is not None and self.batch_idx % self.ada_interval == 0:
+            acc = self._ada_acc
+            if self.num_gpus > 1:
+                torch.distributed.all_reduce(acc)
+            step = (self.batch_size * self.ada_interval) / (self.ada_kimg * 1000)
+            mean = acc[0] / acc[1].clamp(min=1)
+            adjust = torch.sign(mean - self.ada_target) * step * (acc[1] > 0)
+            self.augment_pipe.p.copy_((self.augment_pipe.p + adjust).clamp(min=0))
+            acc.zero_()
         self.batch_idx += 1
 
 #----------------------------------------------------------------------------

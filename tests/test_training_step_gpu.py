@@ -138,3 +138,40 @@ def test_merged_discriminator_pass_equals_separate_passes():
     g_mer = torch.autograd.grad(sum((a * x).sum() for a, x in zip(mer, w)), imgs)
     for a, b in zip(g_sep, g_mer):
         assert rel_err(b, a) < 1e-4
+
+
+def test_ada_controller_moves_p_like_the_reference():
+    """Training with --aug ada (train_wo_flow_fullbody.py:257-313): the pipeline is applied to every discriminator input,
+    and every ada_interval iterations p moves by sign(mean(sign(D(real))) - target) * batch * interval / (ada_kimg * 1000),
+    never below 0 (training_loop_wo_flow_fullbody.py:536-539) -- computed on the device here, recomputed on the host from
+    the reported logits below."""
+    from training.training_loop_wo_flow_fullbody import TrainingStep, fashion_config, augment_options
+
+    class Batch:
+        def __init__(self, inp):
+            self.inp = inp
+        def split(self, n):
+            keys = [k for k in self.inp if k != 'gen_z']
+            return [{k: self.inp[k][i:i + n] for k in keys} for i in range(0, BATCH, n)]
+
+    signs = []
+    cfg = fashion_config(channel_base=2048)
+    cfg.update(augment_options(aug='ada', augpipe='bgc', p=0.3, target=0.6))
+    cfg.ada_interval, cfg.ada_kimg = 2, 0.5                    # step = 4 * 2 / 500 = 0.016 per adjustment
+    cfg.loss_kwargs.report_fn = lambda name, value: signs.append(value.detach()) if name == 'Loss/signs/real' else None
+    step = TrainingStep(torch.device('cuda'), cfg=cfg, num_gpus=1, rank=0, batch_size=BATCH, batch_gpu=BATCH)
+    assert type(step.augment_pipe).__name__ == 'AugmentPipe' and step.loss.augment_pipe is step.augment_pipe
+    assert abs(float(step.augment_pipe.p) - 0.3) < 1e-7
+    prepare(step.G, step.D)
+    data = Batch(_batch())
+    p_host, mark = 0.3, 0
+    for it in range(5):
+        step.run(data)
+        if it % 2 == 0:     # adjustments happen after iterations 0, 2, 4 and use everything reported since the previous one
+            pending = torch.cat([s.flatten() for s in signs[mark:]])
+            mark = len(signs)
+            p_host = max(p_host + float(np.sign(pending.mean().item() - 0.6)) * (BATCH * 2) / (0.5 * 1000), 0.0)
+        assert abs(float(step.augment_pipe.p) - p_host) < 1e-6, (it, float(step.augment_pipe.p), p_host)
+    assert p_host != 0.3
+    for prm in list(step.G.parameters()) + list(step.D.parameters()):
+        assert bool(torch.isfinite(prm).all())
