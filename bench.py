@@ -28,7 +28,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X dense fp32 matrix peak (MI355X_MICROAR
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 matrix peak
 PEAK_HBM_GBS = 8000.0
 BF16X6 = {0: 'conv_fwd_bf16x6_kernel<128,128,3>', 1: 'conv_fwd_bf16x6_kernel<64,256,2>'}
-BF16X6_ROWS = {0: 'conv_fwd_rows_bf16x6_kernel<128,128,2>', 1: 'conv_fwd_rows_bf16x6_kernel<64,256,2>'}
+BF16X6_ROWS = {0: 'conv_fwd_rows_bf16x6_kernel<128,128,2,1>', 1: 'conv_fwd_rows_bf16x6_kernel<64,256,2,1>'}
 
 TILE_NAMES = {0: 'conv_fwd_kernel<128,128,2,2,8,4>', 1: 'conv_fwd_kernel<64,256,2,2,8,4>',
               2: 'conv_fwd_kernel<32,256,1,2,8>', 3: 'conv_fwd_kernel<64,64,1,1,8>'}

@@ -59,6 +59,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // An empty asm that makes a VGPR value opaque to the SLP vectoriser (no instruction is emitted).
 #define PASTA_KEEP_SCALAR(x) asm("" : "+v"(x))
+// every component of a 16-byte vector counts as used: a partly used LDS read stays one ds_read_b128
+#define PASTA_KEEP_WHOLE(q) asm("" : "+v"((q).x), "+v"((q).y), "+v"((q).z), "+v"((q).w))
 
 // Parameters of the weight-gradient kernels: dW[tap][a][b] = sum_pix S[a][pix] * L[b][pix * st + tap offset].
 struct WgradParams {

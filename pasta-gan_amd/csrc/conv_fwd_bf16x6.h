@@ -317,7 +317,11 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
 // pixels; the B
 // image is double-buffered per stage, the A image per step.  Control flow around memory operations is static as in
 // the base kernel.
-template <int BM, int BN, int OCC>
+// PIPE = 1 (default): the weights of a step are fetched TWO steps ahead into one of two register sets and stored to LDS a
+// full step later, so the store never waits for an L2 round trip (+1.5 % on the 128 x 128 x 128 layers; PIPE = 0 fetches
+// and stores within one step).  Also measured and dropped: reading the next step's fragments during the current step's
+// MFMAs (two fragment sets, 236-256 VGPRs) -- no change, the other workgroup of the CU already covers that latency.
+template <int BM, int BN, int OCC, int PIPE>
 __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdParams p) {
     constexpr int WMT = 2, WNT = 2, KC = 16;
     constexpr int WAVES_N = BN / 64;
@@ -433,8 +437,9 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
         a_w2 = wb + (int64_t)p.tap_slab[t + 2] * NC * a_chunk;
     };
     set_a_row(a_dy);
-    float4 areg0, areg1, areg2;
-    auto load_a = [&](int tap_i) {                   // tap_i is a compile-time constant at every call
+    float4 areg0, areg1, areg2;                      // weights in flight; the pipelined variant alternates with a second set
+    float4 breg0, breg1, breg2;
+    auto load_a = [&](int tap_i, int set = 0) {      // tap_i and set are compile-time constants at every call
         const __bf16* wt = (tap_i == 0 ? a_w0 : tap_i == 1 ? a_w1 : a_w2) + (int64_t)a_cc * a_chunk;
         auto unit = [&](int j) {
             int e = tid + 256 * j;
@@ -442,9 +447,15 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
             const int seg = e / BM, within = e - seg * BM;
             return *(const float4*)(wt + ((int64_t)seg * p.Og_pad + o_blk + within) * 8);
         };
-        areg0 = unit(0);
-        areg1 = unit(1);
-        if (APT > 2) areg2 = unit(2);
+        if (set == 0) {
+            areg0 = unit(0);
+            areg1 = unit(1);
+            if (APT > 2) areg2 = unit(2);
+        } else {
+            breg0 = unit(0);
+            breg1 = unit(1);
+            if (APT > 2) breg2 = unit(2);
+        }
     };
     auto next_a_stage = [&]() {
         if (++a_cc >= NC) {
@@ -452,11 +463,11 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
             if (a_dy + 1 < KH) set_a_row(++a_dy);
         }
     };
-    auto store_a = [&](int buf) {
+    auto store_a = [&](int buf, int set = 0) {
         __bf16* d = As + buf * ABUF;
-        *(float4*)&d[tid * 8] = areg0;
-        *(float4*)&d[(tid + 256) * 8] = areg1;
-        if (APT > 2) *(float4*)&d[(tid + 512) * 8] = areg2;
+        *(float4*)&d[tid * 8] = set ? breg0 : areg0;
+        *(float4*)&d[(tid + 256) * 8] = set ? breg1 : areg1;
+        if (APT > 2) *(float4*)&d[(tid + 512) * 8] = set ? breg2 : areg2;
     };
 
     uint32_t q1[BPT][4], q2[BPT][4], q3[BPT][4];
@@ -522,6 +533,12 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     };
     // One tap = one step: 24 MFMAs in six groups; TAP (0, 1, 2: position in the kernel row), ABUF_ and BBUF_ are literals.
     auto step = [&](const int TAP, const int abuf, const int bbuf) {
+        if (PIPE == 1) {
+            // weights of step t + 2 into the register set of this step's parity (abuf = parity); stored by step t + 1
+            if (TAP == 1) next_a_stage();
+            if (TAP == 0) load_b();
+            load_a(TAP == 0 ? 2 : TAP == 1 ? 0 : 1, abuf);
+        } else {
         if (TAP == 2) next_a_stage();
         if (TAP == 0) {
             // halo loads (wave 0) are issued inside load_b ahead of everything else of this step
@@ -529,6 +546,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
             load_a(1);
         } else {
             load_a(TAP == 1 ? 2 : 0);
+        }
         }
         Frag f;
         read_frag(f, abuf, bbuf, p.rows_rev ? 2 - TAP : TAP);
@@ -549,7 +567,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
         PASTA_MM(0, 1)
         if (TAP == 1) store_q(bbuf ^ 1, m_slot, half0);
         if (TAP == 2 && wave == h_owner) store_q(bbuf ^ 1, h_slot, h_half);
-        store_a(abuf ^ 1);
+        store_a(abuf ^ 1, PIPE == 1 ? abuf ^ 1 : 0);        // PIPE 1: the set fetched by the previous step
         PASTA_MM(0, 0)
 #undef PASTA_MM
 #undef PASTA_SPLIT
@@ -572,6 +590,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
         store_q(0, h_slot, h_half);
     }
     store_a(0);
+    if (PIPE == 1) load_a(1, 1);                     // weights of step 1: stored by step 0
     __syncthreads();
     // two stages (six steps) per trip: the B image alternates per stage, the A image per step; an odd stage count runs
     // one all-zero stage
@@ -628,11 +647,16 @@ static void launch_fwd_bf16x6(const ConvFwdParams& p, hipStream_t s) {
             constexpr int APT = (6 * BM + 255) / 256;
             constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 6 * (BN + 16) * 8) * sizeof(__bf16);
             static bool attr_set = false;
+            static int pipe = 1;
             if (!attr_set) {
-                (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                const char* e = getenv("PASTA_ROWS_PIPE");
+                if (e) pipe = e[0] != '0';
                 attr_set = true;
             }
-            hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2>), grid, dim3(256), lds, s, q);
+            if (pipe == 1)      hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1>), grid, dim3(256), lds, s, q);
+            else                hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 0>), grid, dim3(256), lds, s, q);
             return;
         }
     }

@@ -129,6 +129,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
 #pragma unroll
                 for (int row = 0; row < 3; row++) {
                     const __bf16* lb = &Ls[pb * L_PIECE + ((wb * 32 + jl) * 3 + row) * LP + 16 * s + 8 * hl];
+                    // Only dwords 1..6 are used and the compiler narrows the two reads to ds_read2_b64 + ds_read2_b32, whose
+                    // 32-bank rule makes the 60-dword lane stride conflict 2-way (SQ_LDS_BANK_CONFLICT = half of this kernel's
+                    // LDS cycles).  Forcing whole ds_read_b128 (PASTA_KEEP_WHOLE) removes the conflicts but costs two more live
+                    // registers per read in a kernel that sits at 250 of 256: it spills and runs 12 % slower (measured).
                     const uint4 b0 = *(const uint4*)lb, b1 = *(const uint4*)(lb + 8);
                     const uint32_t d[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
                     uint4 w[3];
@@ -304,7 +308,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
 #pragma unroll
             for (int row = 0; row < 3; row++) {
                 const __bf16* lb = &Ls[pb * L_PIECE + ((wb * 32 + jl) * 3 + row) * LP + 16 * hl];
-                const uint4 b0 = *(const uint4*)lb, b1 = *(const uint4*)(lb + 8), b2 = *(const uint4*)(lb + 16);
+                uint4 b0 = *(const uint4*)lb, b1 = *(const uint4*)(lb + 8), b2 = *(const uint4*)(lb + 16);
+                PASTA_KEEP_WHOLE(b0); PASTA_KEEP_WHOLE(b1); PASTA_KEEP_WHOLE(b2);      // whole ds_read_b128 (conflict-free) instead of narrowed read2 pairs: +2 % here
                 const uint32_t d[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
 #pragma unroll
                 for (int ts = 0; ts < 3; ts++) {
