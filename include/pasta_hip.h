@@ -241,6 +241,12 @@ int pasta_ada_matrices(const float* u, const float* z, int64_t n, int u_cols, in
 int pasta_ada_theta(const float* g_inv, int64_t n, const float* a, const float* b, float* theta, void* stream);
 int pasta_color_affine(const float* x, const float* c, float* out, int64_t n, int64_t hw, int mode, void* stream);
 
+/* nan_to_num(t, nan, posinf, neginf) in place over n float tensors in one launch per 96 tensors
+ * (training_loop_wo_flow_fullbody.py:513-515; misc.py:45).  ptrs / numels: HOST arrays of device pointers / element
+ * counts (< 2^31 each); empty tensors are skipped. */
+int pasta_nan_to_num_multi(float* const* ptrs, const int64_t* numels, int n, float nan, float posinf, float neginf,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

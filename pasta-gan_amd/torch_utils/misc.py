@@ -15,6 +15,28 @@ import torch
 
 nan_to_num = torch.nan_to_num
 
+def nan_to_num_(tensors, nan=0.0, posinf=None, neginf=None):
+    """``torch.nan_to_num(t, nan, posinf, neginf, out=t)`` for every tensor of a list (the gradient clean-up before each
+    optimiser step, training_loop_wo_flow_fullbody.py:513-515).  Contiguous float32 GPU tensors go through ONE launch of
+    ``pasta_nan_to_num_multi`` per 96 tensors; anything else (CPU tensors of the gloo tests, other dtypes) is done one by one."""
+    import ctypes
+    fast = [t for t in tensors if t.device.type == 'cuda' and t.dtype == torch.float32 and t.is_contiguous()]
+    rest = [t for t in tensors if not (t.device.type == 'cuda' and t.dtype == torch.float32 and t.is_contiguous())]
+    for t in rest:
+        torch.nan_to_num(t, nan=nan, posinf=posinf, neginf=neginf, out=t)
+    by_device = {}
+    for t in fast:
+        by_device.setdefault(t.device, []).append(t)
+    for device, ts in by_device.items():
+        from .ops import _native
+        fmax = float(torch.finfo(torch.float32).max)
+        ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        numels = (ctypes.c_int64 * len(ts))(*[t.numel() for t in ts])
+        with torch.cuda.device(device):
+            st = _native.lib().pasta_nan_to_num_multi(ptrs, numels, len(ts), float(nan), fmax if posinf is None else float(posinf),
+                                                      -fmax if neginf is None else float(neginf), _native.stream())
+        _native.check(st)
+
 class suppress_tracer_warnings(warnings.catch_warnings):
     def __enter__(self):
         super().__enter__()

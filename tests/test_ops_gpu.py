@@ -32,7 +32,7 @@ def _cases(fname):
 def test_native_library_is_loaded():
     from torch_utils.ops import _native
     lib = _native.lib()
-    assert lib.pasta_abi_version() >= 7
+    assert lib.pasta_abi_version() >= 8
     assert b'gfx950' in lib.pasta_build_info()
 
 
@@ -404,3 +404,27 @@ def test_conv2d_resample_bias_act_fused(case):
     got = run(xc.cuda(), wc.cuda(), bc.cuda() if bc is not None else None, f.cuda(), True)
     for a, b in zip(got, ref):
         assert rel_err(a, b) < 5e-5
+
+
+def test_nan_to_num_multi():
+    """misc.nan_to_num_ == torch.nan_to_num per tensor (training_loop_wo_flow_fullbody.py:513-515): 230 tensors of ragged
+    sizes (more than one launch's table), unaligned views, an empty tensor, sizes around the 16 K chunk."""
+    from torch_utils import misc
+    gen = torch.Generator().manual_seed(77)
+    sizes = [0, 1, 3, 4, 5, 1023, 16383, 16384, 16385, 40000, 3 * 512 * 9, 512 * 512 * 9] + [int(s) for s in torch.randint(1, 5000, [218], generator=gen)]
+    ts = []
+    for k, n in enumerate(sizes):
+        t = torch.randn([n + 1], generator=gen)
+        if n:
+            idx = torch.randint(0, n + 1, [max(1, n // 7)], generator=gen)
+            t[idx[0::3]] = float('nan'); t[idx[1::3]] = float('inf'); t[idx[2::3]] = -float('inf')
+        t = t.cuda()
+        ts.append(t[1:] if k % 2 else t[:n])            # odd ones: 4-byte aligned only
+    want = [torch.nan_to_num(t, nan=0, posinf=1e5, neginf=-1e5) for t in ts]
+    misc.nan_to_num_(ts, nan=0, posinf=1e5, neginf=-1e5)
+    for t, w in zip(ts, want):
+        assert torch.equal(t, w)
+    # defaults: nan -> 0, infinities -> the largest finite values
+    t = torch.tensor([float('nan'), float('inf'), -float('inf'), 1.5], device='cuda')
+    misc.nan_to_num_([t])
+    assert t[0] == 0 and t[1] == torch.finfo(torch.float32).max and t[2] == -torch.finfo(torch.float32).max and t[3] == 1.5
