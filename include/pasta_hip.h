@@ -240,6 +240,8 @@ int pasta_ada_matrices(const float* u, const float* z, int64_t n, int u_cols, in
                        float debug_percentile, float* g_inv, float* c, int32_t* margins, void* stream);
 int pasta_ada_theta(const float* g_inv, int64_t n, const float* a, const float* b, float* theta, void* stream);
 int pasta_color_affine(const float* x, const float* c, float* out, int64_t n, int64_t hw, int mode, void* stream);
+/* grid[n, y, x, :] = theta[n] @ ((2x + 1) / W - 1, (2y + 1) / H - 1, 1): F.affine_grid(theta, [n, C, H, W], align_corners=False) (:297) */
+int pasta_ada_grid(const float* theta, int64_t n, int H, int W, float* grid, void* stream);
 
 /* nan_to_num(t, nan, posinf, neginf) in place over n float tensors in one launch per 96 tensors
  * (training_loop_wo_flow_fullbody.py:513-515; misc.py:45).  ptrs / numels: HOST arrays of device pointers / element

@@ -209,6 +209,23 @@ __global__ void ada_theta_kernel(const float* __restrict__ g, int n, ThetaParams
     for (int k = 0; k < 6; k++) theta[(int64_t)s * 6 + k] = T.m[k];
 }
 
+// Sampling grid of F.affine_grid(theta, [N, C, H, W], align_corners=False) without the batched GEMM it is made of:
+// grid[n, y, x] = theta[n] @ ((2x + 1) / W - 1, (2y + 1) / H - 1, 1).  One thread per 2 horizontally adjacent points (16-byte stores).
+__global__ __launch_bounds__(256) void ada_grid_kernel(const float* __restrict__ theta, int H, int W, float* __restrict__ grid) {
+    const int n = blockIdx.z, y = blockIdx.y;
+    const float* t = theta + (int64_t)n * 6;
+    const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
+    const float yn = (2.f * y + 1.f) / H - 1.f;
+    float* row = grid + ((int64_t)n * H + y) * W * 2;
+    for (int x = 2 * (blockIdx.x * blockDim.x + threadIdx.x); x < W; x += 2 * gridDim.x * blockDim.x) {
+        const float xa = (2.f * x + 1.f) / W - 1.f, xb = (2.f * (x + 1) + 1.f) / W - 1.f;
+        const float4 v = make_float4(fmaf(t0, xa, fmaf(t1, yn, t2)), fmaf(t3, xa, fmaf(t4, yn, t5)),
+                                     fmaf(t0, xb, fmaf(t1, yn, t2)), fmaf(t3, xb, fmaf(t4, yn, t5)));
+        if (x + 1 < W && (W & 1) == 0) *(float4*)(row + 2 * x) = v;
+        else { row[2 * x] = v.x; row[2 * x + 1] = v.y; if (x + 1 < W) { row[2 * x + 2] = v.z; row[2 * x + 3] = v.w; } }
+    }
+}
+
 // mode 0: out[n, i, p] = sum_k M[n][i][k] x[n, k, p] + M[n][i][3];  mode 1: the adjoint (M[n][k][i], no offset);
 // mode 2: the linear part alone (the adjoint's adjoint) -- first and second derivatives with respect to the image.
 template <int V>
@@ -277,4 +294,13 @@ extern "C" int pasta_color_affine(const float* x, const float* c, float* out, in
     if (v4) hipLaunchKernelGGL((color_affine_kernel<4>), dim3(gx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, x, c, out, hw, mode);
     else    hipLaunchKernelGGL((color_affine_kernel<1>), dim3(gx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, x, c, out, hw, mode);
     return launch_status("color_affine");
+}
+
+extern "C" int pasta_ada_grid(const float* theta, int64_t n, int H, int W, float* grid, void* stream) {
+    PASTA_CHECK(theta && grid, "ada_grid: null pointer");
+    PASTA_CHECK(n >= 1 && n <= 65535 && H >= 1 && H <= 65535 && W >= 1, "ada_grid: %lld grids of %d x %d", (long long)n, H, W);
+    PASTA_CHECK(((uintptr_t)grid & 15) == 0, "ada_grid: output must be 16-byte aligned");
+    const unsigned gx = (unsigned)ceil_div64(ceil_div64(W, 2), 256);
+    hipLaunchKernelGGL(ada_grid_kernel, dim3(gx, (unsigned)H, (unsigned)n), dim3(256), 0, (hipStream_t)stream, theta, H, W, grid);
+    return launch_status("ada_grid");
 }

@@ -189,7 +189,11 @@ class AugmentPipe(torch.nn.Module):
             with torch.cuda.device(device):
                 st = _native.lib().pasta_ada_theta(_native.ptr(G_inv), batch_size, a9, b9, _native.ptr(theta), _native.stream())
             _native.check(st)
-            grid = torch.nn.functional.affine_grid(theta=theta, size=[batch_size, num_channels, out_h, out_w], align_corners=False)
+            # affine_grid(theta, [N, C, out_h, out_w], align_corners=False) as one elementwise launch (ATen builds it with a batched GEMM)
+            grid = torch.empty([batch_size, out_h, out_w, 2], device=device)
+            with torch.cuda.device(device):
+                st = _native.lib().pasta_ada_grid(_native.ptr(theta), batch_size, out_h, out_w, _native.ptr(grid), _native.stream())
+            _native.check(st)
             images = grid_sample_gradfix.grid_sample(images, grid)
             images = upfirdn2d.downsample2d(x=images, f=self.Hz_geom, down=2, padding=-hz_pad * 2, flip_filter=True)
 

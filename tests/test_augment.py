@@ -166,3 +166,16 @@ def test_full_size_batch_and_r1_double_backward():
     pipe.p.fill_(0.0)
     y0 = pipe(x.detach())
     assert rel_err(y0, x.detach()) < 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('hw', [(524, 524), (37, 41), (8, 6)])
+def test_sampling_grid_kernel_matches_affine_grid(hw):
+    from torch_utils.ops import _native
+    gen = torch.Generator().manual_seed(4)
+    theta = (torch.randn([5, 2, 3], generator=gen) * 0.7).cuda()
+    H, W = hw
+    grid = torch.empty([5, H, W, 2], device='cuda')
+    _native.check(_native.lib().pasta_ada_grid(_native.ptr(theta), 5, H, W, _native.ptr(grid), _native.stream()))
+    ref = torch.nn.functional.affine_grid(theta.double(), [5, 3, H, W], align_corners=False)
+    assert rel_err(grid, ref) < 1e-6
