@@ -27,8 +27,15 @@ import torch
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 matrix peak
 PEAK_HBM_GBS = 8000.0
-BF16X6 = {0: 'conv_fwd_bf16x6_kernel<128,128,3>', 1: 'conv_fwd_bf16x6_kernel<64,256,2>'}
-BF16X6_ROWS = {0: 'conv_fwd_rows_bf16x6_kernel<128,128,2,1>', 1: 'conv_fwd_rows_bf16x6_kernel<64,256,2,1>'}
+# kernel names as rocprofv3 prints them (without blanks); the last template argument = bf16 pieces per operand
+# (3 = the default six-product arithmetic, 2 = bf16x3, 1 = bf16)
+def _np():
+    from torch_utils.ops import conv2d_gradfix
+    return {'bf16x3': 2, 'bf16': 1}.get(conv2d_gradfix.conv_math, 3)
+def bf16x6_names():
+    return {0: f'conv_fwd_bf16x6_kernel<128,128,3,{_np()}>', 1: f'conv_fwd_bf16x6_kernel<64,256,2,{_np()}>'}
+def bf16x6_rows_names():
+    return {0: f'conv_fwd_rows_bf16x6_kernel<128,128,2,1,{_np()}>', 1: f'conv_fwd_rows_bf16x6_kernel<64,256,2,1,{_np()}>'}
 
 TILE_NAMES = {0: 'conv_fwd_kernel<128,128,2,2,8,4>', 1: 'conv_fwd_kernel<64,256,2,2,8,4>',
               2: 'conv_fwd_kernel<32,256,1,2,8>', 3: 'conv_fwd_kernel<64,64,1,1,8>'}
@@ -63,7 +70,7 @@ class ConvMeter:
             tile, ksplit, math, launches, kernel = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
             self.lib.pasta_conv2d_plan(ctypes.byref(desc), 0, ctypes.byref(tile), ctypes.byref(ksplit), ctypes.byref(math), ctypes.byref(launches),
                                        ctypes.byref(kernel))      # has_iscale = 0: the networks never pass iscale
-            family = {0: TILE_NAMES, 1: BF16X6, 2: BF16X6_ROWS}[kernel.value][tile.value]
+            family = {0: TILE_NAMES, 1: bf16x6_names(), 2: bf16x6_rows_names()}[kernel.value][tile.value]
             kernels = launches.value
         else:
             which = ctypes.c_int()
@@ -180,6 +187,9 @@ def main():
                     "headline; 'ada' = the shipped train.sh default, pipeline 'bgc', target 0.6)")
     ap.add_argument('--aug-p', type=float, default=0.5, help='initial (ada) or constant (fixed) augmentation probability; the reference starts '
                     'ADA at 0 and takes ~100 kimg to reach its working point, a benchmark has to start near it')
+    ap.add_argument('--conv-math', default=None, choices=['default', 'f32', 'bf16x6', 'bf16x3', 'bf16'],
+                    help="matrix-core arithmetic of the convolutions (default: PASTA_CONV_MATH or 'default' = bf16x6, fp32-equivalent). "
+                         "'bf16x3' = what TrainingStep selects for allow_tf32=True; 'bf16' = bf16 operands. Reduced modes are reported as such, never as the headline")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-meter', action='store_true', help='do not bracket convolution launches with events')
     ap.add_argument('--by-shape', action='store_true', help='also print a per-shape convolution table to stderr')
@@ -211,6 +221,8 @@ def main():
     from training.training_loop_wo_flow_fullbody import TrainingStep, SyntheticFullBodyBatch, fashion_config
 
     lib = _native.lib()       # raises if libpasta_hip.so is missing
+    if args.conv_math is not None:
+        conv2d_gradfix.conv_math = args.conv_math
     cfg = fashion_config()
     from training.training_loop_wo_flow_fullbody import augment_options
     cfg.update(augment_options(aug=args.aug, augpipe='bgc', p=args.aug_p))
@@ -263,7 +275,7 @@ def main():
             'metric': 'training images/sec at 256x192 (tensor 256x256), batch 16 per GPU',
             'value': round(images / dt, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1000 * dt / args.steps, 2), 'host_issue_ms_per_step': round(1000 * host_dt / args.steps, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'conv_math': conv2d_gradfix.conv_math, 'data': 'synthetic', 'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            'dtype': {'bf16x3': 'f32 storage, split-bf16 x3 products (reduced: allow_tf32 counterpart)', 'bf16': 'f32 storage, bf16 operands (reduced: mixed precision)'}.get(conv2d_gradfix.conv_math, 'f32'), 'conv_math': conv2d_gradfix.conv_math, 'data': 'synthetic', 'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
             'config': {'workload': 'BASELINE config 2: full training_loop step (Gmain+Dmain every iter, Dreg/16, Greg/4, Adam, EMA), '
                                    'GeneratorFull+Discriminator cfg=fashion 256x256, batch 16/GPU, G and D in fp32, ' +
                                    ('vgg_weight=0 (weights unavailable)' if args.vgg_weight <= 0 else f'vgg_weight={args.vgg_weight:g} with random-init VGG-19') + (', no ADA' if args.aug == 'noaug' else f', ADA pipeline bgc ({args.aug}, p0={args.aug_p:g})') + ', random-init weights; timed iterations ' + f'{args.warmup}..{args.warmup + args.steps - 1}',
@@ -275,12 +287,14 @@ def main():
             name, f = dom
             achieved = f['flops'] / (f['ms'] * 1e-3) / 1e12
             traffic, src = pmc_traffic(name)
-            if name in (BF16X6[0], BF16X6[1], BF16X6_ROWS[0], BF16X6_ROWS[1], WGRAD_NAMES[2], WGRAD_NAMES[3], WGRAD_NAMES[4]):
-                # six bf16 MFMA products per fp32-equivalent multiply-add: the matrix pipes execute 6x the algorithmic FLOPs
-                peak = PEAK_BF16_MFMA_TFLOPS / 6
-                note = ('split-bf16: fp32-equivalent products from 6 x v_mfma_f32_32x32x16_bf16, fp32 accumulate; peak = 2500 TFLOP/s '
-                        'dense bf16 / 6; executed bf16 rate = 6 x achieved = %.0f TFLOP/s = %.1f%% of 2.5 PFLOP/s' %
-                        (6 * achieved, 100 * 6 * achieved / PEAK_BF16_MFMA_TFLOPS))
+            if name in (*bf16x6_names().values(), *bf16x6_rows_names().values(), WGRAD_NAMES[2], WGRAD_NAMES[3], WGRAD_NAMES[4]):
+                # six (three, one) bf16 MFMA products per multiply-add: the matrix pipes execute that multiple of the algorithmic FLOPs
+                nprod = {'bf16x3': 3, 'bf16': 1}.get(conv2d_gradfix.conv_math, 6)
+                peak = PEAK_BF16_MFMA_TFLOPS / nprod
+                note = ('split-bf16: %s products from %d x v_mfma_f32_32x32x16_bf16, fp32 accumulate; peak = 2500 TFLOP/s '
+                        'dense bf16 / %d; executed bf16 rate = %d x achieved = %.0f TFLOP/s = %.1f%% of 2.5 PFLOP/s' %
+                        ({6: 'fp32-equivalent', 3: '2^-16-accurate (opt-in allow_tf32 counterpart)', 1: 'bf16-operand (opt-in mixed precision)'}[nprod],
+                         nprod, nprod, nprod, nprod * achieved, 100 * nprod * achieved / PEAK_BF16_MFMA_TFLOPS))
             else:
                 peak = PEAK_F32_MFMA_TFLOPS
                 note = 'dense fp32-input MFMA (v_mfma_f32_32x32x2_f32), exact-f32 products'

@@ -116,8 +116,14 @@ typedef struct pasta_conv_desc {
  *                     (dropped terms < 2^-22 |ab|) at 2.67x the fp32 matrix-core rate.  Used by the 128x128- and
  *                     64x256-tile forward / input-gradient launches with >= 16 input channels per group and
  *                     by the 3x3 stride-1 weight gradient; all other launches run PASTA_MATH_F32.
+ *   PASTA_MATH_BF16X3 two bf16 pieces per operand, three products (hi*hi, hi*mid, mid*hi): ~2^-16 relative error per
+ *                     product, half of the matrix work -- the counterpart of the reference's `allow_tf32=True`
+ *                     (training_loop_wo_flow_fullbody.py:247-249; TF32 keeps 2^-11).  Opt-in, never the default.
+ *   PASTA_MATH_BF16   operands rounded to bf16, one product, fp32 accumulate and fp32 tensors in HBM: the arithmetic of
+ *                     mixed-precision training (BASELINE config 5).  Opt-in.
+ *   The three split modes share kernels (template argument NP = pieces) and the same coverage.
  *   PASTA_MATH_DEFAULT = PASTA_MATH_BF16X6. */
-enum { PASTA_MATH_DEFAULT = 0, PASTA_MATH_F32 = 1, PASTA_MATH_BF16X6 = 2 };
+enum { PASTA_MATH_DEFAULT = 0, PASTA_MATH_F32 = 1, PASTA_MATH_BF16X6 = 2, PASTA_MATH_BF16X3 = 3, PASTA_MATH_BF16 = 4 };
 
 /* Bytes of scratch the forward / weight-gradient launches need (caller allocs). */
 int64_t pasta_conv2d_workspace(const pasta_conv_desc* d);

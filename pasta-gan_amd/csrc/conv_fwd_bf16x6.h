@@ -58,18 +58,21 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __r
     }
 }
 
-template <int BM, int BN, int OCC>      // (128, 128): waves 2 x 2;  (64, 256): waves 1 x 4; each wave 64 rows x 64 pixels
+// NP = bf16 pieces kept per operand: 3 = six products (fp32-equivalent, the default), 2 = three products (hi*hi, hi*mid,
+// mid*hi: ~2^-16 relative, PASTA_MATH_BF16X3), 1 = one product (plain bf16 operands, PASTA_MATH_BF16).  The packed
+// weights always hold three pieces; NP < 3 fetches and stages the leading ones only.
+template <int BM, int BN, int OCC, int NP>      // (128, 128): waves 2 x 2;  (64, 256): waves 1 x 4; each wave 64 rows x 64 pixels
 __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams p) {
     constexpr int WMT = 2, WNT = 2, KC = 16;
     constexpr int WAVES_N = BN / 64;
     static_assert((BM / 64) * WAVES_N == 4, "four waves per workgroup");
     constexpr int ASEG = BM * 8, BSEG = BN * 8;         // bf16 elements of one (piece, half) segment
-    constexpr int AUNITS = 6 * BM;                      // sixteen-byte units of the A chunk
+    constexpr int AUNITS = 2 * NP * BM;                 // sixteen-byte units of the A chunk
     constexpr int APT = (AUNITS + 255) / 256;           // per thread: 3 (BM 128) or 2 (BM 64, second one guarded)
     constexpr int BPT = BN * 2 / 256;                   // (pixel, k-half) pairs per thread: 1 or 2
     // A buffers are rounded up to APT * 256 units: every thread copies APT units without a guard (see load_chunk)
     __shared__ __attribute__((aligned(16))) __bf16 As[2][APT * 256 * 8];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][6 * BSEG];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][2 * NP * BSEG];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
             return *(const float4*)(wt + ((int64_t)seg * p.Og_pad + o_blk + within) * 8);
         };
         areg0 = unit(0);
-        areg1 = unit(1);
+        if (APT > 1) areg1 = unit(1);
         if (APT > 2) areg2 = unit(2);
         if (++a_cc >= NC) {
             a_cc = 0;
@@ -188,32 +191,36 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
         f32x2 v = {v0, v1};
         uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
         q1[i][j] = w;
-        // the two residual subtractions stay scalar: packed f32 VALU next to MFMAs costs more than it saves
-        // (MI355X_MICROARCH.md, cycle table), and the empty asm keeps the SLP vectoriser from pairing them
-        v0 -= __builtin_bit_cast(float, w << 16);
-        v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
-        PASTA_KEEP_SCALAR(v0);
-        v = f32x2{v0, v1};
-        w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-        q2[i][j] = w;
-        v0 -= __builtin_bit_cast(float, w << 16);
-        v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
-        PASTA_KEEP_SCALAR(v0);
-        v = f32x2{v0, v1};
-        q3[i][j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        if constexpr (NP >= 2) {
+            // the two residual subtractions stay scalar: packed f32 VALU next to MFMAs costs more than it saves
+            // (MI355X_MICROARCH.md, cycle table), and the empty asm keeps the SLP vectoriser from pairing them
+            v0 -= __builtin_bit_cast(float, w << 16);
+            v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
+            PASTA_KEEP_SCALAR(v0);
+            v = f32x2{v0, v1};
+            w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+            q2[i][j] = w;
+        }
+        if constexpr (NP >= 3) {
+            v0 -= __builtin_bit_cast(float, w << 16);
+            v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
+            PASTA_KEEP_SCALAR(v0);
+            v = f32x2{v0, v1};
+            q3[i][j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        }
     };
     auto store_b = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < BPT; i++) {
             __bf16* bd = &Bs[buf][((half0 + i) * BN + bcol) * 8];
             *(uint4*)(bd) = make_uint4(q1[i][0], q1[i][1], q1[i][2], q1[i][3]);
-            *(uint4*)(bd + 2 * BSEG) = make_uint4(q2[i][0], q2[i][1], q2[i][2], q2[i][3]);
-            *(uint4*)(bd + 4 * BSEG) = make_uint4(q3[i][0], q3[i][1], q3[i][2], q3[i][3]);
+            if constexpr (NP >= 2) *(uint4*)(bd + 2 * BSEG) = make_uint4(q2[i][0], q2[i][1], q2[i][2], q2[i][3]);
+            if constexpr (NP >= 3) *(uint4*)(bd + 4 * BSEG) = make_uint4(q3[i][0], q3[i][1], q3[i][2], q3[i][3]);
         }
     };
     auto store_a = [&](int buf) {
         *(float4*)&As[buf][tid * 8] = areg0;
-        *(float4*)&As[buf][(tid + 256) * 8] = areg1;
+        if (APT > 1) *(float4*)&As[buf][(tid + 256) * 8] = areg1;
         if (APT > 2) *(float4*)&As[buf][(tid + 512) * 8] = areg2;
     };
 
@@ -229,8 +236,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     // Fragments of one chunk: [tile][piece], read in the order the MFMA groups consume them.
     struct Frag { bf16x8 a[WMT][3], b[WNT][3]; };
     auto read_frag = [&](Frag& f, int buf) {
-#define PASTA_LDA(PC) _Pragma("unroll") for (int a = 0; a < WMT; a++) f.a[a][PC] = *(const bf16x8*)&As[buf][(((PC) * 2 + hl) * BM + (wm * WMT + a) * 32 + jl) * 8];
-#define PASTA_LDB(PC) _Pragma("unroll") for (int b = 0; b < WNT; b++) f.b[b][PC] = *(const bf16x8*)&Bs[buf][(((PC) * 2 + hl) * BN + (wn * WNT + b) * 32 + jl) * 8];
+#define PASTA_LDA(PC) if constexpr ((PC) < NP) { _Pragma("unroll") for (int a = 0; a < WMT; a++) f.a[a][PC] = *(const bf16x8*)&As[buf][(((PC) * 2 + hl) * BM + (wm * WMT + a) * 32 + jl) * 8]; }
+#define PASTA_LDB(PC) if constexpr ((PC) < NP) { _Pragma("unroll") for (int b = 0; b < WNT; b++) f.b[b][PC] = *(const bf16x8*)&Bs[buf][(((PC) * 2 + hl) * BN + (wn * WNT + b) * 32 + jl) * 8]; }
         PASTA_LDA(2) PASTA_LDB(0) PASTA_LDA(0) PASTA_LDB(2) PASTA_LDA(1) PASTA_LDB(1)
 #undef PASTA_LDA
 #undef PASTA_LDB
@@ -242,8 +249,9 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
         Frag f;
         read_frag(f, buf);
 #define PASTA_MM(PA, PB)                                                                                       \
+        if constexpr ((PA) + (PB) < NP) {                                                                        \
         _Pragma("unroll") for (int a = 0; a < WMT; a++) _Pragma("unroll") for (int b = 0; b < WNT; b++)          \
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][PA], f.b[b][PB], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][PA], f.b[b][PB], acc[a][b], 0, 0, 0); }
 #define PASTA_SPLIT(J) _Pragma("unroll") for (int i = 0; i < BPT; i++) split_pair(cur_next, i, J);
         // smallest terms first: a3b1, a1b3, a2b2, a2b1, a1b2, a1b1
         PASTA_MM(2, 0)
@@ -321,16 +329,16 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
 // full step later, so the store never waits for an L2 round trip (+1.5 % on the 128 x 128 x 128 layers; PIPE = 0 fetches
 // and stores within one step).  Also measured and dropped: reading the next step's fragments during the current step's
 // MFMAs (two fragment sets, 236-256 VGPRs) -- no change, the other workgroup of the CU already covers that latency.
-template <int BM, int BN, int OCC, int PIPE>
+template <int BM, int BN, int OCC, int PIPE, int NP>
 __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdParams p) {
     constexpr int WMT = 2, WNT = 2, KC = 16;
     constexpr int WAVES_N = BN / 64;
     static_assert((BM / 64) * WAVES_N == 4, "four waves per workgroup");
-    constexpr int AUNITS = 6 * BM;
+    constexpr int AUNITS = 2 * NP * BM;
     constexpr int APT = (AUNITS + 255) / 256;
     constexpr int BPT = BN * 2 / 256;                   // (pixel, k-half) pairs per thread: 1 or 2
     constexpr int SLOTS = BN + 16;                      // up to 8 segments with two halo slots each
-    constexpr int ABUF = APT * 256 * 8, BSEG = SLOTS * 8, BBUF = 6 * BSEG;      // bf16 elements
+    constexpr int ABUF = APT * 256 * 8, BSEG = SLOTS * 8, BBUF = 2 * NP * BSEG;      // bf16 elements
     extern __shared__ __attribute__((aligned(16))) __bf16 rows_smem[];
     __bf16* const As = rows_smem;                       // [2][ABUF]
     __bf16* const Bs = rows_smem + 2 * ABUF;            // [2][BBUF]
@@ -449,11 +457,11 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
         };
         if (set == 0) {
             areg0 = unit(0);
-            areg1 = unit(1);
+            if (APT > 1) areg1 = unit(1);
             if (APT > 2) areg2 = unit(2);
         } else {
             breg0 = unit(0);
-            breg1 = unit(1);
+            if (APT > 1) breg1 = unit(1);
             if (APT > 2) breg2 = unit(2);
         }
     };
@@ -466,7 +474,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     auto store_a = [&](int buf, int set = 0) {
         __bf16* d = As + buf * ABUF;
         *(float4*)&d[tid * 8] = set ? breg0 : areg0;
-        *(float4*)&d[(tid + 256) * 8] = set ? breg1 : areg1;
+        if (APT > 1) *(float4*)&d[(tid + 256) * 8] = set ? breg1 : areg1;
         if (APT > 2) *(float4*)&d[(tid + 512) * 8] = set ? breg2 : areg2;
     };
 
@@ -482,27 +490,31 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
         f32x2 v = {v0, v1};
         uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
         q1[i][j] = w;
-        // the two residual subtractions stay scalar: packed f32 VALU next to MFMAs costs more than it saves
-        // (MI355X_MICROARCH.md, cycle table), and the empty asm keeps the SLP vectoriser from pairing them
-        v0 -= __builtin_bit_cast(float, w << 16);
-        v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
-        PASTA_KEEP_SCALAR(v0);
-        v = f32x2{v0, v1};
-        w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-        q2[i][j] = w;
-        v0 -= __builtin_bit_cast(float, w << 16);
-        v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
-        PASTA_KEEP_SCALAR(v0);
-        v = f32x2{v0, v1};
-        q3[i][j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        if constexpr (NP >= 2) {
+            // the two residual subtractions stay scalar: packed f32 VALU next to MFMAs costs more than it saves
+            // (MI355X_MICROARCH.md, cycle table), and the empty asm keeps the SLP vectoriser from pairing them
+            v0 -= __builtin_bit_cast(float, w << 16);
+            v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
+            PASTA_KEEP_SCALAR(v0);
+            v = f32x2{v0, v1};
+            w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+            q2[i][j] = w;
+        }
+        if constexpr (NP >= 3) {
+            v0 -= __builtin_bit_cast(float, w << 16);
+            v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
+            PASTA_KEEP_SCALAR(v0);
+            v = f32x2{v0, v1};
+            q3[i][j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        }
     };
     auto store_q = [&](int buf, int slot, int hbase) {
 #pragma unroll
         for (int i = 0; i < BPT; i++) {
             __bf16* bd = Bs + buf * BBUF + ((hbase + i) * SLOTS + slot) * 8;
             *(uint4*)(bd) = make_uint4(q1[i][0], q1[i][1], q1[i][2], q1[i][3]);
-            *(uint4*)(bd + 2 * BSEG) = make_uint4(q2[i][0], q2[i][1], q2[i][2], q2[i][3]);
-            *(uint4*)(bd + 4 * BSEG) = make_uint4(q3[i][0], q3[i][1], q3[i][2], q3[i][3]);
+            if constexpr (NP >= 2) *(uint4*)(bd + 2 * BSEG) = make_uint4(q2[i][0], q2[i][1], q2[i][2], q2[i][3]);
+            if constexpr (NP >= 3) *(uint4*)(bd + 4 * BSEG) = make_uint4(q3[i][0], q3[i][1], q3[i][2], q3[i][3]);
         }
     };
 
@@ -525,8 +537,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     auto read_frag = [&](Frag& f, int abuf, int bbuf, int off) {
         const __bf16* A_ = As + abuf * ABUF;
         const __bf16* B_ = Bs + bbuf * BBUF;
-#define PASTA_LDA(PC) _Pragma("unroll") for (int a = 0; a < WMT; a++) f.a[a][PC] = *(const bf16x8*)&A_[(((PC) * 2 + hl) * BM + (wm * WMT + a) * 32 + jl) * 8];
-#define PASTA_LDB(PC) _Pragma("unroll") for (int b = 0; b < WNT; b++) f.b[b][PC] = *(const bf16x8*)&B_[(((PC) * 2 + hl) * SLOTS + fslot[b] + off) * 8];
+#define PASTA_LDA(PC) if constexpr ((PC) < NP) { _Pragma("unroll") for (int a = 0; a < WMT; a++) f.a[a][PC] = *(const bf16x8*)&A_[(((PC) * 2 + hl) * BM + (wm * WMT + a) * 32 + jl) * 8]; }
+#define PASTA_LDB(PC) if constexpr ((PC) < NP) { _Pragma("unroll") for (int b = 0; b < WNT; b++) f.b[b][PC] = *(const bf16x8*)&B_[(((PC) * 2 + hl) * SLOTS + fslot[b] + off) * 8]; }
         PASTA_LDA(2) PASTA_LDB(0) PASTA_LDA(0) PASTA_LDB(2) PASTA_LDA(1) PASTA_LDB(1)
 #undef PASTA_LDA
 #undef PASTA_LDB
@@ -551,8 +563,9 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
         Frag f;
         read_frag(f, abuf, bbuf, p.rows_rev ? 2 - TAP : TAP);
 #define PASTA_MM(PA, PB)                                                                                       \
+        if constexpr ((PA) + (PB) < NP) {                                                                        \
         _Pragma("unroll") for (int a = 0; a < WMT; a++) _Pragma("unroll") for (int b = 0; b < WNT; b++)          \
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][PA], f.b[b][PB], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][PA], f.b[b][PB], acc[a][b], 0, 0, 0); }
 #define PASTA_SPLIT(J)                                                                                         \
         if (TAP == 1) { _Pragma("unroll") for (int i = 0; i < BPT; i++) split_pair(mb, m_nvalid, i, J); }        \
         if (TAP == 2 && wave == h_owner) { _Pragma("unroll") for (int i = 0; i < BPT; i++) split_pair(hb, h_nvalid, i, J); }
@@ -630,6 +643,28 @@ static bool rows_tile_ok(int P, int Q, int BN) {
     return Q % 32 == 0 && (seg & (seg - 1)) == 0 && BN % seg == 0 && Q % seg == 0 && ((int64_t)P * Q) % BN == 0;
 }
 
+template <int BM, int BN, int NP>
+static void launch_fwd_bf16_np(const ConvFwdParams& q, dim3 grid, hipStream_t s) {
+    if (q.rows && q.ncls == 1 && rows_tile_ok(q.cls[0].P, q.cls[0].Q, BN)) {
+        // row-reuse kernel: full tiles made of whole row segments inside one image
+        constexpr int APT = (2 * NP * BM + 255) / 256;
+        constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 2 * NP * (BN + 16) * 8) * sizeof(__bf16);
+        static bool attr_set = false;
+        static int pipe = 1;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 0, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            const char* e = getenv("PASTA_ROWS_PIPE");
+            if (e) pipe = e[0] != '0';
+            attr_set = true;
+        }
+        if (pipe == 1)      hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP>), grid, dim3(256), lds, s, q);
+        else                hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 0, NP>), grid, dim3(256), lds, s, q);
+        return;
+    }
+    hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<BM, BN, (BN == 256 ? 2 : 3), NP>), grid, dim3(256), 0, s, q);     // <= 64 KB of LDS: two or three workgroups per CU
+}
+
 template <int BM, int BN>
 static void launch_fwd_bf16x6(const ConvFwdParams& p, hipStream_t s) {
     ConvFwdParams q = p;
@@ -641,26 +676,10 @@ static void launch_fwd_bf16x6(const ConvFwdParams& p, hipStream_t s) {
     }
     tiles *= p.ncls;
     dim3 grid((unsigned)tiles, q.o_tiles * q.ksplit, p.G);
-    if (p.rows && p.ncls == 1) {
-        // row-reuse kernel: full tiles made of whole row segments inside one image
-        if (rows_tile_ok(p.cls[0].P, p.cls[0].Q, BN)) {
-            constexpr int APT = (6 * BM + 255) / 256;
-            constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 6 * (BN + 16) * 8) * sizeof(__bf16);
-            static bool attr_set = false;
-            static int pipe = 1;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                const char* e = getenv("PASTA_ROWS_PIPE");
-                if (e) pipe = e[0] != '0';
-                attr_set = true;
-            }
-            if (pipe == 1)      hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1>), grid, dim3(256), lds, s, q);
-            else                hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 0>), grid, dim3(256), lds, s, q);
-            return;
-        }
-    }
-    hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<BM, BN, (BN == 256 ? 2 : 3)>), grid, dim3(256), 0, s, q);     // 64 KB of LDS: two workgroups per CU
+    // p.bf16x6 = number of bf16 pieces per operand (3: six products, 2: three, 1: one)
+    if (p.bf16x6 == 1)      launch_fwd_bf16_np<BM, BN, 1>(q, grid, s);
+    else if (p.bf16x6 == 2) launch_fwd_bf16_np<BM, BN, 2>(q, grid, s);
+    else                    launch_fwd_bf16_np<BM, BN, 3>(q, grid, s);
 }
 
 // Do the T taps at table positions [0, T) form rows of three horizontally adjacent offsets (ascending or descending)?

@@ -85,6 +85,9 @@ static int64_t fwd_lattice_pixels(const pasta_conv_desc* d) {
 
 // Which kernel a forward-type launch uses: the tile, the number of K slices, and whether the split-bf16 kernel may
 // run (it also needs iscale == nullptr, known only at launch).
+// bf16 pieces per operand of the split-bf16 kernels for a math mode
+static int math_pieces(int math) { return math == PASTA_MATH_BF16 ? 1 : math == PASTA_MATH_BF16X3 ? 2 : 3; }
+
 struct FwdPlan { FwdTile tile; int ksplit; int bf16x6; };
 
 static FwdPlan plan_fwd(const pasta_conv_desc* d) {
@@ -176,7 +179,7 @@ static int check_desc(const pasta_conv_desc* d, const char* who) {
     PASTA_CHECK(d->kh >= 1 && d->kw >= 1 && d->kh * d->kw <= MAX_TAPS, "%s: kernel %dx%d unsupported (max %d taps)", who, d->kh, d->kw, MAX_TAPS);
     PASTA_CHECK(d->stride >= 1 && d->stride <= 4, "%s: stride %d unsupported", who, d->stride);
     PASTA_CHECK(d->pad_h >= 0 && d->pad_w >= 0, "%s: negative padding", who);
-    PASTA_CHECK(d->math >= PASTA_MATH_DEFAULT && d->math <= PASTA_MATH_BF16X6, "%s: unknown math mode %d", who, d->math);
+    PASTA_CHECK(d->math >= PASTA_MATH_DEFAULT && d->math <= PASTA_MATH_BF16, "%s: unknown math mode %d", who, d->math);
     PASTA_CHECK(d->groups >= 1 && d->C_in % d->groups == 0 && d->C_out % d->groups == 0, "%s: channels not divisible by groups=%d", who, d->groups);
     if (!d->transposed) {
         const int oh = (d->H + 2 * d->pad_h - d->kh) / d->stride + 1, ow = (d->W + 2 * d->pad_w - d->kw) / d->stride + 1;
@@ -223,7 +226,7 @@ extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int has_iscale, int* 
     const bool sb = f.bf16x6 && !has_iscale;
     if (tile) *tile = (int)f.tile;
     if (ksplit) *ksplit = f.ksplit;
-    if (math) *math = sb ? PASTA_MATH_BF16X6 : PASTA_MATH_F32;
+    if (math) *math = !sb ? PASTA_MATH_F32 : d->math == PASTA_MATH_BF16X3 ? PASTA_MATH_BF16X3 : d->math == PASTA_MATH_BF16 ? PASTA_MATH_BF16 : PASTA_MATH_BF16X6;
     if (launches) *launches = !d->transposed ? 1 : merged_classes(d, sb) ? 1 : (d->stride < d->OH ? d->stride : d->OH) * (d->stride < d->OW ? d->stride : d->OW);
     if (kernel) {
         // the lattice of a stride-1 launch is the output plane itself, its taps kh rows of kw adjacent offsets
@@ -264,7 +267,7 @@ extern "C" int pasta_conv2d_ex(const float* x, const float* w, float* y, const f
     p.ksplit = plan.ksplit;
     p.o_tiles = 1;
     p.partial = (float*)workspace + round_up((int)(((int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad * 3 + 1) / 2), 4);
-    p.bf16x6 = (plan.bf16x6 && !iscale) ? 1 : 0;
+    p.bf16x6 = (plan.bf16x6 && !iscale) ? math_pieces(d->math) : 0;     // bf16 pieces per operand; 0 = fp32 kernel
     p.rows = 0; p.rows_d0 = 0; p.rows_rev = 0;
 
     const float wscale = d->wscale == 0.f ? 1.f : d->wscale;
@@ -447,27 +450,39 @@ extern "C" int pasta_conv2d_wgrad(const float* x, const float* dy, float* dw, co
         if (w.kp == 16) { if (w.pipe) PASTA_WGRAD1(TR_, TS_, WA_, WB_, 1, 16); else PASTA_WGRAD1(TR_, TS_, WA_, WB_, 0, 16); } \
         else            { if (w.pipe) PASTA_WGRAD1(TR_, TS_, WA_, WB_, 1, 32); else PASTA_WGRAD1(TR_, TS_, WA_, WB_, 0, 32); } \
     } while (0)
+    const int np = math_pieces(d->math);          // bf16 pieces per operand of the split-bf16 kernels
+#define PASTA_NP(LAUNCH_)   /* LAUNCH_(NP) for the runtime np */                                                             \
+    do { if (np == 1) { LAUNCH_(1); } else if (np == 2) { LAUNCH_(2); } else { LAUNCH_(3); } } while (0)
     if (wgrad_bf16x6(d, w)) {
-        const size_t lds = (size_t)(3 * 64 * 40 + 3 * 64 * 3 * 40) * 2;
-        hipLaunchKernelGGL(conv_wgrad3x3_bf16x6_kernel, dim3((unsigned)blocks), dim3(256), lds, s, p);
+        const size_t lds = (size_t)(np * 64 * 40 + np * 64 * 3 * 40) * 2;
+#define PASTA_L(NP_) hipLaunchKernelGGL(conv_wgrad3x3_bf16x6_kernel<NP_>, dim3((unsigned)blocks), dim3(256), lds, s, p)
+        PASTA_NP(PASTA_L);
+#undef PASTA_L
     }
     else if (wgrad_s2_bf16x6(d, w)) {
-        const size_t lds = (size_t)(3 * 64 * 16 + 3 * 64 * 3 * 40) * 2;
-        if (d->pad_w == 1) hipLaunchKernelGGL(conv_wgrad3x3s2_bf16x6_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, s, p);
-        else               hipLaunchKernelGGL(conv_wgrad3x3s2_bf16x6_kernel<0>, dim3((unsigned)blocks), dim3(256), lds, s, p);
+        const size_t lds = (size_t)(np * 64 * 16 + np * 64 * 3 * 40) * 2;
+#define PASTA_L(NP_)                                                                                                          \
+        if (d->pad_w == 1) hipLaunchKernelGGL((conv_wgrad3x3s2_bf16x6_kernel<1, NP_>), dim3((unsigned)blocks), dim3(256), lds, s, p); \
+        else               hipLaunchKernelGGL((conv_wgrad3x3s2_bf16x6_kernel<0, NP_>), dim3((unsigned)blocks), dim3(256), lds, s, p)
+        PASTA_NP(PASTA_L);
+#undef PASTA_L
     }
     else if (w.TR == 3 && w.TS == 3) PASTA_WGRAD(3, 3, 1, 1);
     else if (w.TS == 7) PASTA_WGRAD(1, 7, 1, 1);
     else if (w.TS == 4) PASTA_WGRAD(1, 4, 1, 1);
     else if (wgrad_1x1_bf16x6(d, w)) {
-        const size_t lds = (size_t)(3 * 64 * 40) * 2 * 2 * w.WA;          // S and L images of 64 WA (= 64 WB) channels
-        if (w.WA == 2) hipLaunchKernelGGL((conv_wgrad1x1_bf16x6_kernel<2, 2>), dim3((unsigned)blocks), dim3(256), lds, s, p);
-        else           hipLaunchKernelGGL((conv_wgrad1x1_bf16x6_kernel<1, 1>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+        const size_t lds = (size_t)(np * 64 * 40) * 2 * 2 * w.WA;         // S and L images of 64 WA (= 64 WB) channels
+#define PASTA_L(NP_)                                                                                                          \
+        if (w.WA == 2) hipLaunchKernelGGL((conv_wgrad1x1_bf16x6_kernel<2, 2, NP_>), dim3((unsigned)blocks), dim3(256), lds, s, p); \
+        else           hipLaunchKernelGGL((conv_wgrad1x1_bf16x6_kernel<1, 1, NP_>), dim3((unsigned)blocks), dim3(256), lds, s, p)
+        PASTA_NP(PASTA_L);
+#undef PASTA_L
     }
     else if (w.WA == 2) PASTA_WGRAD(1, 1, 2, 2);
     else PASTA_WGRAD(1, 1, 1, 1);
 #undef PASTA_WGRAD
 #undef PASTA_WGRAD1
+#undef PASTA_NP
     {
         const int64_t total = (int64_t)p.G * p.kh * p.kw * p.Ag * p.Bg;
         int64_t rb = ceil_div64(total, 256);

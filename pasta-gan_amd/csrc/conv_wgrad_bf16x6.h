@@ -14,13 +14,14 @@ namespace pasta {
 //              of two aligned 16-byte blocks with v_alignbit (ts = 0, 2) or by register renaming (ts = 1).
 // One wave owns a 32 x 32 (a, b) tile for all 9 taps (144 accumulator registers): 54 MFMAs per K step.
 
+template <int NP>       // bf16 pieces per operand: 3 (six products), 2 (three), 1 (one); see conv_fwd_bf16x6_kernel
 __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParams p) {
     constexpr int SP = 40, LP = 40;                 // row pitches in bf16 elements (80 B)
     constexpr int S_PIECE = 64 * SP;                // one piece of the S tile
     constexpr int L_PIECE = 64 * 3 * LP;            // one piece of the L halo tile
     extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
     __bf16* Ss = smem16;                            // [3][64][SP]
-    __bf16* Ls = smem16 + 3 * S_PIECE;              // [3][64][3][LP]
+    __bf16* Ls = smem16 + NP * S_PIECE;             // [NP][64][3][LP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wa = wave >> 1, wb = wave & 1;
@@ -84,17 +85,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
             f32x2 v = {vals[2 * j], vals[2 * j + 1]};
             uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
             q1[j] = w;
-            v[0] -= __builtin_bit_cast(float, w << 16);
-            v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
-            w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-            q2[j] = w;
-            v[0] -= __builtin_bit_cast(float, w << 16);
-            v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
-            q3[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+            if constexpr (NP >= 2) {
+                v[0] -= __builtin_bit_cast(float, w << 16);
+                v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
+                w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+                q2[j] = w;
+            }
+            if constexpr (NP >= 3) {
+                v[0] -= __builtin_bit_cast(float, w << 16);
+                v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
+                q3[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+            }
         }
         *(uint4*)(dst) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
-        *(uint4*)(dst + piece_stride) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
-        *(uint4*)(dst + 2 * piece_stride) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+        if constexpr (NP >= 2) *(uint4*)(dst + piece_stride) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+        if constexpr (NP >= 3) *(uint4*)(dst + 2 * piece_stride) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
     };
     auto stash = [&]() {
         split_store(sreg[0], sreg[1], vmask & 1u, vmask & 2u, Ss + s_a * SP + 8 * s_grp, S_PIECE);
@@ -123,9 +128,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
         for (int s = 0; s < 2; s++) {
             bf16x8 af[3];
 #pragma unroll
-            for (int pc = 0; pc < 3; pc++) af[pc] = *(const bf16x8*)&Ss[pc * S_PIECE + (wa * 32 + jl) * SP + 16 * s + 8 * hl];
+            for (int pc = 0; pc < NP; pc++) af[pc] = *(const bf16x8*)&Ss[pc * S_PIECE + (wa * 32 + jl) * SP + 16 * s + 8 * hl];
 #pragma unroll
-            for (int pb = 2; pb >= 0; pb--) {       // B pieces from the smallest to the largest
+            for (int pb = NP - 1; pb >= 0; pb--) {  // B pieces from the smallest to the largest
 #pragma unroll
                 for (int row = 0; row < 3; row++) {
                     const __bf16* lb = &Ls[pb * L_PIECE + ((wb * 32 + jl) * 3 + row) * LP + 16 * s + 8 * hl];
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
                         const int tap = row * 3 + ts;
                         // a_pa * b_pb with pa + pb <= 2, smallest A piece first
 #pragma unroll
-                        for (int pa = 2 - pb; pa >= 0; pa--)
+                        for (int pa = NP - 1 - pb; pa >= 0; pa--)
                             acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa], bw, acc[tap], 0, 0, 0);
                     }
                 }
@@ -178,14 +183,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
 // (the bf16 pairs of a dword are halo columns 2i, 2i + 1: a window of even or of odd columns is the low or the high
 // halves of eight consecutive dwords).  L rows are not 16-byte aligned in general (257-pixel planes), so the halo is
 // fetched with dword loads.
-template <int PW>
+template <int PW, int NP>
 __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradParams p) {
     constexpr int SP = 16, LP = 40;                 // row pitches in bf16 elements
     constexpr int S_PIECE = 64 * SP;
     constexpr int L_PIECE = 64 * 3 * LP;
     extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
     __bf16* Ss = smem16;                            // [3][64][SP]
-    __bf16* Ls = smem16 + 3 * S_PIECE;              // [3][64][3][LP]
+    __bf16* Ls = smem16 + NP * S_PIECE;             // [NP][64][3][LP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wa = wave >> 1, wb = wave & 1;
@@ -258,17 +263,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
             f32x2 v = {vals[2 * j], vals[2 * j + 1]};
             uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
             q1[j] = w;
-            v[0] -= __builtin_bit_cast(float, w << 16);
-            v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
-            w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-            q2[j] = w;
-            v[0] -= __builtin_bit_cast(float, w << 16);
-            v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
-            q3[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+            if constexpr (NP >= 2) {
+                v[0] -= __builtin_bit_cast(float, w << 16);
+                v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
+                w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+                q2[j] = w;
+            }
+            if constexpr (NP >= 3) {
+                v[0] -= __builtin_bit_cast(float, w << 16);
+                v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
+                q3[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+            }
         }
         *(uint4*)(dst) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
-        *(uint4*)(dst + piece_stride) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
-        *(uint4*)(dst + 2 * piece_stride) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+        if constexpr (NP >= 2) *(uint4*)(dst + piece_stride) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+        if constexpr (NP >= 3) *(uint4*)(dst + 2 * piece_stride) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
     };
     auto stash = [&]() {
         if (tid < 128) {
@@ -302,9 +311,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
         if (ch + 1 < c_end) fetch(ch + 1);
         bf16x8 af[3];
 #pragma unroll
-        for (int pc = 0; pc < 3; pc++) af[pc] = *(const bf16x8*)&Ss[pc * S_PIECE + (wa * 32 + jl) * SP + 8 * hl];
+        for (int pc = 0; pc < NP; pc++) af[pc] = *(const bf16x8*)&Ss[pc * S_PIECE + (wa * 32 + jl) * SP + 8 * hl];
 #pragma unroll
-        for (int pb = 2; pb >= 0; pb--) {           // B pieces from the smallest to the largest
+        for (int pb = NP - 1; pb >= 0; pb--) {      // B pieces from the smallest to the largest
 #pragma unroll
             for (int row = 0; row < 3; row++) {
                 const __bf16* lb = &Ls[pb * L_PIECE + ((wb * 32 + jl) * 3 + row) * LP + 16 * hl];
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
                     const bf16x8 bw = __builtin_bit_cast(bf16x8, w);
                     const int tap = row * 3 + ts;
 #pragma unroll
-                    for (int pa = 2 - pb; pa >= 0; pa--)
+                    for (int pa = NP - 1 - pb; pa >= 0; pa--)
                         acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa], bw, acc[tap], 0, 0, 0);
                 }
             }
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
 // split-bf16 arithmetic; workgroup tile (64 WA) x (64 WB) channels, every wave WA x WB tiles of 32 x 32; K chunk = 32
 // consecutive pixels of one image (P*Q % 32 == 0).  Both operands are split and stored as [piece][channel][32 px]
 // (row pitch 40 bf16).  The shape is bandwidth-bound: 2 x 64 x (WA + WB) x 32 floats per 32 x (64 WA)(64 WB) MACs.
-template <int WA, int WB>
+template <int WA, int WB, int NP>
 __global__ __launch_bounds__(256, 2) void conv_wgrad1x1_bf16x6_kernel(WgradParams p) {
     constexpr int SP = 40;
     constexpr int TA = 64 * WA, TB = 64 * WB;
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1x1_bf16x6_kernel(WgradParam
     constexpr int UA = TA * 4 / 256, UB = TB * 4 / 256;             // (channel, 8-pixel group) units per thread
     extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
     __bf16* Ss = smem16;                            // [3][TA][SP]
-    __bf16* Ls = smem16 + 3 * A_PIECE;              // [3][TB][SP]
+    __bf16* Ls = smem16 + NP * A_PIECE;             // [NP][TB][SP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wa = wave >> 1, wb = wave & 1;
@@ -403,17 +412,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1x1_bf16x6_kernel(WgradParam
             f32x2 v = {vals[2 * j], vals[2 * j + 1]};
             uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
             q1[j] = w;
-            v[0] -= __builtin_bit_cast(float, w << 16);
-            v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
-            w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-            q2[j] = w;
-            v[0] -= __builtin_bit_cast(float, w << 16);
-            v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
-            q3[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+            if constexpr (NP >= 2) {
+                v[0] -= __builtin_bit_cast(float, w << 16);
+                v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
+                w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+                q2[j] = w;
+            }
+            if constexpr (NP >= 3) {
+                v[0] -= __builtin_bit_cast(float, w << 16);
+                v[1] -= __builtin_bit_cast(float, w & 0xffff0000u);
+                q3[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+            }
         }
         *(uint4*)(dst) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
-        *(uint4*)(dst + piece_stride) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
-        *(uint4*)(dst + 2 * piece_stride) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+        if constexpr (NP >= 2) *(uint4*)(dst + piece_stride) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+        if constexpr (NP >= 3) *(uint4*)(dst + 2 * piece_stride) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
     };
     auto stash = [&]() {
 #pragma unroll
@@ -448,16 +461,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1x1_bf16x6_kernel(WgradParam
         for (int s = 0; s < 2; s++) {
             bf16x8 af[WA][3], bf[WB][3];
 #pragma unroll
-            for (int pc = 0; pc < 3; pc++) {
+            for (int pc = 0; pc < NP; pc++) {
 #pragma unroll
                 for (int a = 0; a < WA; a++) af[a][pc] = *(const bf16x8*)&Ss[pc * A_PIECE + ((wa * WA + a) * 32 + jl) * SP + 16 * s + 8 * hl];
 #pragma unroll
                 for (int b = 0; b < WB; b++) bf[b][pc] = *(const bf16x8*)&Ls[pc * B_PIECE + ((wb * WB + b) * 32 + jl) * SP + 16 * s + 8 * hl];
             }
 #pragma unroll
-            for (int pb = 2; pb >= 0; pb--)             // smallest terms first
+            for (int pb = NP - 1; pb >= 0; pb--)        // smallest terms first
 #pragma unroll
-                for (int pa = 2 - pb; pa >= 0; pa--)
+                for (int pa = NP - 1 - pb; pa >= 0; pa--)
 #pragma unroll
                     for (int a = 0; a < WA; a++)
 #pragma unroll

@@ -23,7 +23,7 @@ enabled = True                      # Kept for API compatibility; the HIP path i
 # Matrix-core arithmetic of the convolutions (include/pasta_hip.h PASTA_MATH_*): 'bf16x6' (default; split-bf16 with
 # fp32-equivalent products) or 'f32' (fp32 MFMA, bit-exact fp32 FMA chains). Overridable with PASTA_CONV_MATH.
 import os as _os
-MATH_CODES = {'default': 0, 'f32': 1, 'bf16x6': 2}
+MATH_CODES = {'default': 0, 'f32': 1, 'bf16x6': 2, 'bf16x3': 3, 'bf16': 4}
 conv_math = _os.environ.get('PASTA_CONV_MATH', 'default')
 assert conv_math in MATH_CODES, f'PASTA_CONV_MATH must be one of {sorted(MATH_CODES)}'
 weight_gradients_disabled = False   # Forcefully disable computation of gradients with respect to the weights.

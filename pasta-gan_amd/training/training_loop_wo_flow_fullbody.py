@@ -115,6 +115,12 @@ class TrainingStep:
         assert batch_size % (batch_gpu * num_gpus) == 0
         np.random.seed(random_seed * num_gpus + rank)
         torch.manual_seed(random_seed * num_gpus + rank)
+        # allow_tf32 (training_loop_wo_flow_fullbody.py:243, 253-254; default False): the reference lets cuDNN / cuBLAS round
+        # operands to TF32.  gfx950 has no TF32 matrix instructions; the counterpart here is the three-product split-bf16
+        # arithmetic (2^-16 relative, against TF32's 2^-11) at half of the default mode's matrix work.
+        if cfg.get('allow_tf32', False):
+            from torch_utils.ops import conv2d_gradfix
+            conv2d_gradfix.conv_math = 'bf16x3'
 
         self.G = dnnlib.util.construct_class_by_name(**cfg.G_kwargs).train().requires_grad_(False).to(device)
         self.D = dnnlib.util.construct_class_by_name(**cfg.D_kwargs).train().requires_grad_(False).to(device)

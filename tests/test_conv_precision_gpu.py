@@ -184,3 +184,64 @@ def test_pointwise_weight_gradient_split_bf16(n, cin, cout, hw):
     kernel = ctypes.c_int()
     custom_ops.get_plugin().pasta_conv2d_wgrad_plan(ctypes.byref(desc), ctypes.byref(kernel))
     assert kernel.value == (4 if hw * hw % 32 == 0 else 0)       # 4 x 4 planes stay on the fp32 kernel
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Opt-in reduced-product modes (PASTA_MATH_BF16X3 = the counterpart of the reference's allow_tf32, PASTA_MATH_BF16 = plain
+# bf16 operands).  Same kernels with fewer pieces per operand; the bounds are those of the arithmetic: dropped terms of
+# relative size 2^-16 (three of them) resp. operand rounding of 2^-9, over K random-sign products.
+
+REDUCED = {'bf16x3': (2e-5, 1.5e-7), 'bf16': (6e-3, 2e-4)}    # mode: (upper bound, lower bound) on the rms relative error (the six-product mode measures 2-5e-8)
+
+
+def _conv_case(kind):
+    g = torch.Generator().manual_seed(11)
+    if kind == 'rows':        # 3x3 stride 1, 32-multiple width: row-reuse kernel forward / input gradient, 3x3 weight-gradient kernel
+        return torch.randn([8, 128, 32, 32], generator=g), torch.randn([128, 128, 3, 3], generator=g) / 34, dict(padding=1)
+    if kind == 'base':        # width 24: the base forward kernel; fp32 weight-gradient kernel
+        return torch.randn([8, 64, 24, 24], generator=g), torch.randn([160, 64, 3, 3], generator=g) / 24, dict(padding=1)
+    if kind == 'stride2':     # base forward kernel on a stride-2 lattice, stride-2 weight-gradient kernel
+        return torch.randn([8, 64, 65, 65], generator=g), torch.randn([128, 64, 3, 3], generator=g) / 24, dict(stride=2)
+    if kind == 'pointwise':   # 1x1: base forward kernel, 1x1 weight-gradient kernel
+        return torch.randn([8, 192, 32, 32], generator=g), torch.randn([128, 192, 1, 1], generator=g) / 14, dict()
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize('kind', ['rows', 'base', 'stride2', 'pointwise'])
+@pytest.mark.parametrize('mode', ['bf16x3', 'bf16'])
+def test_reduced_product_modes(kind, mode):
+    from torch_utils.ops import conv2d_gradfix as cg
+    x, w, kw = _conv_case(kind)
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y64 = torch.nn.functional.conv2d(x64, w64, **kw)
+    dy = torch.randn(y64.shape, generator=torch.Generator().manual_seed(12))
+    rx, rw = torch.autograd.grad(y64, [x64, w64], dy.double())
+    old = cg.conv_math
+    cg.conv_math = mode
+    try:
+        xg, wg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+        y = cg.conv2d(xg, wg, **kw)
+        gx, gw = torch.autograd.grad(y, [xg, wg], dy.cuda())
+    finally:
+        cg.conv_math = old
+    hi, lo = REDUCED[mode]
+    for name, got, ref in [('y', y, y64.detach()), ('dx', gx, rx), ('dw', gw, rw)]:
+        err = float((got.detach().double().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+        print(kind, mode, name, f'{err:.2e}')
+        assert err < hi, (kind, mode, name, err)
+        if not (kind == 'base' and name in ('dx', 'dw')):      # those two run on fp32 kernels in every mode (64 output channels on few pixels; 24-pixel rows)
+            assert err > lo, (kind, mode, name, err, 'suspiciously exact: did the mode reach the kernel?')
+
+
+def test_plan_reports_the_reduced_modes():
+    import ctypes
+    from torch_utils import custom_ops
+    from torch_utils.ops import _native
+    lib = _native.lib()
+    for mode, code in [('bf16x6', 2), ('bf16x3', 3), ('bf16', 4)]:
+        d = custom_ops.ConvDesc(N=16, C_in=128, H=128, W=128, C_out=128, OH=128, OW=128, kh=3, kw=3, stride=1, pad_h=1, pad_w=1,
+                                groups=1, transposed=0, flip=0, math=code, wscale=1.0)
+        tile, ks, math, launches, kernel = (ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int())
+        _native.check(lib.pasta_conv2d_plan(ctypes.byref(d), 0, ctypes.byref(tile), ctypes.byref(ks), ctypes.byref(math),
+                                            ctypes.byref(launches), ctypes.byref(kernel)))
+        assert math.value == code and kernel.value == 2       # the row-reuse kernel in every split mode

@@ -175,3 +175,37 @@ def test_ada_controller_moves_p_like_the_reference():
     assert p_host != 0.3
     for prm in list(step.G.parameters()) + list(step.D.parameters()):
         assert bool(torch.isfinite(prm).all())
+
+
+def test_allow_tf32_selects_the_three_product_arithmetic():
+    """allow_tf32 (training_loop_wo_flow_fullbody.py:243, 253-254): the counterpart here is PASTA_MATH_BF16X3; a step in that
+    mode lands within 1e-3 of the default step's parameters after one iteration (the north-star parity bar)."""
+    from torch_utils.ops import conv2d_gradfix
+    from training.training_loop_wo_flow_fullbody import TrainingStep, fashion_config
+
+    class Batch:
+        def __init__(self, inp):
+            self.inp = inp
+        def split(self, n):
+            keys = [k for k in self.inp if k != 'gen_z']
+            return [{k: self.inp[k][i:i + n] for k in keys} for i in range(0, BATCH, n)]
+
+    old = conv2d_gradfix.conv_math
+    try:
+        logs = {}
+        for allow in (False, True):
+            conv2d_gradfix.conv_math = 'default'
+            cfg = fashion_config(channel_base=2048)
+            cfg.allow_tf32 = allow
+            log = {}
+            cfg.loss_kwargs.report_fn = lambda name, value, log=log: log.__setitem__(name, value.detach().float().mean().item())
+            step = TrainingStep(torch.device('cuda'), cfg=cfg, num_gpus=1, rank=0, batch_size=BATCH, batch_gpu=BATCH)
+            assert conv2d_gradfix.conv_math == ('bf16x3' if allow else 'default')
+            prepare(step.G, step.D)
+            step.run(Batch(_batch()))
+            logs[allow] = log
+        for k, v in logs[False].items():
+            assert abs(logs[True][k] - v) <= 1e-3 * max(abs(v), 1e-3), (k, v, logs[True][k])
+        assert any(logs[True][k] != v for k, v in logs[False].items())        # the arithmetic really differed
+    finally:
+        conv2d_gradfix.conv_math = old
