@@ -198,7 +198,7 @@ def test_allow_tf32_selects_the_three_product_arithmetic():
             cfg = fashion_config(channel_base=2048)
             cfg.allow_tf32 = allow
             log = {}
-            cfg.loss_kwargs.report_fn = lambda name, value, log=log: log.__setitem__(name, value.detach().float().mean().item())
+            cfg.loss_kwargs.report_fn = lambda name, value, log=log: log.__setitem__(name, torch.as_tensor(value).detach().float().mean().item())
             step = TrainingStep(torch.device('cuda'), cfg=cfg, num_gpus=1, rank=0, batch_size=BATCH, batch_gpu=BATCH)
             assert conv2d_gradfix.conv_math == ('bf16x3' if allow else 'default')
             prepare(step.G, step.D)
