@@ -166,6 +166,12 @@ typedef struct pasta_conv_epilogue {
     const float* bias;            /* [C_out] or NULL */
     int32_t act;
     float alpha, gain, clamp;
+    const float* res;             /* [N, C_out, OH, OW] added to the convolution BEFORE bias / activation, or NULL
+                                     (residual sums and the halves of a convolution over a channel concatenation without a
+                                     pass of their own).  Measured on the two uses this path offers -- merge_conv over
+                                     torch.cat (networks.py:5690-5693) as two 1x1 convolutions, and the SPADE block's
+                                     y + conv(x) (:5273) -- it is time-neutral (+0.4 % / 0.0 %), so the networks keep the
+                                     reference's formulation and the operand stays an option of the operator. */
 } pasta_conv_epilogue;
 
 /* pasta_conv2d with the epilogue above (ep NULL = plain pasta_conv2d). */

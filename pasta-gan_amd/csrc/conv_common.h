@@ -38,6 +38,7 @@ struct ConvFwdParams {
     int o_tiles;                          // output-channel tiles (blockIdx.y = ks * o_tiles + tile)
     int bf16x6;                           // weights packed as split-bf16 pieces, run conv_fwd_bf16x6_kernel
     const float* bias;                    // fused epilogue (pasta_conv_epilogue); act == 0: none
+    const float* res;                     // [N, Cout, OH, OW] added before bias / activation, or null
     int act;
     float alpha, gain, clamp;
     int tap_dy[MAX_TAPS], tap_dx[MAX_TAPS], tap_slab[MAX_TAPS];     // int so that a wave-uniform index reads them with s_load_dword

@@ -293,8 +293,9 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
         const int n = (int)(pix / (P * Q));
         const int rem = (int)(pix - (int64_t)n * P * Q);
         const int pp = rem / Q, qq = rem - pp * Q;
-        float* yb = (p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW : p.y) +
-                    ((int64_t)n * p.Cout + (int64_t)g * p.Og) * OHW + (oy0 + pp * p.osy) * p.OW + ox0 + qq * p.osx;
+        const int64_t yoff = ((int64_t)n * p.Cout + (int64_t)g * p.Og) * OHW + (oy0 + pp * p.osy) * p.OW + ox0 + qq * p.osx;
+        float* yb = (p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW : p.y) + yoff;
+        const float* rb = (p.res && p.ksplit == 1) ? p.res + yoff : nullptr;
         const float* osb = (p.oscale && p.ksplit == 1) ? p.oscale + (int64_t)n * p.Cout + (int64_t)g * p.Og : nullptr;
 #pragma unroll
         for (int a = 0; a < WMT; a++)
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
                 if (o < p.Og) {
                     float v = acc[a][b][r];
                     if (osb) v *= osb[o];
+                    if (rb) v += rb[(int64_t)o * OHW];
                     if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
                     yb[(int64_t)o * OHW] = v;
                 }
@@ -619,8 +621,9 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
         const int n = (int)(pix / (P * Q));
         const int rem = (int)(pix - (int64_t)n * P * Q);
         const int pp = rem / Q, qq = rem - pp * Q;
-        float* yb = (p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW : p.y) +
-                    ((int64_t)n * p.Cout + (int64_t)g * p.Og) * OHW + (oy0 + pp * p.osy) * p.OW + ox0 + qq * p.osx;
+        const int64_t yoff = ((int64_t)n * p.Cout + (int64_t)g * p.Og) * OHW + (oy0 + pp * p.osy) * p.OW + ox0 + qq * p.osx;
+        float* yb = (p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW : p.y) + yoff;
+        const float* rb = (p.res && p.ksplit == 1) ? p.res + yoff : nullptr;
         const float* osb = (p.oscale && p.ksplit == 1) ? p.oscale + (int64_t)n * p.Cout + (int64_t)g * p.Og : nullptr;
 #pragma unroll
         for (int a = 0; a < WMT; a++)
@@ -630,6 +633,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
                 if (o < p.Og) {
                     float v = acc[a][b][r];
                     if (osb) v *= osb[o];
+                    if (rb) v += rb[(int64_t)o * OHW];
                     if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
                     yb[(int64_t)o * OHW] = v;
                 }

@@ -179,8 +179,9 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_kernel(ConvFwdParams p) {
         const int n = (int)(pix / (p.P * p.Q));
         const int rem = (int)(pix - (int64_t)n * p.P * p.Q);
         const int pp = rem / p.Q, qq = rem - pp * p.Q;
-        float* yb = (p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW : p.y) +
-                    ((int64_t)n * p.Cout + (int64_t)g * p.Og) * OHW + (p.oy0 + pp * p.osy) * p.OW + p.ox0 + qq * p.osx;
+        const int64_t yoff = ((int64_t)n * p.Cout + (int64_t)g * p.Og) * OHW + (p.oy0 + pp * p.osy) * p.OW + p.ox0 + qq * p.osx;
+        float* yb = (p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW : p.y) + yoff;
+        const float* rb = (p.res && p.ksplit == 1) ? p.res + yoff : nullptr;
         const float* osb = (p.oscale && p.ksplit == 1) ? p.oscale + (int64_t)n * p.Cout + (int64_t)g * p.Og : nullptr;
 #pragma unroll
         for (int a = 0; a < WMT; a++)
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_kernel(ConvFwdParams p) {
                 if (o < p.Og) {
                     float v = acc[a][b][r];
                     if (osb) v *= osb[o];
+                    if (rb) v += rb[(int64_t)o * OHW];
                     if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
                     yb[(int64_t)o * OHW] = v;
                 }

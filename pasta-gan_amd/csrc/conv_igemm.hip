@@ -60,7 +60,7 @@ static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ y,
                                                             const float* __restrict__ oscale, int64_t numel, int ohw, int ksplit,
                                                             const float* __restrict__ bias, int cout, int act, float alpha, float gain,
-                                                            float clamp) {
+                                                            float clamp, const float* __restrict__ res) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
         float v = 0.f;
         int k = 0;
@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         for (; k < ksplit; k++) v += partial[(int64_t)k * numel + i];
         const int64_t nc = i / ohw;
         if (oscale) v *= oscale[nc];
+        if (res) v += res[i];
         if (act) v = conv_epilogue(v, bias ? bias[nc % cout] : 0.f, act, alpha, gain, clamp);
         y[i] = v;
     }
@@ -262,7 +263,7 @@ extern "C" int pasta_conv2d_ex(const float* x, const float* w, float* y, const f
     const FwdTile tile = plan.tile;
     p.Ig_pad = round_up(p.Ig, fwd_ipad(p.Ig, tile)); p.Og_pad = round_up(p.Og, fwd_tile_bm(tile));
     p.KK = d->kh * d->kw;
-    p.bias = ep ? ep->bias : nullptr; p.act = ep ? ep->act : 0;
+    p.bias = ep ? ep->bias : nullptr; p.act = ep ? ep->act : 0; p.res = ep ? ep->res : nullptr;
     p.alpha = ep ? ep->alpha : 0.f; p.gain = ep ? ep->gain : 1.f; p.clamp = ep ? ep->clamp : -1.f;
     p.ksplit = plan.ksplit;
     p.o_tiles = 1;
@@ -336,7 +337,7 @@ extern "C" int pasta_conv2d_ex(const float* x, const float* w, float* y, const f
         int64_t blocks = ceil_div64(numel, 256);
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)p.partial, y, oscale, numel,
-                           d->OH * d->OW, p.ksplit, p.bias, d->C_out, p.act, p.alpha, p.gain, p.clamp);
+                           d->OH * d->OW, p.ksplit, p.bias, d->C_out, p.act, p.alpha, p.gain, p.clamp, p.res);
     }
     return launch_status("conv2d");
 }

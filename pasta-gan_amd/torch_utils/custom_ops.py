@@ -105,7 +105,7 @@ class ConvDesc(ctypes.Structure):
 
 class ConvEpilogue(ctypes.Structure):
     """Mirror of ``pasta_conv_epilogue`` (include/pasta_hip.h)."""
-    _fields_ = [('bias', _c_ptr), ('act', _c_i32), ('alpha', _c_f32), ('gain', _c_f32), ('clamp', _c_f32)]
+    _fields_ = [('bias', _c_ptr), ('act', _c_i32), ('alpha', _c_f32), ('gain', _c_f32), ('clamp', _c_f32), ('res', _c_ptr)]
 
 class AdaConfig(ctypes.Structure):
     """Mirror of ``pasta_ada_config`` (include/pasta_hip.h)."""

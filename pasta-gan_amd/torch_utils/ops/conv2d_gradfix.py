@@ -77,7 +77,8 @@ def _f32(t):
 
 def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None):
     """y = conv(x * iscale[n,c]) * oscale[n,c'] through ``pasta_conv2d_ex``; fp32 arithmetic.
-    ``epilogue`` = (bias or None, act code 1..3, alpha, gain, clamp) fuses Conv2dLayer's bias_act into the store."""
+    ``epilogue`` = (bias or None, act code 1..3, alpha, gain, clamp[, residual or None]) fuses Conv2dLayer's bias_act into the
+    store; the residual ([N, C_out, OH, OW]) is added to the convolution before the bias."""
     _native.require_gpu(x, 'conv2d')
     if x.ndim != 4 or w.ndim != 4:
         raise RuntimeError('conv2d: x and w must be rank 4')
@@ -113,10 +114,15 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None):
         assert oscale.shape == (x.shape[0], c_out)
     ep = None
     if epilogue is not None:
-        bias, act_code, alpha, gain, clamp = epilogue
+        bias, act_code, alpha, gain, clamp = epilogue[:5]
+        res = epilogue[5] if len(epilogue) > 5 else None
         bias = _f32(bias).contiguous() if bias is not None else None
+        if res is not None:
+            res = _f32(res).contiguous()
+            if res.shape != y.shape:
+                raise RuntimeError(f'conv2d: residual {tuple(res.shape)} does not match the output {tuple(y.shape)}')
         ep = custom_ops.ConvEpilogue(bias=bias.data_ptr() if bias is not None else None, act=int(act_code), alpha=float(alpha),
-                                     gain=float(gain), clamp=float(clamp))
+                                     gain=float(gain), clamp=float(clamp), res=res.data_ptr() if res is not None else None)
     def launch():
         with torch.cuda.device(x.device):
             st = lib.pasta_conv2d_ex(_native.ptr(x), _native.ptr(w), _native.ptr(y), _native.ptr(iscale), _native.ptr(oscale),
@@ -194,10 +200,10 @@ class _ConvBiasActHip(torch.autograd.Function):
     The backward is assembled from the stand-alone differentiable pieces (bias_act gradient kernel, input- and
     weight-gradient convolutions), so gradients of any order keep working."""
     @staticmethod
-    def forward(ctx, x, w, b, cfg, act_cfg):
+    def forward(ctx, x, w, b, cfg, act_cfg, res=None):
         act, alpha, gain, clamp = act_cfg
         from . import bias_act as ba
-        y = _launch_conv(x, w, cfg, epilogue=(b, ba.activation_funcs[act].cuda_idx, alpha, gain, clamp))
+        y = _launch_conv(x, w, cfg, epilogue=(b, ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, res))
         # y is needed by the backward only as the activation / clamp mask; a linear, unclamped layer (the residual
         # skips, whose output the blocks then update in place) must not pin it
         keep_y = act != 'linear' or clamp >= 0
@@ -225,13 +231,15 @@ class _ConvBiasActHip(torch.autograd.Function):
             dw = _ConvWgradHip.apply(dz, x, cfg, tuple(w.shape))
         if want_db and db is None:
             db = ba._BiasSum.apply(dz, 1)
-        return dx, dw, db, None, None
+        dres = dz if len(ctx.needs_input_grad) > 5 and ctx.needs_input_grad[5] else None     # the residual enters before the activation
+        return dx, dw, db, None, None, dres
 
 FUSABLE_ACTS = ('linear', 'relu', 'lrelu')
 
-def conv2d_bias_act(input, weight, bias=None, stride=1, padding=0, groups=1, act='linear', alpha=None, gain=None, clamp=None, wgain=1.0):
-    """``bias_act(conv2d(input, weight), bias, act, alpha, gain, clamp)`` in one launch (fp32 GPU tensors,
-    act in FUSABLE_ACTS); other cases run the two ops separately."""
+def conv2d_bias_act(input, weight, bias=None, stride=1, padding=0, groups=1, act='linear', alpha=None, gain=None, clamp=None, wgain=1.0,
+                    residual=None):
+    """``bias_act(conv2d(input, weight) [+ residual], bias, act, alpha, gain, clamp)`` in one launch (fp32 GPU tensors,
+    act in FUSABLE_ACTS); other cases run the ops separately."""
     from . import bias_act as ba
     spec = ba.activation_funcs[act]
     alpha = float(alpha if alpha is not None else spec.def_alpha)
@@ -242,8 +250,10 @@ def conv2d_bias_act(input, weight, bias=None, stride=1, padding=0, groups=1, act
         ph, pw = _pair(padding)
         assert sh == sw
         cfg = _Cfg((False, sh, ph, pw, 0, 0, int(groups), float(wgain)))
-        return _ConvBiasActHip.apply(input, weight, bias, cfg, (act, alpha, gain, clampf))
+        return _ConvBiasActHip.apply(input, weight, bias, cfg, (act, alpha, gain, clampf), residual)
     y = conv2d(input, weight, stride=stride, padding=padding, groups=groups, wgain=wgain)
+    if residual is not None:
+        y = y + residual
     return ba.bias_act(y, bias, act=act, alpha=alpha, gain=gain, clamp=clamp)
 
 class _ConvWgradHip(torch.autograd.Function):

@@ -31,12 +31,13 @@ def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_w
 #----------------------------------------------------------------------------
 
 def conv2d_resample_bias_act(x, w, b=None, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False,
-                             act='linear', alpha=None, gain=None, clamp=None, wgain=1.0):
+                             act='linear', alpha=None, gain=None, clamp=None, wgain=1.0, residual=None):
     """``bias_act(conv2d_resample(x, w, ...), b, act, alpha, gain, clamp)`` -- the body of ``Conv2dLayer.forward``
     (reference training/networks.py:170-179). When the dense convolution is the last step of the resampling
     decomposition (no upsampling), bias / activation / gain / clamp ride in its epilogue; otherwise the two ops run
     one after the other. ``wgain``: the convolution uses ``w * wgain`` (``Conv2dLayer``'s weight gain) without a
-    multiplication kernel of its own."""
+    multiplication kernel of its own.  ``residual`` (extension, shape of the output): added to the convolution before
+    the bias -- also in the epilogue when the convolution is fused."""
     from . import bias_act
     if up == 1 and x.dtype == torch.float32 and x.device.type == 'cuda' and act in conv2d_gradfix.FUSABLE_ACTS:
         out_channels, in_channels_per_group, kh, kw = _get_weight_shape(w)
@@ -50,14 +51,16 @@ def conv2d_resample_bias_act(x, w, b=None, f=None, up=1, down=1, padding=0, grou
         wc = w if flip_weight else w.flip([2, 3])
         if kw == 1 and kh == 1 and down > 1:          # decimate, then the fused 1x1 convolution
             x = upfirdn2d.upfirdn2d(x=x, f=f, down=down, padding=[px0, px1, py0, py1], flip_filter=flip_filter)
-            return conv2d_gradfix.conv2d_bias_act(x, wc, b, groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp, wgain=wgain)
+            return conv2d_gradfix.conv2d_bias_act(x, wc, b, groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp, wgain=wgain, residual=residual)
         if down > 1:                                  # low-pass, then the fused strided convolution
             x = upfirdn2d.upfirdn2d(x=x, f=f, padding=[px0, px1, py0, py1], flip_filter=flip_filter)
-            return conv2d_gradfix.conv2d_bias_act(x, wc, b, stride=down, groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp, wgain=wgain)
+            return conv2d_gradfix.conv2d_bias_act(x, wc, b, stride=down, groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp, wgain=wgain, residual=residual)
         if px0 == px1 and py0 == py1 and px0 >= 0 and py0 >= 0:
-            return conv2d_gradfix.conv2d_bias_act(x, wc, b, padding=[py0, px0], groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp, wgain=wgain)
+            return conv2d_gradfix.conv2d_bias_act(x, wc, b, padding=[py0, px0], groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp, wgain=wgain, residual=residual)
     x = conv2d_resample(x=x, w=w, f=f, up=up, down=down, padding=padding, groups=groups, flip_weight=flip_weight, flip_filter=flip_filter,
                         wgain=wgain)
+    if residual is not None:
+        x = x + residual
     return bias_act.bias_act(x, b, act=act, alpha=alpha, gain=gain, clamp=clamp)
 
 #----------------------------------------------------------------------------

@@ -32,7 +32,7 @@ def _cases(fname):
 def test_native_library_is_loaded():
     from torch_utils.ops import _native
     lib = _native.lib()
-    assert lib.pasta_abi_version() >= 8
+    assert lib.pasta_abi_version() >= 9
     assert b'gfx950' in lib.pasta_build_info()
 
 
@@ -428,3 +428,35 @@ def test_nan_to_num_multi():
     t = torch.tensor([float('nan'), float('inf'), -float('inf'), 1.5], device='cuda')
     misc.nan_to_num_([t])
     assert t[0] == 0 and t[1] == torch.finfo(torch.float32).max and t[2] == -torch.finfo(torch.float32).max and t[3] == 1.5
+
+
+@pytest.mark.parametrize('case', [
+    dict(x=[2, 48, 32, 32], w=[40, 48, 1, 1], kw=dict(), act='lrelu', clamp=0.7),                  # 1x1, 128-pixel rows: split-bf16 base kernel
+    dict(x=[2, 16, 24, 24], w=[24, 16, 3, 3], kw=dict(padding=1), act='linear', clamp=None),       # fp32 tile kernel
+    dict(x=[4, 128, 32, 32], w=[128, 128, 3, 3], kw=dict(padding=1), act='linear', clamp=None),    # row-reuse kernel
+    dict(x=[4, 512, 4, 4], w=[64, 512, 3, 3], kw=dict(padding=1), act='relu', clamp=None),         # split-K reduce epilogue
+])
+def test_conv_residual_epilogue(case):
+    """conv2d_bias_act(..., residual=r) == bias_act(conv(x, w) + r, b): forward, and gradients of x, w, b and r."""
+    from torch_utils.ops import conv2d_gradfix as cg
+    gen = torch.Generator().manual_seed(31)
+    x = torch.randn(case['x'], generator=gen)
+    w = torch.randn(case['w'], generator=gen) / np.sqrt(np.prod(case['w'][1:]))
+    b = torch.randn([case['w'][0]], generator=gen) * 0.1
+    ref_in = [t.double().requires_grad_(True) for t in (x, w, b)]
+    y0 = torch.nn.functional.conv2d(ref_in[0], ref_in[1], **case['kw'])
+    r = torch.randn(y0.shape, generator=gen)
+    r64 = r.double().requires_grad_(True)
+    z = y0 + r64 + ref_in[2].reshape(1, -1, 1, 1)
+    gain = 1.3
+    yr = {'linear': z, 'relu': torch.relu(z), 'lrelu': torch.nn.functional.leaky_relu(z, 0.2)}[case['act']] * gain
+    if case['clamp'] is not None:
+        yr = yr.clamp(-case['clamp'], case['clamp'])
+    dy = torch.randn(yr.shape, generator=gen)
+    gr = torch.autograd.grad(yr, ref_in + [r64], dy.double())
+    xs = [t.cuda().requires_grad_(True) for t in (x, w, b, r)]
+    y = cg.conv2d_bias_act(xs[0], xs[1], xs[2], act=case['act'], gain=gain, clamp=case['clamp'], residual=xs[3], **case['kw'])
+    assert rel_err(y, yr) < TOL
+    g = torch.autograd.grad(y, xs, dy.cuda())
+    for a, ref in zip(g, gr):
+        assert rel_err(a, ref) < 2e-5
