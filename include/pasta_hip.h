@@ -254,6 +254,12 @@ int pasta_ada_theta(const float* g_inv, int64_t n, const float* a, const float* 
 int pasta_color_affine(const float* x, const float* c, float* out, int64_t n, int64_t hw, int mode, void* stream);
 /* grid[n, y, x, :] = theta[n] @ ((2x + 1) / W - 1, (2y + 1) / H - 1, 1): F.affine_grid(theta, [n, C, H, W], align_corners=False) (:297) */
 int pasta_ada_grid(const float* theta, int64_t n, int H, int W, float* grid, void* stream);
+/* y = grid_sample(x, affine_grid(theta, [n, C, OH, OW], align_corners=False), bilinear, zeros, align_corners=False)
+ * (augment.py:297-298) without the grid tensor; x: [n, C, IH, IW], theta: [n, 2, 3].  The adjoint is the gradient with
+ * respect to x, computed as a gather (no atomics: bitwise reproducible). */
+int pasta_affine_sample(const float* x, const float* theta, float* y, int64_t n, int C, int IH, int IW, int OH, int OW, void* stream);
+int pasta_affine_sample_adjoint(const float* dy, const float* theta, float* dx, int64_t n, int C, int IH, int IW, int OH, int OW,
+                                void* stream);
 
 /* nan_to_num(t, nan, posinf, neginf) in place over n float tensors in one launch per 96 tensors
  * (training_loop_wo_flow_fullbody.py:513-515; misc.py:45).  ptrs / numels: HOST arrays of device pointers / element

@@ -151,6 +151,8 @@ ABI = {
     'pasta_ada_theta':    (ctypes.c_int, [_c_ptr, _c_i64, ctypes.POINTER(_c_f32), ctypes.POINTER(_c_f32), _c_ptr, _c_ptr]),
     'pasta_color_affine': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, ctypes.c_int, _c_ptr]),
     'pasta_ada_grid':     (ctypes.c_int, [_c_ptr, _c_i64, ctypes.c_int, ctypes.c_int, _c_ptr, _c_ptr]),
+    'pasta_affine_sample': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64] + [ctypes.c_int] * 5 + [_c_ptr]),
+    'pasta_affine_sample_adjoint': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64] + [ctypes.c_int] * 5 + [_c_ptr]),
     'pasta_nan_to_num_multi': (ctypes.c_int, [ctypes.POINTER(_c_ptr), ctypes.POINTER(_c_i64), ctypes.c_int, _c_f32, _c_f32, _c_f32, _c_ptr]),
 }
 

@@ -51,3 +51,59 @@ class _SampleAdjoint(torch.autograd.Function):
         grid, = ctx.saved_tensors
         ddy = _Sample.apply(ddx, grid) if ctx.needs_input_grad[0] else None
         return ddy, None, None
+
+
+#----------------------------------------------------------------------------
+# The affine special case on this package's own kernels (ADA's geometric step, training/augment.py).
+
+def affine_sample(x, theta, out_hw):
+    """``grid_sample(x, affine_grid(theta, [N, C, *out_hw], align_corners=False))`` (bilinear, zero padding) without the
+    grid tensor, differentiable to any order in ``x``: forward ``pasta_affine_sample``; gradient ``pasta_affine_sample_adjoint``,
+    a gather over the output lattice points whose footprint covers an input pixel (no atomics); the gradient of the
+    gradient is the forward again."""
+    return _AffineSample.apply(x, theta, (int(out_hw[0]), int(out_hw[1])))
+
+def _affine_launch(name, src, theta, dst_shape, in_hw, out_hw):
+    from . import _native
+    _native.require_gpu(src, name)
+    if src.dtype != torch.float32 or theta.dtype != torch.float32:
+        raise RuntimeError(f'{name}: float32 only')
+    n, c = src.shape[0], src.shape[1]
+    if theta.shape != (n, 2, 3):
+        raise RuntimeError(f'{name}: theta must be [{n}, 2, 3], got {tuple(theta.shape)}')
+    src, theta = src.contiguous(), theta.contiguous()
+    dst = torch.empty(dst_shape, dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        st = getattr(_native.lib(), name)(_native.ptr(src), _native.ptr(theta), _native.ptr(dst), n, c, in_hw[0], in_hw[1], out_hw[0], out_hw[1],
+                                          _native.stream())
+    _native.check(st)
+    return dst
+
+class _AffineSample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, theta, out_hw):
+        assert x.ndim == 4
+        ctx.save_for_backward(theta)
+        ctx.in_hw, ctx.out_hw = (x.shape[2], x.shape[3]), out_hw
+        return _affine_launch('pasta_affine_sample', x, theta, [x.shape[0], x.shape[1], *out_hw], ctx.in_hw, out_hw)
+
+    @staticmethod
+    def backward(ctx, dy):
+        theta, = ctx.saved_tensors
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError('affine_sample: no gradient with respect to theta')
+        dx = _AffineSampleAdjoint.apply(dy, theta, ctx.in_hw) if ctx.needs_input_grad[0] else None
+        return dx, None, None
+
+class _AffineSampleAdjoint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dy, theta, in_hw):
+        ctx.save_for_backward(theta)
+        ctx.in_hw, ctx.out_hw = in_hw, (dy.shape[2], dy.shape[3])
+        return _affine_launch('pasta_affine_sample_adjoint', dy, theta, [dy.shape[0], dy.shape[1], *in_hw], in_hw, ctx.out_hw)
+
+    @staticmethod
+    def backward(ctx, ddx):
+        theta, = ctx.saved_tensors
+        ddy = _AffineSample.apply(ddx, theta, ctx.out_hw) if ctx.needs_input_grad[0] else None
+        return ddy, None, None

@@ -12,7 +12,8 @@ image operations, arranged for the GPU instead of a long chain of tiny tensor op
   point, augment.py:282); the pad / 2x upsampling / sampling-grid bookkeeping matrices are then host constants and fold
   into one more tiny launch (``pasta_ada_theta``);
 * 2x upsampling and the final 2x decimation run on the HIP ``upfirdn2d`` (separable 12-tap ``sym6``), the bilinear
-  resampling on ``grid_sample_gradfix``, the colour transform on ``pasta_color_affine`` (one pass over the images).
+  resampling on ``grid_sample_gradfix.affine_sample`` (``pasta_affine_sample``: no grid tensor; its gradient is a gather,
+  free of atomics), the colour transform on ``pasta_color_affine`` (one pass over the images).
 
 There is no CPU path: the CPU restatement the parity tests use is ``oracle/ref_augment.py``.
 """
@@ -189,12 +190,7 @@ class AugmentPipe(torch.nn.Module):
             with torch.cuda.device(device):
                 st = _native.lib().pasta_ada_theta(_native.ptr(G_inv), batch_size, a9, b9, _native.ptr(theta), _native.stream())
             _native.check(st)
-            # affine_grid(theta, [N, C, out_h, out_w], align_corners=False) as one elementwise launch (ATen builds it with a batched GEMM)
-            grid = torch.empty([batch_size, out_h, out_w, 2], device=device)
-            with torch.cuda.device(device):
-                st = _native.lib().pasta_ada_grid(_native.ptr(theta), batch_size, out_h, out_w, _native.ptr(grid), _native.stream())
-            _native.check(st)
-            images = grid_sample_gradfix.grid_sample(images, grid)
+            images = grid_sample_gradfix.affine_sample(images, theta, (out_h, out_w))    # no grid tensor; gather adjoint, no atomics
             images = upfirdn2d.downsample2d(x=images, f=self.Hz_geom, down=2, padding=-hz_pad * 2, flip_filter=True)
 
         if color:           # augment.py:354-364

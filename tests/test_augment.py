@@ -179,3 +179,34 @@ def test_sampling_grid_kernel_matches_affine_grid(hw):
     _native.check(_native.lib().pasta_ada_grid(_native.ptr(theta), 5, H, W, _native.ptr(grid), _native.stream()))
     ref = torch.nn.functional.affine_grid(theta.double(), [5, 3, H, W], align_corners=False)
     assert rel_err(grid, ref) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [dict(n=3, c=3, ih=40, iw=52, oh=36, ow=44), dict(n=2, c=5, ih=17, iw=9, oh=23, ow=31), dict(n=1, c=1, ih=64, iw=64, oh=8, ow=8)])
+def test_affine_sample_matches_grid_sample(case):
+    """affine_sample == grid_sample(affine_grid(theta)): values, the gather adjoint against autograd's scatter, and the second
+    derivative; maps include rotation, anisotropic scale, a strong zoom-out (many samples per input pixel) and a zoom-in."""
+    from torch_utils.ops import grid_sample_gradfix as gs
+    n, c = case['n'], case['c']
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn([n, c, case['ih'], case['iw']], generator=gen)
+    maps = torch.tensor([[[0.9, 0.35, 0.05], [-0.3, 1.1, -0.1]], [[2.6, 0.4, 0.2], [0.1, 2.2, 0.0]], [[0.3, -0.1, 0.4], [0.05, 0.25, -0.3]]])
+    theta = maps[torch.arange(n) % 3]
+    dy = torch.randn([n, c, case['oh'], case['ow']], generator=gen)
+    x64 = x.double().requires_grad_(True)
+    grid = torch.nn.functional.affine_grid(theta.double(), [n, c, case['oh'], case['ow']], align_corners=False)
+    yr = torch.nn.functional.grid_sample(x64, grid, mode='bilinear', padding_mode='zeros', align_corners=False)
+    gr, = torch.autograd.grad(yr, x64, dy.double())
+    xg = x.cuda().requires_grad_(True)
+    y = gs.affine_sample(xg, theta.cuda(), (case['oh'], case['ow']))
+    assert rel_err(y, yr) < 1e-5
+    dyg = dy.cuda().requires_grad_(True)
+    g, = torch.autograd.grad(y, xg, dyg, create_graph=True)
+    assert rel_err(g, gr) < 1e-5
+    e = torch.randn(x.shape, generator=gen)
+    dd, = torch.autograd.grad(g, dyg, e.cuda())            # d/d(dy) of S^T dy contracted with e = S e
+    er = torch.nn.functional.grid_sample(e.double(), grid, mode='bilinear', padding_mode='zeros', align_corners=False)
+    assert rel_err(dd, er) < 1e-5
+    # the adjoint identity <S x, dy> = <x, S^T dy> in the kernels' own arithmetic
+    lhs, rhs = float((y.detach().double() * dy.cuda().double()).sum()), float((xg.detach().double() * g.detach().double()).sum())
+    assert abs(lhs - rhs) < 1e-5 * max(abs(lhs), 1.0)

@@ -32,7 +32,7 @@ def _cases(fname):
 def test_native_library_is_loaded():
     from torch_utils.ops import _native
     lib = _native.lib()
-    assert lib.pasta_abi_version() >= 9
+    assert lib.pasta_abi_version() >= 10
     assert b'gfx950' in lib.pasta_build_info()
 
 
