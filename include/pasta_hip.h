@@ -222,14 +222,18 @@ int pasta_mod_bias_act_bwd(const float* dy, const float* y, const float* u, cons
  * Optional fused activation (act = 2): out = min(relu(out) * gain, clamp) -- what the Spade_Conv2dLayer that
  * consumes the block's output applies in front of its convolution (networks.py:4346-4352); act 0/1 = none,
  * clamp < 0 = none.  The backward then needs beta (to recompute the activation mask) and a dbeta buffer.
+ * gamma and beta (and dgamma, dbeta) may be the two channel halves of ONE [N, 2C, H, W] tensor -- the output (gradient) of a
+ * single convolution with the concatenated conv_gamma / conv_beta weights: C = channels of x, gb_stride / dgb_stride = the
+ * distance in elements between consecutive samples of gamma (dgamma), 0 = C * HW (separate contiguous tensors).
  * ------------------------------------------------------------------------- */
 int pasta_spade_norm(const float* x, const float* gamma, const float* beta,
                      float* out, float* stats, int64_t planes, int64_t HW,
-                     float eps, int act, float gain, float clamp, void* stream);
+                     float eps, int act, float gain, float clamp, int C, int64_t gb_stride, void* stream);
 int pasta_spade_norm_bwd(const float* dout, const float* x, const float* gamma,
                          const float* stats, float* dx, float* dgamma,
                          float* dbeta, int64_t planes, int64_t HW,
-                         const float* beta, int act, float gain, float clamp, void* stream);
+                         const float* beta, int act, float gain, float clamp, int C, int64_t gb_stride, int64_t dgb_stride,
+                         void* stream);
 
 /* ------------------------------------------------------------------------- *
  * ADA augmentation (training/augment.py:121-431).

@@ -93,7 +93,7 @@ template <int EPT>   // EPT == 0: generic loops
 __global__ __launch_bounds__(1024) void spade_norm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ out,
                                                           float* __restrict__ stats, int64_t planes, int64_t HW, float eps,
-                                                          int act, float gain, float clamp) {
+                                                          int act, float gain, float clamp, int C, int64_t gb_ns) {
     __shared__ float red[16];
     // optional relu * gain with clamp on the way out (the activation Spade_Conv2dLayer applies before its convolution)
     auto post = [&](float v) {
@@ -104,6 +104,8 @@ __global__ __launch_bounds__(1024) void spade_norm_kernel(const float* __restric
     for (int64_t plane = blockIdx.x; plane < planes; plane += gridDim.x) {
         const float* xp = x + plane * HW;
         const float inv = 1.f / (float)HW;
+        // gamma / beta may be the two channel halves of one [N, 2C, H, W] tensor: sample stride gb_ns instead of C * HW
+        const int64_t gb = (plane / C) * gb_ns + (plane % C) * HW;
         float mean, rstd;
         if constexpr (EPT > 0) {
             float4 r[EPT / 4];
@@ -121,8 +123,8 @@ __global__ __launch_bounds__(1024) void spade_norm_kernel(const float* __restric
 #pragma unroll
             for (int k = 0; k < EPT / 4; k++) {
                 const int64_t i = k * 1024 + tid;
-                float4 g = gamma ? ((const float4*)(gamma + plane * HW))[i] : make_float4(0, 0, 0, 0);
-                float4 b = beta ? ((const float4*)(beta + plane * HW))[i] : make_float4(0, 0, 0, 0);
+                float4 g = gamma ? ((const float4*)(gamma + gb))[i] : make_float4(0, 0, 0, 0);
+                float4 b = beta ? ((const float4*)(beta + gb))[i] : make_float4(0, 0, 0, 0);
                 float4 o;
                 o.x = post(fmaf((r[k].x - mean) * rstd, 1.f + g.x, b.x));
                 o.y = post(fmaf((r[k].y - mean) * rstd, 1.f + g.y, b.y));
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(1024) void spade_norm_kernel(const float* __restric
             for (int64_t i = tid; i < HW; i += 1024) { float d = xp[i] - mean; q += d * d; }
             rstd = rsqrtf(block_sum<1024>(q, red) * inv + eps);
             for (int64_t i = tid; i < HW; i += 1024) {
-                float g = gamma ? gamma[plane * HW + i] : 0.f, b = beta ? beta[plane * HW + i] : 0.f;
+                float g = gamma ? gamma[gb + i] : 0.f, b = beta ? beta[gb + i] : 0.f;
                 out[plane * HW + i] = post(fmaf((xp[i] - mean) * rstd, 1.f + g, b));
             }
         }
@@ -154,7 +156,8 @@ __global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const float* __res
                                                               const float* __restrict__ gamma, const float* __restrict__ stats,
                                                               float* __restrict__ dx, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int64_t planes, int64_t HW,
-                                                              const float* __restrict__ beta, int act, float gain, float clamp) {
+                                                              const float* __restrict__ beta, int act, float gain, float clamp,
+                                                              int C, int64_t gb_ns, int64_t dgb_ns) {
     __shared__ float red[16];
     // gradient through the optional relu * gain / clamp of the forward: v = x_hat * (1 + gamma) + beta is recomputed
     auto pre = [&](float d, float h, float g, float b) {
@@ -169,6 +172,8 @@ __global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const float* __res
         const float mean = stats[2 * plane], rstd = stats[2 * plane + 1];
         const float inv = 1.f / (float)HW;
         const int64_t base = plane * HW;
+        const int64_t gb = (plane / C) * gb_ns + (plane % C) * HW;        // gamma / beta (see the forward kernel)
+        const int64_t dgb = (plane / C) * dgb_ns + (plane % C) * HW;      // dgamma / dbeta
         if constexpr (EPT > 0) {
             float xh[EPT], t[EPT];
             float s1 = 0.f, s2 = 0.f;
@@ -177,8 +182,8 @@ __global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const float* __res
                 const int64_t i = k * 1024 + tid;
                 float4 xv = ((const float4*)(x + base))[i];
                 float4 dv = ((const float4*)(dout + base))[i];
-                float4 gv = gamma ? ((const float4*)(gamma + base))[i] : make_float4(0, 0, 0, 0);
-                float4 bv = (act == 2 && beta) ? ((const float4*)(beta + base))[i] : make_float4(0, 0, 0, 0);
+                float4 gv = gamma ? ((const float4*)(gamma + gb))[i] : make_float4(0, 0, 0, 0);
+                float4 bv = (act == 2 && beta) ? ((const float4*)(beta + gb))[i] : make_float4(0, 0, 0, 0);
                 const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w}, bs[4] = {bv.x, bv.y, bv.z, bv.w};
                 float ds[4] = {dv.x, dv.y, dv.z, dv.w};
                 float dg[4];
@@ -191,8 +196,8 @@ __global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const float* __res
                     dg[j] = ds[j] * h;
                     s1 += tt; s2 += tt * h;
                 }
-                if (dgamma) ((float4*)(dgamma + base))[i] = make_float4(dg[0], dg[1], dg[2], dg[3]);
-                if (dbeta) ((float4*)(dbeta + base))[i] = make_float4(ds[0], ds[1], ds[2], ds[3]);
+                if (dgamma) ((float4*)(dgamma + dgb))[i] = make_float4(dg[0], dg[1], dg[2], dg[3]);
+                if (dbeta) ((float4*)(dbeta + dgb))[i] = make_float4(ds[0], ds[1], ds[2], ds[3]);
             }
             if (dx) {
                 const float m1 = block_sum<1024>(s1, red) * inv, m2 = block_sum<1024>(s2, red) * inv;
@@ -210,18 +215,18 @@ __global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const float* __res
             float s1 = 0.f, s2 = 0.f;
             for (int64_t i = tid; i < HW; i += 1024) {
                 float h = (x[base + i] - mean) * rstd;
-                float d = pre(dout[base + i], h, gamma ? gamma[base + i] : 0.f, (act == 2 && beta) ? beta[base + i] : 0.f);
-                float tt = d * (1.f + (gamma ? gamma[base + i] : 0.f));
+                float d = pre(dout[base + i], h, gamma ? gamma[gb + i] : 0.f, (act == 2 && beta) ? beta[gb + i] : 0.f);
+                float tt = d * (1.f + (gamma ? gamma[gb + i] : 0.f));
                 s1 += tt; s2 += tt * h;
-                if (dgamma) dgamma[base + i] = d * h;
-                if (dbeta) dbeta[base + i] = d;
+                if (dgamma) dgamma[dgb + i] = d * h;
+                if (dbeta) dbeta[dgb + i] = d;
             }
             if (dx) {
                 const float m1 = block_sum<1024>(s1, red) * inv, m2 = block_sum<1024>(s2, red) * inv;
                 for (int64_t i = tid; i < HW; i += 1024) {
                     float h = (x[base + i] - mean) * rstd;
-                    float d = pre(dout[base + i], h, gamma ? gamma[base + i] : 0.f, (act == 2 && beta) ? beta[base + i] : 0.f);
-                    float tt = d * (1.f + (gamma ? gamma[base + i] : 0.f));
+                    float d = pre(dout[base + i], h, gamma ? gamma[gb + i] : 0.f, (act == 2 && beta) ? beta[gb + i] : 0.f);
+                    float tt = d * (1.f + (gamma ? gamma[gb + i] : 0.f));
                     dx[base + i] = rstd * (tt - m1 - h * m2);
                 }
             }
@@ -388,34 +393,42 @@ __global__ __launch_bounds__(256) void nan_to_num_multi_kernel(NanToNumTable tab
 }
 
 extern "C" int pasta_spade_norm(const float* x, const float* gamma, const float* beta, float* out, float* stats,
-                                int64_t planes, int64_t HW, float eps, int act, float gain, float clamp, void* stream) {
+                                int64_t planes, int64_t HW, float eps, int act, float gain, float clamp, int C, int64_t gb_stride,
+                                void* stream) {
     using namespace pasta;
     PASTA_CHECK(x && out, "spade_norm: null pointer");
     PASTA_CHECK(act == 0 || act == 1 || act == 2, "spade_norm: fused activation code %d (0/1 = none, 2 = relu)", act);
     PASTA_CHECK(planes >= 1 && HW >= 1, "spade_norm: empty tensor");
+    PASTA_CHECK(C >= 1 && planes % C == 0, "spade_norm: %lld planes are not whole samples of %d channels", (long long)planes, C);
+    const int64_t gb_ns = gb_stride > 0 ? gb_stride : (int64_t)C * HW;
+    PASTA_CHECK(gb_ns >= (int64_t)C * HW, "spade_norm: gamma / beta sample stride %lld below C * HW", (long long)gb_ns);
     int grid = (int)(planes < 65535 ? planes : 65535);
     hipStream_t s = (hipStream_t)stream;
-    const bool al = (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out) & 15) == 0;
-    if (HW == 16384 && al) hipLaunchKernelGGL((spade_norm_kernel<16>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, stats, planes, HW, eps, act, gain, clamp);
-    else if (HW == 4096 && al) hipLaunchKernelGGL((spade_norm_kernel<4>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, stats, planes, HW, eps, act, gain, clamp);
-    else hipLaunchKernelGGL((spade_norm_kernel<0>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, stats, planes, HW, eps, act, gain, clamp);
+    const bool al = (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out) & 15) == 0 && gb_ns % 4 == 0;
+    if (HW == 16384 && al) hipLaunchKernelGGL((spade_norm_kernel<16>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, stats, planes, HW, eps, act, gain, clamp, C, gb_ns);
+    else if (HW == 4096 && al) hipLaunchKernelGGL((spade_norm_kernel<4>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, stats, planes, HW, eps, act, gain, clamp, C, gb_ns);
+    else hipLaunchKernelGGL((spade_norm_kernel<0>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, stats, planes, HW, eps, act, gain, clamp, C, gb_ns);
     return launch_status("spade_norm");
 }
 
 extern "C" int pasta_spade_norm_bwd(const float* dout, const float* x, const float* gamma, const float* stats, float* dx,
                                     float* dgamma, float* dbeta, int64_t planes, int64_t HW, const float* beta, int act, float gain,
-                                    float clamp, void* stream) {
+                                    float clamp, int C, int64_t gb_stride, int64_t dgb_stride, void* stream) {
     using namespace pasta;
     PASTA_CHECK(dout && x && stats, "spade_norm_bwd: null pointer");
     PASTA_CHECK(act == 0 || act == 1 || act == 2, "spade_norm_bwd: fused activation code %d (0/1 = none, 2 = relu)", act);
     PASTA_CHECK(act != 2 || dbeta || !dgamma, "spade_norm_bwd: dbeta buffer required with a fused activation");
     PASTA_CHECK(planes >= 1 && HW >= 1, "spade_norm_bwd: empty tensor");
+    PASTA_CHECK(C >= 1 && planes % C == 0, "spade_norm_bwd: %lld planes are not whole samples of %d channels", (long long)planes, C);
+    const int64_t gb_ns = gb_stride > 0 ? gb_stride : (int64_t)C * HW, dgb_ns = dgb_stride > 0 ? dgb_stride : (int64_t)C * HW;
+    PASTA_CHECK(gb_ns >= (int64_t)C * HW && dgb_ns >= (int64_t)C * HW, "spade_norm_bwd: sample stride below C * HW");
     int grid = (int)(planes < 65535 ? planes : 65535);
     hipStream_t s = (hipStream_t)stream;
-    const bool al = (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dout | (uintptr_t)dx | (uintptr_t)dgamma | (uintptr_t)dbeta | (uintptr_t)beta) & 15) == 0;
-    if (HW == 16384 && al) hipLaunchKernelGGL((spade_norm_bwd_kernel<16>), dim3(grid), dim3(1024), 0, s, dout, x, gamma, stats, dx, dgamma, dbeta, planes, HW, beta, act, gain, clamp);
-    else if (HW == 4096 && al) hipLaunchKernelGGL((spade_norm_bwd_kernel<4>), dim3(grid), dim3(1024), 0, s, dout, x, gamma, stats, dx, dgamma, dbeta, planes, HW, beta, act, gain, clamp);
-    else hipLaunchKernelGGL((spade_norm_bwd_kernel<0>), dim3(grid), dim3(1024), 0, s, dout, x, gamma, stats, dx, dgamma, dbeta, planes, HW, beta, act, gain, clamp);
+    const bool al = (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dout | (uintptr_t)dx | (uintptr_t)dgamma | (uintptr_t)dbeta | (uintptr_t)beta) & 15) == 0 &&
+                    gb_ns % 4 == 0 && dgb_ns % 4 == 0;
+    if (HW == 16384 && al) hipLaunchKernelGGL((spade_norm_bwd_kernel<16>), dim3(grid), dim3(1024), 0, s, dout, x, gamma, stats, dx, dgamma, dbeta, planes, HW, beta, act, gain, clamp, C, gb_ns, dgb_ns);
+    else if (HW == 4096 && al) hipLaunchKernelGGL((spade_norm_bwd_kernel<4>), dim3(grid), dim3(1024), 0, s, dout, x, gamma, stats, dx, dgamma, dbeta, planes, HW, beta, act, gain, clamp, C, gb_ns, dgb_ns);
+    else hipLaunchKernelGGL((spade_norm_bwd_kernel<0>), dim3(grid), dim3(1024), 0, s, dout, x, gamma, stats, dx, dgamma, dbeta, planes, HW, beta, act, gain, clamp, C, gb_ns, dgb_ns);
     return launch_status("spade_norm_bwd");
 }
 

@@ -51,21 +51,31 @@ def scale_planes(x, s):
 
 class _SpadeModulate(torch.autograd.Function):
     """InstanceNorm(x) * (1 + gamma) + beta with statistics, normalisation and modulation in one
-    kernel (networks.py:4371-4379: InstanceNorm2d(affine=False), eps 1e-5, biased variance)."""
+    kernel (networks.py:4371-4379: InstanceNorm2d(affine=False), eps 1e-5, biased variance).
+    ``beta is None``: ``gamma`` is a [N, 2C, H, W] tensor holding gamma in its first C channels and beta in its last C (the
+    output of ONE convolution with the concatenated conv_gamma / conv_beta weights); its gradient comes back as one tensor,
+    so the two input gradients of that convolution accumulate inside its K loop instead of in an addition pass."""
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, post):
         n, c, h, w = x.shape
-        x, gamma, beta = x.contiguous(), gamma.contiguous(), beta.contiguous()
+        x, gamma = x.contiguous(), gamma.contiguous()
+        fused = beta is None
+        if fused:
+            assert gamma.shape == (n, 2 * c, h, w)
+            beta_ptr, gstride = gamma.data_ptr() + 4 * c * h * w, 2 * c * h * w
+        else:
+            beta = beta.contiguous()
+            beta_ptr, gstride = beta.data_ptr(), 0
         out = torch.empty_like(x)
         stats = torch.empty([n * c, 2], dtype=torch.float32, device=x.device)
         act, gain, clamp = post                     # (2, gain, clamp): relu * gain with clamp on the way out; (0, 1, -1): none
         with torch.cuda.device(x.device):
-            st = _native.lib().pasta_spade_norm(_native.ptr(x), _native.ptr(gamma), _native.ptr(beta), _native.ptr(out),
+            st = _native.lib().pasta_spade_norm(_native.ptr(x), _native.ptr(gamma), beta_ptr, _native.ptr(out),
                                                 _native.ptr(stats), n * c, h * w, float(eps), act, float(gain), float(clamp),
-                                                _native.stream())
+                                                c, gstride, _native.stream())
         _native.check(st)
-        ctx.save_for_backward(x, gamma, stats, beta if act == 2 else None)
-        ctx.post = post
+        ctx.save_for_backward(x, gamma, stats, beta if (act == 2 and not fused) else None)
+        ctx.post, ctx.fused = post, fused
         return out
 
     @staticmethod
@@ -75,6 +85,18 @@ class _SpadeModulate(torch.autograd.Function):
         n, c, h, w = x.shape
         dout = dout.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        lib = _native.lib()
+        if ctx.fused:       # gamma | beta and their gradients as channel halves of one tensor each
+            half = 4 * c * h * w
+            dgb = torch.empty_like(gamma) if ctx.needs_input_grad[1] else None
+            if dx is not None or dgb is not None:
+                with torch.cuda.device(x.device):
+                    st = lib.pasta_spade_norm_bwd(_native.ptr(dout), _native.ptr(x), _native.ptr(gamma), _native.ptr(stats), _native.ptr(dx),
+                                                  _native.ptr(dgb), dgb.data_ptr() + half if dgb is not None else None, n * c, h * w,
+                                                  gamma.data_ptr() + half, act, float(gain), float(clamp), c, 2 * c * h * w, 2 * c * h * w,
+                                                  _native.stream())
+                _native.check(st)
+            return dx, dgb, None, None, None
         dgamma = torch.empty_like(x) if ctx.needs_input_grad[1] else None
         # without a fused activation d/dbeta is dout itself; with one it is dout through the activation, written by the kernel
         dbeta = None
@@ -84,15 +106,16 @@ class _SpadeModulate(torch.autograd.Function):
             dbeta = dout
         if dx is not None or dgamma is not None or act == 2:
             with torch.cuda.device(x.device):
-                st = _native.lib().pasta_spade_norm_bwd(_native.ptr(dout), _native.ptr(x), _native.ptr(gamma), _native.ptr(stats),
-                                                        _native.ptr(dx), _native.ptr(dgamma), _native.ptr(dbeta if act == 2 else None),
-                                                        n * c, h * w, _native.ptr(beta), act, float(gain), float(clamp), _native.stream())
+                st = lib.pasta_spade_norm_bwd(_native.ptr(dout), _native.ptr(x), _native.ptr(gamma), _native.ptr(stats),
+                                              _native.ptr(dx), _native.ptr(dgamma), _native.ptr(dbeta if act == 2 else None),
+                                              n * c, h * w, _native.ptr(beta), act, float(gain), float(clamp), c, 0, 0, _native.stream())
             _native.check(st)
         return dx, dgamma, (dbeta if ctx.needs_input_grad[2] else None), None, None
 
 def spade_modulate(x, gamma, beta, eps=1e-5, relu_gain=None, clamp=None):
     """InstanceNorm(x) * (1 + gamma) + beta; ``relu_gain`` not None additionally applies ``min(relu(.) * relu_gain, clamp)``
-    in the same pass (the activation of the Spade_Conv2dLayer that consumes the result)."""
+    in the same pass (the activation of the Spade_Conv2dLayer that consumes the result).  ``beta=None``: ``gamma`` holds
+    gamma | beta as the two channel halves of a [N, 2C, H, W] tensor."""
     _native.require_gpu(x, 'spade_modulate')
     if x.dtype != torch.float32:
         raise RuntimeError('spade_modulate: float32 only (the generator runs in fp32, networks.py:5747-5748)')
@@ -651,8 +674,18 @@ class Spade_Norm_Block(torch.nn.Module):
         actv = conv2d_resample.conv2d_resample_bias_act(x=denorm_feats, w=m.weight.to(denorm_feats.dtype), b=None, f=m.resample_filter,
                                                         up=m.up, down=m.down, padding=m.padding, flip_weight=(m.up == 1),
                                                         act='relu', gain=1, wgain=m.weight_gain)
-        gamma = self.conv_gamma(actv, no_act=True)
-        beta = self.conv_beta(actv, no_act=True)
+        # conv_gamma and conv_beta (:4375-4376) read the same tensor: ONE convolution with the concatenated weights writes
+        # gamma | beta as channel halves, the normalisation kernel reads (and, backwards, writes) the halves in place
+        g, b = self.conv_gamma, self.conv_beta
+        same = (g.weight.shape == b.weight.shape and g.up == b.up == 1 and g.down == b.down == 1 and g.padding == b.padding
+                and g.bias is None and b.bias is None and g.weight_gain == b.weight_gain and actv.dtype == torch.float32)
+        if same:
+            gamma = conv2d_resample.conv2d_resample(x=actv, w=torch.cat([g.weight, b.weight], dim=0), f=g.resample_filter,
+                                                    padding=g.padding, flip_weight=True, wgain=g.weight_gain)
+            beta = None
+        else:
+            gamma = g(actv, no_act=True)
+            beta = b(actv, no_act=True)
         if post_act is not None:        # (relu gain, clamp) of the consuming Spade_Conv2dLayer, applied in the same pass
             return spade_modulate(x, gamma, beta, eps=self.param_free_norm.eps, relu_gain=post_act[0], clamp=post_act[1])
         return spade_modulate(x, gamma, beta, eps=self.param_free_norm.eps)

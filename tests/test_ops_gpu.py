@@ -32,7 +32,7 @@ def _cases(fname):
 def test_native_library_is_loaded():
     from torch_utils.ops import _native
     lib = _native.lib()
-    assert lib.pasta_abi_version() >= 10
+    assert lib.pasta_abi_version() >= 11
     assert b'gfx950' in lib.pasta_build_info()
 
 
@@ -460,3 +460,25 @@ def test_conv_residual_epilogue(case):
     g = torch.autograd.grad(y, xs, dy.cuda())
     for a, ref in zip(g, gr):
         assert rel_err(a, ref) < 2e-5
+
+
+@pytest.mark.parametrize('hw', [(128, 128), (64, 64), (17, 13)])
+@pytest.mark.parametrize('relu_gain', [None, 1.1])
+def test_spade_norm_with_gamma_beta_halves(hw, relu_gain):
+    """spade_modulate(x, gb, None): gamma | beta as the channel halves of one tensor (the output of one convolution with the
+    concatenated conv_gamma / conv_beta weights) == spade_modulate(x, gamma, beta); the gradient comes back as one tensor."""
+    from training import networks
+    gen = torch.Generator().manual_seed(29)
+    n, c = 2, 3
+    x = (torch.randn([n, c, *hw], generator=gen) * 2 + 0.5).cuda().requires_grad_(True)
+    gb = (torch.randn([n, 2 * c, *hw], generator=gen) * 0.3).cuda().requires_grad_(True)
+    dy = torch.randn([n, c, *hw], generator=gen).cuda()
+    kw = dict(relu_gain=relu_gain, clamp=0.9) if relu_gain is not None else {}
+    y1 = networks.spade_modulate(x, gb[:, :c], gb[:, c:], **kw)
+    g1 = torch.autograd.grad(y1, [x, gb], dy)
+    y2 = networks.spade_modulate(x, gb, None, **kw)
+    g2 = torch.autograd.grad(y2, [x, gb], dy)
+    assert torch.equal(y1, y2)
+    assert torch.equal(g1[0], g2[0]) and torch.equal(g1[1], g2[1])
+    dx_only, = torch.autograd.grad(networks.spade_modulate(x, gb.detach(), None, **kw), [x], dy)
+    assert torch.equal(dx_only, g2[0])
