@@ -193,6 +193,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-meter', action='store_true', help='do not bracket convolution launches with events')
     ap.add_argument('--by-shape', action='store_true', help='also print a per-shape convolution table to stderr')
+    ap.add_argument('--by-shape-top', type=int, default=40, help='rows of that table')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -314,7 +315,7 @@ def main():
                                         'launches_per_step': round(v['launches'] / nit, 1)} for k, v in sorted(allfam.items())}
             out['conv_total'] = {'tflop_per_step': round(tot_flops / nit / 1e12, 3), 'ms_per_step': round(tot_ms / nit, 2), 'source': src}
         if args.by_shape:
-            for shape, calls, ms, tf in meter.by_shape()[:40]:
+            for shape, calls, ms, tf in meter.by_shape()[:args.by_shape_top]:
                 print(f'{str(shape):70s} calls/step={calls / args.steps:6.1f} ms/step={ms / args.steps:8.2f} TF/s={tf:7.1f}', file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline()
