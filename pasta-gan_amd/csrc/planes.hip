@@ -381,7 +381,18 @@ __global__ __launch_bounds__(256) void nan_to_num_multi_kernel(NanToNumTable tab
     const int tid = threadIdx.x;
     if (((uintptr_t)base & 15) == 0) {      // chunks start at multiples of 16 K elements: float4 accesses, then <= 3 tail elements
         const int vend = begin + ((end - begin) & ~3);
-        for (int i = begin + 4 * tid; i < vend; i += 1024) {
+        int i = begin + 4 * tid;
+        for (; i + 3 * 1024 < vend; i += 4 * 1024) {       // four 16-byte loads in flight per thread
+            float4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = *(float4*)(base + i + 1024 * k);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                v[k].x = fix(v[k].x); v[k].y = fix(v[k].y); v[k].z = fix(v[k].z); v[k].w = fix(v[k].w);
+                *(float4*)(base + i + 1024 * k) = v[k];
+            }
+        }
+        for (; i < vend; i += 1024) {
             float4 v = *(float4*)(base + i);
             v.x = fix(v.x); v.y = fix(v.y); v.z = fix(v.z); v.w = fix(v.w);
             *(float4*)(base + i) = v;

@@ -62,14 +62,35 @@ def main():
         rows.append(('scale_add (demod+noise)', list(x.shape), 2 * x.numel() * 4, ms))
         ms = timeit(lambda: fma.plane_dot(x, g))
         rows.append(('plane_dot', list(x.shape), 2 * x.numel() * 4, ms))
+        # fused tails and the ADA kernels
+        gbt = torch.randn([16, 256, 128, 128], device=dev)
+        ms = timeit(lambda: networks.spade_modulate(x, gbt, None, relu_gain=1.2, clamp=256))
+        rows.append(('spade_norm fwd (gamma|beta, relu)', list(x.shape), 4 * x.numel() * 4, ms))
+        from torch_utils import misc
+        grads = [torch.randn([n], device=dev) for n in [512 * 512 * 9] * 20 + [128 * 128 * 9] * 60 + [512] * 120]
+        ms = timeit(lambda: misc.nan_to_num_(grads, nan=0, posinf=1e5, neginf=-1e5))
+        rows.append(('nan_to_num over 200 tensors', [sum(t.numel() for t in grads)], 2 * sum(t.numel() for t in grads) * 4, ms))
+        from torch_utils.ops import grid_sample_gradfix as gs
+        from training.augment import _ColorAffine
+        img = torch.randn([48, 3, 256, 256], device=dev); C = torch.randn([48, 4, 4], device=dev)
+        ms = timeit(lambda: _ColorAffine.apply(img, C, 0))
+        rows.append(('color_affine', list(img.shape), 2 * img.numel() * 4, ms))
+        big = torch.randn([48, 3, 700, 700], device=dev)
+        th = torch.tensor([[0.8, 0.3, 0.02], [-0.3, 0.8, -0.01]], device=dev).repeat(48, 1, 1)
+        out = gs.affine_sample(big, th, (524, 524))
+        ms = timeit(lambda: gs.affine_sample(big, th, (524, 524)))
+        rows.append(('affine_sample fwd', list(out.shape), (out.numel() * 2) * 4, ms))           # reads ~ the sampled footprint
+        dyo = torch.randn_like(out)
+        ms = timeit(lambda: gs._AffineSampleAdjoint.apply(dyo, th, (700, 700)))
+        rows.append(('affine_sample adjoint (gather)', list(big.shape), (big.numel() + out.numel()) * 4, ms))
         ms = timeit(lambda: x + g)
         rows.append(('torch add (reference point)', list(x.shape), 3 * x.numel() * 4, ms))
         ms = timeit(lambda: x.clone())
         rows.append(('torch copy (reference point)', list(x.shape), 2 * x.numel() * 4, ms))
-    print(f"{'kernel':30s} {'shape':24s} {'MB':>8s} {'us':>8s} {'GB/s':>8s} {'of 8 TB/s':>9s}")
+    print(f"{'kernel':34s} {'shape':24s} {'MB':>8s} {'us':>8s} {'GB/s':>8s} {'of 8 TB/s':>9s}")
     for name, shape, nbytes, ms in rows:
         gbs = nbytes / ms / 1e6
-        print(f'{name:30s} {str(shape):24s} {nbytes / 1e6:8.1f} {ms * 1e3:8.1f} {gbs:8.0f} {gbs / 8000:9.2f}')
+        print(f'{name:34s} {str(shape):24s} {nbytes / 1e6:8.1f} {ms * 1e3:8.1f} {gbs:8.0f} {gbs / 8000:9.2f}')
 
 
 if __name__ == '__main__':
