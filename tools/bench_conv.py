@@ -30,6 +30,9 @@ SHAPES = [  # name, N, Cin, H, Cout, k, stride, transposed
     ('skip 64->128 1x1 @128', 16, 64, 128, 128, 1, 1, False),
     ('torgb 64->3 1x1 @256', 16, 64, 256, 3, 1, 1, False),
     ('stem 3->64 7x7 @256', 16, 3, 256, 64, 7, 1, False),
+    ('stem 3->64 3x3 @256', 16, 3, 256, 64, 3, 1, False),
+    ('fromrgb 3->64 1x1 @256 x48', 48, 3, 256, 64, 1, 1, False),
+    ('stem 6->64 1x1 @256', 16, 6, 256, 64, 1, 1, False),
 ]
 
 
