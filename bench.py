@@ -1,6 +1,10 @@
 """Benchmark: PASTA-GAN 256x192 (tensor 256x256) training images/sec on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched through torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU.  Started through ``torch.distributed.run`` (RANK / LOCAL_RANK / WORLD_SIZE in the environment)
+each process is one rank; started plainly, this process only spawns the N ranks itself -- before any GPU call, like the
+reference's launcher (train_wo_flow_fullbody.py:393-400, 567) -- waits for them and relays rank 0's JSON line.
 
 A step = one iteration of the reference hot loop (training_loop_wo_flow_fullbody.py:484-529) on a
 synthetic, HBM-resident batch of 16 images per GPU: Gmain + Dmain every iteration, Dreg every 16th,
@@ -175,6 +179,49 @@ def cpu_baseline(budget_s=20.0):
                        f'{n} timed step(s) of {dt / n:.2f} s after 1 warm-up (oracle/ref_networks.py on the host)')
 
 
+def launch_ranks(n, argv):
+    """Start ``n`` rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), wait for
+    them and relay rank 0's stdout.  This process makes no GPU call (``import torch`` and the hipcc build do not touch the
+    device) and never re-executes itself; a rank that fails takes the others down and the exit status is non-zero."""
+    import socket
+    import subprocess
+    import tempfile
+    from torch_utils import custom_ops
+    custom_ops.build()                      # once, before the ranks race for it
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    procs = []
+    out0 = tempfile.TemporaryFile(mode='w+')
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.setdefault('OMP_NUM_THREADS', str(max(1, host_threads() // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=out0 if r == 0 else sys.stderr))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        failed = next((p for p in procs if p.poll() not in (None, 0)), None)
+    if failed is None:
+        failed = next((p for p in procs if p.returncode != 0), None)
+    if failed is not None:
+        for p in procs:                     # exactly the processes started above, by PID
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        print(f'bench.py: rank {procs.index(failed)} exited with status {failed.returncode}', file=sys.stderr)
+    out0.seek(0)
+    sys.stdout.write(out0.read())
+    sys.stdout.flush()
+    return 0 if failed is None else (failed.returncode or 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -190,22 +237,31 @@ def main():
     ap.add_argument('--conv-math', default=None, choices=['default', 'f32', 'bf16x6', 'bf16x3', 'bf16'],
                     help="matrix-core arithmetic of the convolutions (default: PASTA_CONV_MATH or 'default' = bf16x6, fp32-equivalent). "
                          "'bf16x3' = what TrainingStep selects for allow_tf32=True; 'bf16' = bf16 operands. Reduced modes are reported as such, never as the headline")
+    ap.add_argument('--ddp-mode', default='flat', choices=['flat', 'torch'], help="gradient exchange at N > 1: 'flat' = one bucketed reducer per "
+                    "optimised module (training/grad_reducer.py); 'torch' = the reference's five DistributedDataParallel wrappers")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-meter', action='store_true', help='do not bracket convolution launches with events')
     ap.add_argument('--by-shape', action='store_true', help='also print a per-shape convolution table to stderr')
     ap.add_argument('--by-shape-top', type=int, default=40, help='rows of that table')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 through torch.distributed.run'
-    assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     # One rank per GPU. PASTA_DIST_BACKEND=gloo lets several ranks share one card for a rehearsal on a 1-GPU box.
     backend = os.environ.get('PASTA_DIST_BACKEND', 'nccl')
-    dev_index = local_rank % torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()
+    assert n_dev > 0, 'bench.py needs a GPU (the HIP path has no CPU fallback)'
+    if backend == 'nccl' and world > n_dev:
+        raise SystemExit(f'--gpus {world} over RCCL needs {world} GPUs, this node shows {n_dev} '
+                         f'(PASTA_DIST_BACKEND=gloo rehearses several ranks on one card)')
+    dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
+    transport = 'single process'
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
@@ -217,6 +273,10 @@ def main():
             from torch_utils import custom_ops
             custom_ops.build()
         torch.distributed.barrier()
+        used = torch.distributed.get_backend()
+        transport = ('RCCL all-reduce over xGMI (torch.distributed backend nccl)' if used == 'nccl' else
+                     f'{used} all-reduce, REHEARSAL transport: ranks share {n_dev} GPU(s)') + \
+                    f', process-group world_size {torch.distributed.get_world_size()}, gradient exchange: {args.ddp_mode}'
 
     from torch_utils.ops import conv2d_gradfix, _native
     from training.training_loop_wo_flow_fullbody import TrainingStep, SyntheticFullBodyBatch, fashion_config
@@ -224,13 +284,13 @@ def main():
     lib = _native.lib()       # raises if libpasta_hip.so is missing
     if args.conv_math is not None:
         conv2d_gradfix.conv_math = args.conv_math
-    cfg = fashion_config()
+    cfg = fashion_config(mbstd_group_size=min(args.batch_gpu, 4))      # train_wo_flow_fullbody.py:184: mbstd = min(batch_gpu, 4)
     from training.training_loop_wo_flow_fullbody import augment_options
     cfg.update(augment_options(aug=args.aug, augpipe='bgc', p=args.aug_p))
     if args.vgg_weight > 0:
         cfg.loss_kwargs.vgg_weight = args.vgg_weight
         cfg.loss_kwargs.vgg_random_init = True
-    step = TrainingStep(device, cfg=cfg, num_gpus=world, rank=rank, batch_size=args.batch_gpu * world, batch_gpu=args.batch_gpu)
+    step = TrainingStep(device, cfg=cfg, num_gpus=world, rank=rank, batch_size=args.batch_gpu * world, batch_gpu=args.batch_gpu, ddp_mode=args.ddp_mode)
     data = SyntheticFullBodyBatch(args.batch_gpu, device, seed=rank)
     meter = ConvMeter(lib)
     if not args.no_meter:
@@ -280,7 +340,7 @@ def main():
             'config': {'workload': 'BASELINE config 2: full training_loop step (Gmain+Dmain every iter, Dreg/16, Greg/4, Adam, EMA), '
                                    'GeneratorFull+Discriminator cfg=fashion 256x256, batch 16/GPU, G and D in fp32, ' +
                                    ('vgg_weight=0 (weights unavailable)' if args.vgg_weight <= 0 else f'vgg_weight={args.vgg_weight:g} with random-init VGG-19') + (', no ADA' if args.aug == 'noaug' else f', ADA pipeline bgc ({args.aug}, p0={args.aug_p:g})') + ', random-init weights; timed iterations ' + f'{args.warmup}..{args.warmup + args.steps - 1}',
-                       'global_batch': args.batch_gpu * world, 'parallelism': f'dp{world}' + (' (RCCL all-reduce)' if world > 1 else '')},
+                       'global_batch': args.batch_gpu * world, 'parallelism': f'dp{world} ({transport})'},
         }
         fam = meter.summary()
         if fam:

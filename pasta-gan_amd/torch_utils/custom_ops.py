@@ -9,6 +9,7 @@ There is no fallback: if the library cannot be built or loaded, every op raises.
 """
 
 import ctypes
+import fcntl
 import hashlib
 import os
 import shutil
@@ -50,23 +51,39 @@ def _digest(sources):
 def _hipcc():
     return shutil.which('hipcc') or ('/opt/rocm/bin/hipcc' if os.path.exists('/opt/rocm/bin/hipcc') else None)
 
+def _stamp_matches(lib_path, stamp, digest):
+    if not (os.path.exists(lib_path) and os.path.exists(stamp)):
+        return False
+    with open(stamp) as f:
+        return f.read().strip() == digest
+
 def build(force=False, verbose=False, extra_flags=()):
     """Compile every ``csrc/*.hip`` for gfx950 and link ``lib/libpasta_hip.so``.
 
-    Skips the work when the stored source digest matches. Returns the library path."""
+    Skips the work when the stored source digest matches. Returns the library path.  Concurrent callers (several ranks
+    importing the ops at once) are serialised by an exclusive lock on ``lib/.build.lock`` -- the reference loader does
+    the same with a file baton (custom_ops.py:86-92) -- and whoever gets the lock second finds the stamp up to date."""
     sources = _sources()
     lib_path = os.path.join(_LIBDIR, LIB_NAME)
     stamp = lib_path + '.md5'
     digest = _digest(sources)
-    if not force and os.path.exists(lib_path) and os.path.exists(stamp):
-        with open(stamp) as f:
-            if f.read().strip() == digest:
-                return lib_path
+    if not force and _stamp_matches(lib_path, stamp, digest):
+        return lib_path
     hipcc = _hipcc()
     if hipcc is None:
         raise RuntimeError('hipcc not found: cannot build ' + LIB_NAME)
     os.makedirs(_LIBDIR, exist_ok=True)
     os.makedirs(_OBJDIR, exist_ok=True)
+    with open(os.path.join(_LIBDIR, '.build.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and _stamp_matches(lib_path, stamp, digest):
+                return lib_path
+            return _compile_and_link(hipcc, sources, lib_path, stamp, digest, verbose, extra_flags)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+def _compile_and_link(hipcc, sources, lib_path, stamp, digest, verbose, extra_flags):
     flags = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast', '-I', _INCLUDE] + list(extra_flags)
     objs, procs = [], []
     for src in sources:

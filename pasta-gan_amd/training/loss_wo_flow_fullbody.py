@@ -148,14 +148,25 @@ class StyleGAN2Loss(Loss):
         return logits
 
     def _mbstd_groups(self, n):
-        """Number of minibatch-std groups a batch of n splits into (networks.py:1007-1022), or None when several
-        batches cannot share one discriminator pass (no mbstd group size, or n not a multiple of it)."""
+        """Number of minibatch-std groups a batch of n splits into (networks.py:1007-1022), or None when k such batches
+        cannot share one discriminator pass with unchanged statistics: a layer without a group size (its group is the
+        whole batch), a group size above n (the merged batch of k*n would form larger groups than n does), or n not a
+        multiple of the group size."""
         D = self.D.module if hasattr(self.D, 'module') else self.D
-        sizes = [m.group_size for m in D.modules() if type(m).__name__ == 'MinibatchStdLayer']
-        if any(g is None for g in sizes):
+        sizes = {m.group_size for m in D.modules() if type(m).__name__ == 'MinibatchStdLayer'}
+        if not sizes:
+            return n                      # nothing couples the samples: any stacking order works
+        if None in sizes or len(sizes) != 1:
             return None
-        g = min([min(int(g), n) for g in sizes], default=1)
-        return n // g if sizes and n % g == 0 and all(min(int(s), n) == g for s in sizes) else (n if not sizes else None)
+        g = int(next(iter(sizes)))
+        return n // g if 0 < g <= n and n % g == 0 else None
+
+    @staticmethod
+    def backward_passes(phase):
+        """How many ``backward()`` calls of one ``accumulate_gradients(phase)`` reach the phase's module (the gradient
+        reducer overlaps its all-reduce with the last of them): Gmain / Dmain / Dreg one each, Dboth two (:227, :254),
+        Greg none (pl_weight = 0: only the style encoder's forward runs)."""
+        return {'Gmain': 1, 'Gboth': 1, 'Greg': 0, 'Dmain': 1, 'Dreg': 1, 'Dboth': 2}[phase]
 
     def run_D_multi(self, imgs, cs, sync):
         """``[run_D(img, c) for img, c in zip(imgs, cs)]`` in ONE discriminator pass (the reference calls the

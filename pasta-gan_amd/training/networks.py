@@ -34,6 +34,7 @@ class _ScalePlanes(torch.autograd.Function):
         return fma.scale_planes(x, s)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         x, s = ctx.saved_tensors
         dx = ds = None
@@ -79,6 +80,7 @@ class _SpadeModulate(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, dout):
         x, gamma, stats, beta = ctx.saved_tensors
         act, gain, clamp = ctx.post

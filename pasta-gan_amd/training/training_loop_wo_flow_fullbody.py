@@ -1,11 +1,12 @@
 """The data-parallel training step of PASTA-GAN's full-body model.
 
 Mirrors the hot loop of the reference's training/training_loop_wo_flow_fullbody.py: module
-construction (:274-277), one DistributedDataParallel wrapper per sub-module with
-``broadcast_buffers=False`` (:312-324), lazily regularised Adam phases Gmain/Greg/Dmain/Dreg
-(:332-349), gradient accumulation with ``sync`` only on the last round (:484-505), gradient
-``nan_to_num`` + optimiser step (:508-516) and the generator EMA (:521-529). One process per GPU;
-gradients are all-reduced by RCCL (``backend='nccl'`` on ROCm) over xGMI, overlapped with backward.
+construction (:274-277), replica synchronisation and gradient exchange (:312-324), lazily regularised Adam
+phases Gmain/Greg/Dmain/Dreg (:332-349), gradient accumulation with ``sync`` only on the last round
+(:484-505), gradient ``nan_to_num`` + optimiser step (:508-516) and the generator EMA (:521-529).
+One process per GPU; gradients are all-reduced by RCCL (``backend='nccl'`` on ROCm) over xGMI, overlapped
+with backward: by default through one ``FlatGradReducer`` per optimised module (``ddp_mode='flat'``,
+training/grad_reducer.py), or through the reference's five DistributedDataParallel wrappers (``ddp_mode='torch'``).
 
 Dataset loading, snapshots, image grids, ADA and metrics of the reference loop are host
 orchestration outside this path; ``SyntheticFullBodyBatch`` supplies tensors of the dataset's
@@ -19,6 +20,7 @@ import torch
 
 import dnnlib
 from torch_utils import misc
+from training.grad_reducer import FlatGradReducer, broadcast_module_states
 
 #----------------------------------------------------------------------------
 
@@ -108,8 +110,9 @@ class TrainingStep:
     """Owns G, D, G_ema, the DDP wrappers, the loss and the four optimiser phases; ``run()`` executes one
     iteration of the reference's hot loop on a device-resident batch."""
 
-    def __init__(self, device, cfg=None, num_gpus=1, rank=0, batch_size=16, batch_gpu=16, random_seed=0, ddp_bucket_mb=25):
-        cfg = cfg if cfg is not None else fashion_config()
+    def __init__(self, device, cfg=None, num_gpus=1, rank=0, batch_size=16, batch_gpu=16, random_seed=0, ddp_bucket_mb=None, ddp_mode='flat'):
+        cfg = cfg if cfg is not None else fashion_config(mbstd_group_size=min(batch_gpu, 4))
+        assert ddp_mode in ('flat', 'torch')
         self.device, self.num_gpus, self.rank = device, num_gpus, rank
         self.batch_size, self.batch_gpu = batch_size, batch_gpu
         assert batch_size % (batch_gpu * num_gpus) == 0
@@ -127,19 +130,33 @@ class TrainingStep:
         self.G_ema = copy.deepcopy(self.G).eval()
         self.ema_kimg, self.ema_rampup = cfg.ema_kimg, cfg.ema_rampup
 
-        # One DDP wrapper per sub-module so that loss code can gate their all-reduces separately (:316-324).
+        # Replicas: rank 0's state everywhere, then a gradient exchange per optimised module.
+        #   'flat'  - one FlatGradReducer for G and one for D (64 MiB buckets: G = 3 all-reduces, D = 2), gated by this
+        #             class on the last accumulation round; the loss sees plain modules, its ddp_sync calls are no-ops.
+        #   'torch' - the reference's arrangement (:316-324): one DistributedDataParallel wrapper per sub-module so that
+        #             the loss can gate their all-reduces separately with ddp_sync; find_unused_parameters only where a
+        #             parameter really takes no gradient (G.synthesis: b4.const; the parsing head when mask_weight = 0).
         G, D = self.G, self.D
-        ddp = dict()
-        for name, module in [('G_mapping', G.mapping), ('G_synthesis', G.synthesis), ('G_const_encoding', G.const_encoding),
-                             ('G_style_encoding', G.style_encoding), ('D', D), (None, self.G_ema)]:
-            if num_gpus > 1 and len(list(module.parameters())) != 0:
-                module.requires_grad_(True)
-                ids = [device] if device.type == 'cuda' else None
-                module = torch.nn.parallel.DistributedDataParallel(module, device_ids=ids, broadcast_buffers=False,
-                                                                   find_unused_parameters=True, bucket_cap_mb=ddp_bucket_mb)
-                module.requires_grad_(False)
-            if name is not None:
-                ddp[name] = module
+        ddp = dict(G_mapping=G.mapping, G_synthesis=G.synthesis, G_const_encoding=G.const_encoding,
+                   G_style_encoding=G.style_encoding, D=D)
+        self.reducers = {}
+        if num_gpus > 1 and ddp_mode == 'flat':
+            with torch.no_grad():
+                broadcast_module_states([G, D, self.G_ema])
+            for name, module in [('G', G), ('D', D)]:
+                if any(True for _ in module.parameters()):
+                    self.reducers[name] = FlatGradReducer(module, num_gpus, bucket_mb=ddp_bucket_mb or 64)
+        elif num_gpus > 1:
+            for name, module in list(ddp.items()) + [(None, self.G_ema)]:
+                if len(list(module.parameters())) != 0:
+                    module.requires_grad_(True)
+                    ids = [device] if device.type == 'cuda' else None
+                    module = torch.nn.parallel.DistributedDataParallel(module, device_ids=ids, broadcast_buffers=False,
+                                                                       find_unused_parameters=(name == 'G_synthesis'),
+                                                                       bucket_cap_mb=ddp_bucket_mb or 25)
+                    module.requires_grad_(False)
+                if name is not None:
+                    ddp[name] = module
         self.ddp_modules = ddp
 
         # ADA (training_loop_wo_flow_fullbody.py:301-310): the pipeline, its probability p, and the statistic that steers p
@@ -190,13 +207,23 @@ class TrainingStep:
         for phase, phase_gen_z in zip(self.phases, all_gen_z):
             if self.batch_idx % phase.interval != 0:
                 continue
-            phase.opt.zero_grad(set_to_none=True)
+            reducer = self.reducers.get(phase.name[0])
             phase.module.requires_grad_(True)
+            if reducer is not None:
+                reducer.begin()
+            else:
+                phase.opt.zero_grad(set_to_none=True)
             for round_idx, (r, gen_z) in enumerate(zip(rounds, phase_gen_z.split(self.batch_gpu))):
                 sync = (round_idx == self.batch_size // (self.batch_gpu * self.num_gpus) - 1)
+                if reducer is not None and sync:     # the exchange overlaps the backward pass(es) of the last round
+                    reducer.arm(getattr(self.loss, 'backward_passes', lambda phase: None)(phase.name))
                 self.loss.accumulate_gradients(phase=phase.name, gen_z=gen_z, sync=sync, gain=phase.interval, **r)
             phase.module.requires_grad_(False)
-            grads = [param.grad for param in phase.module.parameters() if param.grad is not None]
+            if reducer is not None:
+                reducer.finish()
+                grads = reducer.flat_gradients()
+            else:
+                grads = [param.grad for param in phase.module.parameters() if param.grad is not None]
             if grads:       # nan_to_num(grad, nan=0, posinf=1e5, neginf=-1e5) (:513-515), one launch per 96 gradients
                 misc.nan_to_num_(grads, nan=0, posinf=1e5, neginf=-1e5)
             phase.opt.step()
@@ -221,6 +248,7 @@ class TrainingStep:
 
         # ADA adjustment (:536-539): p += sign(E[sign(D(real))] - target) * batch_size * ada_interval / (ada_kimg * 1000), p >= 0;
         # evaluated on the device, no read-back
+        self.batch_idx += 1
         if self.augment_pipe is not None and self.ada_target is not None and self.batch_idx % self.ada_interval == 0:
             acc = self._ada_acc
             if self.num_gpus > 1:
@@ -230,7 +258,6 @@ class TrainingStep:
             adjust = torch.sign(mean - self.ada_target) * step * (acc[1] > 0)
             self.augment_pipe.p.copy_((self.augment_pipe.p + adjust).clamp(min=0))
             acc.zero_()
-        self.batch_idx += 1
 
 #----------------------------------------------------------------------------
 

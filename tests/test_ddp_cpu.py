@@ -1,5 +1,6 @@
-"""The data-parallel step at world size 2 over gloo (CPU): gradients are averaged across ranks exactly once per phase,
-replicas stay identical, and the style-encoder-only Greg phase does not wedge DistributedDataParallel."""
+"""The data-parallel step at world size 2 over gloo (CPU), in both exchange modes (the flat gradient reducer and the
+reference's DistributedDataParallel wrappers): gradients are averaged across ranks exactly once per phase, replicas stay
+identical, parameters no backward reaches keep ``grad = None``, and the style-encoder-only Greg phase wedges nothing."""
 
 import os
 import sys
@@ -12,7 +13,7 @@ import torch.multiprocessing as mp
 from conftest import ROOT, PKG
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, ddp_mode):
     for p in (PKG, ROOT, os.path.join(ROOT, 'tests')):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -27,7 +28,7 @@ def _worker(rank, world, port, out):
         cfg.D_kwargs = dnnlib.EasyDict(class_name='tiny_models.TinyD')
         cfg.loss_kwargs.style_mixing_prob = 0
         dev = torch.device('cpu')
-        step = TrainingStep(dev, cfg=cfg, num_gpus=world, rank=rank, batch_size=4 * world, batch_gpu=2, random_seed=0)
+        step = TrainingStep(dev, cfg=cfg, num_gpus=world, rank=rank, batch_size=4 * world, batch_gpu=2, random_seed=0, ddp_mode=ddp_mode)
         data = SyntheticFullBodyBatch(4, dev, seed=rank, res=16)
 
         # replicas start identical (DDP constructor broadcast from rank 0), although seeds differ per rank
@@ -51,10 +52,19 @@ def _worker(rank, world, port, out):
             dist.all_reduce(g)
             expected.append(g / world)
 
-        # the same phase through the DDP-wrapped modules (rounds: no_sync on the first, all-reduce on the last)
+        # the same phase through the step's exchange (rounds: nothing sent on the first, all-reduce on the last)
         step.D.requires_grad_(True)
+        red = step.reducers.get('D')
+        assert (red is not None) == (ddp_mode == 'flat')
+        if red is not None:
+            red.begin()
         for i, r in enumerate(data.split(2)):
+            if red is not None and i == 1:
+                red.arm(step.loss.backward_passes('Dmain'))
             step.loss.accumulate_gradients(phase='Dmain', gen_z=torch.zeros([2, 0]), sync=(i == 1), gain=1, **r)
+        if red is not None:
+            red.finish()
+            assert red.launched_early == len(red.buckets)       # every bucket left during backward, none waited for finish()
         for p, e in zip(step.D.parameters(), expected):
             assert torch.allclose(p.grad, e, rtol=1e-5, atol=1e-7)
         step.D.requires_grad_(False)
@@ -70,6 +80,8 @@ def _worker(rank, world, port, out):
             assert torch.equal(ref, p.detach()), f'{name} diverged across ranks'
         from torch_utils import misc
         misc.check_ddp_consistency(step.G, ignore_regex=r'.*\.w_avg')
+        # a parameter no backward reaches is skipped by Adam (grad None), as under the reference's find_unused_parameters
+        assert step.G.synthesis.unused.grad is None and float(step.G.synthesis.unused.abs().sum()) == 0
         out.put((rank, 'ok'))
     except Exception as e:  # noqa: BLE001
         import traceback
@@ -79,11 +91,12 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(300)
-def test_data_parallel_step_world_size_2():
+@pytest.mark.parametrize('ddp_mode', ['flat', 'torch'])
+def test_data_parallel_step_world_size_2(ddp_mode):
     ctx = mp.get_context('spawn')
     out = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    port = 29500 + (os.getpid() + (7 if ddp_mode == 'torch' else 0)) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, ddp_mode)) for r in range(2)]
     for p in procs:
         p.start()
     results = [out.get(timeout=240) for _ in procs]

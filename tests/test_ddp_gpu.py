@@ -1,6 +1,6 @@
 """The real generator / discriminator under DistributedDataParallel: two ranks sharing the one GPU of the test box
-(gloo transport, device tensors), so that the native autograd Functions meet DDP's hooks, no_sync rounds and
-find_unused_parameters before the multi-GPU run on RCCL."""
+(gloo transport, device tensors), so that the native autograd Functions meet the flat gradient reducer's hooks and, in the
+reference's arrangement, DDP's hooks, no_sync rounds and find_unused_parameters before the multi-GPU run on RCCL."""
 
 import os
 import sys
@@ -15,7 +15,7 @@ from conftest import ROOT, PKG
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, ddp_mode):
     for p in (PKG, ROOT, os.path.join(ROOT, 'tests')):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -26,7 +26,7 @@ def _worker(rank, world, port, out):
         torch.cuda.set_device(0)
         dev = torch.device('cuda', 0)
         cfg = fashion_config(channel_base=2048)
-        step = TrainingStep(dev, cfg=cfg, num_gpus=world, rank=rank, batch_size=8 * world, batch_gpu=4, random_seed=0)
+        step = TrainingStep(dev, cfg=cfg, num_gpus=world, rank=rank, batch_size=8 * world, batch_gpu=4, random_seed=0, ddp_mode=ddp_mode)
         data = SyntheticFullBodyBatch(8, dev, seed=rank)
         for _ in range(2):      # iteration 0 runs all four phases (incl. R1), two accumulation rounds each
             step.run(data)
@@ -47,11 +47,12 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(600)
-def test_generator_discriminator_ddp_two_ranks_one_gpu():
+@pytest.mark.parametrize('ddp_mode', ['flat', 'torch'])
+def test_generator_discriminator_ddp_two_ranks_one_gpu(ddp_mode):
     ctx = mp.get_context('spawn')
     out = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    port = 29500 + (os.getpid() + (11 if ddp_mode == 'torch' else 0)) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, ddp_mode)) for r in range(2)]
     for p in procs:
         p.start()
     results = [out.get(timeout=500) for _ in procs]
