@@ -3,14 +3,15 @@
 API-compatible subset of the reference's torch_utils/misc.py: ``assert_shape`` (:80-95),
 ``profiled_function`` (:104-109), ``suppress_tracer_warnings`` (:67-71), ``nan_to_num`` (:45),
 ``params_and_buffers`` / ``named_params_and_buffers`` / ``copy_params_and_buffers`` (:151-166),
-``ddp_sync`` (:172-179), ``check_ddp_consistency`` (:184-196) and ``InfiniteSampler`` (:115-146).
+``ddp_sync`` (:172-179) and ``check_ddp_consistency`` (:184-196).  The dataset sampler (``InfiniteSampler``, :115-146)
+belongs to the data pipeline, which is outside this path; the synthetic batch is sharded by seed.
 """
 
 import contextlib
+import functools
 import re
 import warnings
 
-import numpy as np
 import torch
 
 nan_to_num = torch.nan_to_num
@@ -37,93 +38,73 @@ def nan_to_num_(tensors, nan=0.0, posinf=None, neginf=None):
                                                       -fmax if neginf is None else float(neginf), _native.stream())
         _native.check(st)
 
-class suppress_tracer_warnings(warnings.catch_warnings):
-    def __enter__(self):
-        super().__enter__()
+@contextlib.contextmanager
+def suppress_tracer_warnings():
+    """Silence torch.jit.TracerWarning inside the block."""
+    with warnings.catch_warnings():
         warnings.simplefilter('ignore', category=torch.jit.TracerWarning)
-        return self
+        yield
 
 def assert_shape(tensor, ref_shape):
-    """Raise AssertionError unless ``tensor.shape`` matches ``ref_shape`` (``None`` = any size)."""
-    if tensor.ndim != len(ref_shape):
-        raise AssertionError(f'Wrong number of dimensions: got {tensor.ndim}, expected {len(ref_shape)}')
-    for idx, (size, ref_size) in enumerate(zip(tensor.shape, ref_shape)):
-        if ref_size is not None and int(size) != int(ref_size):
-            raise AssertionError(f'Wrong size for dimension {idx}: got {size}, expected {ref_size}')
+    """AssertionError unless ``tensor`` has the rank of ``ref_shape`` and every size that ``ref_shape`` names (None = any)."""
+    got = tuple(int(s) for s in tensor.shape)
+    if len(got) != len(ref_shape):
+        raise AssertionError(f'Wrong number of dimensions: got {len(got)}, expected {len(ref_shape)}')
+    bad = [(d, g, int(r)) for d, (g, r) in enumerate(zip(got, ref_shape)) if r is not None and g != int(r)]
+    if bad:
+        d, g, r = bad[0]
+        raise AssertionError(f'Wrong size for dimension {d}: got {g}, expected {r}')
 
 def profiled_function(fn):
-    """Wrap ``fn`` in a ``record_function`` scope named after it (shows up in torch.profiler traces)."""
-    def decorator(*args, **kwargs):
+    """Decorator: run ``fn`` inside a ``record_function`` range carrying its name (visible in torch.profiler traces)."""
+    @functools.wraps(fn)
+    def ranged(*args, **kwargs):
         with torch.autograd.profiler.record_function(fn.__name__):
             return fn(*args, **kwargs)
-    decorator.__name__ = fn.__name__
-    return decorator
+    return ranged
 
 #----------------------------------------------------------------------------
 
-def params_and_buffers(module):
-    assert isinstance(module, torch.nn.Module)
-    return list(module.parameters()) + list(module.buffers())
-
 def named_params_and_buffers(module):
     assert isinstance(module, torch.nn.Module)
-    return list(module.named_parameters()) + list(module.named_buffers())
+    return [*module.named_parameters(), *module.named_buffers()]
+
+def params_and_buffers(module):
+    return [t for _name, t in named_params_and_buffers(module)]
 
 def copy_params_and_buffers(src_module, dst_module, require_all=False):
-    """Copy same-named parameters and buffers; with ``require_all`` every destination name must exist in the source."""
-    src = dict(named_params_and_buffers(src_module))
-    for name, tensor in named_params_and_buffers(dst_module):
-        assert (name in src) or (not require_all), name
-        if name in src:
-            tensor.copy_(src[name].detach()).requires_grad_(tensor.requires_grad)
+    """Overwrite ``dst_module``'s tensors with the same-named tensors of ``src_module`` (``requires_grad`` flags stay);
+    ``require_all``: a destination name missing from the source is an error."""
+    source = dict(named_params_and_buffers(src_module))
+    for name, dst in named_params_and_buffers(dst_module):
+        if name not in source:
+            assert not require_all, f'{name} missing from the source module'
+            continue
+        keep = dst.requires_grad
+        dst.copy_(source[name].detach()).requires_grad_(keep)
 
 #----------------------------------------------------------------------------
 
 @contextlib.contextmanager
 def ddp_sync(module, sync):
-    """Run the block with DistributedDataParallel gradient all-reduce on (``sync``) or suppressed."""
+    """``with ddp_sync(m, sync):`` -- gradients produced inside are all-reduced by a DistributedDataParallel ``m`` only
+    when ``sync``; any other module (single GPU, or the flat gradient reducer, which is gated by the step) passes through."""
     assert isinstance(module, torch.nn.Module)
-    if sync or not isinstance(module, torch.nn.parallel.DistributedDataParallel):
+    wrapped = isinstance(module, torch.nn.parallel.DistributedDataParallel)
+    with (module.no_sync() if wrapped and not sync else contextlib.nullcontext()):
         yield
-    else:
-        with module.no_sync():
-            yield
 
 def check_ddp_consistency(module, ignore_regex=None):
-    """Assert that every parameter / buffer equals rank 0's copy (broadcast + compare)."""
+    """Every parameter / buffer must equal rank 0's copy bit for bit (NaNs compare equal); names matching
+    ``ignore_regex`` (as ``<ClassName>.<tensor name>``) are exempt."""
     assert isinstance(module, torch.nn.Module)
+    prefix = type(module).__name__ + '.'
     for name, tensor in named_params_and_buffers(module):
-        fullname = type(module).__name__ + '.' + name
-        if ignore_regex is not None and re.fullmatch(ignore_regex, fullname):
+        if ignore_regex is not None and re.fullmatch(ignore_regex, prefix + name):
             continue
-        tensor = tensor.detach()
-        other = tensor.clone()
-        torch.distributed.broadcast(tensor=other, src=0)
-        assert (nan_to_num(tensor) == nan_to_num(other)).all(), fullname
+        mine = nan_to_num(tensor.detach())
+        theirs = mine.clone()
+        torch.distributed.broadcast(tensor=theirs, src=0)
+        assert torch.equal(mine, theirs), prefix + name
 
 #----------------------------------------------------------------------------
-
-class InfiniteSampler(torch.utils.data.Sampler):
-    """Endless index stream, sharded ``rank::num_replicas``, with a sliding-window shuffle."""
-    def __init__(self, dataset, rank=0, num_replicas=1, shuffle=True, seed=0, window_size=0.5):
-        assert len(dataset) > 0 and num_replicas > 0 and 0 <= rank < num_replicas and 0 <= window_size <= 1
-        super().__init__()
-        self.dataset, self.rank, self.num_replicas = dataset, rank, num_replicas
-        self.shuffle, self.seed, self.window_size = shuffle, seed, window_size
-
-    def __iter__(self):
-        order = np.arange(len(self.dataset))
-        rnd, window = None, 0
-        if self.shuffle:
-            rnd = np.random.RandomState(self.seed)
-            rnd.shuffle(order)
-            window = int(np.rint(order.size * self.window_size))
-        idx = 0
-        while True:
-            i = idx % order.size
-            if idx % self.num_replicas == self.rank:
-                yield order[i]
-            if window >= 2:
-                j = (i - rnd.randint(window)) % order.size
-                order[i], order[j] = order[j], order[i]
-            idx += 1

@@ -17,6 +17,7 @@ import torch.nn as nn
 
 from torch_utils import misc
 from torch_utils import persistence
+from torch_utils.ops import conv2d_gradfix
 from torch_utils.ops import conv2d_resample
 from torch_utils.ops import upfirdn2d
 from torch_utils.ops import bias_act
@@ -185,95 +186,95 @@ def mod_bias_act(u, dcoefs, noise, strength, bias, act='lrelu', alpha=None, gain
 
 #----------------------------------------------------------------------------
 
-@misc.profiled_function
+#----------------------------------------------------------------------------
+# Helpers shared by the layer classes.
+
 def normalize_2nd_moment(x, dim=1, eps=1e-8):
-    """networks.py:30-32"""
-    return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
+    """x / rms(x) along ``dim`` (networks.py:30-32)."""
+    return x * torch.rsqrt(x.square().mean(dim=dim, keepdim=True) + eps)
+
+def _attach_filter(module, taps):
+    module.register_buffer('resample_filter', upfirdn2d.setup_filter(taps))
+
+def _fresh_weight(out_channels, in_channels, kernel_size, channels_last=False):
+    w = torch.randn([out_channels, in_channels, kernel_size, kernel_size])
+    return w.to(memory_format=torch.channels_last) if channels_last else w
+
+def _fan_in_gain(in_channels, kernel_size):
+    return 1 / np.sqrt(in_channels * kernel_size * kernel_size)
+
+def _scaled_act(activation, gain, conv_clamp):
+    """Activation gain and clamp of a layer invoked with an extra ``gain``; the clamp scales with it (networks.py:176-177)."""
+    return bias_act.activation_funcs[activation].def_gain * gain, (None if conv_clamp is None else conv_clamp * gain)
+
+def _hip_fp32(x):
+    return x.dtype == torch.float32 and x.device.type == 'cuda'
+
+def _block_dtype(use_fp16, channels_last, force_fp32):
+    half = use_fp16 and not force_fp32
+    return (torch.float16 if half else torch.float32), (torch.channels_last if channels_last and not force_fp32 else torch.contiguous_format)
 
 #----------------------------------------------------------------------------
+# Modulated convolution.
+
+def _demodulation(weight, styles):
+    """rsqrt(sum_{i,kh,kw} (w[o,i] s[n,i])^2 + 1e-8) as a [N, O] matrix product of the squared styles with the tap-summed
+    squared weights: the per-sample weight tensor [N,O,I,k,k] of networks.py:65-68 is never formed."""
+    return torch.rsqrt(styles.square() @ weight.square().sum(dim=[2, 3]).t() + 1e-8)
 
 def _modulate_and_convolve(x, weight, styles, up, down, padding, resample_filter, demodulate, flip_weight):
-    """Non-fused modulated convolution up to, not including, the demodulation (networks.py:65-76): returns the
-    convolution of the style-scaled activations and the demodulation coefficients ``rsqrt(s^2 @ sum_k w^2 + 1e-8)``."""
-    dcoefs = None
-    if demodulate:
-        wsq = weight.square().sum(dim=[2, 3])                                   # [O, I]
-        dcoefs = (styles.square() @ wsq.t() + 1e-8).rsqrt()                     # [N, O]
-    x = scale_planes(x, styles)
-    x = conv2d_resample.conv2d_resample(x=x, w=weight.to(x.dtype), f=resample_filter, up=up, down=down,
+    """Shared-weight form of the modulated convolution up to, not including, the demodulation (networks.py:72-76):
+    returns conv(x * s) and the demodulation coefficients (None without demodulation)."""
+    dcoefs = _demodulation(weight, styles) if demodulate else None
+    y = conv2d_resample.conv2d_resample(x=scale_planes(x, styles), w=weight.to(x.dtype), f=resample_filter, up=up, down=down,
                                         padding=padding, flip_weight=flip_weight)
-    return x, dcoefs
+    return y, dcoefs
 
-@misc.profiled_function
-def modulated_conv2d(
-    x,                          # Input tensor of shape [batch_size, in_channels, in_height, in_width].
-    weight,                     # Weight tensor of shape [out_channels, in_channels, kernel_height, kernel_width].
-    styles,                     # Modulation coefficients of shape [batch_size, in_channels].
-    noise           = None,     # Optional noise tensor to add to the output activations.
-    up              = 1,        # Integer upsampling factor.
-    down            = 1,        # Integer downsampling factor.
-    padding         = 0,        # Padding with respect to the upsampled image.
-    resample_filter = None,     # Low-pass filter to apply when resampling activations (upfirdn2d.setup_filter()).
-    demodulate      = True,     # Apply weight demodulation?
-    flip_weight     = True,     # False = convolution, True = correlation (matches torch.nn.functional.conv2d).
-    fused_modconv   = True,     # Perform modulation, convolution, and demodulation as a single fused operation?
-):
-    """StyleGAN2 modulated convolution (networks.py:36-94).
-
-    ``fused_modconv=False`` (training): scale activations by the styles, run one shared-weight
-    convolution, scale by the demodulation coefficients and add noise. The coefficients
-    ``rsqrt(sum_{i,k} (w*s)^2 + 1e-8)`` are evaluated as ``rsqrt(s^2 @ sum_k w^2 + 1e-8)`` so the
-    per-sample weight tensor [N,O,I,k,k] is never materialised.
-    ``fused_modconv=True`` (inference): per-sample weights and one grouped convolution."""
-    batch_size = x.shape[0]
-    out_channels, in_channels, kh, kw = weight.shape
-    misc.assert_shape(weight, [out_channels, in_channels, kh, kw])
-    misc.assert_shape(x, [batch_size, in_channels, None, None])
-    misc.assert_shape(styles, [batch_size, in_channels])
-
-    # Pre-normalize inputs to avoid FP16 overflow (networks.py:57-59).
-    if x.dtype == torch.float16 and demodulate:
-        weight = weight * (1 / np.sqrt(in_channels * kh * kw) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
-        styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)
-
-    if not fused_modconv:
-        x, dcoefs = _modulate_and_convolve(x, weight, styles, up, down, padding, resample_filter, demodulate, flip_weight)
-        if demodulate and noise is not None:
-            x = fma.fma(x, dcoefs.to(x.dtype).reshape(batch_size, -1, 1, 1), noise.to(x.dtype))
-        elif demodulate:
-            x = scale_planes(x, dcoefs)
-        elif noise is not None:
-            x = x.add_(noise.to(x.dtype))
-        return x
-
-    # One grouped convolution with per-sample weights (networks.py:84-94).
-    w = weight.unsqueeze(0) * styles.reshape(batch_size, 1, -1, 1, 1)               # [N, O, I, k, k]
+def _per_sample_convolve(x, weight, styles, up, down, padding, resample_filter, demodulate, flip_weight):
+    """Per-sample-weight form (networks.py:84-94): the batch becomes the group dimension of one grouped convolution."""
+    n = int(x.shape[0])
+    o, i, kh, kw = weight.shape
+    w = weight[None] * styles[:, None, :, None, None]                               # [N, O, I, kh, kw]
     if demodulate:
-        dcoefs = (w.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt()
-        w = w * dcoefs.reshape(batch_size, -1, 1, 1, 1)
-    batch_size = int(batch_size)
-    x = x.reshape(1, -1, *x.shape[2:])
-    w = w.reshape(-1, in_channels, kh, kw)
-    x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=resample_filter, up=up, down=down, padding=padding,
-                                        groups=batch_size, flip_weight=flip_weight)
-    x = x.reshape(batch_size, -1, *x.shape[2:])
-    if noise is not None:
-        x = x.add_(noise)
-    return x
+        w = w * torch.rsqrt(w.square().sum(dim=[2, 3, 4], keepdim=True) + 1e-8)
+    y = conv2d_resample.conv2d_resample(x=x.reshape(1, n * i, *x.shape[2:]), w=w.reshape(n * o, i, kh, kw).to(x.dtype),
+                                        f=resample_filter, up=up, down=down, padding=padding, groups=n, flip_weight=flip_weight)
+    return y.reshape(n, o, *y.shape[2:])
+
+def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
+                     flip_weight=True, fused_modconv=True):
+    """StyleGAN2 modulated convolution (networks.py:36-94).  ``x`` [N,I,H,W], ``weight`` [O,I,kh,kw], ``styles`` [N,I],
+    ``noise`` broadcastable to the output or None; ``padding`` is relative to the upsampled image.
+
+    ``fused_modconv=False`` (training): activations are scaled by the styles, ONE shared-weight convolution runs for the
+    whole batch, and its output is scaled by the demodulation coefficients (+ noise).
+    ``fused_modconv=True`` (inference): per-sample weights, one grouped convolution."""
+    n = x.shape[0]
+    o, i, kh, kw = weight.shape
+    misc.assert_shape(x, [n, i, None, None])
+    misc.assert_shape(styles, [n, i])
+    if x.dtype == torch.float16 and demodulate:
+        # fp16 cannot hold the products of raw weights and styles; demodulation cancels any common factor, so both are
+        # brought to unit max-norm first (networks.py:57-59)
+        weight = weight * (_fan_in_gain(i, np.sqrt(kh * kw)) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
+        styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)
+    if fused_modconv:
+        y = _per_sample_convolve(x, weight, styles, up, down, padding, resample_filter, demodulate, flip_weight)
+        return y if noise is None else y.add_(noise)
+    y, dcoefs = _modulate_and_convolve(x, weight, styles, up, down, padding, resample_filter, demodulate, flip_weight)
+    if dcoefs is None:
+        return y if noise is None else y.add_(noise.to(y.dtype))
+    if noise is None:
+        return scale_planes(y, dcoefs)
+    return fma.fma(y, dcoefs.to(y.dtype).reshape(n, -1, 1, 1), noise.to(y.dtype))
 
 #----------------------------------------------------------------------------
+# Dense layers.
 
 @persistence.persistent_class
 class FullyConnectedLayer(torch.nn.Module):
-    """networks.py:98-128"""
-    def __init__(self,
-        in_features,                # Number of input features.
-        out_features,               # Number of output features.
-        bias            = True,     # Apply additive bias before the activation function?
-        activation      = 'linear', # Activation function: 'relu', 'lrelu', etc.
-        lr_multiplier   = 1,        # Learning rate multiplier.
-        bias_init       = 0,        # Initial value for the additive bias.
-    ):
+    """y = act(x @ (w * lr_multiplier / sqrt(in)).T + b * lr_multiplier) (networks.py:98-128)."""
+    def __init__(self, in_features, out_features, bias=True, activation='linear', lr_multiplier=1, bias_init=0):
         super().__init__()
         self.activation = activation
         self.weight = torch.nn.Parameter(torch.randn([out_features, in_features]) / lr_multiplier)
@@ -282,386 +283,324 @@ class FullyConnectedLayer(torch.nn.Module):
         self.bias_gain = lr_multiplier
 
     def forward(self, x):
-        # networks.py:115-128.  The weight and bias gains ride in the GEMM's alpha / beta instead of two scaling kernels.
+        # both gains ride in the GEMM's alpha / beta: no scaling kernels
         w = self.weight.to(x.dtype)
-        b = self.bias
-        if b is not None:
-            y = torch.addmm(b.to(x.dtype).unsqueeze(0), x, w.t(), beta=float(self.bias_gain), alpha=float(self.weight_gain))
-            return y if self.activation == 'linear' else bias_act.bias_act(y, None, act=self.activation)
-        x = x.matmul((w * self.weight_gain).t())
-        return bias_act.bias_act(x, None, act=self.activation)
-
-#----------------------------------------------------------------------------
-
-def _make_conv_params(module, in_channels, out_channels, kernel_size, bias, channels_last, trainable):
-    """weight / bias as Parameters (trainable) or buffers (frozen), networks.py:158-168."""
-    memory_format = torch.channels_last if channels_last else torch.contiguous_format
-    weight = torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=memory_format)
-    bias = torch.zeros([out_channels]) if bias else None
-    if trainable:
-        module.weight = torch.nn.Parameter(weight)
-        module.bias = torch.nn.Parameter(bias) if bias is not None else None
-    else:
-        module.register_buffer('weight', weight)
-        if bias is not None:
-            module.register_buffer('bias', bias)
+        if self.bias is None:
+            y = torch.mm(x, w.t()) * self.weight_gain
         else:
-            module.bias = None
-
-@persistence.persistent_class
-class Conv2dLayer(torch.nn.Module):
-    """conv2d_resample -> bias_act (networks.py:132-179)."""
-    def __init__(self,
-        in_channels,                    # Number of input channels.
-        out_channels,                   # Number of output channels.
-        kernel_size,                    # Width and height of the convolution kernel.
-        bias            = True,         # Apply additive bias before the activation function?
-        activation      = 'linear',     # Activation function: 'relu', 'lrelu', etc.
-        up              = 1,            # Integer upsampling factor.
-        down            = 1,            # Integer downsampling factor.
-        resample_filter = [1,3,3,1],    # Low-pass filter to apply when resampling activations.
-        conv_clamp      = None,         # Clamp the output to +-X, None = disable clamping.
-        channels_last   = False,        # Expect the input to have memory_format=channels_last?
-        trainable       = True,         # Update the weights of this layer during training?
-    ):
-        super().__init__()
-        self.activation = activation
-        self.up = up
-        self.down = down
-        self.conv_clamp = conv_clamp
-        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
-        self.padding = kernel_size // 2
-        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
-        self.act_gain = bias_act.activation_funcs[activation].def_gain
-        _make_conv_params(self, in_channels, out_channels, kernel_size, bias, channels_last, trainable)
-
-    def forward(self, x, gain=1):
-        # `w = self.weight * self.weight_gain` (networks.py:171) is folded into the convolution's weight packing (wgain)
-        b = self.bias.to(x.dtype) if self.bias is not None else None
-        flip_weight = (self.up == 1)
-        act_gain = self.act_gain * gain
-        act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
-        return conv2d_resample.conv2d_resample_bias_act(x=x, w=self.weight.to(x.dtype), b=b, f=self.resample_filter, up=self.up,
-                                                        down=self.down, padding=self.padding, flip_weight=flip_weight,
-                                                        act=self.activation, gain=act_gain, clamp=act_clamp, wgain=self.weight_gain)
-
-#----------------------------------------------------------------------------
+            y = torch.addmm(self.bias.to(x.dtype)[None], x, w.t(), beta=float(self.bias_gain), alpha=float(self.weight_gain))
+        return y if self.activation == 'linear' else bias_act.bias_act(y, None, act=self.activation)
 
 @persistence.persistent_class
 class MappingNetwork(torch.nn.Module):
-    """Label embedding + FC stack -> w, with the running average ``w_avg`` (networks.py:183-259)."""
-    def __init__(self,
-        z_dim,                      # Input latent (Z) dimensionality, 0 = no latent.
-        c_dim,                      # Conditioning label (C) dimensionality, 0 = no label.
-        w_dim,                      # Intermediate latent (W) dimensionality.
-        num_ws,                     # Number of intermediate latents to output, None = do not broadcast.
-        num_layers      = 8,        # Number of mapping layers.
-        embed_features  = None,     # Label embedding dimensionality, None = same as w_dim.
-        layer_features  = None,     # Number of intermediate features in the mapping layers, None = same as w_dim.
-        activation      = 'lrelu',  # Activation function: 'relu', 'lrelu', etc.
-        lr_multiplier   = 0.01,     # Learning rate multiplier for the mapping layers.
-        w_avg_beta      = 0.995,    # Decay for tracking the moving average of W during training, None = do not track.
-    ):
+    """(z, embed(c)) -> FC stack -> w, broadcast to ``num_ws`` rows; keeps the running mean ``w_avg`` (networks.py:183-259)."""
+    def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=8, embed_features=None, layer_features=None,
+                 activation='lrelu', lr_multiplier=0.01, w_avg_beta=0.995):
         super().__init__()
-        self.z_dim = z_dim
-        self.c_dim = c_dim
-        self.w_dim = w_dim
-        self.num_ws = num_ws
-        self.num_layers = num_layers
-        self.w_avg_beta = w_avg_beta
-        if embed_features is None:
-            embed_features = w_dim
-        if c_dim == 0:
-            embed_features = 0
-        if layer_features is None:
-            layer_features = w_dim
-        features = [z_dim + embed_features] + [layer_features] * (num_layers - 1) + [w_dim]
+        self.z_dim, self.c_dim, self.w_dim = z_dim, c_dim, w_dim
+        self.num_ws, self.num_layers, self.w_avg_beta = num_ws, num_layers, w_avg_beta
+        embed = 0 if c_dim == 0 else (w_dim if embed_features is None else embed_features)
+        hidden = w_dim if layer_features is None else layer_features
+        widths = [z_dim + embed] + [hidden] * (num_layers - 1) + [w_dim]
         if c_dim > 0:
-            self.embed = FullyConnectedLayer(c_dim, embed_features)
-        for idx in range(num_layers):
-            setattr(self, f'fc{idx}', FullyConnectedLayer(features[idx], features[idx + 1], activation=activation, lr_multiplier=lr_multiplier))
+            self.embed = FullyConnectedLayer(c_dim, embed)
+        for idx, (fan_in, fan_out) in enumerate(zip(widths[:-1], widths[1:])):
+            setattr(self, f'fc{idx}', FullyConnectedLayer(fan_in, fan_out, activation=activation, lr_multiplier=lr_multiplier))
         if num_ws is not None and w_avg_beta is not None:
             self.register_buffer('w_avg', torch.zeros([w_dim]))
 
     def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, skip_w_avg_update=False):
-        x = None
+        parts = []
         if self.z_dim > 0:
             misc.assert_shape(z, [None, self.z_dim])
-            x = normalize_2nd_moment(z.to(torch.float32))
+            parts.append(normalize_2nd_moment(z.to(torch.float32)))
         if self.c_dim > 0:
             misc.assert_shape(c, [None, self.c_dim])
-            y = normalize_2nd_moment(self.embed(c.to(torch.float32)))
-            x = torch.cat([x, y], dim=1) if x is not None else y
+            parts.append(normalize_2nd_moment(self.embed(c.to(torch.float32))))
+        x = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
         for idx in range(self.num_layers):
             x = getattr(self, f'fc{idx}')(x)
-        if self.w_avg_beta is not None and self.training and not skip_w_avg_update:
+        if self.training and self.w_avg_beta is not None and not skip_w_avg_update:
             self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
         if self.num_ws is not None:
-            x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
+            x = x[:, None, :].repeat([1, self.num_ws, 1])
         if truncation_psi != 1:
             assert self.w_avg_beta is not None
-            if self.num_ws is None or truncation_cutoff is None:
+            rows = slice(None) if (self.num_ws is None or truncation_cutoff is None) else slice(0, truncation_cutoff)
+            if self.num_ws is None:
                 x = self.w_avg.lerp(x, truncation_psi)
             else:
-                x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
+                x[:, rows] = self.w_avg.lerp(x[:, rows], truncation_psi)
         return x
 
 #----------------------------------------------------------------------------
+# Convolution layers with a fixed (non-modulated) weight.
+
+class _FilteredConv(torch.nn.Module):
+    """State shared by ``Conv2dLayer`` (convolution then activation) and ``Spade_Conv2dLayer`` (activation then
+    convolution): weight / bias as parameters or, frozen, as buffers (networks.py:158-168), the resampling filter, and
+    the equalised-learning-rate gain, which the convolution's weight packing applies (no kernel for ``w * gain``)."""
+    def __init__(self, in_channels, out_channels, kernel_size, bias=True, activation='linear', up=1, down=1,
+                 resample_filter=[1,3,3,1], conv_clamp=None, channels_last=False, trainable=True):
+        super().__init__()
+        self.activation, self.up, self.down, self.conv_clamp = activation, up, down, conv_clamp
+        _attach_filter(self, resample_filter)
+        self.padding = kernel_size // 2
+        self.weight_gain = _fan_in_gain(in_channels, kernel_size)
+        self.act_gain = bias_act.activation_funcs[activation].def_gain
+        weight = _fresh_weight(out_channels, in_channels, kernel_size, channels_last)
+        bias = torch.zeros([out_channels]) if bias else None
+        if trainable:
+            self.weight = torch.nn.Parameter(weight)
+            self.bias = torch.nn.Parameter(bias) if bias is not None else None
+        else:
+            self.register_buffer('weight', weight)
+            if bias is None:
+                self.bias = None
+            else:
+                self.register_buffer('bias', bias)
+
+    def _resample_args(self, x):
+        return dict(w=self.weight.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down, padding=self.padding,
+                    flip_weight=(self.up == 1), wgain=self.weight_gain)     # up: the transposed convolution wants true-convolution taps
 
 @persistence.persistent_class
-class SynthesisLayer(torch.nn.Module):
-    """Affine -> modulated conv (+noise) -> bias_act (networks.py:263-315)."""
-    def __init__(self,
-        in_channels,                    # Number of input channels.
-        out_channels,                   # Number of output channels.
-        w_dim,                          # Intermediate latent (W) dimensionality.
-        resolution,                     # Resolution of this layer.
-        kernel_size     = 3,            # Convolution kernel size.
-        up              = 1,            # Integer upsampling factor.
-        use_noise       = True,         # Enable noise input?
-        activation      = 'lrelu',      # Activation function: 'relu', 'lrelu', etc.
-        resample_filter = [1,3,3,1],    # Low-pass filter to apply when resampling activations.
-        conv_clamp      = None,         # Clamp the output of convolution layers to +-X, None = disable clamping.
-        channels_last   = False,        # Use channels_last format for the weights?
-    ):
+class Conv2dLayer(_FilteredConv):
+    """conv2d_resample -> bias_act, bias / activation / gain / clamp in the convolution's epilogue where the dense
+    convolution is the last step (networks.py:132-179)."""
+    def forward(self, x, gain=1):
+        act_gain, act_clamp = _scaled_act(self.activation, gain, self.conv_clamp)
+        return conv2d_resample.conv2d_resample_bias_act(x=x, b=(None if self.bias is None else self.bias.to(x.dtype)), act=self.activation,
+                                                        gain=act_gain, clamp=act_clamp, **self._resample_args(x))
+
+@persistence.persistent_class
+class Spade_Conv2dLayer(_FilteredConv):
+    """bias_act first, convolution second (networks.py:4304-4355).  ``no_act=True``: the caller already applied the
+    activation (the SPADE normalisation kernel does it in the same pass)."""
+    def __init__(self, in_channels, out_channels, kernel_size, bias=True, activation='relu', up=1, down=1,
+                 resample_filter=[1,3,3,1], conv_clamp=None, channels_last=False, trainable=True):
+        super().__init__(in_channels, out_channels, kernel_size, bias=bias, activation=activation, up=up, down=down,
+                         resample_filter=resample_filter, conv_clamp=conv_clamp, channels_last=channels_last, trainable=trainable)
+
+    def fusable_activation(self, gain=1):
+        """(relu gain, clamp) when the producer of this layer's input may apply its activation (bias-free relu), else None."""
+        if self.bias is None and self.activation == 'relu':
+            return _scaled_act(self.activation, gain, self.conv_clamp)
+        return None
+
+    def forward(self, x, gain=1, no_act=False):
+        if not no_act:
+            act_gain, act_clamp = _scaled_act(self.activation, gain, self.conv_clamp)
+            x = bias_act.bias_act(x, (None if self.bias is None else self.bias.to(x.dtype)), act=self.activation, gain=act_gain, clamp=act_clamp)
+        return conv2d_resample.conv2d_resample(x=x, **self._resample_args(x))
+
+#----------------------------------------------------------------------------
+# Style-modulated layers.
+
+class _StyledConv(torch.nn.Module):
+    """affine (w -> per-channel styles, bias initialised to 1), a weight and a bias."""
+    def _make_styled(self, in_channels, out_channels, w_dim, kernel_size, channels_last):
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        self.weight = torch.nn.Parameter(_fresh_weight(out_channels, in_channels, kernel_size, channels_last))
+
+@persistence.persistent_class
+class SynthesisLayer(_StyledConv):
+    """affine -> modulated 3x3 convolution (optionally x2) + noise -> bias, lrelu, clamp (networks.py:263-315)."""
+    def __init__(self, in_channels, out_channels, w_dim, resolution, kernel_size=3, up=1, use_noise=True, activation='lrelu',
+                 resample_filter=[1,3,3,1], conv_clamp=None, channels_last=False):
         super().__init__()
-        self.resolution = resolution
-        self.up = up
-        self.use_noise = use_noise
-        self.activation = activation
-        self.conv_clamp = conv_clamp
-        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.resolution, self.up, self.use_noise = resolution, up, use_noise
+        self.activation, self.conv_clamp = activation, conv_clamp
+        _attach_filter(self, resample_filter)
         self.padding = kernel_size // 2
         self.act_gain = bias_act.activation_funcs[activation].def_gain
-        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
-        memory_format = torch.channels_last if channels_last else torch.contiguous_format
-        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=memory_format))
+        self._make_styled(in_channels, out_channels, w_dim, kernel_size, channels_last)
         if use_noise:
             self.register_buffer('noise_const', torch.randn([resolution, resolution]))
             self.noise_strength = torch.nn.Parameter(torch.zeros([]))
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
 
+    def _unit_noise(self, x, noise_mode):
+        """Unit-variance noise plane(s) for this call, before the learnt strength; None when the layer adds none."""
+        if not self.use_noise or noise_mode == 'none':
+            return None
+        if noise_mode == 'const':
+            return self.noise_const
+        return torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device)
+
     def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1):
         assert noise_mode in ['random', 'const', 'none']
-        in_resolution = self.resolution // self.up
-        misc.assert_shape(x, [None, self.weight.shape[1], in_resolution, in_resolution])
+        side = self.resolution // self.up
+        misc.assert_shape(x, [None, self.weight.shape[1], side, side])
         styles = self.affine(w)
-        flip_weight = (self.up == 1)
-        act_gain = self.act_gain * gain
-        act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
-        if not fused_modconv and x.dtype == torch.float32 and x.device.type == 'cuda' and self.activation in ('linear', 'lrelu'):
-            # training path: demodulation, noise, bias and activation as one pass over the convolution's output
-            unit = None
-            if self.use_noise and noise_mode == 'random':
-                unit = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device)
-            if self.use_noise and noise_mode == 'const':
-                unit = self.noise_const
-            u, dcoefs = _modulate_and_convolve(x, self.weight, styles, self.up, 1, self.padding, self.resample_filter, True, flip_weight)
-            return mod_bias_act(u, dcoefs, unit, self.noise_strength if unit is not None else None, self.bias, act=self.activation,
+        unit = self._unit_noise(x, noise_mode)
+        act_gain, act_clamp = _scaled_act(self.activation, gain, self.conv_clamp)
+        conv = dict(up=self.up, padding=self.padding, resample_filter=self.resample_filter, flip_weight=(self.up == 1))
+        if not fused_modconv and _hip_fp32(x) and self.activation in ('linear', 'lrelu'):
+            # training: demodulation, noise, bias, activation and clamp are ONE pass over the convolution's output
+            u, dcoefs = _modulate_and_convolve(x, self.weight, styles, down=1, demodulate=True, **conv)
+            return mod_bias_act(u, dcoefs, unit, (None if unit is None else self.noise_strength), self.bias, act=self.activation,
                                 gain=act_gain, clamp=act_clamp)
-        noise = None
-        if self.use_noise and noise_mode == 'random':
-            noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
-        if self.use_noise and noise_mode == 'const':
-            noise = self.noise_const * self.noise_strength
-        x = modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
-                             resample_filter=self.resample_filter, flip_weight=flip_weight, fused_modconv=fused_modconv)
-        return bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=act_gain, clamp=act_clamp)
+        noise = None if unit is None else unit * self.noise_strength
+        y = modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, fused_modconv=fused_modconv, **conv)
+        return bias_act.bias_act(y, self.bias.to(y.dtype), act=self.activation, gain=act_gain, clamp=act_clamp)
 
-#----------------------------------------------------------------------------
+class _StyledHeads(_StyledConv):
+    """1x1 modulated convolution without demodulation -> bias -> clamp, for the image and for any extra per-pixel heads
+    that read the same styled activations.  ``heads`` = ((suffix, channels, activation), ...) creates ``m_weight<suffix>``
+    / ``m_bias<suffix>``.  All linear outputs (image + linear heads) come from ONE convolution over the concatenated
+    weights: the activations (268 MB at 256^2, batch 16) are scaled and read once instead of once per head."""
+    def _make_heads(self, in_channels, out_channels, w_dim, kernel_size, conv_clamp, channels_last, heads=()):
+        self.conv_clamp = conv_clamp
+        self._make_styled(in_channels, out_channels, w_dim, kernel_size, channels_last)
+        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+        self.weight_gain = _fan_in_gain(in_channels, kernel_size)
+        self._heads = tuple(heads)
+        for suffix, channels, _act in self._heads:
+            setattr(self, f'm_weight{suffix}', torch.nn.Parameter(_fresh_weight(channels, in_channels, kernel_size, channels_last)))
+            setattr(self, f'm_bias{suffix}', torch.nn.Parameter(torch.zeros([channels])))
+
+    def _project(self, x, w, fused_modconv):
+        """-> (image, [head outputs in declaration order])"""
+        styles = self.affine(w) * self.weight_gain
+        def run(weight, bias, act):
+            y = modulated_conv2d(x=x, weight=weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
+            return bias_act.bias_act(y, bias.to(y.dtype), act=act, clamp=self.conv_clamp)
+        linear = [s for s, _c, act in self._heads if act == 'linear']
+        weights = [self.weight] + [getattr(self, f'm_weight{s}') for s in linear]
+        biases = [self.bias] + [getattr(self, f'm_bias{s}') for s in linear]
+        if len(weights) == 1:
+            merged = [run(self.weight, self.bias, 'linear')]
+        else:
+            merged = run(torch.cat(weights, dim=0), torch.cat(biases, dim=0), 'linear').split([wt.shape[0] for wt in weights], dim=1)
+        by_suffix = dict(zip(linear, merged[1:]))
+        for s, _c, act in self._heads:
+            if act != 'linear':
+                by_suffix[s] = run(getattr(self, f'm_weight{s}'), getattr(self, f'm_bias{s}'), act)
+        return merged[0], [by_suffix[s] for s, _c, _a in self._heads]
 
 @persistence.persistent_class
-class ToRGBLayer(torch.nn.Module):
-    """1x1 modulated conv without demodulation -> bias_act(linear, clamp) (networks.py:319-334)."""
+class ToRGBLayer(_StyledHeads):
+    """networks.py:319-334"""
     def __init__(self, in_channels, out_channels, w_dim, kernel_size=1, conv_clamp=None, channels_last=False):
         super().__init__()
-        self.conv_clamp = conv_clamp
-        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
-        memory_format = torch.channels_last if channels_last else torch.contiguous_format
-        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=memory_format))
-        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
-        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
+        self._make_heads(in_channels, out_channels, w_dim, kernel_size, conv_clamp, channels_last)
 
     def forward(self, x, w, fused_modconv=True):
-        styles = self.affine(w) * self.weight_gain
-        x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
-        return bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
+        return self._project(x, w, fused_modconv)[0]
 
 @persistence.persistent_class
-class ToRGBLayerFull(torch.nn.Module):
-    """ToRGB with an extra 6-class parsing head on the last style block (networks.py:5582-5611)."""
+class ToRGBLayerFull(_StyledHeads):
+    """ToRGB whose last style-branch instance also emits the 6-class parsing logits (networks.py:5582-5611).
+    Returns (image, parsing logits or None)."""
     def __init__(self, in_channels, out_channels, w_dim, kernel_size=1, conv_clamp=None, channels_last=False, is_last=False, is_style=False):
         super().__init__()
-        self.conv_clamp = conv_clamp
-        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
-        memory_format = torch.channels_last if channels_last else torch.contiguous_format
-        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=memory_format))
-        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
-        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
-        self.is_last = is_last
-        self.is_style = is_style
-        if self.is_last and self.is_style:
-            self.m_weight1 = torch.nn.Parameter(torch.randn([6, in_channels, kernel_size, kernel_size]).to(memory_format=memory_format))
-            self.m_bias1 = torch.nn.Parameter(torch.zeros([6]))
+        self.is_last, self.is_style = is_last, is_style
+        self._make_heads(in_channels, out_channels, w_dim, kernel_size, conv_clamp, channels_last,
+                         heads=[('1', 6, 'linear')] if (is_last and is_style) else [])
 
     def forward(self, x, w, fused_modconv=True):
-        styles = self.affine(w) * self.weight_gain
-        pred_parsing = None
-        if self.is_last and self.is_style:
-            pred_parsing = modulated_conv2d(x=x, weight=self.m_weight1, styles=styles, demodulate=False, fused_modconv=fused_modconv)
-            pred_parsing = bias_act.bias_act(pred_parsing, self.m_bias1.to(x.dtype), clamp=self.conv_clamp)
-        x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
-        x = bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
-        return x, pred_parsing
+        img, heads = self._project(x, w, fused_modconv)
+        return img, (heads[0] if heads else None)
 
 @persistence.persistent_class
-class ToRGBLayerV18(torch.nn.Module):
-    """ToRGB of the released 256 inference model: the last block also predicts sigmoid upper/lower clothing
-    masks (networks.py:5276-5310)."""
+class ToRGBLayerV18(_StyledHeads):
+    """ToRGB of the released 256x192 inference model: its last instance also emits sigmoid upper / lower clothing masks
+    (networks.py:5276-5310).  Returns (image, upper mask or None, lower mask or None)."""
     def __init__(self, in_channels, out_channels, w_dim, kernel_size=1, conv_clamp=None, channels_last=False, is_last=False):
         super().__init__()
-        self.conv_clamp = conv_clamp
-        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
-        memory_format = torch.channels_last if channels_last else torch.contiguous_format
-        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=memory_format))
-        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
-        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
         self.is_last = is_last
-        if self.is_last:
-            self.m_weight1 = torch.nn.Parameter(torch.randn([1, in_channels, kernel_size, kernel_size]).to(memory_format=memory_format))
-            self.m_bias1 = torch.nn.Parameter(torch.zeros([1]))
-            self.m_weight2 = torch.nn.Parameter(torch.randn([1, in_channels, kernel_size, kernel_size]).to(memory_format=memory_format))
-            self.m_bias2 = torch.nn.Parameter(torch.zeros([1]))
+        self._make_heads(in_channels, out_channels, w_dim, kernel_size, conv_clamp, channels_last,
+                         heads=[('1', 1, 'sigmoid'), ('2', 1, 'sigmoid')] if is_last else [])
 
     def forward(self, x, w, fused_modconv=True):
-        styles = self.affine(w) * self.weight_gain
-        upper_mask = lower_mask = None
-        if self.is_last:
-            upper_mask = modulated_conv2d(x=x, weight=self.m_weight1, styles=styles, demodulate=False, fused_modconv=fused_modconv)
-            upper_mask = bias_act.bias_act(upper_mask, self.m_bias1.to(x.dtype), clamp=self.conv_clamp, act='sigmoid')
-            lower_mask = modulated_conv2d(x=x, weight=self.m_weight2, styles=styles, demodulate=False, fused_modconv=fused_modconv)
-            lower_mask = bias_act.bias_act(lower_mask, self.m_bias2.to(x.dtype), clamp=self.conv_clamp, act='sigmoid')
-        x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
-        x = bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
-        return x, upper_mask, lower_mask
+        img, heads = self._project(x, w, fused_modconv)
+        return (img, *heads) if heads else (img, None, None)
 
 #----------------------------------------------------------------------------
 # Encoders.
 
 @persistence.persistent_class
 class ResBlock(torch.nn.Module):
-    """3x3 -> 3x3 with a 1x1 skip, each branch scaled by sqrt(1/2) (networks.py:528-558)."""
+    """sqrt(1/2) * (1x1 skip + 3x3 -> 3x3), resampling in skip and first 3x3 (networks.py:528-558).  ``kernel_size`` is
+    accepted and ignored, as in the reference (its callers pass 4)."""
     def __init__(self, in_channels, out_channels, kernel_size, bias=True, activation='linear', up=1, down=1,
                  resample_filter=[1,3,3,1], conv_clamp=None, channels_last=False, trainable=True):
         super().__init__()
-        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
-        common = dict(resample_filter=resample_filter, conv_clamp=conv_clamp, channels_last=channels_last)
-        self.conv0 = Conv2dLayer(in_channels, out_channels, kernel_size=3, activation=activation, up=up, down=down, bias=bias, **common)
-        self.conv1 = Conv2dLayer(out_channels, out_channels, kernel_size=3, activation=activation, bias=bias, **common)
-        self.skip = Conv2dLayer(in_channels, out_channels, kernel_size=1, bias=False, up=up, down=down, **common)
+        _attach_filter(self, resample_filter)
+        shared = dict(resample_filter=resample_filter, conv_clamp=conv_clamp, channels_last=channels_last)
+        self.conv0 = Conv2dLayer(in_channels, out_channels, kernel_size=3, activation=activation, up=up, down=down, bias=bias, **shared)
+        self.conv1 = Conv2dLayer(out_channels, out_channels, kernel_size=3, activation=activation, bias=bias, **shared)
+        self.skip = Conv2dLayer(in_channels, out_channels, kernel_size=1, bias=False, up=up, down=down, **shared)
 
     def forward(self, x):
-        y = self.skip(x, gain=np.sqrt(0.5))
-        x = self.conv0(x)
-        x = self.conv1(x, gain=np.sqrt(0.5))
-        return y.add_(x)
+        half = np.sqrt(0.5)
+        shortcut = self.skip(x, gain=half)
+        return shortcut.add_(self.conv1(self.conv0(x), gain=half))
+
+# channel multipliers (in, out) of the pose encoder's stride-2 stages (networks.py:564-565); the table continues at
+# 8 -> 8 for pyramids deeper than the reference's six stages (512^2 and up, own generalisation)
+_POSE_STAGES = [(1, 2), (2, 4), (4, 4), (4, 4), (4, 8), (8, 8)]
 
 @persistence.persistent_class
 class ConstEncoderNetwork(nn.Module):
-    """Pose encoder: 1x1 stem then ``n_downsampling`` stride-2 3x3 convs (networks.py:560-579)."""
+    """Pose (+ retained image) encoder: 1x1 stem, then ``n_downsampling`` stride-2 3x3 layers (networks.py:560-579)."""
     def __init__(self, input_nc, output_nc, ngf=64, n_downsampling=4):
         super().__init__()
-        mult_ins = [1, 2, 4, 4, 4, 8]
-        mult_outs = [2, 4, 4, 4, 8, 8]
-        layers = [Conv2dLayer(input_nc, ngf, kernel_size=1)]
-        for i in range(n_downsampling):
-            layers.append(Conv2dLayer(ngf * mult_ins[i], ngf * mult_outs[i], kernel_size=3, down=2))
-        self.model = nn.Sequential(*layers)
+        stages = (_POSE_STAGES + [(8, 8)] * n_downsampling)[:n_downsampling]
+        self.model = nn.Sequential(Conv2dLayer(input_nc, ngf, kernel_size=1),
+                                   *[Conv2dLayer(ngf * a, ngf * b, kernel_size=3, down=2) for a, b in stages])
 
     def forward(self, x):
         return self.model(x)
 
 class Dense(nn.Module):
-    """Per-pixel Linear -> InstanceNorm -> LeakyReLU(0.01) (networks.py:594-611)."""
+    """Per-pixel Linear -> InstanceNorm -> LeakyReLU(0.01) (networks.py:594-611).  The Linear runs as a 1x1 convolution on
+    the NCHW tensor (bias in its epilogue), so the reference's two permutes - full copies of the activation - do not exist."""
     def __init__(self, in_channels, out_channels):
         super().__init__()
-        self.in_channels = in_channels
-        self.out_channels = out_channels
+        self.in_channels, self.out_channels = in_channels, out_channels
         self.bn = nn.InstanceNorm2d(out_channels)
         self.activation = nn.LeakyReLU()
         self.linear = nn.Linear(in_channels, out_channels)
 
     def forward(self, x):
-        out = self.linear(x.permute((0, 2, 3, 1))).permute((0, 3, 1, 2))
-        return self.activation(self.bn(out))
+        if _hip_fp32(x):
+            y = conv2d_gradfix.conv2d_bias_act(x, self.linear.weight[:, :, None, None], self.linear.bias)
+        else:
+            y = self.linear(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+        return self.activation(self.bn(y))
 
 @persistence.persistent_class
 class StyleEncoderNetworkV16(nn.Module):
-    """Patch style encoder (-> 512-d code) plus the retain-image feature pyramid (networks.py:4836-4883)."""
-    def __init__(self, input_nc, output_nc, ngf=64, n_downsampling=4):
+    """Garment-patch encoder -> style code, plus the feature pyramid of the retained image that the synthesis blocks
+    merge in (networks.py:4836-4883).  ``feat_levels`` (own extension, default = the reference's 4) is the depth of that
+    pyramid: one full-resolution 3x3 layer and ``feat_levels - 1`` stride-2 layers."""
+    def __init__(self, input_nc, output_nc, ngf=64, n_downsampling=4, feat_levels=4):
         super().__init__()
-        encoder = [Conv2dLayer(input_nc, ngf, kernel_size=1)]
-        for mult_in, mult_out in zip([1, 2, 4], [2, 4, 8]):
-            encoder += [Dense(ngf * mult_in, ngf * mult_in), Conv2dLayer(ngf * mult_in, ngf * mult_out, kernel_size=3, down=2)]
-        for mult_in, mult_out in zip([8, 8, 8], [8, 8, 8]):
-            encoder += [Dense(ngf * mult_in, ngf * mult_in), Conv2dLayer(ngf * mult_in, ngf * mult_out, kernel_size=3)]
-        encoder += [nn.AdaptiveAvgPool2d(1)]
-        self.model = nn.Sequential(*encoder)
+        plan = [(1, 2, 2), (2, 4, 2), (4, 8, 2), (8, 8, 1), (8, 8, 1), (8, 8, 1)]           # (in, out, stride) after the stem
+        trunk = [Conv2dLayer(input_nc, ngf, kernel_size=1)]
+        for a, b, stride in plan:
+            trunk += [Dense(ngf * a, ngf * a), Conv2dLayer(ngf * a, ngf * b, kernel_size=3, down=stride)]
+        self.model = nn.Sequential(*trunk, nn.AdaptiveAvgPool2d(1))
         self.fc = FullyConnectedLayer(output_nc, output_nc)
-        feat_enc = [Conv2dLayer(3, ngf, kernel_size=3)]
-        for _ in range(3):
-            feat_enc += [Conv2dLayer(ngf, ngf, kernel_size=3, down=2)]
-        self.feat_enc = nn.Sequential(*feat_enc)
+        self.feat_enc = nn.Sequential(Conv2dLayer(3, ngf, kernel_size=3),
+                                      *[Conv2dLayer(ngf, ngf, kernel_size=3, down=2) for _ in range(feat_levels - 1)])
 
     def forward(self, x, const_input):
-        const_feats = []
-        for module in self.feat_enc:
-            const_input = module(const_input)
-            const_feats.append(const_input)
-        for module in self.model:
-            x = module(x)
-        x = self.fc(x.view(x.size(0), -1))
-        return x, const_feats
+        pyramid = []
+        for layer in self.feat_enc:
+            const_input = layer(const_input)
+            pyramid.append(const_input)
+        code = self.fc(self.model(x).flatten(1))
+        return code, pyramid
 
 #----------------------------------------------------------------------------
 # SPADE blocks.
 
 @persistence.persistent_class
-class Spade_Conv2dLayer(torch.nn.Module):
-    """Activation-before-convolution layer (networks.py:4304-4355)."""
-    def __init__(self, in_channels, out_channels, kernel_size, bias=True, activation='relu', up=1, down=1,
-                 resample_filter=[1,3,3,1], conv_clamp=None, channels_last=False, trainable=True):
-        super().__init__()
-        self.activation = activation
-        self.up = up
-        self.down = down
-        self.conv_clamp = conv_clamp
-        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
-        self.padding = kernel_size // 2
-        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
-        self.act_gain = bias_act.activation_funcs[activation].def_gain
-        _make_conv_params(self, in_channels, out_channels, kernel_size, bias, channels_last, trainable)
-
-    def fusable_activation(self, gain=1):
-        """(relu gain, clamp) of the activation this layer applies in front of its convolution, when the producer of
-        its input can apply it instead (no bias, relu); else None."""
-        if self.bias is not None or self.activation != 'relu':
-            return None
-        return self.act_gain * gain, (self.conv_clamp * gain if self.conv_clamp is not None else None)
-
-    def forward(self, x, gain=1, no_act=False):
-        b = self.bias.to(x.dtype) if self.bias is not None else None
-        if not no_act:
-            act_gain = self.act_gain * gain
-            act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
-            x = bias_act.bias_act(x, b, act=self.activation, gain=act_gain, clamp=act_clamp)
-        flip_weight = (self.up == 1)
-        return conv2d_resample.conv2d_resample(x=x, w=self.weight.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
-                                               padding=self.padding, flip_weight=flip_weight, wgain=self.weight_gain)
-
-@persistence.persistent_class
 class Spade_Norm_Block(torch.nn.Module):
-    """InstanceNorm(x) * (1 + gamma(feat)) + beta(feat) (networks.py:4358-4379)."""
+    """InstanceNorm(x) * (1 + gamma(feat)) + beta(feat), gamma / beta = conv3x3(relu(conv3x3(feat))) (networks.py:4358-4379)."""
     def __init__(self, in_channels, norm_channels):
         super().__init__()
         self.conv_mlp = Spade_Conv2dLayer(in_channels, norm_channels, kernel_size=3, bias=False)
@@ -670,573 +609,458 @@ class Spade_Norm_Block(torch.nn.Module):
         self.conv_beta = Spade_Conv2dLayer(norm_channels, norm_channels, kernel_size=3, bias=False)
         self.param_free_norm = nn.InstanceNorm2d(norm_channels, affine=False)
 
-    def forward(self, x, denorm_feats, post_act=None):
-        # conv_mlp (no activation in front, no bias) followed by nn.ReLU (:4373-4374): the ReLU rides in the convolution's epilogue
-        m = self.conv_mlp
-        actv = conv2d_resample.conv2d_resample_bias_act(x=denorm_feats, w=m.weight.to(denorm_feats.dtype), b=None, f=m.resample_filter,
-                                                        up=m.up, down=m.down, padding=m.padding, flip_weight=(m.up == 1),
-                                                        act='relu', gain=1, wgain=m.weight_gain)
-        # conv_gamma and conv_beta (:4375-4376) read the same tensor: ONE convolution with the concatenated weights writes
-        # gamma | beta as channel halves, the normalisation kernel reads (and, backwards, writes) the halves in place
+    def _twin_convs(self, actv):
         g, b = self.conv_gamma, self.conv_beta
-        same = (g.weight.shape == b.weight.shape and g.up == b.up == 1 and g.down == b.down == 1 and g.padding == b.padding
-                and g.bias is None and b.bias is None and g.weight_gain == b.weight_gain and actv.dtype == torch.float32)
-        if same:
-            gamma = conv2d_resample.conv2d_resample(x=actv, w=torch.cat([g.weight, b.weight], dim=0), f=g.resample_filter,
+        return (actv.dtype == torch.float32 and g.weight.shape == b.weight.shape and g.bias is None and b.bias is None
+                and (g.up, g.down, g.padding, g.weight_gain) == (b.up, b.down, b.padding, b.weight_gain) and g.up == g.down == 1)
+
+    def forward(self, x, denorm_feats, post_act=None):
+        mlp = self.conv_mlp         # no activation in front, nn.ReLU behind (:4373-4374): the ReLU rides in the epilogue
+        actv = conv2d_resample.conv2d_resample_bias_act(x=denorm_feats, b=None, act='relu', gain=1, **mlp._resample_args(denorm_feats))
+        if self._twin_convs(actv):
+            # conv_gamma and conv_beta read the same tensor (:4375-4376): ONE convolution over the concatenated weights
+            # writes gamma | beta as channel halves, which the normalisation kernel reads (and, backwards, writes) in place
+            g = self.conv_gamma
+            gamma = conv2d_resample.conv2d_resample(x=actv, w=torch.cat([g.weight, self.conv_beta.weight], dim=0), f=g.resample_filter,
                                                     padding=g.padding, flip_weight=True, wgain=g.weight_gain)
             beta = None
         else:
-            gamma = g(actv, no_act=True)
-            beta = b(actv, no_act=True)
-        if post_act is not None:        # (relu gain, clamp) of the consuming Spade_Conv2dLayer, applied in the same pass
-            return spade_modulate(x, gamma, beta, eps=self.param_free_norm.eps, relu_gain=post_act[0], clamp=post_act[1])
-        return spade_modulate(x, gamma, beta, eps=self.param_free_norm.eps)
+            gamma, beta = self.conv_gamma(actv, no_act=True), self.conv_beta(actv, no_act=True)
+        relu_gain, clamp = post_act if post_act is not None else (None, None)      # the consuming layer's activation, same pass
+        return spade_modulate(x, gamma, beta, eps=self.param_free_norm.eps, relu_gain=relu_gain, clamp=clamp)
 
 @persistence.persistent_class
 class Spade_ResBlockV2(torch.nn.Module):
-    """networks.py:5229-5273"""
+    """conv -> sqrt(1/2) * [skip(spade_skip(.)) + conv1(spade1(conv0(spade0(.))))] with activation-first layers
+    (networks.py:5229-5273).  ``feat_channels`` (own extension) overrides the reference's rule for the width of the
+    SPADE feature map (256 at ``resolution == 128``, else 128)."""
     def __init__(self, in_channels, out_channels, kernel_size=3, bias=True, activation='linear', up=1, down=1,
-                 resample_filter=[1,3,3,1], conv_clamp=None, channels_last=False, trainable=True, resolution=128):
+                 resample_filter=[1,3,3,1], conv_clamp=None, channels_last=False, trainable=True, resolution=128, feat_channels=None):
         super().__init__()
-        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
-        common = dict(bias=False, resample_filter=resample_filter, conv_clamp=conv_clamp, channels_last=channels_last)
-        self.conv = Spade_Conv2dLayer(in_channels, in_channels, kernel_size=3, **common)
-        self.conv0 = Spade_Conv2dLayer(in_channels, out_channels, kernel_size=3, **common)
-        self.conv1 = Spade_Conv2dLayer(out_channels, out_channels, kernel_size=3, **common)
-        self.skip = Spade_Conv2dLayer(in_channels, out_channels, kernel_size=1, **common)
-        feat_channels = 128 * 2 if resolution == 128 else 64 * 2
+        _attach_filter(self, resample_filter)
+        def layer(cin, cout, k):
+            return Spade_Conv2dLayer(cin, cout, kernel_size=k, bias=False, resample_filter=resample_filter, conv_clamp=conv_clamp,
+                                     channels_last=channels_last)
+        self.conv = layer(in_channels, in_channels, 3)
+        self.conv0 = layer(in_channels, out_channels, 3)
+        self.conv1 = layer(out_channels, out_channels, 3)
+        self.skip = layer(in_channels, out_channels, 1)
+        if feat_channels is None:
+            feat_channels = 256 if resolution == 128 else 128
         self.spade_skip = Spade_Norm_Block(feat_channels, in_channels)
         self.spade0 = Spade_Norm_Block(feat_channels, in_channels)
         self.spade1 = Spade_Norm_Block(feat_channels, out_channels)
 
-    def forward(self, x, denorm_feat):
-        x = self.conv(x, no_act=True)
-        y = self._normed_conv(self.spade_skip, self.skip, x, denorm_feat, np.sqrt(0.5))
-        x = self._normed_conv(self.spade0, self.conv0, x, denorm_feat, 1)
-        x = self._normed_conv(self.spade1, self.conv1, x, denorm_feat, np.sqrt(0.5))
-        return y.add_(x)
-
     @staticmethod
-    def _normed_conv(norm, conv, x, denorm_feat, gain):
-        """conv(norm(x, feat), gain): the activation in front of the convolution is applied by the SPADE kernel when
-        the layer allows it."""
+    def _norm_then_conv(norm, conv, x, feat, gain):
+        """conv(norm(x, feat), gain); the activation in front of the convolution is applied by the SPADE kernel when the
+        layer allows it (bias-free relu)."""
         post = conv.fusable_activation(gain)
         if post is None:
-            return conv(norm(x, denorm_feat), gain=gain)
-        return conv(norm(x, denorm_feat, post_act=post), no_act=True)
+            return conv(norm(x, feat), gain=gain)
+        return conv(norm(x, feat, post_act=post), no_act=True)
+
+    def forward(self, x, denorm_feat):
+        half = np.sqrt(0.5)
+        x = self.conv(x, no_act=True)
+        shortcut = self._norm_then_conv(self.spade_skip, self.skip, x, denorm_feat, half)
+        x = self._norm_then_conv(self.spade0, self.conv0, x, denorm_feat, 1)
+        x = self._norm_then_conv(self.spade1, self.conv1, x, denorm_feat, half)
+        return shortcut.add_(x)
 
 #----------------------------------------------------------------------------
-# Full-body generator.
+# Full-body generator: pose-seeded style pyramid, parsing-routed SPADE stage, texture block.
 
-@persistence.persistent_class
-class SynthesisBlockFull(torch.nn.Module):
-    """networks.py:5614-5719"""
-    def __init__(self,
-        in_channels,                        # Number of input channels, 0 = first block.
-        out_channels,                       # Number of output channels.
-        w_dim,                              # Intermediate latent (W) dimensionality.
-        resolution,                         # Resolution of this block.
-        img_channels,                       # Number of output color channels.
-        is_last,                            # Is this the last block?
-        is_style            = False,        # Is this the block in the sytle synthesis branch
-        architecture        = 'skip',       # Architecture: 'orig', 'skip', 'resnet'.
-        resample_filter     = [1,3,3,1],    # Low-pass filter to apply when resampling activations.
-        conv_clamp          = None,         # Clamp the output of convolution layers to +-X, None = disable clamping.
-        use_fp16            = False,        # Use FP16 for this block?
-        fp16_channels_last  = False,        # Use channels-last memory format with FP16?
-        **layer_kwargs,                     # Arguments for SynthesisLayer.
-    ):
+class _PoseStyleBlock(torch.nn.Module):
+    """One resolution of the pyramid (networks.py:5614-5719, 5313-5418).  The 4x4 block starts from the pose feature
+    (its ``const`` parameter exists for state-dict compatibility and is never read); the others run an upsampling and a
+    plain styled 3x3 layer; above 16x16 the retained-image feature of the block's resolution is concatenated and merged by
+    a 1x1 layer; in the 'skip' architecture every block adds its ToRGB output to the upsampled running image."""
+    torgb_class = None          # set by the concrete classes
+    extra_outputs = 0           # outputs of torgb_class besides the image
+
+    def _build(self, in_channels, out_channels, w_dim, resolution, img_channels, is_last, architecture, resample_filter,
+               conv_clamp, use_fp16, fp16_channels_last, torgb_kwargs, layer_kwargs):
         assert architecture in ['orig', 'skip', 'resnet']
-        super().__init__()
-        self.in_channels = in_channels
-        self.w_dim = w_dim
-        self.resolution = resolution
-        self.img_channels = img_channels
-        self.is_last = is_last
-        self.architecture = architecture
-        self.use_fp16 = use_fp16
-        self.channels_last = (use_fp16 and fp16_channels_last)
-        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
-        self.num_conv = 0
-        self.num_torgb = 0
-        if in_channels == 0:
-            self.const = torch.nn.Parameter(torch.randn([out_channels, resolution, resolution]))   # unused: the pose feature replaces it
-        if in_channels != 0:
-            self.conv0 = SynthesisLayer(in_channels, out_channels, w_dim=w_dim, resolution=resolution, up=2,
-                                        resample_filter=resample_filter, conv_clamp=conv_clamp, channels_last=self.channels_last, **layer_kwargs)
-            self.num_conv += 1
-        self.conv1 = SynthesisLayer(out_channels, out_channels, w_dim=w_dim, resolution=resolution,
-                                    conv_clamp=conv_clamp, channels_last=self.channels_last, **layer_kwargs)
-        self.num_conv += 1
-        if is_last or architecture == 'skip':
-            self.torgb = self._make_torgb(out_channels, img_channels, w_dim, conv_clamp, is_last, is_style)
-            self.num_torgb += 1
-        if in_channels != 0 and architecture == 'resnet':
-            self.skip = Conv2dLayer(in_channels, out_channels, kernel_size=1, bias=False, up=2,
-                                    resample_filter=resample_filter, channels_last=self.channels_last)
-        if self.resolution > 16:
-            self.merge_conv = Conv2dLayer(out_channels + 64, out_channels, kernel_size=1,
-                                          resample_filter=resample_filter, channels_last=self.channels_last)
-
-    def _make_torgb(self, out_channels, img_channels, w_dim, conv_clamp, is_last, is_style):
-        return ToRGBLayerFull(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp,
-                              channels_last=self.channels_last, is_last=is_last, is_style=is_style)
-
-    _num_heads = 1      # extra outputs of the ToRGB layer besides the image (parsing logits)
+        self.in_channels, self.w_dim, self.resolution, self.img_channels = in_channels, w_dim, resolution, img_channels
+        self.is_last, self.architecture, self.use_fp16 = is_last, architecture, use_fp16
+        self.channels_last = bool(use_fp16 and fp16_channels_last)
+        _attach_filter(self, resample_filter)
+        styled = dict(w_dim=w_dim, resolution=resolution, conv_clamp=conv_clamp, channels_last=self.channels_last, **layer_kwargs)
+        first = (in_channels == 0)
+        if first:
+            self.const = torch.nn.Parameter(torch.randn([out_channels, resolution, resolution]))
+        else:
+            self.conv0 = SynthesisLayer(in_channels, out_channels, up=2, resample_filter=resample_filter, **styled)
+        self.conv1 = SynthesisLayer(out_channels, out_channels, **styled)
+        self.num_conv = 1 if first else 2
+        self.num_torgb = int(is_last or architecture == 'skip')
+        if self.num_torgb:
+            self.torgb = self.torgb_class(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp, channels_last=self.channels_last,
+                                          is_last=is_last, **torgb_kwargs)
+        if not first and architecture == 'resnet':
+            self.skip = Conv2dLayer(in_channels, out_channels, kernel_size=1, bias=False, up=2, resample_filter=resample_filter,
+                                    channels_last=self.channels_last)
+        if resolution > 16:
+            self.merge_conv = Conv2dLayer(out_channels + 64, out_channels, kernel_size=1, resample_filter=resample_filter,
+                                          channels_last=self.channels_last)
 
     def forward(self, x, img, ws, pose_feature, cat_feat, force_fp32=False, fused_modconv=None, **layer_kwargs):
         misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
-        w_iter = iter(ws.unbind(dim=1))
-        dtype = torch.float16 if self.use_fp16 and not force_fp32 else torch.float32
-        memory_format = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
-        if fused_modconv is None:
+        latents = list(ws.unbind(dim=1))
+        dtype, memory_format = _block_dtype(self.use_fp16, self.channels_last, force_fp32)
+        if fused_modconv is None:       # per-sample weights only outside training, and in fp16 only for a single sample
             fused_modconv = (not self.training) and (dtype == torch.float32 or int(x.shape[0]) == 1)
+        styled = dict(fused_modconv=fused_modconv, **layer_kwargs)
 
         if self.in_channels == 0:
-            x = pose_feature.to(dtype=dtype, memory_format=memory_format)
+            x = self.conv1(pose_feature.to(dtype=dtype, memory_format=memory_format), latents.pop(0), **styled)
         else:
             misc.assert_shape(x, [None, self.in_channels, self.resolution // 2, self.resolution // 2])
             x = x.to(dtype=dtype, memory_format=memory_format)
+            if self.architecture == 'resnet':
+                half = np.sqrt(0.5)
+                shortcut = self.skip(x, gain=half)
+                x = self.conv1(self.conv0(x, latents.pop(0), **styled), latents.pop(0), gain=half, **styled)
+                x = shortcut.add_(x)
+            else:
+                x = self.conv1(self.conv0(x, latents.pop(0), **styled), latents.pop(0), **styled)
+                if x.shape[2] > 16:
+                    side = cat_feat[str(x.shape[2])].to(dtype=dtype, memory_format=memory_format)
+                    x = self.merge_conv(torch.cat([x, side], dim=1))
 
-        if self.in_channels == 0:
-            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
-        elif self.architecture == 'resnet':
-            y = self.skip(x, gain=np.sqrt(0.5))
-            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
-            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, gain=np.sqrt(0.5), **layer_kwargs)
-            x = y.add_(x)
-        else:
-            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
-            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
-            if x.shape[2] > 16:     # merge the warped-clothing feature of this resolution
-                x = torch.cat([x, cat_feat[str(x.shape[2])].to(dtype=dtype, memory_format=memory_format)], dim=1)
-                x = self.merge_conv(x)
-
-        heads = (None,) * self._num_heads
+        extras = (None,) * self.extra_outputs
         if img is not None:
             misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
             img = upfirdn2d.upsample2d(img, self.resample_filter)
-        if self.is_last or self.architecture == 'skip':
-            y, *heads = self.torgb(x, next(w_iter), fused_modconv=fused_modconv)
-            y = y.to(dtype=torch.float32, memory_format=torch.contiguous_format)
-            img = img.add_(y) if img is not None else y
-        return (x, img, *heads)
+        if self.num_torgb:
+            rgb, *extras = self.torgb(x, latents.pop(0), fused_modconv=fused_modconv)
+            rgb = rgb.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+            img = rgb if img is None else img.add_(rgb)
+        return (x, img, *extras)
 
 @persistence.persistent_class
-class SynthesisNetworkFull(torch.nn.Module):
-    """Style branch b4..b256, parsing-routed SPADE blocks at 128^2 and the texture block (networks.py:5722-5840)."""
-    def __init__(self,
-        w_dim,                      # Intermediate latent (W) dimensionality.
-        img_resolution,             # Output image resolution.
-        img_channels,               # Number of color channels.
-        channel_base    = 32768,    # Overall multiplier for the number of channels.
-        channel_max     = 512,      # Maximum number of channels in any layer.
-        num_fp16_res    = 0,        # Use FP16 for the N highest resolutions.
-        **block_kwargs,             # Arguments for SynthesisBlock.
-    ):
-        assert img_resolution >= 4 and img_resolution & (img_resolution - 1) == 0
-        super().__init__()
-        self.w_dim = w_dim
-        self.img_resolution = img_resolution
-        self.img_resolution_log2 = int(np.log2(img_resolution))
-        self.img_channels = img_channels
-        self.block_resolutions = [2 ** i for i in range(2, self.img_resolution_log2 + 1)]
-        channels_dict = {res: min(channel_base // res, channel_max) for res in self.block_resolutions}
+class SynthesisBlockFull(_PoseStyleBlock):
+    """networks.py:5614-5719; returns (x, img, parsing logits or None)."""
+    torgb_class, extra_outputs = ToRGBLayerFull, 1
 
+    def __init__(self, in_channels, out_channels, w_dim, resolution, img_channels, is_last, is_style=False, architecture='skip',
+                 resample_filter=[1,3,3,1], conv_clamp=None, use_fp16=False, fp16_channels_last=False, **layer_kwargs):
+        super().__init__()
+        self._build(in_channels, out_channels, w_dim, resolution, img_channels, is_last, architecture, resample_filter, conv_clamp,
+                    use_fp16, fp16_channels_last, dict(is_style=is_style), layer_kwargs)
+
+@persistence.persistent_class
+class SynthesisBlockV18(_PoseStyleBlock):
+    """networks.py:5313-5418; returns (x, img, upper mask or None, lower mask or None)."""
+    torgb_class, extra_outputs = ToRGBLayerV18, 2
+
+    def __init__(self, in_channels, out_channels, w_dim, resolution, img_channels, is_last, architecture='skip',
+                 resample_filter=[1,3,3,1], conv_clamp=None, use_fp16=False, fp16_channels_last=False, **layer_kwargs):
+        super().__init__()
+        self._build(in_channels, out_channels, w_dim, resolution, img_channels, is_last, architecture, resample_filter, conv_clamp,
+                    use_fp16, fp16_channels_last, dict(), layer_kwargs)
+
+class _PatchRoutedSynthesis(torch.nn.Module):
+    """Style pyramid b4 .. b<R>; three SPADE residual blocks at R/2 whose modulation maps come from the warped garment
+    patches, routed by the pyramid's own region prediction; and a second top block (``texture_b<R>``) that renders the
+    fine-tuned image from the SPADE output (networks.py:5722-5840, 5419-5531).
+
+    The reference hard-codes R = 256 (``res == 128``, ``128*128``, ``spade_b128_*``).  Here every one of those is
+    derived from ``img_resolution``: at 256 names, shapes and arithmetic are the reference's; other powers of two (the
+    512x320 model of test_512.py, whose class the reference does not ship) are this package's own generalisation."""
+    block_class = None
+    block_kwargs_extra = staticmethod(lambda style: dict())
+
+    def _build(self, w_dim, img_resolution, img_channels, channel_base, channel_max, block_kwargs):
+        assert img_resolution >= 8 and img_resolution & (img_resolution - 1) == 0
+        self.w_dim, self.img_resolution, self.img_channels = w_dim, img_resolution, img_channels
+        self.img_resolution_log2 = int(np.log2(img_resolution))
+        self.block_resolutions = [2 ** k for k in range(2, self.img_resolution_log2 + 1)]
+        width = {res: min(channel_base // res, channel_max) for res in self.block_resolutions}
+        top, below = self.block_resolutions[-1], self.block_resolutions[-2]
+        self.spade_resolution = below
+
+        def block(res, style):          # every block of the generator computes in fp32 (networks.py:5747-5748)
+            return self.block_class(width[res // 2] if res > 4 else 0, width[res], w_dim=w_dim, resolution=res, img_channels=img_channels,
+                                    is_last=(res == top), use_fp16=False, **self.block_kwargs_extra(style), **block_kwargs)
         self.num_ws = 0
         for res in self.block_resolutions:
-            in_channels = channels_dict[res // 2] if res > 4 else 0
-            out_channels = channels_dict[res]
-            is_last = (res == self.img_resolution)
-            block = SynthesisBlockFull(in_channels, out_channels, w_dim=w_dim, resolution=res, img_channels=img_channels,
-                                       is_last=is_last, is_style=True, use_fp16=False, **block_kwargs)   # fp32 always (networks.py:5747-5748)
-            self.num_ws += block.num_conv
-            if is_last:
-                self.num_ws += block.num_torgb
-            setattr(self, f'b{res}', block)
+            b = block(res, True)
+            setattr(self, f'b{res}', b)
+            self.num_ws += b.num_conv + (b.num_torgb if res == top else 0)
 
-        res = self.block_resolutions[-2]
-        self.spade_b128_1 = Spade_ResBlockV2(channels_dict[res], channels_dict[res])
-        self.spade_b128_2 = Spade_ResBlockV2(channels_dict[res], channels_dict[res])
-        self.spade_b128_3 = Spade_ResBlockV2(channels_dict[res], channels_dict[res])
-
-        res = self.block_resolutions[-1]
-        self.texture_b256 = SynthesisBlockFull(channels_dict[res // 2], channels_dict[res], w_dim=w_dim, resolution=res,
-                                               img_channels=img_channels, is_last=True, is_style=False, use_fp16=False, **block_kwargs)
         ngf = 64
-        self.spade_encoder = nn.Sequential(
-            Conv2dLayer(3, ngf, kernel_size=7, activation='relu'),
-            ResBlock(ngf, ngf, kernel_size=4, activation='relu'),
-            ResBlock(ngf, ngf * 2, kernel_size=4, activation='relu', down=2))
+        feat_width = 2 * (2 * ngf)                                  # upper | lower garment features of the SPADE encoder
+        extra = dict() if below == 128 else dict(resolution=below, feat_channels=feat_width)
+        for i in (1, 2, 3):
+            setattr(self, f'spade_b{below}_{i}', Spade_ResBlockV2(width[below], width[below], **extra))
+        setattr(self, f'texture_b{top}', block(top, False))
+        self.spade_encoder = nn.Sequential(Conv2dLayer(3, ngf, kernel_size=7, activation='relu'),
+                                           ResBlock(ngf, ngf, kernel_size=4, activation='relu'),
+                                           ResBlock(ngf, 2 * ngf, kernel_size=4, activation='relu', down=2))
 
     def get_spade_feat(self, mask_256, denorm_mask, denorm_input):
-        """Clothing features at 128^2; where the predicted region is not covered by the warped
-        clothing, fill with the masked mean feature (networks.py:5777-5800)."""
+        """Garment features at the SPADE resolution (networks.py:5777-5800).  ``mask_256``: the region the pyramid predicts
+        for this garment, at image resolution; ``denorm_mask`` / ``denorm_input``: the warped patches and their coverage.
+        Where the predicted region is not covered by a patch the feature is replaced by the mean feature of the covered
+        part (of the whole map when fewer than 11 pixels are covered: the mean over ``spade_resolution^2`` positions)."""
         dt = mask_256.dtype
-        mask_256 = (mask_256 > 0.9).to(dt)
-        mask_128 = (torch.nn.functional.interpolate(mask_256, scale_factor=0.5) > 0.9).to(dt)
-        denorm_mask_128 = (torch.nn.functional.interpolate(denorm_mask, scale_factor=0.5) > 0.9).to(dt)
-        valid_mask = ((mask_128 + denorm_mask_128) == 2.0).to(dt)
-        res_mask = mask_128 - valid_mask
+        halve = lambda m: torch.nn.functional.interpolate(m, scale_factor=0.5)
+        region = (mask_256 > 0.9).to(dt)
+        region_s = (halve(region) > 0.9).to(dt)
+        covered_s = (halve(denorm_mask) > 0.9).to(dt)
+        valid = ((region_s + covered_s) == 2.0).to(dt)
+        hole = region_s - valid
+        feat = self.spade_encoder(denorm_input * region - (1 - region))
+        total = (feat * valid).sum(dim=(2, 3), keepdim=True)
+        count = valid.sum(dim=(2, 3), keepdim=True)
+        enough = (count > 10).to(dt)
+        count = count * enough + float(self.spade_resolution ** 2) * (1 - enough)
+        return feat * (1 - hole) + (total / count) * hole
 
-        denorm_input = denorm_input * mask_256 - (1 - mask_256)
-        feat = self.spade_encoder(denorm_input)
-        valid_feat_sum = torch.sum(feat * valid_mask, dim=(2, 3), keepdim=True)
-        valid_mask_sum = torch.sum(valid_mask, dim=(2, 3), keepdim=True)
-        valid_index = (valid_mask_sum > 10).to(dt)
-        valid_mask_sum = valid_mask_sum * valid_index + (128 * 128) * (1 - valid_index)
-        average_feat = valid_feat_sum / valid_mask_sum
-        return feat * (1 - res_mask) + average_feat * res_mask
+    def _regions(self, heads):
+        """(upper, lower) garment regions at image resolution from the last block's extra ToRGB outputs."""
+        raise NotImplementedError
 
-    def forward(self, ws, pose_feat, cat_feat, denorm_upper_input, denorm_lower_input, denorm_upper_mask,
-                denorm_lower_mask, **block_kwargs):
+    def _pyramid(self, ws, pose_feat, cat_feat, block_kwargs):
         misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
         ws = ws.to(torch.float32)
-        block_ws = []
-        w_idx = 0
+        x = img = None
+        heads, keep, start = (), None, 0
         for res in self.block_resolutions:
-            block = getattr(self, f'b{res}')
-            block_ws.append(ws.narrow(1, w_idx, block.num_conv + block.num_torgb))
-            w_idx += block.num_conv
+            b = getattr(self, f'b{res}')
+            rows = ws.narrow(1, start, b.num_conv + b.num_torgb)      # a block's ToRGB shares the next block's first latent
+            start += b.num_conv
+            x, img, *heads = b(x, img, rows, pose_feat, cat_feat, force_fp32=True, **block_kwargs)
+            if res == self.spade_resolution:
+                keep = (x.clone(), img.clone())                         # later blocks update both in place
+        return img, heads, keep, rows
 
-        x = img = pred_parsing = None
-        for res, cur_ws in zip(self.block_resolutions, block_ws):
-            block = getattr(self, f'b{res}')
-            x, img, pred_parsing = block(x, img, cur_ws, pose_feat, cat_feat, force_fp32=True, **block_kwargs)
-            if res == 128:
-                x_128, img_128 = x.clone(), img.clone()
-
-        parsing_index = torch.argmax(torch.softmax(pred_parsing.detach(), dim=1), dim=1)[:, None, ...].float()
-        upper_mask = (parsing_index == 1).float()
-        lower_mask = (parsing_index == 2).float()
-        spade_upper_feat = self.get_spade_feat(upper_mask.detach(), denorm_upper_mask, denorm_upper_input)
-        spade_lower_feat = self.get_spade_feat(lower_mask.detach(), denorm_lower_mask, denorm_lower_input)
-        spade_feat = torch.cat([spade_upper_feat, spade_lower_feat], dim=1)
-
-        x_spade_128 = self.spade_b128_1(x_128, spade_feat)
-        x_spade_128 = self.spade_b128_2(x_spade_128, spade_feat)
-        x_spade_128 = self.spade_b128_3(x_spade_128, spade_feat)
-
-        _, finetune_img, _ = self.texture_b256(x_spade_128, img_128, block_ws[-1], pose_feat, cat_feat, force_fp32=True, **block_kwargs)
-        return img, finetune_img, pred_parsing
+    def _finetune(self, keep, top_rows, heads, pose_feat, cat_feat, denorm, block_kwargs):
+        du_in, dl_in, du_mask, dl_mask = denorm
+        upper, lower = self._regions(heads)
+        feat = torch.cat([self.get_spade_feat(upper.detach(), du_mask, du_in), self.get_spade_feat(lower.detach(), dl_mask, dl_in)], dim=1)
+        x, img_below = keep
+        for i in (1, 2, 3):
+            x = getattr(self, f'spade_b{self.spade_resolution}_{i}')(x, feat)
+        texture = getattr(self, f'texture_b{self.img_resolution}')
+        return texture(x, img_below, top_rows, pose_feat, cat_feat, force_fp32=True, **block_kwargs)[1]
 
 @persistence.persistent_class
-class GeneratorFull(torch.nn.Module):
-    """Pose encoder + patch style encoder + mapping + synthesis (networks.py:5843-5881)."""
-    def __init__(self,
-        z_dim,                      # Input latent (Z) dimensionality.
-        c_dim,                      # Conditioning label (C) dimensionality.
-        w_dim,                      # Intermediate latent (W) dimensionality.
-        img_resolution,             # Output resolution.
-        img_channels,               # Number of output color channels.
-        mapping_kwargs      = {},   # Arguments for MappingNetwork.
-        synthesis_kwargs    = {},   # Arguments for SynthesisNetwork.
-    ):
-        super().__init__()
-        self.z_dim = z_dim
-        self.c_dim = c_dim
-        self.w_dim = w_dim
-        self.img_resolution = img_resolution
-        self.img_channels = img_channels
-        self.synthesis = SynthesisNetworkFull(w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels, **synthesis_kwargs)
-        self.num_ws = self.synthesis.num_ws
-        self.mapping = MappingNetwork(z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=self.num_ws, **mapping_kwargs)
-        self.const_encoding = ConstEncoderNetwork(input_nc=3 + 3, output_nc=512, ngf=64, n_downsampling=6)
-        self.style_encoding = StyleEncoderNetworkV16(input_nc=(10 * 3 + 4 * 3), output_nc=512, ngf=64, n_downsampling=6)
+class SynthesisNetworkFull(_PatchRoutedSynthesis):
+    """Training-time synthesis network (networks.py:5722-5840): regions = argmax of the 6-class parsing logits
+    (class 1 upper garment, class 2 lower garment).  Returns (img, finetune_img, pred_parsing)."""
+    block_class = SynthesisBlockFull
+    block_kwargs_extra = staticmethod(lambda style: dict(is_style=style))
 
-    def forward(self, z, c, retain, pose, denorm_upper_input, denorm_lower_input, denorm_upper_mask, denorm_lower_mask,
-                truncation_psi=1, truncation_cutoff=None, **synthesis_kwargs):
-        pose_feat = self.const_encoding(pose)
-        stylecode, feats = self.style_encoding(c, retain)
-        ws = self.mapping(z, stylecode, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
-        cat_feats = {str(feat.shape[2]): feat for feat in feats}
-        return self.synthesis(ws, pose_feat, cat_feats, denorm_upper_input, denorm_lower_input,
-                              denorm_upper_mask, denorm_lower_mask, **synthesis_kwargs)
-
-#----------------------------------------------------------------------------
-# The released 256x192 inference model (test.py): same skeleton, sigmoid mask heads instead of parsing logits.
-
-@persistence.persistent_class
-class SynthesisBlockV18(SynthesisBlockFull.__mro__[1]):
-    """networks.py:5313-5418: SynthesisBlockFull with ToRGBLayerV18 (returns x, img, upper_mask, lower_mask)."""
-    _num_heads = 2
-
-    def __init__(self, in_channels, out_channels, w_dim, resolution, img_channels, is_last, **kwargs):
-        super().__init__(in_channels, out_channels, w_dim, resolution, img_channels, is_last, **kwargs)
-
-    def _make_torgb(self, out_channels, img_channels, w_dim, conv_clamp, is_last, is_style):
-        return ToRGBLayerV18(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp, channels_last=self.channels_last, is_last=is_last)
-
-@persistence.persistent_class
-class SynthesisNetworkV18(torch.nn.Module):
-    """networks.py:5419-5531"""
     def __init__(self, w_dim, img_resolution, img_channels, channel_base=32768, channel_max=512, num_fp16_res=0, **block_kwargs):
-        assert img_resolution >= 4 and img_resolution & (img_resolution - 1) == 0
         super().__init__()
-        self.w_dim = w_dim
-        self.img_resolution = img_resolution
-        self.img_resolution_log2 = int(np.log2(img_resolution))
-        self.img_channels = img_channels
-        self.block_resolutions = [2 ** i for i in range(2, self.img_resolution_log2 + 1)]
-        channels_dict = {res: min(channel_base // res, channel_max) for res in self.block_resolutions}
-        self.num_ws = 0
-        for res in self.block_resolutions:
-            in_channels = channels_dict[res // 2] if res > 4 else 0
-            is_last = (res == self.img_resolution)
-            block = SynthesisBlockV18(in_channels, channels_dict[res], w_dim=w_dim, resolution=res, img_channels=img_channels,
-                                      is_last=is_last, use_fp16=False, **block_kwargs)
-            self.num_ws += block.num_conv
-            if is_last:
-                self.num_ws += block.num_torgb
-            setattr(self, f'b{res}', block)
-        res = self.block_resolutions[-2]
-        self.spade_b128_1 = Spade_ResBlockV2(channels_dict[res], channels_dict[res])
-        self.spade_b128_2 = Spade_ResBlockV2(channels_dict[res], channels_dict[res])
-        self.spade_b128_3 = Spade_ResBlockV2(channels_dict[res], channels_dict[res])
-        res = self.block_resolutions[-1]
-        self.texture_b256 = SynthesisBlockV18(channels_dict[res // 2], channels_dict[res], w_dim=w_dim, resolution=res,
-                                              img_channels=img_channels, is_last=True, use_fp16=False, **block_kwargs)
-        ngf = 64
-        self.spade_encoder = nn.Sequential(
-            Conv2dLayer(3, ngf, kernel_size=7, activation='relu'),
-            ResBlock(ngf, ngf, kernel_size=4, activation='relu'),
-            ResBlock(ngf, ngf * 2, kernel_size=4, activation='relu', down=2))
+        self._build(w_dim, img_resolution, img_channels, channel_base, channel_max, block_kwargs)
 
-    get_spade_feat = SynthesisNetworkFull.__mro__[1].get_spade_feat
+    def _regions(self, heads):
+        label = heads[0].detach().argmax(dim=1, keepdim=True)           # softmax is monotone: argmax of the logits (:5826)
+        return (label == 1).float(), (label == 2).float()
 
     def forward(self, ws, pose_feat, cat_feat, denorm_upper_input, denorm_lower_input, denorm_upper_mask, denorm_lower_mask, **block_kwargs):
-        misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
-        ws = ws.to(torch.float32)
-        block_ws = []
-        w_idx = 0
-        for res in self.block_resolutions:
-            block = getattr(self, f'b{res}')
-            block_ws.append(ws.narrow(1, w_idx, block.num_conv + block.num_torgb))
-            w_idx += block.num_conv
-        x = img = upper_mask = lower_mask = None
-        for res, cur_ws in zip(self.block_resolutions, block_ws):
-            x, img, upper_mask, lower_mask = getattr(self, f'b{res}')(x, img, cur_ws, pose_feat, cat_feat, force_fp32=True, **block_kwargs)
-            if res == 128:
-                x_128, img_128 = x.clone(), img.clone()
-        spade_feat = torch.cat([self.get_spade_feat(upper_mask.detach(), denorm_upper_mask, denorm_upper_input),
-                                self.get_spade_feat(lower_mask.detach(), denorm_lower_mask, denorm_lower_input)], dim=1)
-        x_spade_128 = self.spade_b128_1(x_128, spade_feat)
-        x_spade_128 = self.spade_b128_2(x_spade_128, spade_feat)
-        x_spade_128 = self.spade_b128_3(x_spade_128, spade_feat)
-        _, finetune_img, _, _ = self.texture_b256(x_spade_128, img_128, block_ws[-1], pose_feat, cat_feat, force_fp32=True, **block_kwargs)
-        return img, finetune_img, upper_mask, lower_mask
+        img, heads, keep, top_rows = self._pyramid(ws, pose_feat, cat_feat, block_kwargs)
+        denorm = (denorm_upper_input, denorm_lower_input, denorm_upper_mask, denorm_lower_mask)
+        return img, self._finetune(keep, top_rows, heads, pose_feat, cat_feat, denorm, block_kwargs), heads[0]
 
 @persistence.persistent_class
-class GeneratorV18(torch.nn.Module):
-    """networks.py:5534-5577 (the class test.py's pretrained pickle instantiates; 60-channel patch input)."""
-    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs={}, synthesis_kwargs={}):
+class SynthesisNetworkV18(_PatchRoutedSynthesis):
+    """Synthesis network of the released inference model (networks.py:5419-5531): regions = the two sigmoid mask heads.
+    Returns (img, finetune_img, upper_mask, lower_mask)."""
+    block_class = SynthesisBlockV18
+
+    def __init__(self, w_dim, img_resolution, img_channels, channel_base=32768, channel_max=512, num_fp16_res=0, **block_kwargs):
         super().__init__()
-        self.z_dim = z_dim
-        self.c_dim = c_dim
-        self.w_dim = w_dim
-        self.img_resolution = img_resolution
-        self.img_channels = img_channels
-        self.synthesis = SynthesisNetworkV18(w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels, **synthesis_kwargs)
+        self._build(w_dim, img_resolution, img_channels, channel_base, channel_max, block_kwargs)
+
+    def _regions(self, heads):
+        return heads[0], heads[1]
+
+    def forward(self, ws, pose_feat, cat_feat, denorm_upper_input, denorm_lower_input, denorm_upper_mask, denorm_lower_mask, **block_kwargs):
+        img, heads, keep, top_rows = self._pyramid(ws, pose_feat, cat_feat, block_kwargs)
+        denorm = (denorm_upper_input, denorm_lower_input, denorm_upper_mask, denorm_lower_mask)
+        return img, self._finetune(keep, top_rows, heads, pose_feat, cat_feat, denorm, block_kwargs), heads[0], heads[1]
+
+class _TryOnGenerator(torch.nn.Module):
+    """Pose encoder + garment-patch style encoder + mapping + synthesis (networks.py:5843-5881, 5534-5577).
+    At 256 the sub-networks have the reference's depths (6 pose stages -> 4x4, 4 retained-image features for the merges
+    at 32..256); other resolutions scale both with log2(img_resolution) (own generalisation, see _PatchRoutedSynthesis)."""
+    synthesis_class = None
+    patch_channels = None       # channels of the stacked garment patches fed to the style encoder
+
+    def _build(self, z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs, synthesis_kwargs):
+        self.z_dim, self.c_dim, self.w_dim = z_dim, c_dim, w_dim
+        self.img_resolution, self.img_channels = img_resolution, img_channels
+        self.synthesis = self.synthesis_class(w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels, **synthesis_kwargs)
         self.num_ws = self.synthesis.num_ws
         self.mapping = MappingNetwork(z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=self.num_ws, **mapping_kwargs)
-        self.const_encoding = ConstEncoderNetwork(input_nc=3 + 3, output_nc=512, ngf=64, n_downsampling=6)
-        self.style_encoding = StyleEncoderNetworkV16(input_nc=30 * 2, output_nc=512, ngf=64, n_downsampling=6)
+        log2 = int(np.log2(img_resolution))
+        self.const_encoding = ConstEncoderNetwork(input_nc=3 + 3, output_nc=512, ngf=64, n_downsampling=log2 - 2)
+        levels = dict() if log2 == 8 else dict(feat_levels=log2 - 4)
+        self.style_encoding = StyleEncoderNetworkV16(input_nc=self.patch_channels, output_nc=512, ngf=64, n_downsampling=6, **levels)
 
     def forward(self, z, c, retain, pose, denorm_upper_input, denorm_lower_input, denorm_upper_mask, denorm_lower_mask,
                 truncation_psi=1, truncation_cutoff=None, **synthesis_kwargs):
         pose_feat = self.const_encoding(pose)
-        stylecode, feats = self.style_encoding(c, retain)
-        ws = self.mapping(z, stylecode, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
-        cat_feats = {str(feat.shape[2]): feat for feat in feats}
-        return self.synthesis(ws, pose_feat, cat_feats, denorm_upper_input, denorm_lower_input,
-                              denorm_upper_mask, denorm_lower_mask, **synthesis_kwargs)
+        code, pyramid = self.style_encoding(c, retain)
+        ws = self.mapping(z, code, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
+        by_size = {str(f.shape[2]): f for f in pyramid}
+        return self.synthesis(ws, pose_feat, by_size, denorm_upper_input, denorm_lower_input, denorm_upper_mask, denorm_lower_mask,
+                              **synthesis_kwargs)
+
+@persistence.persistent_class
+class GeneratorFull(_TryOnGenerator):
+    """The training generator (networks.py:5843-5881): 14 garment patches x 3 channels."""
+    synthesis_class, patch_channels = SynthesisNetworkFull, 10 * 3 + 4 * 3
+
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs={}, synthesis_kwargs={}):
+        super().__init__()
+        self._build(z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs, synthesis_kwargs)
+
+@persistence.persistent_class
+class GeneratorV18(_TryOnGenerator):
+    """The generator inside test.py's released pickle (networks.py:5534-5577): 60-channel patch stack."""
+    synthesis_class, patch_channels = SynthesisNetworkV18, 30 * 2
+
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs={}, synthesis_kwargs={}):
+        super().__init__()
+        self._build(z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs, synthesis_kwargs)
 
 #----------------------------------------------------------------------------
 # Discriminator.
 
 @persistence.persistent_class
 class DiscriminatorBlock(torch.nn.Module):
-    """fromrgb (first block) -> [3x3, 3x3 /2] + 1x1 /2 skip (networks.py:916-996)."""
-    def __init__(self,
-        in_channels,                        # Number of input channels, 0 = first block.
-        tmp_channels,                       # Number of intermediate channels.
-        out_channels,                       # Number of output channels.
-        resolution,                         # Resolution of this block.
-        img_channels,                       # Number of input color channels.
-        first_layer_idx,                    # Index of the first layer.
-        architecture        = 'resnet',     # Architecture: 'orig', 'skip', 'resnet'.
-        activation          = 'lrelu',      # Activation function: 'relu', 'lrelu', etc.
-        resample_filter     = [1,3,3,1],    # Low-pass filter to apply when resampling activations.
-        conv_clamp          = None,         # Clamp the output of convolution layers to +-X, None = disable clamping.
-        use_fp16            = False,        # Use FP16 for this block?
-        fp16_channels_last  = False,        # Use channels-last memory format with FP16?
-        freeze_layers       = 0,            # Freeze-D: Number of layers to freeze.
-    ):
+    """[fromrgb ->] 3x3 -> 3x3 /2, with a 1x1 /2 residual branch in the 'resnet' architecture (networks.py:916-996)."""
+    def __init__(self, in_channels, tmp_channels, out_channels, resolution, img_channels, first_layer_idx, architecture='resnet',
+                 activation='lrelu', resample_filter=[1,3,3,1], conv_clamp=None, use_fp16=False, fp16_channels_last=False, freeze_layers=0):
         assert in_channels in [0, tmp_channels]
         assert architecture in ['orig', 'skip', 'resnet']
         super().__init__()
-        self.in_channels = in_channels
-        self.resolution = resolution
-        self.img_channels = img_channels
-        self.first_layer_idx = first_layer_idx
-        self.architecture = architecture
-        self.use_fp16 = use_fp16
-        self.channels_last = (use_fp16 and fp16_channels_last)
-        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
-
-        self.num_layers = 0
-        def next_trainable():
-            trainable = (self.first_layer_idx + self.num_layers >= freeze_layers)
-            self.num_layers += 1
-            return trainable
-
+        self.in_channels, self.resolution, self.img_channels = in_channels, resolution, img_channels
+        self.first_layer_idx, self.architecture, self.use_fp16 = first_layer_idx, architecture, use_fp16
+        self.channels_last = bool(use_fp16 and fp16_channels_last)
+        _attach_filter(self, resample_filter)
+        # Freeze-D: layers are numbered through the whole discriminator; those below ``freeze_layers`` hold buffers
+        plan = []
         if in_channels == 0 or architecture == 'skip':
-            self.fromrgb = Conv2dLayer(img_channels, tmp_channels, kernel_size=1, activation=activation,
-                                       trainable=next_trainable(), conv_clamp=conv_clamp, channels_last=self.channels_last)
-        self.conv0 = Conv2dLayer(tmp_channels, tmp_channels, kernel_size=3, activation=activation,
-                                 trainable=next_trainable(), conv_clamp=conv_clamp, channels_last=self.channels_last)
-        self.conv1 = Conv2dLayer(tmp_channels, out_channels, kernel_size=3, activation=activation, down=2,
-                                 trainable=next_trainable(), resample_filter=resample_filter, conv_clamp=conv_clamp, channels_last=self.channels_last)
+            plan.append(('fromrgb', img_channels, tmp_channels, dict(kernel_size=1, activation=activation, conv_clamp=conv_clamp)))
+        plan.append(('conv0', tmp_channels, tmp_channels, dict(kernel_size=3, activation=activation, conv_clamp=conv_clamp)))
+        plan.append(('conv1', tmp_channels, out_channels, dict(kernel_size=3, activation=activation, down=2, conv_clamp=conv_clamp,
+                                                               resample_filter=resample_filter)))
         if architecture == 'resnet':
-            self.skip = Conv2dLayer(tmp_channels, out_channels, kernel_size=1, bias=False, down=2,
-                                    trainable=next_trainable(), resample_filter=resample_filter, channels_last=self.channels_last)
+            plan.append(('skip', tmp_channels, out_channels, dict(kernel_size=1, bias=False, down=2, resample_filter=resample_filter)))
+        for offset, (name, cin, cout, kw) in enumerate(plan):
+            setattr(self, name, Conv2dLayer(cin, cout, trainable=(first_layer_idx + offset >= freeze_layers),
+                                            channels_last=self.channels_last, **kw))
+        self.num_layers = len(plan)
 
     def forward(self, x, img, force_fp32=False):
-        dtype = torch.float16 if self.use_fp16 and not force_fp32 else torch.float32
-        memory_format = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
+        dtype, memory_format = _block_dtype(self.use_fp16, self.channels_last, force_fp32)
         if x is not None:
             misc.assert_shape(x, [None, self.in_channels, self.resolution, self.resolution])
             x = x.to(dtype=dtype, memory_format=memory_format)
-        if self.in_channels == 0 or self.architecture == 'skip':
+        if hasattr(self, 'fromrgb'):
             misc.assert_shape(img, [None, self.img_channels, self.resolution, self.resolution])
             img = img.to(dtype=dtype, memory_format=memory_format)
             y = self.fromrgb(img)
-            x = x + y if x is not None else y
+            x = y if x is None else x + y
             img = upfirdn2d.downsample2d(img, self.resample_filter) if self.architecture == 'skip' else None
         if self.architecture == 'resnet':
-            y = self.skip(x, gain=np.sqrt(0.5))
-            x = self.conv0(x)
-            x = self.conv1(x, gain=np.sqrt(0.5))
-            x = y.add_(x)
+            half = np.sqrt(0.5)
+            shortcut = self.skip(x, gain=half)
+            x = shortcut.add_(self.conv1(self.conv0(x), gain=half))
         else:
-            x = self.conv0(x)
-            x = self.conv1(x)
+            x = self.conv1(self.conv0(x))
         assert x.dtype == dtype
         return x, img
 
 @persistence.persistent_class
 class MinibatchStdLayer(torch.nn.Module):
-    """Append the per-group feature standard deviation as extra channels (networks.py:1000-1022)."""
+    """Appends, per group of ``group_size`` samples, the feature standard deviation averaged over channels (in
+    ``num_channels`` slices) and pixels, as constant extra channels (networks.py:1000-1022).  Groups are strided: sample m
+    belongs with m + B, m + 2B, ... where B = N / group size."""
     def __init__(self, group_size, num_channels=1):
         super().__init__()
-        self.group_size = group_size
-        self.num_channels = num_channels
+        self.group_size, self.num_channels = group_size, num_channels
 
     def forward(self, x):
-        N, C, H, W = x.shape
-        G = min(int(self.group_size), int(N)) if self.group_size is not None else int(N)
-        F = self.num_channels
-        c = C // F
-        y = x.reshape(G, -1, F, c, H, W)
-        y = y - y.mean(dim=0)
-        y = y.square().mean(dim=0)
-        y = (y + 1e-8).sqrt()
-        y = y.mean(dim=[2, 3, 4])
-        y = y.reshape(-1, F, 1, 1).repeat(G, 1, H, W)
-        return torch.cat([x, y], dim=1)
+        n, c, h, w = x.shape
+        g = int(n) if self.group_size is None else min(int(self.group_size), int(n))
+        f = self.num_channels
+        grouped = x.reshape(g, n // g, f, c // f, h, w)
+        std = (grouped.var(dim=0, unbiased=False) + 1e-8).sqrt()                # [B, F, c/F, H, W]
+        stat = std.mean(dim=[2, 3, 4]).reshape(n // g, f, 1, 1)
+        return torch.cat([x, stat.repeat(g, 1, h, w)], dim=1)
 
 @persistence.persistent_class
 class DiscriminatorEpilogue(torch.nn.Module):
-    """mbstd -> 3x3 -> FC -> FC -> projection on the conditioning vector (networks.py:1026-1080)."""
-    def __init__(self,
-        in_channels,                    # Number of input channels.
-        cmap_dim,                       # Dimensionality of mapped conditioning label, 0 = no label.
-        resolution,                     # Resolution of this block.
-        img_channels,                   # Number of input color channels.
-        architecture        = 'resnet', # Architecture: 'orig', 'skip', 'resnet'.
-        mbstd_group_size    = 4,        # Group size for the minibatch standard deviation layer, None = entire minibatch.
-        mbstd_num_channels  = 1,        # Number of features for the minibatch standard deviation layer, 0 = disable.
-        activation          = 'lrelu',  # Activation function: 'relu', 'lrelu', etc.
-        conv_clamp          = None,     # Clamp the output of convolution layers to +-X, None = disable clamping.
-    ):
+    """4x4 tail: minibatch-std -> 3x3 -> FC -> FC, then the projection onto the mapped conditioning vector
+    (networks.py:1026-1080)."""
+    def __init__(self, in_channels, cmap_dim, resolution, img_channels, architecture='resnet', mbstd_group_size=4,
+                 mbstd_num_channels=1, activation='lrelu', conv_clamp=None):
         assert architecture in ['orig', 'skip', 'resnet']
         super().__init__()
-        self.in_channels = in_channels
-        self.cmap_dim = cmap_dim
-        self.resolution = resolution
-        self.img_channels = img_channels
-        self.architecture = architecture
+        self.in_channels, self.cmap_dim, self.resolution = in_channels, cmap_dim, resolution
+        self.img_channels, self.architecture = img_channels, architecture
         if architecture == 'skip':
             self.fromrgb = Conv2dLayer(img_channels, in_channels, kernel_size=1, activation=activation)
         self.mbstd = MinibatchStdLayer(group_size=mbstd_group_size, num_channels=mbstd_num_channels) if mbstd_num_channels > 0 else None
         self.conv = Conv2dLayer(in_channels + mbstd_num_channels, in_channels, kernel_size=3, activation=activation, conv_clamp=conv_clamp)
-        self.fc = FullyConnectedLayer(in_channels * (resolution ** 2), in_channels, activation=activation)
-        self.out = FullyConnectedLayer(in_channels, 1 if cmap_dim == 0 else cmap_dim)
+        self.fc = FullyConnectedLayer(in_channels * resolution * resolution, in_channels, activation=activation)
+        self.out = FullyConnectedLayer(in_channels, cmap_dim if cmap_dim > 0 else 1)
 
     def forward(self, x, img, cmap, force_fp32=False):
+        del force_fp32                  # the tail always computes in fp32
         misc.assert_shape(x, [None, self.in_channels, self.resolution, self.resolution])
-        _ = force_fp32
         x = x.to(dtype=torch.float32, memory_format=torch.contiguous_format)
         if self.architecture == 'skip':
             misc.assert_shape(img, [None, self.img_channels, self.resolution, self.resolution])
             x = x + self.fromrgb(img.to(dtype=torch.float32, memory_format=torch.contiguous_format))
         if self.mbstd is not None:
             x = self.mbstd(x)
-        x = self.conv(x)
-        x = self.fc(x.flatten(1))
-        x = self.out(x)
+        x = self.out(self.fc(self.conv(x).flatten(1)))
         if self.cmap_dim > 0:
             misc.assert_shape(cmap, [None, self.cmap_dim])
-            x = (x * cmap).sum(dim=1, keepdim=True) * (1 / np.sqrt(self.cmap_dim))
+            x = (x * cmap).sum(dim=1, keepdim=True) / np.sqrt(self.cmap_dim)
         assert x.dtype == torch.float32
         return x
 
 @persistence.persistent_class
 class Discriminator(torch.nn.Module):
-    """Residual StyleGAN2 discriminator with projection conditioning (networks.py:1084-1139)."""
-    def __init__(self,
-        c_dim,                          # Conditioning label (C) dimensionality.
-        img_resolution,                 # Input resolution.
-        img_channels,                   # Number of input color channels.
-        architecture        = 'resnet', # Architecture: 'orig', 'skip', 'resnet'.
-        channel_base        = 32768,    # Overall multiplier for the number of channels.
-        channel_max         = 512,      # Maximum number of channels in any layer.
-        num_fp16_res        = 0,        # Use FP16 for the N highest resolutions.
-        conv_clamp          = None,     # Clamp the output of convolution layers to +-X, None = disable clamping.
-        cmap_dim            = None,     # Dimensionality of mapped conditioning label, None = default.
-        block_kwargs        = {},       # Arguments for DiscriminatorBlock.
-        mapping_kwargs      = {},       # Arguments for MappingNetwork.
-        epilogue_kwargs     = {},       # Arguments for DiscriminatorEpilogue.
-    ):
+    """Residual StyleGAN2 discriminator, projection-conditioned on the style code (networks.py:1084-1139).  The
+    ``num_fp16_res`` highest resolutions compute in fp16 (none when 0)."""
+    def __init__(self, c_dim, img_resolution, img_channels, architecture='resnet', channel_base=32768, channel_max=512,
+                 num_fp16_res=0, conv_clamp=None, cmap_dim=None, block_kwargs={}, mapping_kwargs={}, epilogue_kwargs={}):
         super().__init__()
-        self.c_dim = c_dim
-        self.img_resolution = img_resolution
+        self.c_dim, self.img_resolution, self.img_channels = c_dim, img_resolution, img_channels
         self.img_resolution_log2 = int(np.log2(img_resolution))
-        self.img_channels = img_channels
-        self.block_resolutions = [2 ** i for i in range(self.img_resolution_log2, 2, -1)]
-        channels_dict = {res: min(channel_base // res, channel_max) for res in self.block_resolutions + [4]}
-        fp16_resolution = max(2 ** (self.img_resolution_log2 + 1 - num_fp16_res), 8)
-        if cmap_dim is None:
-            cmap_dim = channels_dict[4]
+        self.block_resolutions = [2 ** k for k in range(self.img_resolution_log2, 2, -1)]
+        width = {res: min(channel_base // res, channel_max) for res in self.block_resolutions + [4]}
+        first_fp16 = max(2 ** (self.img_resolution_log2 + 1 - num_fp16_res), 8)
         if c_dim == 0:
             cmap_dim = 0
-        common_kwargs = dict(img_channels=img_channels, architecture=architecture, conv_clamp=conv_clamp)
-        cur_layer_idx = 0
+        elif cmap_dim is None:
+            cmap_dim = width[4]
+        shared = dict(img_channels=img_channels, architecture=architecture, conv_clamp=conv_clamp)
+        layer_idx = 0
         for res in self.block_resolutions:
-            in_channels = channels_dict[res] if res < img_resolution else 0
-            block = DiscriminatorBlock(in_channels, channels_dict[res], channels_dict[res // 2], resolution=res,
-                                       first_layer_idx=cur_layer_idx, use_fp16=(res >= fp16_resolution), **block_kwargs, **common_kwargs)
-            setattr(self, f'b{res}', block)
-            cur_layer_idx += block.num_layers
+            blk = DiscriminatorBlock(width[res] if res < img_resolution else 0, width[res], width[res // 2], resolution=res,
+                                     first_layer_idx=layer_idx, use_fp16=(res >= first_fp16), **block_kwargs, **shared)
+            setattr(self, f'b{res}', blk)
+            layer_idx += blk.num_layers
         if c_dim > 0:
             self.mapping = MappingNetwork(z_dim=0, c_dim=c_dim, w_dim=cmap_dim, num_ws=None, w_avg_beta=None, **mapping_kwargs)
-        self.b4 = DiscriminatorEpilogue(channels_dict[4], cmap_dim=cmap_dim, resolution=4, **epilogue_kwargs, **common_kwargs)
+        self.b4 = DiscriminatorEpilogue(width[4], cmap_dim=cmap_dim, resolution=4, **epilogue_kwargs, **shared)
 
     def forward(self, img, c, **block_kwargs):
         x = None
         for res in self.block_resolutions:
             x, img = getattr(self, f'b{res}')(x, img, **block_kwargs)
-        cmap = self.mapping(None, c) if self.c_dim > 0 else None
-        return self.b4(x, img, cmap)
+        return self.b4(x, img, self.mapping(None, c) if self.c_dim > 0 else None)
 
 #----------------------------------------------------------------------------
