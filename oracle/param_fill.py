@@ -67,10 +67,10 @@ G_KWARGS = dict(z_dim=0, c_dim=512, w_dim=512, img_resolution=256, img_channels=
 D_KWARGS = dict(c_dim=512, img_resolution=256, img_channels=3, channel_base=2048, channel_max=512, conv_clamp=256)
 
 
-def summarize(t):
+def summarize(t, samples=4096):
     """Compact fingerprint of a tensor: strided samples + moments (what the golden files store)."""
     t = t.detach().float().cpu()
     flat = t.reshape(-1)
-    step = max(flat.numel() // 4096, 1)
-    return dict(sample=flat[::step][:4096].numpy().copy(),
+    step = max(flat.numel() // samples, 1)
+    return dict(sample=flat[::step][:samples].numpy().copy(),
                 moments=np.array([flat.sum().item(), flat.abs().sum().item(), flat.square().sum().item()], dtype=np.float64))

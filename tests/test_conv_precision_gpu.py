@@ -245,3 +245,55 @@ def test_plan_reports_the_reduced_modes():
         _native.check(lib.pasta_conv2d_plan(ctypes.byref(d), 0, ctypes.byref(tile), ctypes.byref(ks), ctypes.byref(math),
                                             ctypes.byref(launches), ctypes.byref(kernel)))
         assert math.value == code and kernel.value == 2       # the row-reuse kernel in every split mode
+
+
+# ---- edge of the split-bf16 operand range ------------------------------------------------------------------------------
+# v = v1 + v2 + v3 with bf16 pieces keeps fp32's exponent range (bf16 has the same 8 exponent bits), so large and small
+# NORMAL operands behave like fp32.  Two deliberate differences from an fp32 FMA chain, both outside the model's operating
+# range (activations are clamped to +-256 after every layer, networks.py:176-178, and gradients pass nan_to_num before the
+# optimiser, training_loop_wo_flow_fullbody.py:513-515):
+#  * an infinite operand gives NaN where fp32 gives +-inf: the second piece is bf16(inf - inf).  Outputs whose receptive field
+#    does not contain the infinite element are unaffected;
+#  * operands below ~2^-110 lose their low pieces to bf16 subnormals (flushed), i.e. the result keeps 8..16 significant bits
+#    instead of 24 -- at magnitudes where the products themselves are at the edge of fp32's range.
+
+@pytest.mark.parametrize('scale', [1e30, 1e-30])
+def test_split_bf16_at_large_and_small_normal_magnitudes(scale):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn([4, 64, 32, 32], generator=g) * scale
+    w = torch.randn([64, 64, 3, 3], generator=g) / 24
+    ref64 = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    e16 = _errs('bf16x6', x.cuda(), w.cuda(), ref64)
+    e32 = _errs('f32', x.cuda(), w.cuda(), ref64)
+    print(f'scale {scale}: split-bf16 {e16[0]:.3e}, fp32 MFMA {e32[0]:.3e}')
+    assert e16[0] < 5e-6 and e32[0] < 5e-6
+
+
+def test_split_bf16_subnormal_pieces_lose_precision_gracefully():
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn([4, 64, 32, 32], generator=g) * 1e-36
+    w = torch.randn([64, 64, 3, 3], generator=g) / 24
+    ref64 = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    e16 = _errs('bf16x6', x.cuda(), w.cuda(), ref64)
+    print(f'scale 1e-36: split-bf16 max-rel {e16[0]:.3e}')
+    assert e16[0] < 2e-2                # at least the leading bf16 piece survives: no garbage, no NaN
+
+
+@pytest.mark.parametrize('bad', [float('inf'), float('-inf'), float('nan')])
+def test_non_finite_operand_stays_local(bad):
+    """One non-finite input element: every output whose 3x3 window contains it is non-finite (fp32 gives inf or NaN there as
+    well), every other output is exactly what it is without the poisoned element."""
+    from torch_utils.ops import conv2d_gradfix as cg
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn([2, 64, 32, 32], generator=g).cuda()
+    w = (torch.randn([64, 64, 3, 3], generator=g) / 24).cuda()
+    clean = cg.conv2d(x, w, padding=1)
+    xp = x.clone()
+    xp[1, 7, 10, 20] = bad
+    y = cg.conv2d(xp, w, padding=1)
+    hit = torch.zeros_like(y, dtype=torch.bool)
+    hit[1, :, 9:12, 19:22] = True
+    assert not torch.isfinite(y[hit]).any()
+    assert torch.equal(y[~hit], clean[~hit])
+    ref = torch.nn.functional.conv2d(xp.cpu(), w.cpu(), padding=1)
+    assert not torch.isfinite(ref[hit.cpu()]).any()          # the fp32 reference is non-finite at the same outputs

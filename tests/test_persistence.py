@@ -133,3 +133,56 @@ def test_loaded_generator_runs_on_the_hip_path():
                inp['denorm_upper_mask'], inp['denorm_lower_mask'], noise_mode='const')
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+# ---- a snapshot written by the reference's own classes (oracle/make_golden_snapshot.py) --------------------------------
+
+def _reference_snapshot():
+    import legacy
+    from conftest import GOLDEN
+    import os
+    with open(os.path.join(GOLDEN, 'reference_snapshot.pkl'), 'rb') as f:
+        return legacy.load_network_pkl(f)
+
+
+def test_reference_written_snapshot_binds_to_local_classes():
+    """``legacy.load_network_pkl`` on a pickle produced by the reference's persistence + networks modules (reference
+    persistence.py:99-126, training_loop_wo_flow_fullbody.py:588-602): every pickled class name resolves to this package's
+    class, constructor arguments survive, and the tensors are the ones the reference stored."""
+    from oracle import make_golden_snapshot as MS
+    from torch_utils import persistence
+    from training import networks
+    data = _reference_snapshot()
+    assert data['training_set_kwargs']['class_name'] == 'training.dataset.UvitonDatasetFull' and data['augment_pipe'] is None
+    D, block, spade = data['D'], data['G'], data['G_ema']
+    assert type(D) is networks.Discriminator and type(block) is networks.SynthesisBlockFull and type(spade) is networks.Spade_ResBlockV2
+    assert type(D.b64.conv1) is networks.Conv2dLayer and type(D.mapping.fc3) is networks.FullyConnectedLayer
+    assert type(block.torgb) is networks.ToRGBLayerFull and type(block.conv0) is networks.SynthesisLayer
+    assert type(spade.spade0) is networks.Spade_Norm_Block and type(spade.spade0.conv_mlp) is networks.Spade_Conv2dLayer
+    assert all(persistence.is_persistent(m) for m in (D, D.b4, D.b4.mbstd, block.merge_conv, spade.skip))
+    assert dict(D.init_kwargs) == MS.D_KWARGS and dict(block.init_kwargs) == MS.BLOCK_ARGS and dict(spade.init_kwargs) == MS.SPADE_ARGS
+    assert not D.training and not any(p.requires_grad for p in D.parameters())
+    # the weights are the closed form the generator script filled in: a locally constructed twin, filled the same way, is equal
+    for loaded, twin in [(D, networks.Discriminator(**MS.D_KWARGS)), (block, networks.SynthesisBlockFull(**MS.BLOCK_ARGS)),
+                         (spade, networks.Spade_ResBlockV2(**MS.SPADE_ARGS))]:
+        want = PF.fill_module(twin).state_dict()
+        got = loaded.state_dict()
+        assert list(got) == list(want)
+        assert all(torch.equal(got[k], want[k]) for k in want)
+    # derived attributes come from the local constructor, not from the pickled __dict__
+    assert block.torgb._heads == (('1', 6, 'linear'),) and D.b256.num_layers == 4
+
+
+@pytest.mark.gpu
+def test_reference_written_snapshot_reproduces_the_reference_outputs():
+    from conftest import load_golden, rel_err
+    from oracle import make_golden_snapshot as MS
+    g = load_golden('reference_snapshot_outputs.npz')
+    data = _reference_snapshot()
+    inp = {k: v.cuda() for k, v in MS.snapshot_inputs().items()}
+    D, block, spade = data['D'].cuda(), data['G'].cuda(), data['G_ema'].cuda()
+    with torch.no_grad():
+        assert rel_err(D(inp['d_img'], inp['d_c']), g['D.logits']) < 1e-4
+        x, img, parsing = block(inp['b_x'], inp['b_img'], inp['b_ws'], None, {'32': inp['b_cat']}, noise_mode='const', fused_modconv=False)
+        assert rel_err(x, g['G.x']) < 1e-4 and rel_err(img, g['G.img']) < 1e-4 and rel_err(parsing, g['G.parsing']) < 1e-4
+        assert rel_err(spade(inp['s_x'], inp['s_feat']), g['G_ema.y']) < 1e-4
