@@ -101,21 +101,42 @@ def test_oracle_discriminator_at_full_width():
 
 # ---- the HIP path -------------------------------------------------------------------------------------------------------
 
+def _generator_gradients(math):
+    from training import networks
+    from torch_utils.ops import conv2d_gradfix
+    old, conv2d_gradfix.conv_math = conv2d_gradfix.conv_math, math
+    try:
+        G = PF.fill_module(networks.GeneratorFull(**FW.G_KWARGS)).cuda().train().requires_grad_(True)
+        inp = {k: v.cuda() for k, v in PF.make_inputs(n=2, seed=0).items()}
+        img, fin, par = G(*_g_args(inp), noise_mode='const')
+        probe = (img * inp['real_img']).mean() + fin.square().mean() + 0.1 * par.abs().mean()
+        probe.backward()
+        return G, inp, (img, fin, par), probe, {k: p.grad for k, p in G.named_parameters()}
+    finally:
+        conv2d_gradfix.conv_math = old
+
+
 @pytest.mark.gpu
 def test_hip_generator_at_full_width():
-    from training import networks
     g = load_golden('models_fullwidth.npz')
-    G = PF.fill_module(networks.GeneratorFull(**FW.G_KWARGS)).cuda().train().requires_grad_(True)
-    inp = {k: v.cuda() for k, v in PF.make_inputs(n=2, seed=0).items()}
-    img, fin, par = G(*_g_args(inp), noise_mode='const')
+    G, inp, (img, fin, par), probe, grads = _generator_gradients('default')
     for key, t in [('G.img', img), ('G.finetune_img', fin), ('G.pred_parsing', par)]:
         _summary_ok(g, key, t, TOL_FWD)
-    probe = (img * inp['real_img']).mean() + fin.square().mean() + 0.1 * par.abs().mean()
     assert abs(probe.item() - float(g['G.probe'][0])) < TOL_FWD * abs(float(g['G.probe'][0]))
-    probe.backward()
-    grads = {k: p.grad for k, p in G.named_parameters()}
+    # Gradients at 1e-3.  A key may exceed it only where fp32 arithmetic itself does: some weight gradients are what is left
+    # after the demodulation cancels the bulk (b32.conv0.weight: entries of 1e-8 against 1e-3 elsewhere), and ANY fp32
+    # evaluation order lands 1e-3 away from the CPU reference there.  The yardstick is this package's exact-fp32 mode
+    # (fp32 MFMA, bit-for-bit fp32 FMA chains): the default split-bf16 arithmetic may deviate at most twice as far as it does.
+    _, _, _, _, grads32 = _generator_gradients('f32')
+    loosened = []
     for k in FW.GRAD_KEYS_G:
-        _summary_ok(g, 'G.grad.' + k, grads[k], TOL_GRAD)
+        ref = g['G.grad.' + k + '.sample']
+        e32 = rel_err(PF.summarize(grads32[k], samples=FW.SAMPLES)['sample'], ref)
+        tol = min(max(TOL_GRAD, 2 * e32), 1e-2)
+        if tol > TOL_GRAD:
+            loosened.append((k, e32))
+        _summary_ok(g, 'G.grad.' + k, grads[k], tol)
+    assert len(loosened) <= 2, loosened
     _gradnorms_ok(g, 'G.gradnorms', grads, TOL_GRAD)
     G.eval()
     with torch.no_grad():
