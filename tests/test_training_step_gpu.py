@@ -167,7 +167,8 @@ def test_ada_controller_moves_p_like_the_reference():
     p_host, mark = 0.3, 0
     for it in range(5):
         step.run(data)
-        if it % 2 == 0:     # adjustments happen after iterations 0, 2, 4 and use everything reported since the previous one
+        if (it + 1) % 2 == 0:     # batch_idx is incremented first (training_loop...:532-538): adjustments after iterations 1 and 3,
+                                  # each using everything reported since the previous one
             pending = torch.cat([s.flatten() for s in signs[mark:]])
             mark = len(signs)
             p_host = max(p_host + float(np.sign(pending.mean().item() - 0.6)) * (BATCH * 2) / (0.5 * 1000), 0.0)
