@@ -179,6 +179,107 @@ def cpu_baseline(budget_s=20.0):
                        f'{n} timed step(s) of {dt / n:.2f} s after 1 warm-up (oracle/ref_networks.py on the host)')
 
 
+class BytesMeter:
+    """HIP-event brackets around upfirdn2d launches (on the launch stream): algorithmic bytes and time per shape."""
+    def __init__(self):
+        self.records, self.enabled = [], False
+
+    def __call__(self, nbytes, key, launch):
+        if not self.enabled:
+            return launch()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); launch(); e.record()
+        self.records.append((key, nbytes, s, e))
+
+    def table(self):
+        tab = {}
+        for key, nbytes, s, e in self.records:
+            t = tab.setdefault(key, [0, 0.0, 0.0])
+            t[0] += 1; t[1] += s.elapsed_time(e); t[2] += nbytes
+        return tab
+
+
+def run_infer(args, device):
+    """BASELINE config 4: generator inference, batch 8, the call sequence of test.py:120-128 / test_512.py:127-134."""
+    import dnnlib  # noqa: F401
+    from training import networks
+    from training.training_loop_wo_flow_fullbody import SyntheticFullBodyBatch
+    from torch_utils.ops import upfirdn2d, conv2d_gradfix
+    res = args.res or 512
+    batch = args.batch_gpu if args.batch_gpu != 16 else 8
+    common = dict(z_dim=0, c_dim=512, w_dim=512, img_resolution=res, img_channels=3, mapping_kwargs=dict(num_layers=1),
+                  synthesis_kwargs=dict(channel_base=16384, channel_max=512, conv_clamp=256))
+    torch.manual_seed(0)
+    if res == 256:
+        G, patch_ch, cls_note = networks.GeneratorV18(**common), 60, "GeneratorV18 (test.py's released class; parity pinned by the reference fixture)"
+    else:
+        G, patch_ch, cls_note = networks.GeneratorFull(**common), 42, ('GeneratorFull generalised to 512 (test_512.py drives a class the reference does not '
+                                                                       'ship; this is the package\'s own generalisation, parity UNPINNED)')
+    G = G.eval().requires_grad_(False).to(device)
+    data = SyntheticFullBodyBatch(batch, device, seed=0, res=res).tensors
+    patches = data['style_input'].repeat(1, 2, 1, 1)[:, :patch_ch].contiguous()
+    z = torch.zeros([batch, 0], device=device)
+
+    def step():
+        with torch.no_grad():
+            code, pyramid = G.style_encoding(patches, data['retain'])
+            pose_feat = G.const_encoding(data['pose'])
+            ws = G.mapping(z, code)
+            feats = {str(f.shape[2]): f for f in pyramid}
+            return G.synthesis(ws, pose_feat, feats, data['denorm_upper_input'], data['denorm_lower_input'], data['denorm_upper_mask'],
+                               data['denorm_lower_mask'], noise_mode='const')
+
+    meter = BytesMeter()
+    upfirdn2d.launch_hook = meter
+    conv = ConvMeter(_native_lib())
+    conv2d_gradfix.launch_hook = conv
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    meter.enabled = conv.enabled = not args.no_meter
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    meter.enabled = conv.enabled = False
+    upfirdn2d.launch_hook = conv2d_gradfix.launch_hook = None
+    assert all(torch.isfinite(t).all() for t in out[:2])
+    line = {'metric': f'generator inference images/sec at {res}x{res * 5 // 8 if res == 512 else 192} (tensor {res}x{res}), batch {batch}', 'value': round(args.steps * batch / dt, 2),
+            'unit': 'images/sec', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000 * dt / args.steps, 2),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'conv_math': conv2d_gradfix.conv_math, 'data': 'synthetic',
+            'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            'config': {'workload': f'BASELINE config 4: generator inference, eval mode, per-sample modulated weights (grouped convolution, groups = batch), '
+                                   f'noise_mode const, cfg=fashion widths, random-init weights; {cls_note}', 'global_batch': batch, 'parallelism': 'dp1 (single process)'}}
+    tab = meter.table()
+    if tab:
+        nbytes, ms = sum(v[2] for v in tab.values()), sum(v[1] for v in tab.values())
+        big = max(tab.items(), key=lambda kv: kv[1][1])
+        line['roofline'] = {'bound': 'hbm', 'kernel': 'upfirdn2d (all launches of the generator)', 'achieved': round(nbytes / (ms * 1e-3) / 1e9, 1), 'peak': PEAK_HBM_GBS,
+                            'unit': 'GB/s', 'frac': round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), 'traffic': None,
+                            'traffic_note': 'no PMC pass committed for the inference workload',
+                            'algorithmic_bytes_per_step': round(nbytes / args.steps), 'launches_per_step': round(sum(v[0] for v in tab.values()) / args.steps, 1),
+                            'share_of_step': round(ms / (1000 * dt), 3),
+                            'largest_shape': {'shape': str(big[0]), 'gbps': round(big[1][2] / (big[1][1] * 1e-3) / 1e9, 1), 'ms_per_step': round(big[1][1] / args.steps, 3)}}
+    fam = conv.summary()
+    if fam:
+        line['conv_families'] = {k: {'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2), 'ms_per_step': round(v['ms'] / args.steps, 2),
+                                     'launches_per_step': round(v['launches'] / args.steps, 1)} for k, v in sorted(fam.items())}
+        line['conv_total'] = {'tflop_per_step': round(sum(v['flops'] for v in fam.values()) / args.steps / 1e12, 3),
+                              'ms_per_step': round(sum(v['ms'] for v in fam.values()) / args.steps, 2)}
+    if args.by_shape:
+        for key, (calls, ms, nb) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
+            print(f'upfirdn2d {str(key):60s} calls/step={calls / args.steps:5.1f} ms/step={ms / args.steps:7.3f} GB/s={nb / (ms * 1e-3) / 1e9:7.1f}', file=sys.stderr)
+        for shape, calls, ms, tf in conv.by_shape()[:args.by_shape_top]:
+            print(f'{str(shape):70s} calls/step={calls / args.steps:6.1f} ms/step={ms / args.steps:8.2f} TF/s={tf:7.1f}', file=sys.stderr)
+    print(json.dumps(line), flush=True)
+
+
+def _native_lib():
+    from torch_utils.ops import _native
+    return _native.lib()
+
+
 def launch_ranks(n, argv):
     """Start ``n`` rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), wait for
     them and relay rank 0's stdout.  This process makes no GPU call (``import torch`` and the hipcc build do not touch the
@@ -239,6 +340,11 @@ def main():
                          "'bf16x3' = what TrainingStep selects for allow_tf32=True; 'bf16' = bf16 operands. Reduced modes are reported as such, never as the headline")
     ap.add_argument('--ddp-mode', default='flat', choices=['flat', 'torch'], help="gradient exchange at N > 1: 'flat' = one bucketed reducer per "
                     "optimised module (training/grad_reducer.py); 'torch' = the reference's five DistributedDataParallel wrappers")
+    ap.add_argument('--mode', default='train', choices=['train', 'infer'], help="'train' (default, the headline): the full training step of BASELINE "
+                    "config 2.  'infer': generator inference as test.py / test_512.py run it (BASELINE config 4): eval mode, per-sample weights "
+                    "(fused_modconv, grouped convolution), const noise; reports generated images/sec and the HBM roofline of upfirdn2d")
+    ap.add_argument('--res', type=int, default=None, choices=[256, 512], help="--mode infer: 256 = GeneratorV18 (test.py's class, parity pinned); "
+                    "512 (default) = the resolution-generalised GeneratorFull standing in for test_512.py's unreleased class (parity unpinned)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-meter', action='store_true', help='do not bracket convolution launches with events')
     ap.add_argument('--by-shape', action='store_true', help='also print a per-shape convolution table to stderr')
@@ -284,6 +390,9 @@ def main():
     lib = _native.lib()       # raises if libpasta_hip.so is missing
     if args.conv_math is not None:
         conv2d_gradfix.conv_math = args.conv_math
+    if args.mode == 'infer':
+        assert world == 1, '--mode infer is a single-GPU measurement (replicas only: nothing is exchanged)'
+        return run_infer(args, device)
     cfg = fashion_config(mbstd_group_size=min(args.batch_gpu, 4))      # train_wo_flow_fullbody.py:184: mbstd = min(batch_gpu, 4)
     from training.training_loop_wo_flow_fullbody import augment_options
     cfg.update(augment_options(aug=args.aug, augpipe='bgc', p=args.aug_p))

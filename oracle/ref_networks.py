@@ -5,9 +5,14 @@ the reference's modules, which the product modules share) plus the activations, 
 layer with the op restatements of ``oracle/ref_ops.py``. No module classes, no caching, CPU only.
 Citations are to the reference's ``training/networks.py``.
 
-Parity status: PINNED -- ``oracle/make_golden_models.py`` runs the reference's own
+Parity status: PINNED at ``img_resolution=256`` -- ``oracle/make_golden_models.py`` runs the reference's own
 ``GeneratorFull`` / ``Discriminator`` on deterministic weights (``oracle/param_fill.py``) and
 ``tests/test_oracle_golden.py`` checks this file against the stored outputs and gradients.
+PARITY UNPINNED for any other ``img_resolution``: the reference ships no generator class for 512x320 (its
+``GeneratorFull`` hard-codes 128 / 256: SURVEY F9; test_512.py drives a class that exists only inside an unreleased
+pickle).  For those resolutions this file restates THIS REPOSITORY's generalisation (training/networks.py,
+``_PatchRoutedSynthesis`` / ``_TryOnGenerator``: pose encoder log2(R) - 2 stages deep, log2(R) - 4 retained-image
+feature levels, SPADE stage at R / 2, texture block at R); the tests then check the HIP path against that restatement only.
 """
 
 import numpy as np
@@ -110,7 +115,7 @@ def resblock(sd, p, x, activation='relu', down=1):
     return y + x
 
 def const_encoder(sd, p, pose, n_downsampling=6):
-    """ConstEncoderNetwork, networks.py:560-579."""
+    """ConstEncoderNetwork, networks.py:560-579 (n_downsampling = 6 at 256)."""
     x = conv2d_layer(sd, f'{p}.model.0', pose)
     for i in range(n_downsampling):
         x = conv2d_layer(sd, f'{p}.model.{i + 1}', x, down=2)
@@ -121,11 +126,11 @@ def dense(sd, p, x):
     out = F.linear(x.permute(0, 2, 3, 1), sd[p + '.linear.weight'], sd[p + '.linear.bias']).permute(0, 3, 1, 2)
     return F.leaky_relu(F.instance_norm(out, eps=1e-5), 0.01)
 
-def style_encoder(sd, p, c, retain):
-    """StyleEncoderNetworkV16.forward, networks.py:4872-4883."""
+def style_encoder(sd, p, c, retain, feat_levels=4):
+    """StyleEncoderNetworkV16.forward, networks.py:4872-4883 (four feature levels at 256)."""
     feats = []
     x = retain
-    for i in range(4):
+    for i in range(feat_levels):
         x = conv2d_layer(sd, f'{p}.feat_enc.{i}', x, down=(1 if i == 0 else 2))
         feats.append(x)
     x = conv2d_layer(sd, f'{p}.model.0', c)
@@ -156,8 +161,8 @@ def spade_resblock(sd, p, x, feat, conv_clamp=None):
     x = spade_conv2d_layer(sd, p + '.conv1', spade_norm_block(sd, p + '.spade1', x, feat), gain=np.sqrt(0.5))
     return y + x
 
-def get_spade_feat(sd, p, mask_256, denorm_mask, denorm_input):
-    """SynthesisNetworkFull.get_spade_feat, networks.py:5777-5800."""
+def get_spade_feat(sd, p, mask_256, denorm_mask, denorm_input, spade_resolution=128):
+    """SynthesisNetworkFull.get_spade_feat, networks.py:5777-5800 (the fill count ``128 * 128`` is the SPADE plane)."""
     mask_256 = (mask_256 > 0.9).float()
     mask_128 = (F.interpolate(mask_256, scale_factor=0.5) > 0.9).float()
     denorm_mask_128 = (F.interpolate(denorm_mask, scale_factor=0.5) > 0.9).float()
@@ -170,7 +175,7 @@ def get_spade_feat(sd, p, mask_256, denorm_mask, denorm_input):
     feat_sum = (feat * valid).sum(dim=(2, 3), keepdim=True)
     mask_sum = valid.sum(dim=(2, 3), keepdim=True)
     ok = (mask_sum > 10).float()
-    mask_sum = mask_sum * ok + (128 * 128) * (1 - ok)
+    mask_sum = mask_sum * ok + (spade_resolution * spade_resolution) * (1 - ok)
     return feat * (1 - res_mask) + (feat_sum / mask_sum) * res_mask
 
 #----------------------------------------------------------------------------
@@ -206,24 +211,26 @@ def synthesis_full(sd, p, ws, pose_feat, cat_feat, du_in, dl_in, du_mask, dl_mas
     for res, cur in zip(resolutions, block_ws):
         x, img, parsing = synthesis_block_full(sd, f'{p}.b{res}', x, img, cur, pose_feat, cat_feat, res, res == 4, conv_clamp,
                                                noise_mode, fused_modconv)
-        if res == 128:
+        if res == img_resolution // 2:
             x_128, img_128 = x, img
+    sres = img_resolution // 2
     index = torch.argmax(torch.softmax(parsing.detach(), dim=1), dim=1)[:, None].float()
-    upper = get_spade_feat(sd, p, (index == 1).float(), du_mask, du_in)
-    lower = get_spade_feat(sd, p, (index == 2).float(), dl_mask, dl_in)
+    upper = get_spade_feat(sd, p, (index == 1).float(), du_mask, du_in, sres)
+    lower = get_spade_feat(sd, p, (index == 2).float(), dl_mask, dl_in, sres)
     feat = torch.cat([upper, lower], dim=1)
-    xs = spade_resblock(sd, p + '.spade_b128_1', x_128, feat)
-    xs = spade_resblock(sd, p + '.spade_b128_2', xs, feat)
-    xs = spade_resblock(sd, p + '.spade_b128_3', xs, feat)
-    _, finetune, _ = synthesis_block_full(sd, p + '.texture_b256', xs, img_128, block_ws[-1], pose_feat, cat_feat, 256, False,
-                                          conv_clamp, noise_mode, fused_modconv)
+    xs = x_128
+    for i in (1, 2, 3):
+        xs = spade_resblock(sd, f'{p}.spade_b{sres}_{i}', xs, feat)
+    _, finetune, _ = synthesis_block_full(sd, f'{p}.texture_b{img_resolution}', xs, img_128, block_ws[-1], pose_feat, cat_feat,
+                                          img_resolution, False, conv_clamp, noise_mode, fused_modconv)
     return img, finetune, parsing
 
 def generator_full(sd, z, c, retain, pose, du_in, dl_in, du_mask, dl_mask, img_resolution=256, conv_clamp=256,
                    mapping_layers=1, noise_mode='const', fused_modconv=False):
     """GeneratorFull.forward, networks.py:5866-5881."""
-    pose_feat = const_encoder(sd, 'const_encoding', pose)
-    code, feats = style_encoder(sd, 'style_encoding', c, retain)
+    log2 = int(np.log2(img_resolution))
+    pose_feat = const_encoder(sd, 'const_encoding', pose, n_downsampling=log2 - 2)
+    code, feats = style_encoder(sd, 'style_encoding', c, retain, feat_levels=log2 - 4)
     num_ws = 2 * int(np.log2(img_resolution)) - 2      # 1 + 2*(blocks-1) convs + the last ToRGB
     ws = mapping(sd, 'mapping', z, code, mapping_layers, num_ws, z_dim=(z.shape[1] if z is not None else 0), c_dim=code.shape[1])
     cat = {str(f.shape[2]): f for f in feats}
@@ -264,8 +271,9 @@ def _block_v18(sd, p, x, img, ws, pose_feat, cat_feat, first, conv_clamp, noise_
 def generator_v18(sd, z, c, retain, pose, du_in, dl_in, du_mask, dl_mask, img_resolution=256, conv_clamp=256,
                   mapping_layers=1, noise_mode='const', fused_modconv=True):
     """GeneratorV18.forward + SynthesisNetworkV18.forward, networks.py:5481-5577."""
-    pose_feat = const_encoder(sd, 'const_encoding', pose)
-    code, feats = style_encoder(sd, 'style_encoding', c, retain)
+    log2 = int(np.log2(img_resolution))
+    pose_feat = const_encoder(sd, 'const_encoding', pose, n_downsampling=log2 - 2)
+    code, feats = style_encoder(sd, 'style_encoding', c, retain, feat_levels=log2 - 4)
     num_ws = 2 * int(np.log2(img_resolution)) - 2
     ws = mapping(sd, 'mapping', z, code, mapping_layers, num_ws, z_dim=(z.shape[1] if z is not None else 0), c_dim=code.shape[1])
     cat = {str(f.shape[2]): f for f in feats}
@@ -278,13 +286,16 @@ def generator_v18(sd, z, c, retain, pose, du_in, dl_in, du_mask, dl_mask, img_re
         w_idx += nconv
     for res, cur in zip(resolutions, block_ws):
         x, img, um, lm = _block_v18(sd, f'synthesis.b{res}', x, img, cur, pose_feat, cat, res == 4, conv_clamp, noise_mode, fused_modconv)
-        if res == 128:
+        if res == img_resolution // 2:
             x_128, img_128 = x, img
-    feat = torch.cat([get_spade_feat(sd, 'synthesis', um.detach(), du_mask, du_in), get_spade_feat(sd, 'synthesis', lm.detach(), dl_mask, dl_in)], dim=1)
-    xs = spade_resblock(sd, 'synthesis.spade_b128_1', x_128, feat)
-    xs = spade_resblock(sd, 'synthesis.spade_b128_2', xs, feat)
-    xs = spade_resblock(sd, 'synthesis.spade_b128_3', xs, feat)
-    _, finetune, _, _ = _block_v18(sd, 'synthesis.texture_b256', xs, img_128, block_ws[-1], pose_feat, cat, False, conv_clamp, noise_mode, fused_modconv)
+    sres = img_resolution // 2
+    feat = torch.cat([get_spade_feat(sd, 'synthesis', um.detach(), du_mask, du_in, sres),
+                      get_spade_feat(sd, 'synthesis', lm.detach(), dl_mask, dl_in, sres)], dim=1)
+    xs = x_128
+    for i in (1, 2, 3):
+        xs = spade_resblock(sd, f'synthesis.spade_b{sres}_{i}', xs, feat)
+    _, finetune, _, _ = _block_v18(sd, f'synthesis.texture_b{img_resolution}', xs, img_128, block_ws[-1], pose_feat, cat, False, conv_clamp,
+                                   noise_mode, fused_modconv)
     return img, finetune, um, lm
 
 #----------------------------------------------------------------------------

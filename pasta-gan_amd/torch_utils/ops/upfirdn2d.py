@@ -73,6 +73,10 @@ def setup_filter(f, device=torch.device('cpu'), normalize=True, flip_filter=Fals
 #----------------------------------------------------------------------------
 # Native call + autograd.
 
+# Optional measurement hook (bench.py): when set, called as hook(algorithmic_bytes, shape_key, launch) around every native
+# launch; ``launch()`` performs it. None = no overhead.
+launch_hook = None
+
 def _launch(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain):
     """One ``pasta_upfirdn2d`` launch. ``f2d`` is a dense float32 [fh, fw] tensor on x's device."""
     _native.require_gpu(x, 'upfirdn2d')
@@ -96,13 +100,18 @@ def _launch(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, ga
     if y.numel() == 0:
         return y
     f2d = f2d.contiguous()
-    with torch.cuda.device(x.device):
-        st = _native.lib().pasta_upfirdn2d(
-            _native.ptr(x), _native.ptr(f2d), _native.ptr(y), _native.dtype_code(x, 'upfirdn2d'),
-            _native.i32x(*x.shape), _native.i64x(*x.stride()), _native.i32x(fh, fw),
-            _native.i32x(*y.shape), _native.i64x(*y.stride()),
-            upx, upy, downx, downy, padx0, padx1, pady0, pady1, int(bool(flip)), float(gain), _native.stream())
-    _native.check(st)
+    def launch():
+        with torch.cuda.device(x.device):
+            st = _native.lib().pasta_upfirdn2d(
+                _native.ptr(x), _native.ptr(f2d), _native.ptr(y), _native.dtype_code(x, 'upfirdn2d'),
+                _native.i32x(*x.shape), _native.i64x(*x.stride()), _native.i32x(fh, fw),
+                _native.i32x(*y.shape), _native.i64x(*y.stride()),
+                upx, upy, downx, downy, padx0, padx1, pady0, pady1, int(bool(flip)), float(gain), _native.stream())
+        _native.check(st)
+    if launch_hook is None:
+        launch()
+    else:       # algorithmic bytes of the launch: (numel_in + numel_out) * sizeof(T)
+        launch_hook((x.numel() + y.numel()) * x.element_size(), (tuple(x.shape), upx, downx, fw), launch)
     return y
 
 class _Upfirdn2dHip(torch.autograd.Function):
