@@ -6,14 +6,22 @@
 //     Z[u] = x[u/U] if u % U == 0 and 0 <= u/U < W, else 0
 //     g[t] = f[F-1-t]   (flip == 0, true convolution)   or   f[t]  (flip == 1)
 //
-// Two kernels:
+// Three kernels:
 //   * tile kernel  -- NCHW-contiguous planes, compile-time (U, D, F, phase):
 //     a 256-thread workgroup stages the input footprint of one output tile in LDS
 //     with row-coalesced loads, every thread produces an MX x MY micro-tile whose
 //     tap positions are all compile-time constants, filter taps live in SGPRs.
 //     HBM traffic = read each input once (+ halo) and write each output once.
+//     Planes of k * tile + 1 columns / rows (257, 129, 65, 33: every blur in front of a stride-2 convolution) are
+//     covered by k tiles whose last thread column / row computes the extra output (REM).
+//   * small-plane kernel -- the 4..16-pixel layers: several whole planes per workgroup through LDS.
 //   * generic kernel -- any strides / factors / filter size / dtype, one output per
 //     thread, no LDS (correctness net for every configuration the API admits).
+// Measured and dropped (round 2, [16,64,256,256] -> 257 x 257, 176 us with the tile kernel): an XCD-aware tile order
+// that keeps the tiles of one tile row on one XCD (195 us, and 15 % slower on every aligned shape), and a full-width
+// strip kernel whose wave stores are 256-byte aligned in the output address (235 us: sixteen LDS reads per output and no
+// load / compute overlap cost more than the aligned stores return).  What the odd plane width costs is in the stores:
+// the same filter into 256-column rows takes 136 us, an odd number of rows costs nothing.
 #include "common.h"
 
 namespace pasta {
@@ -85,15 +93,19 @@ __host__ __device__ constexpr int c_in0(int a, int D, int U, int PH) { return (a
 // number of taps of output a
 __host__ __device__ constexpr int c_ntaps(int a, int D, int U, int PH, int F) { return (F - c_tap0(a, D, U, PH) + U - 1) / U; }
 
+// REM = 1 (1:1 kernels only): an output plane of k * TOW + 1 columns (k * TOH + 1 rows) is covered by k tiles per row
+// (column); the last tile's last thread column (row) computes the one extra output column (row).  Every blur behind a
+// pad-2 convolution has such planes (257, 129, 65, 33): without this a fifth 64-column tile runs 1/64 used.
 template <class T, int UX, int UY, int DX, int DY, int FW, int FH, int PHX, int PHY,
-          int MX, int MY, int BX, int BY>
-__global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p, int tiles_x, int tiles_y, int nitems) {
+          int MX, int MY, int BX, int BY, int REM>
+__global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p, int tiles_x, int tiles_y, int nitems, int rem_x, int rem_y) {
     static_assert(MX % UX == 0 && MY % UY == 0, "micro-tile must cover whole phases");
     static_assert((BX * BY) % 64 == 0, "whole wavefronts");
+    static_assert(REM == 0 || (UX == 1 && UY == 1 && DX == 1 && DY == 1), "remainder strips exist for the 1:1 kernels only");
     constexpr int NT = BX * BY;
     constexpr int TOW = BX * MX, TOH = BY * MY;
-    constexpr int TIW = ((TOW - 1) * DX + FW - 1) / UX + 2;
-    constexpr int TIH = ((TOH - 1) * DY + FH - 1) / UY + 2;
+    constexpr int TIW = ((TOW + REM - 1) * DX + FW - 1) / UX + 2;
+    constexpr int TIH = ((TOH + REM - 1) * DY + FH - 1) / UY + 2;
     constexpr int LDW = TIW | 1;   // odd row pitch keeps strided column reads off one bank
     constexpr int NLOAD = (TIH * TIW + NT - 1) / NT;
     __shared__ float sx[TIH * LDW];
@@ -172,18 +184,110 @@ __global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p,
             for (int a = 0; a < MX; a++)
                 if (ox + a < p.outW) st<T>(yp + (int64_t)(oy + b) * p.outW + ox + a, acc[b][a]);
         }
+        if constexpr (REM == 1) {
+            // one extra output column / row / corner of the plane, by the last thread column / row of the last tile
+            const bool ex = rem_x && tile_x == tiles_x - 1 && tx == BX - 1;
+            const bool ey = rem_y && tile_y == tiles_y - 1 && ty == BY - 1;
+            auto one = [&](int yy, int xx) {          // output (yy, xx) relative to the tile origin
+                float v = 0.f;
+#pragma unroll
+                for (int jy = 0; jy < FH; jy++)
+#pragma unroll
+                    for (int jx = 0; jx < FW; jx++) v = fmaf(g[jy][jx], sx[(yy + jy) * LDW + xx + jx], v);
+                st<T>(yp + (int64_t)(tile_y * TOH + yy) * p.outW + tile_x * TOW + xx, v * p.gain);
+            };
+            if (ex) {
+#pragma unroll
+                for (int b = 0; b < MY; b++) one(ty * MY + b, TOW);
+            }
+            if (ey) {
+#pragma unroll
+                for (int a = 0; a < MX; a++) one(TOH, tx * MX + a);
+            }
+            if (ex && ey) one(TOH, TOW);
+        }
         item = next;
     }
+}
+
+//------------------------------------------------------------------------------------
+// Small-plane kernel: the 4..16-pixel layers.  A plane is a few hundred bytes, so a workgroup takes PL consecutive
+// planes of the NCHW tensor: one contiguous, fully coalesced read of PL * inH * inW elements into LDS, every thread
+// then produces outputs of those planes from LDS (any factors / filter size, taps from a scalar table), and the PL
+// output planes leave as one contiguous write.
+constexpr int SMALL_LDS_FLOATS = 8192;      // 32 KB of input planes per workgroup
+
+template <class T>
+__global__ __launch_bounds__(256) void upfirdn2d_small_kernel(UpfirdnParams p, int planes, int PL) {
+    __shared__ float sx[SMALL_LDS_FLOATS];
+    const int in_sz = p.inH * p.inW, out_sz = p.outH * p.outW;
+    for (int p0 = blockIdx.x * PL; p0 < planes; p0 += gridDim.x * PL) {
+        const int np = planes - p0 < PL ? planes - p0 : PL;
+        const T* xp = (const T*)p.x + (int64_t)p0 * in_sz;
+        __syncthreads();
+        for (int e = threadIdx.x; e < np * in_sz; e += 256) sx[e] = ld<T>(xp + e);
+        __syncthreads();
+        T* yp = (T*)p.y + (int64_t)p0 * out_sz;
+        for (int e = threadIdx.x; e < np * out_sz; e += 256) {
+            const int pl = e / out_sz, r = e - pl * out_sz;
+            const int oy = r / p.outW, ox = r - oy * p.outW;
+            const int ux0 = ox * p.downx - p.padx0, uy0 = oy * p.downy - p.pady0;
+            const float* sp = sx + pl * in_sz;
+            float v = 0.f;
+            for (int ty = posmod(-uy0, p.upy); ty < p.fh; ty += p.upy) {
+                const int uy = uy0 + ty;
+                if (uy < 0) continue;
+                const int iy = uy / p.upy;
+                if (iy >= p.inH) break;
+                const int gy = p.flip ? ty : p.fh - 1 - ty;
+                for (int tx = posmod(-ux0, p.upx); tx < p.fw; tx += p.upx) {
+                    const int ux = ux0 + tx;
+                    if (ux < 0) continue;
+                    const int ix = ux / p.upx;
+                    if (ix >= p.inW) break;
+                    const int gx = p.flip ? tx : p.fw - 1 - tx;
+                    v = fmaf(sp[iy * p.inW + ix], p.f[gy * p.fw + gx], v);
+                }
+            }
+            st<T>(yp + e, v * p.gain);
+        }
+    }
+}
+
+template <class T>
+static bool try_small(const UpfirdnParams& p, hipStream_t s) {
+    const int in_sz = p.inH * p.inW;
+    const int64_t planes = (int64_t)p.N * p.C;
+    if (in_sz > 1024 || (int64_t)p.outH * p.outW > 4096 || planes > INT32_MAX) return false;
+    int PL = SMALL_LDS_FLOATS / in_sz;
+    // enough workgroups to fill the chip before planes are stacked deeper
+    while (PL > 1 && planes / PL < 512) PL >>= 1;
+    const int64_t groups = (planes + PL - 1) / PL;
+    hipLaunchKernelGGL((upfirdn2d_small_kernel<T>), dim3((unsigned)(groups < 4096 ? groups : 4096)), dim3(256), 0, s, p, (int)planes, PL);
+    return true;
 }
 
 template <class T, int UX, int UY, int DX, int DY, int FW, int FH, int PHX, int PHY, int MX, int MY, int BX, int BY>
 static void launch_tile(const UpfirdnParams& p, hipStream_t s) {
     constexpr int TOW = BX * MX, TOH = BY * MY;
-    const int tiles_x = (p.outW + TOW - 1) / TOW, tiles_y = (p.outH + TOH - 1) / TOH;
+    int tiles_x = (p.outW + TOW - 1) / TOW, tiles_y = (p.outH + TOH - 1) / TOH;
+    int rem_x = 0, rem_y = 0;
+    if constexpr (UX == 1 && UY == 1 && DX == 1 && DY == 1) {
+        rem_x = (p.outW > TOW && p.outW % TOW == 1) ? 1 : 0;
+        rem_y = (p.outH > TOH && p.outH % TOH == 1) ? 1 : 0;
+        tiles_x -= rem_x; tiles_y -= rem_y;
+    }
     const int64_t nitems = (int64_t)tiles_x * tiles_y * p.N * p.C;
     const int64_t grid = nitems < 256 * 16 ? nitems : 256 * 16;     // up to 16 resident-or-queued workgroups per CU
-    hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, UX, UY, DX, DY, FW, FH, PHX, PHY, MX, MY, BX, BY>), dim3((unsigned)grid), dim3(BX * BY), 0, s,
-                       p, tiles_x, tiles_y, (int)nitems);
+    if constexpr (UX == 1 && UY == 1 && DX == 1 && DY == 1) {
+        if (rem_x || rem_y) {
+            hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, UX, UY, DX, DY, FW, FH, PHX, PHY, MX, MY, BX, BY, 1>), dim3((unsigned)grid), dim3(BX * BY), 0, s,
+                               p, tiles_x, tiles_y, (int)nitems, rem_x, rem_y);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, UX, UY, DX, DY, FW, FH, PHX, PHY, MX, MY, BX, BY, 0>), dim3((unsigned)grid), dim3(BX * BY), 0, s,
+                       p, tiles_x, tiles_y, (int)nitems, 0, 0);
 }
 
 // Phase dispatch (runtime pad0 mod U -> template constant).
@@ -212,8 +316,7 @@ static void launch_phase(const UpfirdnParams& p, hipStream_t s) {
 // Returns true when a tile kernel was launched.
 template <class T>
 static bool try_tile(const UpfirdnParams& p, hipStream_t s) {
-    // Planes narrower than half a wavefront (the 4..16 pixel layers) carry a few MB at
-    // most; the generic kernel keeps every lane busy there.
+    // Planes narrower than half a wavefront (the 4..16 pixel layers): several planes per workgroup (try_small)
     if (p.outW < 24) return false;
 #define PASTA_UPF(UX, UY, DX, DY, FW_, FH_, MX, MY)                                                           \
     if (p.upx == UX && p.upy == UY && p.downx == DX && p.downy == DY && p.fw == FW_ && p.fh == FH_) {        \
@@ -235,7 +338,7 @@ static bool try_tile(const UpfirdnParams& p, hipStream_t s) {
 
 template <class T>
 static int run(const UpfirdnParams& p, bool dense_nchw, hipStream_t s) {
-    if (!(dense_nchw && try_tile<T>(p, s))) {
+    if (!(dense_nchw && (try_tile<T>(p, s) || try_small<T>(p, s)))) {
         const int64_t total = (int64_t)p.N * p.C * p.outH * p.outW;
         int64_t blocks = ceil_div64(total, 256);
         if (blocks > 256 * 32) blocks = 256 * 32;
@@ -286,7 +389,7 @@ extern "C" int pasta_upfirdn2d(const void* x, const float* f, void* y, int dtype
     switch (dtype) {
         case PASTA_F32: return run<float>(p, dense_nchw, s);
         case PASTA_F16: return run<__half>(p, dense_nchw, s);
-        case PASTA_F64: return run<double>(p, false, s);
+        case PASTA_F64: return run<double>(p, false, s);       // generic kernel only (fp64 accumulation)
         default: return fail("upfirdn2d: unsupported dtype code %d", dtype);
     }
 }
