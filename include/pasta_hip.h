@@ -15,7 +15,7 @@
  *   - return 0 on success, non-zero on error; pasta_last_error() then returns a
  *     thread-local, NUL-terminated description (the Python shim raises
  *     RuntimeError with it, mirroring TORCH_CHECK in the reference wrappers).
- *   - dtype codes: PASTA_F32 = 0, PASTA_F16 = 1, PASTA_F64 = 2.
+ *   - dtype codes: PASTA_F32 = 0, PASTA_F16 = 1, PASTA_F64 = 2, PASTA_BF16 = 3.
  */
 #ifndef PASTA_HIP_H
 #define PASTA_HIP_H
@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-enum { PASTA_F32 = 0, PASTA_F16 = 1, PASTA_F64 = 2 };
+enum { PASTA_F32 = 0, PASTA_F16 = 1, PASTA_F64 = 2, PASTA_BF16 = 3 };
 
 /* Library identification / error reporting. */
 const char* pasta_last_error(void);
@@ -107,6 +107,15 @@ typedef struct pasta_conv_desc {
     float   wscale;               /* the weights are used as w * wscale (0 = 1): Conv2dLayer's `self.weight *
                                      self.weight_gain` (networks.py:171) folded into the weight packing; the weight
                                      gradient is returned with respect to the unscaled w (i.e. times wscale)        */
+    int32_t io_dtype;             /* storage type of x, y, dy (and the fused residual): PASTA_F32 (default), PASTA_F16 or
+                                     PASTA_BF16.  With 16-bit storage the stored element is the matrix-core operand: ONE
+                                     product per multiply-add (v_mfma_f32_32x32x16_f16 / _bf16), fp32 accumulation and
+                                     epilogue, one rounding on the way out -- the arithmetic of the reference's fp16
+                                     blocks (networks.py:1107-1120) and of BASELINE config 5.  Weights, weight gradients,
+                                     bias and the scale vectors stay fp32.  Only shapes the matrix-core kernels cover
+                                     (>= 16 input channels per group, > 32 output channels; 3x3 / 1x1 weight gradients on
+                                     rows of a multiple of 16 / 32 pixels): pasta_conv2d_plan / pasta_conv2d_wgrad_plan
+                                     return an error otherwise and the caller converts that launch to fp32.            */
 } pasta_conv_desc;
 
 /* Arithmetic of the convolution products.  Accumulation is fp32 in every mode.
@@ -154,7 +163,7 @@ int pasta_conv2d_wgrad_plan(const pasta_conv_desc* d, int* kernel);
  *   y = y * oscale[n, c] (NULL = 1)  -- demodulation, networks.py:77-79
  * and optional fused prologue on x:
  *   x'[n, c, :, :] = x * iscale[n, c] (NULL = 1) -- modulation, networks.py:74. */
-int pasta_conv2d(const float* x, const float* w, float* y,
+int pasta_conv2d(const void* x, const float* w, void* y,      /* x, y: elements of d->io_dtype; w: fp32 */
                  const float* iscale, const float* oscale,
                  const pasta_conv_desc* d, void* workspace, int64_t workspace_bytes,
                  void* stream);
@@ -166,7 +175,7 @@ typedef struct pasta_conv_epilogue {
     const float* bias;            /* [C_out] or NULL */
     int32_t act;
     float alpha, gain, clamp;
-    const float* res;             /* [N, C_out, OH, OW] added to the convolution BEFORE bias / activation, or NULL
+    const void* res;              /* (elements of d->io_dtype) [N, C_out, OH, OW] added to the convolution BEFORE bias / activation, or NULL
                                      (residual sums and the halves of a convolution over a channel concatenation without a
                                      pass of their own).  Measured on the two uses this path offers -- merge_conv over
                                      torch.cat (networks.py:5690-5693) as two 1x1 convolutions, and the SPADE block's
@@ -175,13 +184,13 @@ typedef struct pasta_conv_epilogue {
 } pasta_conv_epilogue;
 
 /* pasta_conv2d with the epilogue above (ep NULL = plain pasta_conv2d). */
-int pasta_conv2d_ex(const float* x, const float* w, float* y,
+int pasta_conv2d_ex(const void* x, const float* w, void* y,
                     const float* iscale, const float* oscale, const pasta_conv_epilogue* ep,
                     const pasta_conv_desc* d, void* workspace, int64_t workspace_bytes,
                     void* stream);
 
-/* dw = d(conv)/dw given x and dy (same descriptor as the forward). */
-int pasta_conv2d_wgrad(const float* x, const float* dy, float* dw,
+/* dw = d(conv)/dw given x and dy (same descriptor as the forward); x, dy: elements of d->io_dtype, dw: fp32. */
+int pasta_conv2d_wgrad(const void* x, const void* dy, float* dw,
                        const pasta_conv_desc* d, void* workspace,
                        int64_t workspace_bytes, void* stream);
 

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void bias_act_grad_db_kernel(BiasActParams p, 
 
 // Shapes the fused kernel takes; 0 chunks = not supported (callers use pasta_bias_act + pasta_bias_grad).
 static int grad_db_chunks(int dtype, int64_t n, int size_b, int64_t step_b, int act) {
-    if (dtype != PASTA_F32 && dtype != PASTA_F16) return 0;
+    if (dtype != PASTA_F32 && dtype != PASTA_F16 && dtype != PASTA_BF16) return 0;
     const int V = dtype == PASTA_F32 ? 4 : 8;
     if (act < 1 || act > 3 || n <= 0 || size_b <= 0 || step_b <= 0 || n % ((int64_t)size_b * step_b) != 0) return 0;
     if (step_b % V != 0 || step_b / V < 256 || step_b / V > INT32_MAX / 2 || n / step_b > INT32_MAX) return 0;
@@ -268,6 +268,7 @@ extern "C" int pasta_bias_act_grad_db(const void* dy, const void* yref, void* dx
     const int outer = (int)(n / ((int64_t)size_b * step_b));
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PASTA_F32) return launch_grad_db<float, 4>(p, work, db, act, outer, chunks, s);
+    if (dtype == PASTA_BF16) return launch_grad_db<__bf16, 8>(p, work, db, act, outer, chunks, s);
     return launch_grad_db<__half, 8>(p, work, db, act, outer, chunks, s);
 }
 
@@ -289,6 +290,7 @@ extern "C" int pasta_bias_act(const void* x, const void* b, const void* xref, co
     switch (dtype) {
         case PASTA_F32: return launch_act<float>(p, act, grad, s);
         case PASTA_F16: return launch_act<__half>(p, act, grad, s);
+        case PASTA_BF16: return launch_act<__bf16>(p, act, grad, s);
         case PASTA_F64: return launch_act<double>(p, act, grad, s);
         default: return fail("bias_act: unsupported dtype code %d", dtype);
     }
@@ -317,6 +319,10 @@ extern "C" int pasta_bias_grad(const void* dx, void* db, float* work, int dtype,
         case PASTA_F16:
             hipLaunchKernelGGL((bias_grad_partial_kernel<__half>), grid, dim3(256), 0, s, (const __half*)dx, work, outer, size_b, step_b, nsplit);
             hipLaunchKernelGGL((bias_grad_final_kernel<__half>), dim3(size_b), dim3(64), 0, s, work, (__half*)db, nsplit);
+            break;
+        case PASTA_BF16:
+            hipLaunchKernelGGL((bias_grad_partial_kernel<__bf16>), grid, dim3(256), 0, s, (const __bf16*)dx, work, outer, size_b, step_b, nsplit);
+            hipLaunchKernelGGL((bias_grad_final_kernel<__bf16>), dim3(size_b), dim3(64), 0, s, work, (__bf16*)db, nsplit);
             break;
         case PASTA_F64:
             hipLaunchKernelGGL((bias_grad_partial_kernel<double>), grid, dim3(256), 0, s, (const double*)dx, work, outer, size_b, step_b, nsplit);

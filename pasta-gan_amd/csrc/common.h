@@ -40,6 +40,8 @@ template <class T> __device__ __forceinline__ typename acc_of<T>::type ld(const 
 template <>        __device__ __forceinline__ float ld<__half>(const __half* p)              { return __half2float(*p); }
 template <class T> __device__ __forceinline__ void st(T* p, typename acc_of<T>::type v)      { *p = (T)v; }
 template <>        __device__ __forceinline__ void st<__half>(__half* p, float v)            { *p = __float2half(v); }
+template <>        __device__ __forceinline__ float ld<__bf16>(const __bf16* p)              { return (float)(*p); }
+template <>        __device__ __forceinline__ void st<__bf16>(__bf16* p, float v)            { *p = (__bf16)v; }
 
 // V elements moved as one 16-byte (or narrower) access.
 template <class T, int V> struct alignas(sizeof(T) * V) Pack { T v[V]; };

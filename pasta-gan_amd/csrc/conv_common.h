@@ -22,10 +22,74 @@ __device__ __forceinline__ float conv_epilogue(float v, float b, int act, float 
     return v;
 }
 
+//------------------------------------------------------------------------------------
+// Storage type of the activations (x, y, dy) of the split-bf16 kernel family.  IO_F32: fp32 tensors, split into bf16 pieces
+// by the staging code.  IO_BF16 / IO_F16: 16-bit tensors in HBM (BASELINE config 5; the fp16 discriminator blocks of the
+// reference, networks.py:1107-1120): the element IS the matrix-core operand, one product per multiply-add on
+// v_mfma_f32_32x32x16_bf16 / _f16, fp32 accumulation, fp32 epilogue, result rounded once on the way out.  Weights and
+// weight gradients stay fp32 in HBM (master copies); the packing kernel rounds the weights to the operand type.
+enum { IO_F32 = 0, IO_F16 = 1, IO_BF16 = 3 };          // = the PASTA_F32 / PASTA_F16 / PASTA_BF16 dtype codes
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+template <int IO> struct io_size { static constexpr int value = IO == IO_F32 ? 4 : 2; };
+
+// one element at BYTE offset `off` of `base`, as fp32
+template <int IO> __device__ __forceinline__ float io_ld(const char* base, unsigned off) {
+    if constexpr (IO == IO_F32) return *(const float*)(base + off);
+    else if constexpr (IO == IO_BF16) return __builtin_bit_cast(float, (uint32_t)(*(const uint16_t*)(base + off)) << 16);
+    else return (float)(*(const _Float16*)(base + off));
+}
+// four consecutive elements starting at element pointer `p` (naturally aligned to the four-pack), as fp32
+template <int IO> __device__ __forceinline__ float4 io_ld4(const void* p) {
+    if constexpr (IO == IO_F32) return *(const float4*)p;
+    else {
+        const uint2 r = *(const uint2*)p;
+        if constexpr (IO == IO_BF16)
+            return make_float4(__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xffff0000u),
+                               __builtin_bit_cast(float, r.y << 16), __builtin_bit_cast(float, r.y & 0xffff0000u));
+        else {
+            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+            const f16x4 h = __builtin_bit_cast(f16x4, r);
+            return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+        }
+    }
+}
+template <int IO> __device__ __forceinline__ float io_ld1(const void* p) {
+    if constexpr (IO == IO_F32) return *(const float*)p;
+    else if constexpr (IO == IO_BF16) return __builtin_bit_cast(float, (uint32_t)(*(const uint16_t*)p) << 16);
+    else return (float)(*(const _Float16*)p);
+}
+// store fp32 `v` as element `idx` of `base`
+template <int IO> __device__ __forceinline__ void io_st(void* base, int64_t idx, float v) {
+    if constexpr (IO == IO_F32) ((float*)base)[idx] = v;
+    else if constexpr (IO == IO_BF16) ((__bf16*)base)[idx] = (__bf16)v;
+    else ((_Float16*)base)[idx] = (_Float16)v;
+}
+// two fp32 values -> one dword of two matrix-core operand elements (bf16 for fp32 / bf16 storage, f16 for f16 storage)
+template <int IO> __device__ __forceinline__ uint32_t io_pack2(float a, float b) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ v = {a, b};
+    if constexpr (IO == IO_F16) {
+        typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_));
+    } else {
+        typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));
+    }
+}
+// acc += A * B on the matrix cores, operands given as eight packed 16-bit elements
+template <int IO> __device__ __forceinline__ f32x16 io_mfma(bf16x8_t a, bf16x8_t b, f32x16 acc) {
+    if constexpr (IO == IO_F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+
 // Parameters of the forward-type kernels (conv2d, conv_transpose2d and both input gradients).
 struct ConvFwdParams {
-    const float* x; const float* wp; float* y;
+    const float* x; const float* wp; float* y;         // x, y (and res): elements of type `io` behind these pointers
     const float* iscale; const float* oscale;
+    int io;                                             // IO_F32 / IO_F16 / IO_BF16
     int N, Cin, H, W;
     int Cout, OH, OW;
     int G, Ig, Og, Ig_pad, Og_pad, KK;   // KK = kh*kw slabs per group in wp
@@ -65,7 +129,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // Parameters of the weight-gradient kernels: dW[tap][a][b] = sum_pix S[a][pix] * L[b][pix * st + tap offset].
 struct WgradParams {
-    const float* S; const float* L; float* slab;
+    const float* S; const float* L; float* slab;        // S, L: elements of type `io`; slab: fp32
+    int io;                 // IO_F32 / IO_F16 / IO_BF16
     int N, SC, P, Q;        // S: [N, SC, P, Q]
     int LC, LH, LW;         // L: [N, LC, LH, LW]
     int G, Ag, Bg;

@@ -29,7 +29,7 @@ __device__ __forceinline__ void split3(float v, __bf16& a, __bf16& b, __bf16& c)
 // [g][tap][chunk of 16 channels][piece 3][half 2][O_pad][8]
 __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int G, int Ig,
                                                                 int Og, int Ig_pad, int Og_pad, int kh, int kw, int transposed,
-                                                                int flip, float wscale) {
+                                                                int flip, float wscale, int f16) {
     const int64_t total = (int64_t)G * kh * kw * Ig_pad * Og_pad;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int j = (int)(idx & 7);
@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __r
         }
         __bf16 p1, p2, p3;
         split3(v, p1, p2, p3);
+        if (f16) p1 = __builtin_bit_cast(__bf16, (_Float16)v);      // fp16 storage: the leading piece is the fp16 operand (the others are unused)
         const int64_t chunk = (((int64_t)g * kh * kw + t) * (Ig_pad / 16) + cc) * 6 * Og_pad * 8;
         const int64_t within = ((int64_t)half * Og_pad + o) * 8 + j;
         wp[chunk + within] = p1;
@@ -61,8 +62,11 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __r
 // NP = bf16 pieces kept per operand: 3 = six products (fp32-equivalent, the default), 2 = three products (hi*hi, hi*mid,
 // mid*hi: ~2^-16 relative, PASTA_MATH_BF16X3), 1 = one product (plain bf16 operands, PASTA_MATH_BF16).  The packed
 // weights always hold three pieces; NP < 3 fetches and stages the leading ones only.
-template <int BM, int BN, int OCC, int NP>      // (128, 128): waves 2 x 2;  (64, 256): waves 1 x 4; each wave 64 rows x 64 pixels
+// IO = storage type of x / y / res (conv_common.h): 16-bit storage runs NP = 1 on the matching matrix-core type.
+template <int BM, int BN, int OCC, int NP, int IO = IO_F32>      // (128, 128): waves 2 x 2;  (64, 256): waves 1 x 4; each wave 64 rows x 64 pixels
 __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams p) {
+    static_assert(IO == IO_F32 || NP == 1, "16-bit storage: the element is the operand, one product");
+    constexpr unsigned ES = io_size<IO>::value;
     constexpr int WMT = 2, WNT = 2, KC = 16;
     constexpr int WAVES_N = BN / 64;
     static_assert((BM / 64) * WAVES_N == 4, "four waves per workgroup");
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     }
     // Activation addressing: byte offset = (per-thread pixel part, VGPR) + (per-wave channel part, SGPR); the host only
     // selects this kernel for tensors below 2^30 elements, so 32-bit byte offsets suffice.
-    const unsigned xb_off = (unsigned)(((int64_t)n_in * p.Cin + (int64_t)g * p.Ig) * HW) * 4u;
+    const unsigned xb_off = (unsigned)(((int64_t)n_in * p.Cin + (int64_t)g * p.Ig) * HW) * ES;
     const char* const xbytes = (const char*)p.x;
     const int iy_base = py * p.isy, ix_base = px * p.isx;
     const __bf16* wb = (const __bf16*)p.wp + (int64_t)g * p.KK * NC * 6 * p.Og_pad * 8;
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
         const int t = __builtin_amdgcn_readfirstlane(tap0 + t_in);   // the tap tables are read with scalar loads
         const int iy = iy_base + p.tap_dy[t], ix = ix_base + p.tap_dx[t];
         ld_ok = pix_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        ld_pix = ld_ok ? xb_off + (unsigned)(iy * p.W + ix) * 4u : xb_off;
+        ld_pix = ld_ok ? xb_off + (unsigned)(iy * p.W + ix) * ES : xb_off;
     };
     if (ld_t >= T) { ld_t = T - 1; ld_cc = 0; a_t = ld_t; a_cc = 0; }      // empty K slice: nothing is accumulated, addresses stay valid
     set_tap(ld_t);
@@ -149,8 +153,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
             const int c0 = cc * KC + (half0 + i) * 8;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const unsigned coff = (unsigned)(c0 + j < last ? c0 + j : last) * (unsigned)HW * 4u;    // scalar
-                st.b[8 * i + j] = *(const float*)(xbytes + (ld_pix + coff));
+                const unsigned coff = (unsigned)(c0 + j < last ? c0 + j : last) * (unsigned)HW * ES;    // scalar
+                st.b[8 * i + j] = io_ld<IO>(xbytes, ld_pix + coff);
             }
             st.nvalid[i] = (ld_ok && real) ? p.Ig - c0 : 0;     // elements j < nvalid are real
         }
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
             v1 = 2 * j + 1 < st.nvalid[i] ? v1 : 0.f;
         }
         f32x2 v = {v0, v1};
-        uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        uint32_t w = io_pack2<IO>(v0, v1);
         q1[i][j] = w;
         if constexpr (NP >= 2) {
             // the two residual subtractions stay scalar: packed f32 VALU next to MFMAs costs more than it saves
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
 #define PASTA_MM(PA, PB)                                                                                       \
         if constexpr ((PA) + (PB) < NP) {                                                                        \
         _Pragma("unroll") for (int a = 0; a < WMT; a++) _Pragma("unroll") for (int b = 0; b < WNT; b++)          \
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][PA], f.b[b][PB], acc[a][b], 0, 0, 0); }
+            acc[a][b] = io_mfma<IO>(f.a[a][PA], f.b[b][PB], acc[a][b]); }
 #define PASTA_SPLIT(J) _Pragma("unroll") for (int i = 0; i < BPT; i++) split_pair(cur_next, i, J);
         // smallest terms first: a3b1, a1b3, a2b2, a2b1, a1b2, a1b1
         PASTA_MM(2, 0)
@@ -294,8 +298,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
         const int rem = (int)(pix - (int64_t)n * P * Q);
         const int pp = rem / Q, qq = rem - pp * Q;
         const int64_t yoff = ((int64_t)n * p.Cout + (int64_t)g * p.Og) * OHW + (oy0 + pp * p.osy) * p.OW + ox0 + qq * p.osx;
-        float* yb = (p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW : p.y) + yoff;
-        const float* rb = (p.res && p.ksplit == 1) ? p.res + yoff : nullptr;
+        float* pb = p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW + yoff : nullptr;      // K slices: fp32 partial sums
+        const bool has_res = p.res && p.ksplit == 1;
         const float* osb = (p.oscale && p.ksplit == 1) ? p.oscale + (int64_t)n * p.Cout + (int64_t)g * p.Og : nullptr;
 #pragma unroll
         for (int a = 0; a < WMT; a++)
@@ -305,9 +309,10 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
                 if (o < p.Og) {
                     float v = acc[a][b][r];
                     if (osb) v *= osb[o];
-                    if (rb) v += rb[(int64_t)o * OHW];
+                    if (has_res) v += io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES);
                     if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
-                    yb[(int64_t)o * OHW] = v;
+                    if (pb) pb[(int64_t)o * OHW] = v;
+                    else io_st<IO>(p.y, yoff + (int64_t)o * OHW, v);
                 }
             }
     }
@@ -331,8 +336,10 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
 // full step later, so the store never waits for an L2 round trip (+1.5 % on the 128 x 128 x 128 layers; PIPE = 0 fetches
 // and stores within one step).  Also measured and dropped: reading the next step's fragments during the current step's
 // MFMAs (two fragment sets, 236-256 VGPRs) -- no change, the other workgroup of the CU already covers that latency.
-template <int BM, int BN, int OCC, int PIPE, int NP>
+template <int BM, int BN, int OCC, int PIPE, int NP, int IO = IO_F32>
 __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdParams p) {
+    static_assert(IO == IO_F32 || NP == 1, "16-bit storage: the element is the operand, one product");
+    constexpr unsigned ES = io_size<IO>::value;
     constexpr int WMT = 2, WNT = 2, KC = 16;
     constexpr int WAVES_N = BN / 64;
     static_assert((BM / 64) * WAVES_N == 4, "four waves per workgroup");
@@ -369,7 +376,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     const int py = rem_in / Q, px = rem_in - py * Q;
     const int m_slot = bcol + 2 * (bcol >> seg_log2) + 1;
     const int m_cx = px + d0 + 1;
-    const unsigned xb_off = (unsigned)(((int64_t)n_in * p.Cin + (int64_t)g * p.Ig) * HW) * 4u;
+    const unsigned xb_off = (unsigned)(((int64_t)n_in * p.Cin + (int64_t)g * p.Ig) * HW) * ES;
     // halo pixels (one wave per stage, in turn): BN 128: lane = segment * 4 + side * 2 + k-half; BN 256: lane = segment * 2 + side, both halves.
     // Lanes beyond the last segment repeat it (identical data to the identical slot).
     int h_r = BPT == 1 ? lane >> 2 : lane >> 1;
@@ -382,7 +389,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     const int h_py = h_rem / Q, h_qs = h_rem - h_py * Q;
     const int h_slot = h_r * (SEG + 2) + (h_side ? SEG + 1 : 0);
     const int h_cx = h_side ? h_qs + SEG + d0 + 1 : h_qs + d0;
-    const unsigned hb_off = (unsigned)(((int64_t)h_n * p.Cin + (int64_t)g * p.Ig) * HW) * 4u;
+    const unsigned hb_off = (unsigned)(((int64_t)h_n * p.Cin + (int64_t)g * p.Ig) * HW) * ES;
 
     const char* const xbytes = (const char*)p.x;
     const __bf16* wb = (const __bf16*)p.wp + (int64_t)g * p.KK * NC * 6 * p.Og_pad * 8;
@@ -398,9 +405,9 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
         const int dy = p.tap_dy[__builtin_amdgcn_readfirstlane(3 * dyi)];
         const int iy = py + dy, hy = h_py + dy;
         m_ok = (unsigned)iy < (unsigned)p.H && (unsigned)m_cx < (unsigned)p.W;
-        m_pix = m_ok ? xb_off + (unsigned)(iy * p.W + m_cx) * 4u : xb_off;
+        m_pix = m_ok ? xb_off + (unsigned)(iy * p.W + m_cx) * ES : xb_off;
         h_ok = (unsigned)hy < (unsigned)p.H && (unsigned)h_cx < (unsigned)p.W;
-        h_pix = h_ok ? hb_off + (unsigned)(hy * p.W + h_cx) * 4u : hb_off;
+        h_pix = h_ok ? hb_off + (unsigned)(hy * p.W + h_cx) * ES : hb_off;
     };
     set_row(b_dy);
     float mb[8 * BPT], hb[8 * BPT];
@@ -417,7 +424,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
                 const int c0 = cc * KC + (h_half + i) * 8;
 #pragma unroll
                 for (int j = 0; j < 8; j++)
-                    hb[8 * i + j] = *(const float*)(xbytes + (h_pix + (unsigned)(c0 + j < last ? c0 + j : last) * (unsigned)HW * 4u));
+                    hb[8 * i + j] = io_ld<IO>(xbytes, h_pix + (unsigned)(c0 + j < last ? c0 + j : last) * (unsigned)HW * ES);
                 h_nvalid[i] = (h_ok && real) ? p.Ig - c0 : 0;
             }
         }
@@ -426,8 +433,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
             const int c0 = cc * KC + (half0 + i) * 8;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const unsigned coff = (unsigned)(c0 + j < last ? c0 + j : last) * (unsigned)HW * 4u;    // scalar
-                mb[8 * i + j] = *(const float*)(xbytes + (m_pix + coff));
+                const unsigned coff = (unsigned)(c0 + j < last ? c0 + j : last) * (unsigned)HW * ES;    // scalar
+                mb[8 * i + j] = io_ld<IO>(xbytes, m_pix + coff);
             }
             m_nvalid[i] = (m_ok && real) ? p.Ig - c0 : 0;
         }
@@ -490,7 +497,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
             v1 = 2 * j + 1 < nvalid[i] ? v1 : 0.f;
         }
         f32x2 v = {v0, v1};
-        uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        uint32_t w = io_pack2<IO>(v0, v1);
         q1[i][j] = w;
         if constexpr (NP >= 2) {
             // the two residual subtractions stay scalar: packed f32 VALU next to MFMAs costs more than it saves
@@ -567,7 +574,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
 #define PASTA_MM(PA, PB)                                                                                       \
         if constexpr ((PA) + (PB) < NP) {                                                                        \
         _Pragma("unroll") for (int a = 0; a < WMT; a++) _Pragma("unroll") for (int b = 0; b < WNT; b++)          \
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][PA], f.b[b][PB], acc[a][b], 0, 0, 0); }
+            acc[a][b] = io_mfma<IO>(f.a[a][PA], f.b[b][PB], acc[a][b]); }
 #define PASTA_SPLIT(J)                                                                                         \
         if (TAP == 1) { _Pragma("unroll") for (int i = 0; i < BPT; i++) split_pair(mb, m_nvalid, i, J); }        \
         if (TAP == 2 && wave == h_owner) { _Pragma("unroll") for (int i = 0; i < BPT; i++) split_pair(hb, h_nvalid, i, J); }
@@ -622,8 +629,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
         const int rem = (int)(pix - (int64_t)n * P * Q);
         const int pp = rem / Q, qq = rem - pp * Q;
         const int64_t yoff = ((int64_t)n * p.Cout + (int64_t)g * p.Og) * OHW + (oy0 + pp * p.osy) * p.OW + ox0 + qq * p.osx;
-        float* yb = (p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW : p.y) + yoff;
-        const float* rb = (p.res && p.ksplit == 1) ? p.res + yoff : nullptr;
+        float* pb = p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW + yoff : nullptr;      // K slices: fp32 partial sums
+        const bool has_res = p.res && p.ksplit == 1;
         const float* osb = (p.oscale && p.ksplit == 1) ? p.oscale + (int64_t)n * p.Cout + (int64_t)g * p.Og : nullptr;
 #pragma unroll
         for (int a = 0; a < WMT; a++)
@@ -633,9 +640,10 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
                 if (o < p.Og) {
                     float v = acc[a][b][r];
                     if (osb) v *= osb[o];
-                    if (rb) v += rb[(int64_t)o * OHW];
+                    if (has_res) v += io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES);
                     if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
-                    yb[(int64_t)o * OHW] = v;
+                    if (pb) pb[(int64_t)o * OHW] = v;
+                    else io_st<IO>(p.y, yoff + (int64_t)o * OHW, v);
                 }
             }
     }
@@ -647,7 +655,7 @@ static bool rows_tile_ok(int P, int Q, int BN) {
     return Q % 32 == 0 && (seg & (seg - 1)) == 0 && BN % seg == 0 && Q % seg == 0 && ((int64_t)P * Q) % BN == 0;
 }
 
-template <int BM, int BN, int NP>
+template <int BM, int BN, int NP, int IO>
 static void launch_fwd_bf16_np(const ConvFwdParams& q, dim3 grid, hipStream_t s) {
     if (q.rows && q.ncls == 1 && rows_tile_ok(q.cls[0].P, q.cls[0].Q, BN)) {
         // row-reuse kernel: full tiles made of whole row segments inside one image
@@ -656,17 +664,20 @@ static void launch_fwd_bf16_np(const ConvFwdParams& q, dim3 grid, hipStream_t s)
         static bool attr_set = false;
         static int pipe = 1;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 0, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if constexpr (IO == IO_F32)
+                (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 0, NP, IO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP, IO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             const char* e = getenv("PASTA_ROWS_PIPE");
             if (e) pipe = e[0] != '0';
             attr_set = true;
         }
-        if (pipe == 1)      hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP>), grid, dim3(256), lds, s, q);
-        else                hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 0, NP>), grid, dim3(256), lds, s, q);
+        if constexpr (IO == IO_F32) {
+            if (pipe != 1) { hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 0, NP, IO>), grid, dim3(256), lds, s, q); return; }
+        }
+        hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP, IO>), grid, dim3(256), lds, s, q);
         return;
     }
-    hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<BM, BN, (BN == 256 ? 2 : 3), NP>), grid, dim3(256), 0, s, q);     // <= 64 KB of LDS: two or three workgroups per CU
+    hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<BM, BN, (BN == 256 ? 2 : 3), NP, IO>), grid, dim3(256), 0, s, q);     // <= 64 KB of LDS: two or three workgroups per CU
 }
 
 template <int BM, int BN>
@@ -681,9 +692,11 @@ static void launch_fwd_bf16x6(const ConvFwdParams& p, hipStream_t s) {
     tiles *= p.ncls;
     dim3 grid((unsigned)tiles, q.o_tiles * q.ksplit, p.G);
     // p.bf16x6 = number of bf16 pieces per operand (3: six products, 2: three, 1: one)
-    if (p.bf16x6 == 1)      launch_fwd_bf16_np<BM, BN, 1>(q, grid, s);
-    else if (p.bf16x6 == 2) launch_fwd_bf16_np<BM, BN, 2>(q, grid, s);
-    else                    launch_fwd_bf16_np<BM, BN, 3>(q, grid, s);
+    if (p.io == IO_BF16)    launch_fwd_bf16_np<BM, BN, 1, IO_BF16>(q, grid, s);       // 16-bit storage: always one product
+    else if (p.io == IO_F16) launch_fwd_bf16_np<BM, BN, 1, IO_F16>(q, grid, s);
+    else if (p.bf16x6 == 1) launch_fwd_bf16_np<BM, BN, 1, IO_F32>(q, grid, s);
+    else if (p.bf16x6 == 2) launch_fwd_bf16_np<BM, BN, 2, IO_F32>(q, grid, s);
+    else                    launch_fwd_bf16_np<BM, BN, 3, IO_F32>(q, grid, s);
 }
 
 // Do the T taps at table positions [0, T) form rows of three horizontally adjacent offsets (ascending or descending)?

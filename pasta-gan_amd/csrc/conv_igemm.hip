@@ -57,10 +57,11 @@ static void dispatch_fwd(FwdTile t, const ConvFwdParams& p, hipStream_t s) {
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 // y[n,c,:] = oscale[n,c] * sum_ks partial[ks][n,c,:]   (fixed order; split-K epilogue)
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ y,
+template <int IO>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, void* __restrict__ y,
                                                             const float* __restrict__ oscale, int64_t numel, int ohw, int ksplit,
                                                             const float* __restrict__ bias, int cout, int act, float alpha, float gain,
-                                                            float clamp, const float* __restrict__ res) {
+                                                            float clamp, const void* __restrict__ res) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
         float v = 0.f;
         int k = 0;
@@ -72,9 +73,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         for (; k < ksplit; k++) v += partial[(int64_t)k * numel + i];
         const int64_t nc = i / ohw;
         if (oscale) v *= oscale[nc];
-        if (res) v += res[i];
+        if (res) v += io_ld1<IO>((const char*)res + i * io_size<IO>::value);
         if (act) v = conv_epilogue(v, bias ? bias[nc % cout] : 0.f, act, alpha, gain, clamp);
-        y[i] = v;
+        io_st<IO>(y, i, v);
     }
 }
 
@@ -94,7 +95,7 @@ struct FwdPlan { FwdTile tile; int ksplit; int bf16x6; };
 static FwdPlan plan_fwd(const pasta_conv_desc* d) {
     const int Og = d->C_out / d->groups, Ig = d->C_in / d->groups;
     const int64_t npix = fwd_lattice_pixels(d);
-    const bool sb = d->math != PASTA_MATH_F32 && Ig >= 16 && (int64_t)d->N * d->C_in * d->H * d->W < (1ll << 30);
+    const bool sb = (d->math != PASTA_MATH_F32 || d->io_dtype != PASTA_F32) && Ig >= 16 && (int64_t)d->N * d->C_in * d->H * d->W < (1ll << 30);
     FwdPlan f;
     if (Og <= 32) f.tile = T32x256;                                   // ToRGB / parsing heads: HBM-bound, few rows
     else if (npix <= 8192) f.tile = (sb && Og > 64) ? T128x128 : T64x64;     // 4..16 pixel layers: K is sliced to fill the chip
@@ -181,6 +182,7 @@ static int check_desc(const pasta_conv_desc* d, const char* who) {
     PASTA_CHECK(d->stride >= 1 && d->stride <= 4, "%s: stride %d unsupported", who, d->stride);
     PASTA_CHECK(d->pad_h >= 0 && d->pad_w >= 0, "%s: negative padding", who);
     PASTA_CHECK(d->math >= PASTA_MATH_DEFAULT && d->math <= PASTA_MATH_BF16, "%s: unknown math mode %d", who, d->math);
+    PASTA_CHECK(d->io_dtype == PASTA_F32 || d->io_dtype == PASTA_F16 || d->io_dtype == PASTA_BF16, "%s: io_dtype %d is not PASTA_F32 / PASTA_F16 / PASTA_BF16", who, d->io_dtype);
     PASTA_CHECK(d->groups >= 1 && d->C_in % d->groups == 0 && d->C_out % d->groups == 0, "%s: channels not divisible by groups=%d", who, d->groups);
     if (!d->transposed) {
         const int oh = (d->H + 2 * d->pad_h - d->kh) / d->stride + 1, ow = (d->W + 2 * d->pad_w - d->kw) / d->stride + 1;
@@ -225,9 +227,11 @@ extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int has_iscale, int* 
     if (int e = check_desc(d, "conv2d_plan")) return e;
     const FwdPlan f = plan_fwd(d);
     const bool sb = f.bf16x6 && !has_iscale;
+    if (d->io_dtype != PASTA_F32 && !sb) return fail("conv2d: no 16-bit-storage kernel for this shape (fewer than 16 input channels per group, at most 32 "
+                                                      "output channels, or an input scale): convert the tensors to fp32 for this launch");
     if (tile) *tile = (int)f.tile;
     if (ksplit) *ksplit = f.ksplit;
-    if (math) *math = !sb ? PASTA_MATH_F32 : d->math == PASTA_MATH_BF16X3 ? PASTA_MATH_BF16X3 : d->math == PASTA_MATH_BF16 ? PASTA_MATH_BF16 : PASTA_MATH_BF16X6;
+    if (math) *math = !sb ? PASTA_MATH_F32 : d->io_dtype != PASTA_F32 ? PASTA_MATH_BF16 : d->math == PASTA_MATH_BF16X3 ? PASTA_MATH_BF16X3 : d->math == PASTA_MATH_BF16 ? PASTA_MATH_BF16 : PASTA_MATH_BF16X6;
     if (launches) *launches = !d->transposed ? 1 : merged_classes(d, sb) ? 1 : (d->stride < d->OH ? d->stride : d->OH) * (d->stride < d->OW ? d->stride : d->OW);
     if (kernel) {
         // the lattice of a stride-1 launch is the output plane itself, its taps kh rows of kw adjacent offsets
@@ -237,12 +241,12 @@ extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int has_iscale, int* 
     return 0;
 }
 
-extern "C" int pasta_conv2d(const float* x, const float* w, float* y, const float* iscale, const float* oscale,
+extern "C" int pasta_conv2d(const void* x, const float* w, void* y, const float* iscale, const float* oscale,
                             const pasta_conv_desc* d, void* workspace, int64_t workspace_bytes, void* stream) {
     return pasta_conv2d_ex(x, w, y, iscale, oscale, nullptr, d, workspace, workspace_bytes, stream);
 }
 
-extern "C" int pasta_conv2d_ex(const float* x, const float* w, float* y, const float* iscale, const float* oscale,
+extern "C" int pasta_conv2d_ex(const void* x, const float* w, void* y, const float* iscale, const float* oscale,
                                const pasta_conv_epilogue* ep, const pasta_conv_desc* d, void* workspace, int64_t workspace_bytes,
                                void* stream) {
     using namespace pasta;
@@ -255,7 +259,7 @@ extern "C" int pasta_conv2d_ex(const float* x, const float* w, float* y, const f
     hipStream_t s = (hipStream_t)stream;
 
     ConvFwdParams p;
-    p.x = x; p.y = y; p.wp = (const float*)workspace; p.iscale = iscale; p.oscale = oscale;
+    p.x = (const float*)x; p.y = (float*)y; p.wp = (const float*)workspace; p.iscale = iscale; p.oscale = oscale;
     p.N = d->N; p.Cin = d->C_in; p.H = d->H; p.W = d->W;
     p.Cout = d->C_out; p.OH = d->OH; p.OW = d->OW;
     p.G = d->groups; p.Ig = d->C_in / d->groups; p.Og = d->C_out / d->groups;
@@ -263,12 +267,17 @@ extern "C" int pasta_conv2d_ex(const float* x, const float* w, float* y, const f
     const FwdTile tile = plan.tile;
     p.Ig_pad = round_up(p.Ig, fwd_ipad(p.Ig, tile)); p.Og_pad = round_up(p.Og, fwd_tile_bm(tile));
     p.KK = d->kh * d->kw;
-    p.bias = ep ? ep->bias : nullptr; p.act = ep ? ep->act : 0; p.res = ep ? ep->res : nullptr;
+    p.bias = ep ? ep->bias : nullptr; p.act = ep ? ep->act : 0; p.res = ep ? (const float*)ep->res : nullptr;
     p.alpha = ep ? ep->alpha : 0.f; p.gain = ep ? ep->gain : 1.f; p.clamp = ep ? ep->clamp : -1.f;
     p.ksplit = plan.ksplit;
     p.o_tiles = 1;
     p.partial = (float*)workspace + round_up((int)(((int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad * 3 + 1) / 2), 4);
     p.bf16x6 = (plan.bf16x6 && !iscale) ? math_pieces(d->math) : 0;     // bf16 pieces per operand; 0 = fp32 kernel
+    p.io = d->io_dtype;
+    if (p.io != IO_F32) {
+        PASTA_CHECK(p.bf16x6, "conv2d: no 16-bit-storage kernel for this shape (pasta_conv2d_plan tells beforehand)");
+        p.bf16x6 = 1;           // the stored element is the operand
+    }
     p.rows = 0; p.rows_d0 = 0; p.rows_rev = 0;
 
     const float wscale = d->wscale == 0.f ? 1.f : d->wscale;
@@ -278,7 +287,7 @@ extern "C" int pasta_conv2d_ex(const float* x, const float* w, float* y, const f
         if (blocks > 4096) blocks = 4096;
         if (p.bf16x6)
             hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, (__bf16*)workspace, p.G, p.Ig, p.Og,
-                               p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip, wscale);
+                               p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip, wscale, p.io == IO_F16 ? 1 : 0);
         else
             hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, (float*)workspace, p.G, p.Ig, p.Og,
                                p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip, wscale);
@@ -336,8 +345,10 @@ extern "C" int pasta_conv2d_ex(const float* x, const float* w, float* y, const f
         const int64_t numel = (int64_t)d->N * d->C_out * d->OH * d->OW;
         int64_t blocks = ceil_div64(numel, 256);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)p.partial, y, oscale, numel,
-                           d->OH * d->OW, p.ksplit, p.bias, d->C_out, p.act, p.alpha, p.gain, p.clamp, p.res);
+#define PASTA_SK(IO_) hipLaunchKernelGGL(splitk_reduce_kernel<IO_>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)p.partial, (void*)y, oscale, numel, \
+                                         d->OH * d->OW, p.ksplit, p.bias, d->C_out, p.act, p.alpha, p.gain, p.clamp, (const void*)p.res)
+        if (p.io == IO_BF16) PASTA_SK(IO_BF16); else if (p.io == IO_F16) PASTA_SK(IO_F16); else PASTA_SK(IO_F32);
+#undef PASTA_SK
     }
     return launch_status("conv2d");
 }
@@ -347,13 +358,13 @@ namespace pasta {
 static bool wgrad_bf16x6(const pasta_conv_desc* d, const WgradPlan& w) {
     const int P = d->transposed ? d->H : d->OH, Q = d->transposed ? d->W : d->OW;
     const int LH = d->transposed ? d->OH : d->H, LW = d->transposed ? d->OW : d->W;
-    return d->math != PASTA_MATH_F32 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 &&
+    return (d->math != PASTA_MATH_F32 || d->io_dtype != PASTA_F32) && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 &&
            Q % 32 == 0 && LH == P && LW == Q && w.kp == 32 && w.cw_log2 == 5;
 }
 // ... and its stride-2 sibling: 3x3, stride 2, equal pads of 0 or 1, rows of a multiple of 16 pixels.
 static bool wgrad_s2_bf16x6(const pasta_conv_desc* d, const WgradPlan& w) {
     const int Q = d->transposed ? d->W : d->OW;
-    return d->math != PASTA_MATH_F32 && d->kh == 3 && d->kw == 3 && d->stride == 2 && d->pad_h == d->pad_w && d->pad_h <= 1 &&
+    return (d->math != PASTA_MATH_F32 || d->io_dtype != PASTA_F32) && d->kh == 3 && d->kw == 3 && d->stride == 2 && d->pad_h == d->pad_w && d->pad_h <= 1 &&
            Q % 16 == 0 && w.kp == 16 && w.cw_log2 == 4;
 }
 // ... and the pointwise one: 1x1, stride 1, no padding, planes of a multiple of 32 pixels (ToRGB heads included: the shape is
@@ -361,7 +372,7 @@ static bool wgrad_s2_bf16x6(const pasta_conv_desc* d, const WgradPlan& w) {
 static bool wgrad_1x1_bf16x6(const pasta_conv_desc* d, const WgradPlan& w) {
     const int P = d->transposed ? d->H : d->OH, Q = d->transposed ? d->W : d->OW;
     const int Ig = d->C_in / d->groups, Og = d->C_out / d->groups;
-    return d->math != PASTA_MATH_F32 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 &&
+    return (d->math != PASTA_MATH_F32 || d->io_dtype != PASTA_F32) && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 &&
            ((int64_t)P * Q) % 32 == 0 && (Ig >= 16 || Og >= 16) && w.kp == 32 && w.WA == w.WB &&
            d->H == d->OH && d->W == d->OW && (int64_t)w.chunks_total == (int64_t)d->N * P * Q / 32;
 }
@@ -381,6 +392,8 @@ extern "C" int pasta_conv2d_wgrad_plan(const pasta_conv_desc* d, int* kernel) {
         else if (wgrad_1x1_bf16x6(d, w)) k = 4;
     }
     if (kernel) *kernel = k;
+    if (d->io_dtype != PASTA_F32 && k < 2)
+        return fail("conv2d_wgrad: no 16-bit-storage kernel for this shape: convert the tensors to fp32 for this launch");
     return 0;
 }
 
@@ -395,10 +408,11 @@ extern "C" int64_t pasta_conv2d_wgrad_workspace(const pasta_conv_desc* d) {
     return w.slab_floats * (int64_t)sizeof(float);
 }
 
-extern "C" int pasta_conv2d_wgrad(const float* x, const float* dy, float* dw, const pasta_conv_desc* d, void* workspace,
+extern "C" int pasta_conv2d_wgrad(const void* xv, const void* dyv, float* dw, const pasta_conv_desc* d, void* workspace,
                                   int64_t workspace_bytes, void* stream) {
     using namespace pasta;
     if (int e = check_desc(d, "conv2d_wgrad")) return e;
+    const float* x = (const float*)xv; const float* dy = (const float*)dyv;       // elements of d->io_dtype behind these pointers
     PASTA_CHECK(x && dy && dw, "conv2d_wgrad: null pointer");
     const int64_t need = pasta_conv2d_wgrad_workspace(d);
     PASTA_CHECK(workspace && workspace_bytes >= need, "conv2d_wgrad: workspace of %lld bytes needed, %lld given", (long long)need, (long long)workspace_bytes);
@@ -406,6 +420,7 @@ extern "C" int pasta_conv2d_wgrad(const float* x, const float* dy, float* dw, co
     const int Ig = d->C_in / d->groups, Og = d->C_out / d->groups;
 
     const WgradSmallPlan ws = plan_wgrad_small(d);
+    PASTA_CHECK(d->io_dtype == PASTA_F32 || !ws.use, "conv2d_wgrad: no 16-bit-storage kernel for this shape (pasta_conv2d_wgrad_plan tells beforehand)");
     if (ws.use) {
         WgradSmallParams q;
         q.S = dy; q.L = x; q.slab = (float*)workspace;
@@ -423,6 +438,7 @@ extern "C" int pasta_conv2d_wgrad(const float* x, const float* dy, float* dw, co
 
     WgradParams p;
     p.slab = (float*)workspace;
+    p.io = d->io_dtype;
     p.G = d->groups; p.kh = d->kh; p.kw = d->kw; p.st = d->stride; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
     p.N = d->N;
     if (!d->transposed) {   // dw[o][i]: S = dy, L = x
@@ -451,20 +467,23 @@ extern "C" int pasta_conv2d_wgrad(const float* x, const float* dy, float* dw, co
         if (w.kp == 16) { if (w.pipe) PASTA_WGRAD1(TR_, TS_, WA_, WB_, 1, 16); else PASTA_WGRAD1(TR_, TS_, WA_, WB_, 0, 16); } \
         else            { if (w.pipe) PASTA_WGRAD1(TR_, TS_, WA_, WB_, 1, 32); else PASTA_WGRAD1(TR_, TS_, WA_, WB_, 0, 32); } \
     } while (0)
-    const int np = math_pieces(d->math);          // bf16 pieces per operand of the split-bf16 kernels
-#define PASTA_NP(LAUNCH_)   /* LAUNCH_(NP) for the runtime np */                                                             \
-    do { if (np == 1) { LAUNCH_(1); } else if (np == 2) { LAUNCH_(2); } else { LAUNCH_(3); } } while (0)
+    const int np = p.io != IO_F32 ? 1 : math_pieces(d->math);          // bf16 pieces per operand of the split-bf16 kernels
+    PASTA_CHECK(p.io == IO_F32 || wgrad_bf16x6(d, w) || wgrad_s2_bf16x6(d, w) || (wgrad_1x1_bf16x6(d, w) && !(w.TR == 3 && w.TS == 3) && w.TS != 7 && w.TS != 4),
+                "conv2d_wgrad: no 16-bit-storage kernel for this shape (pasta_conv2d_wgrad_plan tells beforehand)");
+#define PASTA_NP(LAUNCH_)   /* LAUNCH_(NP, IO) for the runtime np and storage type */                                        \
+    do { if (p.io == IO_BF16) { LAUNCH_(1, IO_BF16); } else if (p.io == IO_F16) { LAUNCH_(1, IO_F16); }                      \
+         else if (np == 1) { LAUNCH_(1, IO_F32); } else if (np == 2) { LAUNCH_(2, IO_F32); } else { LAUNCH_(3, IO_F32); } } while (0)
     if (wgrad_bf16x6(d, w)) {
         const size_t lds = (size_t)(np * 64 * 40 + np * 64 * 3 * 40) * 2;
-#define PASTA_L(NP_) hipLaunchKernelGGL(conv_wgrad3x3_bf16x6_kernel<NP_>, dim3((unsigned)blocks), dim3(256), lds, s, p)
+#define PASTA_L(NP_, IO_) hipLaunchKernelGGL((conv_wgrad3x3_bf16x6_kernel<NP_, IO_>), dim3((unsigned)blocks), dim3(256), lds, s, p)
         PASTA_NP(PASTA_L);
 #undef PASTA_L
     }
     else if (wgrad_s2_bf16x6(d, w)) {
         const size_t lds = (size_t)(np * 64 * 16 + np * 64 * 3 * 40) * 2;
-#define PASTA_L(NP_)                                                                                                          \
-        if (d->pad_w == 1) hipLaunchKernelGGL((conv_wgrad3x3s2_bf16x6_kernel<1, NP_>), dim3((unsigned)blocks), dim3(256), lds, s, p); \
-        else               hipLaunchKernelGGL((conv_wgrad3x3s2_bf16x6_kernel<0, NP_>), dim3((unsigned)blocks), dim3(256), lds, s, p)
+#define PASTA_L(NP_, IO_)                                                                                                     \
+        if (d->pad_w == 1) hipLaunchKernelGGL((conv_wgrad3x3s2_bf16x6_kernel<1, NP_, IO_>), dim3((unsigned)blocks), dim3(256), lds, s, p); \
+        else               hipLaunchKernelGGL((conv_wgrad3x3s2_bf16x6_kernel<0, NP_, IO_>), dim3((unsigned)blocks), dim3(256), lds, s, p)
         PASTA_NP(PASTA_L);
 #undef PASTA_L
     }
@@ -473,9 +492,9 @@ extern "C" int pasta_conv2d_wgrad(const float* x, const float* dy, float* dw, co
     else if (w.TS == 4) PASTA_WGRAD(1, 4, 1, 1);
     else if (wgrad_1x1_bf16x6(d, w)) {
         const size_t lds = (size_t)(np * 64 * 40) * 2 * 2 * w.WA;         // S and L images of 64 WA (= 64 WB) channels
-#define PASTA_L(NP_)                                                                                                          \
-        if (w.WA == 2) hipLaunchKernelGGL((conv_wgrad1x1_bf16x6_kernel<2, 2, NP_>), dim3((unsigned)blocks), dim3(256), lds, s, p); \
-        else           hipLaunchKernelGGL((conv_wgrad1x1_bf16x6_kernel<1, 1, NP_>), dim3((unsigned)blocks), dim3(256), lds, s, p)
+#define PASTA_L(NP_, IO_)                                                                                                     \
+        if (w.WA == 2) hipLaunchKernelGGL((conv_wgrad1x1_bf16x6_kernel<2, 2, NP_, IO_>), dim3((unsigned)blocks), dim3(256), lds, s, p); \
+        else           hipLaunchKernelGGL((conv_wgrad1x1_bf16x6_kernel<1, 1, NP_, IO_>), dim3((unsigned)blocks), dim3(256), lds, s, p)
         PASTA_NP(PASTA_L);
 #undef PASTA_L
     }

@@ -14,8 +14,10 @@ namespace pasta {
 //              of two aligned 16-byte blocks with v_alignbit (ts = 0, 2) or by register renaming (ts = 1).
 // One wave owns a 32 x 32 (a, b) tile for all 9 taps (144 accumulator registers): 54 MFMAs per K step.
 
-template <int NP>       // bf16 pieces per operand: 3 (six products), 2 (three), 1 (one); see conv_fwd_bf16x6_kernel
+template <int NP, int IO = IO_F32>       // bf16 pieces per operand: 3 (six products), 2 (three), 1 (one); IO: storage type of S and L (conv_common.h)
 __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParams p) {
+    static_assert(IO == IO_F32 || NP == 1, "16-bit storage: one product");
+    constexpr int ES = io_size<IO>::value;
     constexpr int SP = 40, LP = 40;                 // row pitches in bf16 elements (80 B)
     constexpr int S_PIECE = 64 * SP;                // one piece of the S tile
     constexpr int L_PIECE = 64 * 3 * LP;            // one piece of the L halo tile
@@ -34,8 +36,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
     const int g = bid;
     const int a_blk = at * 64, b_blk = bt * 64;
     const int PQ = p.P * p.Q;
-    const float* const Sg = p.S + ((int64_t)g * p.Ag + a_blk) * PQ;
-    const float* const Lg = p.L + ((int64_t)g * p.Bg + b_blk) * PQ;       // LH == P, LW == Q for this kernel
+    const char* const Sg = (const char*)p.S + ((int64_t)g * p.Ag + a_blk) * PQ * ES;
+    const char* const Lg = (const char*)p.L + ((int64_t)g * p.Bg + b_blk) * PQ * ES;       // LH == P, LW == Q for this kernel
 
     // staging roles (fixed): S unit = (channel a, group of 8 pixels); L units = (channel b, halo row, group of 8 columns)
     const int s_a = tid >> 2, s_grp = tid & 3;
@@ -58,9 +60,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
         const int n = row / p.P, pp = row - n * p.P, q0 = qb * 32;
         vmask = 0;
         {
-            const float* sp = Sg + (int64_t)n * p.SC * PQ + (int64_t)s_a * PQ + pp * p.Q + q0 + 8 * s_grp;
+            const char* sp = Sg + ((int64_t)n * p.SC * PQ + (int64_t)s_a * PQ + pp * p.Q + q0 + 8 * s_grp) * ES;
             if (s_ch_ok) {
-                sreg[0] = *(const float4*)sp; sreg[1] = *(const float4*)(sp + 4);
+                sreg[0] = io_ld4<IO>(sp); sreg[1] = io_ld4<IO>(sp + 4 * ES);
                 vmask |= 3u;
             }
         }
@@ -68,9 +70,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
         for (int j = 0; j < 4; j++) {
             const int ly = pp + l_row[j] - 1, lx = q0 - 4 + 8 * l_grp[j];
             const bool rok = l_ch_ok[j] && (unsigned)ly < (unsigned)p.P;
-            const float* lp = Lg + (int64_t)n * p.LC * PQ + (int64_t)l_b[j] * PQ + ly * p.Q + lx;
-            if (rok && lx >= 0 && lx + 4 <= p.Q) { lreg[j][0] = *(const float4*)lp; vmask |= 4u << (2 * j); }
-            if (rok && lx + 4 >= 0 && lx + 8 <= p.Q) { lreg[j][1] = *(const float4*)(lp + 4); vmask |= 8u << (2 * j); }
+            const char* lp = Lg + ((int64_t)n * p.LC * PQ + (int64_t)l_b[j] * PQ + ly * p.Q + lx) * ES;
+            if (rok && lx >= 0 && lx + 4 <= p.Q) { lreg[j][0] = io_ld4<IO>(lp); vmask |= 4u << (2 * j); }
+            if (rok && lx + 4 >= 0 && lx + 8 <= p.Q) { lreg[j][1] = io_ld4<IO>(lp + 4 * ES); vmask |= 8u << (2 * j); }
         }
     };
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             f32x2 v = {vals[2 * j], vals[2 * j + 1]};
-            uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+            uint32_t w = io_pack2<IO>(vals[2 * j], vals[2 * j + 1]);
             q1[j] = w;
             if constexpr (NP >= 2) {
                 v[0] -= __builtin_bit_cast(float, w << 16);
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
                         // a_pa * b_pb with pa + pb <= 2, smallest A piece first
 #pragma unroll
                         for (int pa = NP - 1 - pb; pa >= 0; pa--)
-                            acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa], bw, acc[tap], 0, 0, 0);
+                            acc[tap] = io_mfma<IO>(af[pa], bw, acc[tap]);
                     }
                 }
             }
@@ -183,8 +185,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
 // (the bf16 pairs of a dword are halo columns 2i, 2i + 1: a window of even or of odd columns is the low or the high
 // halves of eight consecutive dwords).  L rows are not 16-byte aligned in general (257-pixel planes), so the halo is
 // fetched with dword loads.
-template <int PW, int NP>
+template <int PW, int NP, int IO = IO_F32>
 __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradParams p) {
+    static_assert(IO == IO_F32 || NP == 1, "16-bit storage: one product");
+    constexpr int ES = io_size<IO>::value;
     constexpr int SP = 16, LP = 40;                 // row pitches in bf16 elements
     constexpr int S_PIECE = 64 * SP;
     constexpr int L_PIECE = 64 * 3 * LP;
@@ -203,8 +207,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
     const int g = bid;
     const int a_blk = at * 64, b_blk = bt * 64;
     const int PQ = p.P * p.Q, LHW = p.LH * p.LW;
-    const float* const Sg = p.S + ((int64_t)g * p.Ag + a_blk) * PQ;
-    const float* const Lg = p.L + ((int64_t)g * p.Bg + b_blk) * LHW;
+    const char* const Sg = (const char*)p.S + ((int64_t)g * p.Ag + a_blk) * PQ * ES;
+    const char* const Lg = (const char*)p.L + ((int64_t)g * p.Bg + b_blk) * LHW * ES;
 
     // staging roles (fixed): S unit = (channel a, group of 8 pixels), threads 0..127; L units = (channel b, halo row,
     // group of 8 columns), 960 of them
@@ -230,26 +234,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
         const int n = row / p.P, pp = row - n * p.P, q0 = qb * 16;
         s_ok = s_on;
         if (s_on) {
-            const float* sp = Sg + (int64_t)n * p.SC * PQ + (int64_t)s_a * PQ + pp * p.Q + q0 + 8 * s_grp;
-            sreg[0] = *(const float4*)sp; sreg[1] = *(const float4*)(sp + 4);
+            const char* sp = Sg + ((int64_t)n * p.SC * PQ + (int64_t)s_a * PQ + pp * p.Q + q0 + 8 * s_grp) * ES;
+            sreg[0] = io_ld4<IO>(sp); sreg[1] = io_ld4<IO>(sp + 4 * ES);
         }
         lmask = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int ly = 2 * pp + l_row[j] - p.pad_h, lx = 2 * q0 - 4 + 8 * l_grp[j];
             const bool rok = l_ch_ok[j] && (unsigned)ly < (unsigned)p.LH;
-            const float* lp = Lg + (int64_t)n * p.LC * LHW + (int64_t)l_b[j] * LHW + ly * p.LW + lx;
+            const char* lp = Lg + ((int64_t)n * p.LC * LHW + (int64_t)l_b[j] * LHW + ly * p.LW + lx) * ES;
             int first = lx < 0 ? -lx : 0, last = p.LW - lx < 8 ? p.LW - lx : 8;
             if (!rok || last < 0) last = 0;
             if (first > last) first = last;
             const unsigned m = ((1u << last) - 1u) & ~((1u << first) - 1u);
             if (m == 0xffu) {
 #pragma unroll
-                for (int e = 0; e < 8; e++) lreg[j][e] = lp[e];
+                for (int e = 0; e < 8; e++) lreg[j][e] = io_ld1<IO>(lp + e * ES);
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; e++)
-                    if ((m >> e) & 1u) lreg[j][e] = lp[e];
+                    if ((m >> e) & 1u) lreg[j][e] = io_ld1<IO>(lp + e * ES);
             }
             lmask |= m << (8 * j);
         }
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             f32x2 v = {vals[2 * j], vals[2 * j + 1]};
-            uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+            uint32_t w = io_pack2<IO>(vals[2 * j], vals[2 * j + 1]);
             q1[j] = w;
             if constexpr (NP >= 2) {
                 v[0] -= __builtin_bit_cast(float, w << 16);
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
                     const int tap = row * 3 + ts;
 #pragma unroll
                     for (int pa = NP - 1 - pb; pa >= 0; pa--)
-                        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa], bw, acc[tap], 0, 0, 0);
+                        acc[tap] = io_mfma<IO>(af[pa], bw, acc[tap]);
                 }
             }
         }
@@ -356,8 +360,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
 // split-bf16 arithmetic; workgroup tile (64 WA) x (64 WB) channels, every wave WA x WB tiles of 32 x 32; K chunk = 32
 // consecutive pixels of one image (P*Q % 32 == 0).  Both operands are split and stored as [piece][channel][32 px]
 // (row pitch 40 bf16).  The shape is bandwidth-bound: 2 x 64 x (WA + WB) x 32 floats per 32 x (64 WA)(64 WB) MACs.
-template <int WA, int WB, int NP>
+template <int WA, int WB, int NP, int IO = IO_F32>
 __global__ __launch_bounds__(256, 2) void conv_wgrad1x1_bf16x6_kernel(WgradParams p) {
+    static_assert(IO == IO_F32 || NP == 1, "16-bit storage: one product");
+    constexpr int ES = io_size<IO>::value;
     constexpr int SP = 40;
     constexpr int TA = 64 * WA, TB = 64 * WB;
     constexpr int A_PIECE = TA * SP, B_PIECE = TB * SP;
@@ -377,8 +383,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1x1_bf16x6_kernel(WgradParam
     const int g = bid;
     const int a_blk = at * TA, b_blk = bt * TB;
     const int PQ = p.P * p.Q;
-    const float* const Sg = p.S + ((int64_t)g * p.Ag + a_blk) * PQ;
-    const float* const Lg = p.L + ((int64_t)g * p.Bg + b_blk) * PQ;
+    const char* const Sg = (const char*)p.S + ((int64_t)g * p.Ag + a_blk) * PQ * ES;
+    const char* const Lg = (const char*)p.L + ((int64_t)g * p.Bg + b_blk) * PQ * ES;
     const int chunks_per_image = PQ / 32;
 
     float4 sreg[UA][2], lreg[UB][2];
@@ -388,16 +394,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1x1_bf16x6_kernel(WgradParam
         for (int j = 0; j < UA; j++) {
             const int u = tid + 256 * j, c = u >> 2, grp = u & 3;
             if (a_blk + c < p.Ag) {
-                const float* sp = Sg + (int64_t)n * p.SC * PQ + (int64_t)c * PQ + px0 + 8 * grp;
-                sreg[j][0] = *(const float4*)sp; sreg[j][1] = *(const float4*)(sp + 4);
+                const char* sp = Sg + ((int64_t)n * p.SC * PQ + (int64_t)c * PQ + px0 + 8 * grp) * ES;
+                sreg[j][0] = io_ld4<IO>(sp); sreg[j][1] = io_ld4<IO>(sp + 4 * ES);
             }
         }
 #pragma unroll
         for (int j = 0; j < UB; j++) {
             const int u = tid + 256 * j, c = u >> 2, grp = u & 3;
             if (b_blk + c < p.Bg) {
-                const float* lp = Lg + (int64_t)n * p.LC * PQ + (int64_t)c * PQ + px0 + 8 * grp;
-                lreg[j][0] = *(const float4*)lp; lreg[j][1] = *(const float4*)(lp + 4);
+                const char* lp = Lg + ((int64_t)n * p.LC * PQ + (int64_t)c * PQ + px0 + 8 * grp) * ES;
+                lreg[j][0] = io_ld4<IO>(lp); lreg[j][1] = io_ld4<IO>(lp + 4 * ES);
             }
         }
     };
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1x1_bf16x6_kernel(WgradParam
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             f32x2 v = {vals[2 * j], vals[2 * j + 1]};
-            uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+            uint32_t w = io_pack2<IO>(vals[2 * j], vals[2 * j + 1]);
             q1[j] = w;
             if constexpr (NP >= 2) {
                 v[0] -= __builtin_bit_cast(float, w << 16);
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1x1_bf16x6_kernel(WgradParam
                     for (int a = 0; a < WA; a++)
 #pragma unroll
                         for (int b = 0; b < WB; b++)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][pa], bf[b][pb], acc[a][b], 0, 0, 0);
+                            acc[a][b] = io_mfma<IO>(af[a][pa], bf[b][pb], acc[a][b]);
         }
     }
 

@@ -389,6 +389,7 @@ extern "C" int pasta_upfirdn2d(const void* x, const float* f, void* y, int dtype
     switch (dtype) {
         case PASTA_F32: return run<float>(p, dense_nchw, s);
         case PASTA_F16: return run<__half>(p, dense_nchw, s);
+        case PASTA_BF16: return run<__bf16>(p, dense_nchw, s);
         case PASTA_F64: return run<double>(p, false, s);       // generic kernel only (fp64 accumulation)
         default: return fail("upfirdn2d: unsupported dtype code %d", dtype);
     }

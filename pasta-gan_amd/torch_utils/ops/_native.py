@@ -5,7 +5,7 @@ import torch
 
 from .. import custom_ops
 
-DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.float64: 2}
+DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.float64: 2, torch.bfloat16: 3}
 
 _lib = None
 

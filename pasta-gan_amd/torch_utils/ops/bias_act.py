@@ -85,7 +85,7 @@ def _bias_grad(dx, dim):
 
 def _grad_db_workspace(dy, dim, act_idx):
     """Bytes of scratch for the fused (dx, db) launch, 0 when the case is not covered by it."""
-    if dy.device.type != 'cuda' or dy.dtype not in (torch.float32, torch.float16) or not dy.is_contiguous() or dy.numel() == 0:
+    if dy.device.type != 'cuda' or dy.dtype not in (torch.float32, torch.float16, torch.bfloat16) or not dy.is_contiguous() or dy.numel() == 0:
         return 0
     return _native.lib().pasta_bias_act_grad_db_workspace(_native.dtype_code(dy, 'bias_act'), dy.numel(), dy.shape[dim], dy.stride(dim), act_idx)
 

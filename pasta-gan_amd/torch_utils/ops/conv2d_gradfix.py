@@ -62,11 +62,31 @@ def _out_hw(cfg, h, w, kh, kw):
                 (w - 1) * cfg.stride - 2 * cfg.pad_w + kw + cfg.outpad_w)
     return ((h + 2 * cfg.pad_h - kh) // cfg.stride + 1, (w + 2 * cfg.pad_w - kw) // cfg.stride + 1)
 
-def _desc(cfg, x_shape, c_out, oh, ow, kh, kw):
+IO_CODES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 3}      # pasta_conv_desc.io_dtype (PASTA_F32 / _F16 / _BF16)
+
+def _desc(cfg, x_shape, c_out, oh, ow, kh, kw, io=torch.float32):
     n, c_in, h, w = x_shape
     return custom_ops.ConvDesc(N=n, C_in=c_in, H=h, W=w, C_out=c_out, OH=oh, OW=ow, kh=kh, kw=kw, stride=cfg.stride,
                                pad_h=cfg.pad_h, pad_w=cfg.pad_w, groups=cfg.groups, transposed=int(cfg.transposed), flip=0,
-                               math=MATH_CODES[conv_math], wscale=float(cfg.wgain))
+                               math=MATH_CODES[conv_math], wscale=float(cfg.wgain), io_dtype=IO_CODES[io])
+
+# 16-bit storage (fp16 / bf16 tensors in HBM, one matrix-core product per multiply-add, fp32 accumulation; include/pasta_hip.h,
+# pasta_conv_desc.io_dtype) exists for the shapes the matrix-core kernel family covers; the planners say which.  Everything
+# else -- the few-channel stems and heads -- is converted to fp32 for that launch and back.
+_native16_cache = {}
+
+def _native16(kind, desc, has_iscale=False):
+    key = (kind, desc.N, desc.C_in, desc.H, desc.W, desc.C_out, desc.OH, desc.OW, desc.kh, desc.kw, desc.stride, desc.pad_h, desc.pad_w,
+           desc.groups, desc.transposed, desc.io_dtype, bool(has_iscale))
+    hit = _native16_cache.get(key)
+    if hit is None:
+        lib = _native.lib()
+        if kind == 'conv':
+            hit = lib.pasta_conv2d_plan(ctypes.byref(desc), int(bool(has_iscale)), None, None, None, None, None) == 0
+        else:
+            hit = lib.pasta_conv2d_wgrad_plan(ctypes.byref(desc), None) == 0
+        _native16_cache[key] = hit
+    return hit
 
 # Optional measurement hook (bench.py): when set, called as hook(kind, desc, launch) around every native
 # convolution launch; ``launch()`` performs it. None = no overhead.
@@ -76,14 +96,15 @@ def _f32(t):
     return t if t.dtype == torch.float32 else t.float()
 
 def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None):
-    """y = conv(x * iscale[n,c]) * oscale[n,c'] through ``pasta_conv2d_ex``; fp32 arithmetic.
+    """y = conv(x * iscale[n,c]) * oscale[n,c'] through ``pasta_conv2d_ex``; fp32 accumulation.  fp32 tensors run the
+    split-bf16 (fp32-equivalent) or fp32 matrix-core kernels; fp16 / bf16 tensors stay 16-bit in HBM where a kernel exists
+    (``_native16``) and are converted for the launch otherwise.
     ``epilogue`` = (bias or None, act code 1..3, alpha, gain, clamp[, residual or None]) fuses Conv2dLayer's bias_act into the
     store; the residual ([N, C_out, OH, OW]) is added to the convolution before the bias."""
     _native.require_gpu(x, 'conv2d')
     if x.ndim != 4 or w.ndim != 4:
         raise RuntimeError('conv2d: x and w must be rank 4')
     out_dtype = x.dtype
-    x = _f32(x).contiguous()
     w = _f32(w).contiguous()
     kh, kw = w.shape[2], w.shape[3]
     if cfg.transposed:
@@ -97,10 +118,14 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None):
     oh, ow = _out_hw(cfg, x.shape[2], x.shape[3], kh, kw)
     if oh < 1 or ow < 1:
         raise RuntimeError('conv2d: output must be at least 1x1')
-    y = torch.empty([x.shape[0], c_out, oh, ow], dtype=torch.float32, device=x.device)
-    if y.numel() == 0 or x.numel() == 0:
-        return y.zero_().to(out_dtype)
-    desc = _desc(cfg, x.shape, c_out, oh, ow, kh, kw)
+    if x.numel() == 0 or c_out * oh * ow == 0:
+        return torch.zeros([x.shape[0], c_out, oh, ow], dtype=out_dtype, device=x.device)
+    io = torch.float32
+    if x.dtype in (torch.float16, torch.bfloat16) and _native16('conv', _desc(cfg, x.shape, c_out, oh, ow, kh, kw, x.dtype), iscale is not None):
+        io = x.dtype
+    x = x.contiguous() if io is not torch.float32 else _f32(x).contiguous()
+    y = torch.empty([x.shape[0], c_out, oh, ow], dtype=io, device=x.device)
+    desc = _desc(cfg, x.shape, c_out, oh, ow, kh, kw, io)
     lib = _native.lib()
     nbytes = lib.pasta_conv2d_workspace(ctypes.byref(desc))
     if nbytes < 0:
@@ -118,7 +143,7 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None):
         res = epilogue[5] if len(epilogue) > 5 else None
         bias = _f32(bias).contiguous() if bias is not None else None
         if res is not None:
-            res = _f32(res).contiguous()
+            res = res.to(io).contiguous()
             if res.shape != y.shape:
                 raise RuntimeError(f'conv2d: residual {tuple(res.shape)} does not match the output {tuple(y.shape)}')
         ep = custom_ops.ConvEpilogue(bias=bias.data_ptr() if bias is not None else None, act=int(act_code), alpha=float(alpha),
@@ -135,19 +160,24 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None):
         launch_hook('conv', desc, launch)
     return y.to(out_dtype)
 
-def _launch_wgrad(x, dy, cfg, w_shape):
-    """dw of ``conv(x, w)`` given dy through ``pasta_conv2d_wgrad``."""
+def _launch_wgrad(x, dy, cfg, w_shape, out_dtype=None):
+    """dw of ``conv(x, w)`` given dy through ``pasta_conv2d_wgrad``; the gradient comes out fp32 (weights are fp32 masters)
+    and is returned as ``out_dtype`` (default: dy's)."""
     _native.require_gpu(x, 'conv2d_wgrad')
-    out_dtype = dy.dtype
-    x = _f32(x).contiguous()
-    dy = _f32(dy).contiguous()
+    out_dtype = dy.dtype if out_dtype is None else out_dtype
     kh, kw = w_shape[2], w_shape[3]
     dw = torch.empty(list(w_shape), dtype=torch.float32, device=x.device)
     if dw.numel() == 0:
         return dw.to(out_dtype)
     if x.numel() == 0 or dy.numel() == 0:
         return dw.zero_().to(out_dtype)
-    desc = _desc(cfg, x.shape, dy.shape[1], dy.shape[2], dy.shape[3], kh, kw)
+    io = torch.float32
+    if x.dtype == dy.dtype and x.dtype in (torch.float16, torch.bfloat16) and \
+            _native16('wgrad', _desc(cfg, x.shape, dy.shape[1], dy.shape[2], dy.shape[3], kh, kw, x.dtype)):
+        io = x.dtype
+    x = x.contiguous() if io is not torch.float32 else _f32(x).contiguous()
+    dy = dy.contiguous() if io is not torch.float32 else _f32(dy).contiguous()
+    desc = _desc(cfg, x.shape, dy.shape[1], dy.shape[2], dy.shape[3], kh, kw, io)
     lib = _native.lib()
     nbytes = lib.pasta_conv2d_wgrad_workspace(ctypes.byref(desc))
     if nbytes < 0:
@@ -192,7 +222,7 @@ class _ConvHip(torch.autograd.Function):
             dx = _ConvHip.apply(dy, w, gcfg)
             assert dx.shape == x.shape
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
-            dw = _ConvWgradHip.apply(dy, x, cfg, tuple(w.shape))
+            dw = _ConvWgradHip.apply(dy, x, cfg, tuple(w.shape), w.dtype)
         return dx, dw, None
 
 class _ConvBiasActHip(torch.autograd.Function):
@@ -228,7 +258,7 @@ class _ConvBiasActHip(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _ConvHip.apply(dz, w, _grad_cfg(cfg, x.shape[2:], dz.shape[2:], w.shape[2], w.shape[3]))
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
-            dw = _ConvWgradHip.apply(dz, x, cfg, tuple(w.shape))
+            dw = _ConvWgradHip.apply(dz, x, cfg, tuple(w.shape), w.dtype)
         if want_db and db is None:
             db = ba._BiasSum.apply(dz, 1)
         dres = dz if len(ctx.needs_input_grad) > 5 and ctx.needs_input_grad[5] else None     # the residual enters before the activation
@@ -245,7 +275,7 @@ def conv2d_bias_act(input, weight, bias=None, stride=1, padding=0, groups=1, act
     alpha = float(alpha if alpha is not None else spec.def_alpha)
     gain = float(gain if gain is not None else spec.def_gain)
     clampf = float(clamp if clamp is not None else -1)
-    if act in FUSABLE_ACTS and input.dtype == torch.float32 and input.device.type == 'cuda' and input.numel() > 0:
+    if act in FUSABLE_ACTS and input.dtype in IO_CODES and input.device.type == 'cuda' and input.numel() > 0:
         sh, sw = _pair(stride)
         ph, pw = _pair(padding)
         assert sh == sw
@@ -258,8 +288,8 @@ def conv2d_bias_act(input, weight, bias=None, stride=1, padding=0, groups=1, act
 
 class _ConvWgradHip(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, dy, x, cfg, w_shape):
-        dw = _launch_wgrad(x, dy, cfg, w_shape)
+    def forward(ctx, dy, x, cfg, w_shape, w_dtype=None):
+        dw = _launch_wgrad(x, dy, cfg, w_shape, w_dtype)
         ctx.save_for_backward(dy, x)
         ctx.cfg = cfg
         return dw
@@ -276,7 +306,7 @@ class _ConvWgradHip(torch.autograd.Function):
             gcfg = _grad_cfg(cfg, x.shape[2:], dy.shape[2:], d_dw.shape[2], d_dw.shape[3])
             d_x = _ConvHip.apply(dy, d_dw, gcfg)
             assert d_x.shape == x.shape
-        return d_dy, d_x, None, None
+        return d_dy, d_x, None, None, None
 
 #----------------------------------------------------------------------------
 

@@ -39,7 +39,7 @@ def conv2d_resample_bias_act(x, w, b=None, f=None, up=1, down=1, padding=0, grou
     multiplication kernel of its own.  ``residual`` (extension, shape of the output): added to the convolution before
     the bias -- also in the epilogue when the convolution is fused."""
     from . import bias_act
-    if up == 1 and x.dtype == torch.float32 and x.device.type == 'cuda' and act in conv2d_gradfix.FUSABLE_ACTS:
+    if up == 1 and x.dtype in conv2d_gradfix.IO_CODES and x.device.type == 'cuda' and act in conv2d_gradfix.FUSABLE_ACTS:
         out_channels, in_channels_per_group, kh, kw = _get_weight_shape(w)
         fw, fh = _get_filter_size(f)
         px0, px1, py0, py1 = _parse_padding(padding)
@@ -72,7 +72,7 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
     ``padding`` is relative to the upsampled image (int, [x, y] or [x0, x1, y0, y1]).
     ``flip_weight=True`` is correlation (``torch.nn.functional.conv2d``), ``False`` convolution."""
     assert isinstance(x, torch.Tensor) and x.ndim == 4
-    assert isinstance(w, torch.Tensor) and w.ndim == 4 and w.dtype == x.dtype
+    assert isinstance(w, torch.Tensor) and w.ndim == 4 and (w.dtype == x.dtype or w.dtype == torch.float32)    # fp32 master weights may meet 16-bit activations
     assert f is None or (isinstance(f, torch.Tensor) and f.ndim in [1, 2] and f.dtype == torch.float32)
     assert isinstance(up, int) and up >= 1
     assert isinstance(down, int) and down >= 1

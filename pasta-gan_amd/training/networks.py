@@ -361,7 +361,10 @@ class _FilteredConv(torch.nn.Module):
                 self.register_buffer('bias', bias)
 
     def _resample_args(self, x):
-        return dict(w=self.weight.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down, padding=self.padding,
+        # 16-bit activations on the GPU meet the fp32 master weight directly: the convolution's packing kernel rounds it to
+        # the operand type (what `self.weight.to(x.dtype)` does in the reference, networks.py:171, without the cast kernel)
+        w = self.weight if (x.device.type == 'cuda' and x.dtype != torch.float32) else self.weight.to(x.dtype)
+        return dict(w=w, f=self.resample_filter, up=self.up, down=self.down, padding=self.padding,
                     flip_weight=(self.up == 1), wgain=self.weight_gain)     # up: the transposed convolution wants true-convolution taps
 
 @persistence.persistent_class
