@@ -345,6 +345,9 @@ def main():
                     "(fused_modconv, grouped convolution), const noise; reports generated images/sec and the HBM roofline of upfirdn2d")
     ap.add_argument('--res', type=int, default=None, choices=[256, 512], help="--mode infer: 256 = GeneratorV18 (test.py's class, parity pinned); "
                     "512 (default) = the resolution-generalised GeneratorFull standing in for test_512.py's unreleased class (parity unpinned)")
+    ap.add_argument('--d-fp16-res', type=int, default=0, help="discriminator blocks of the N highest resolutions store and multiply in fp16 "
+                    "(networks.py:1107-1120).  The reference's train script sets 4 (train_wo_flow_fullbody.py:195-196); the headline keeps 0 = "
+                    "everything fp32-equivalent, which is what the parity oracle (the reference's force_fp32 CPU path) computes")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-meter', action='store_true', help='do not bracket convolution launches with events')
     ap.add_argument('--by-shape', action='store_true', help='also print a per-shape convolution table to stderr')
@@ -393,7 +396,7 @@ def main():
     if args.mode == 'infer':
         assert world == 1, '--mode infer is a single-GPU measurement (replicas only: nothing is exchanged)'
         return run_infer(args, device)
-    cfg = fashion_config(mbstd_group_size=min(args.batch_gpu, 4))      # train_wo_flow_fullbody.py:184: mbstd = min(batch_gpu, 4)
+    cfg = fashion_config(mbstd_group_size=min(args.batch_gpu, 4), d_fp16_res=args.d_fp16_res)      # train_wo_flow_fullbody.py:184: mbstd = min(batch_gpu, 4)
     from training.training_loop_wo_flow_fullbody import augment_options
     cfg.update(augment_options(aug=args.aug, augpipe='bgc', p=args.aug_p))
     if args.vgg_weight > 0:
@@ -445,9 +448,10 @@ def main():
             'metric': 'training images/sec at 256x192 (tensor 256x256), batch 16 per GPU',
             'value': round(images / dt, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1000 * dt / args.steps, 2), 'host_issue_ms_per_step': round(1000 * host_dt / args.steps, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'bf16x3': 'f32 storage, split-bf16 x3 products (reduced: allow_tf32 counterpart)', 'bf16': 'f32 storage, bf16 operands (reduced: mixed precision)'}.get(conv2d_gradfix.conv_math, 'f32'), 'conv_math': conv2d_gradfix.conv_math, 'data': 'synthetic', 'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            'dtype': {'bf16x3': 'f32 storage, split-bf16 x3 products (reduced: allow_tf32 counterpart)', 'bf16': 'f32 storage, bf16 operands (reduced: mixed precision)'}.get(conv2d_gradfix.conv_math, 'f32') +
+                     (f'; discriminator b256..b{256 >> (args.d_fp16_res - 1)} in fp16 storage and products (reduced: the reference train script\'s mixed precision)' if args.d_fp16_res > 0 else ''), 'conv_math': conv2d_gradfix.conv_math, 'data': 'synthetic', 'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
             'config': {'workload': 'BASELINE config 2: full training_loop step (Gmain+Dmain every iter, Dreg/16, Greg/4, Adam, EMA), '
-                                   'GeneratorFull+Discriminator cfg=fashion 256x256, batch 16/GPU, G and D in fp32, ' +
+                                   'GeneratorFull+Discriminator cfg=fashion 256x256, batch 16/GPU, ' + ('G and D in fp32, ' if args.d_fp16_res == 0 else f'G in fp32, D num_fp16_res={args.d_fp16_res}, ') +
                                    ('vgg_weight=0 (weights unavailable)' if args.vgg_weight <= 0 else f'vgg_weight={args.vgg_weight:g} with random-init VGG-19') + (', no ADA' if args.aug == 'noaug' else f', ADA pipeline bgc ({args.aug}, p0={args.aug_p:g})') + ', random-init weights; timed iterations ' + f'{args.warmup}..{args.warmup + args.steps - 1}',
                        'global_batch': args.batch_gpu * world, 'parallelism': f'dp{world} ({transport})'},
         }

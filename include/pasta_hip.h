@@ -201,12 +201,14 @@ int pasta_conv2d_wgrad(const void* x, const void* dy, float* dw,
  * ------------------------------------------------------------------------- */
 /* y[n,c,h,w] = x[n,c,h,w] * a[n,c] + (b ? b[n,0,h,w] : 0)   fma.py:15 with the
  * broadcast shapes modulated_conv2d uses (a: [N,C], b: [N,HW] or [HW], or NULL) */
-int pasta_scale_add(const float* x, const float* a, const float* b, float* y,
+/* (this and the following plane kernels: `dtype` = storage type of the activation tensors -- PASTA_F32, PASTA_F16 or
+ * PASTA_BF16; per-channel scales, statistics, bias, noise strength and partial sums are always fp32, as is the arithmetic) */
+int pasta_scale_add(const void* x, const float* a, const void* b, void* y, int dtype,
                     int N, int C, int64_t HW, int b_per_sample, void* stream);
 
 /* Per-(n,c) plane reductions used by fma / modulation backward:
  * out[n,c] = sum_hw p[n,c,hw] * q[n,c,hw]   (q NULL => sum of p) */
-int pasta_plane_dot(const float* p, const float* q, float* out, int64_t planes,
+int pasta_plane_dot(const void* p, const void* q, float* out, int dtype, int64_t planes,
                     int64_t HW, void* stream);
 
 /* Tail of SynthesisLayer in one pass (networks.py:72-82 demodulation + noise, :313-314 bias_act):
@@ -216,12 +218,12 @@ int pasta_plane_dot(const float* p, const float* q, float* out, int64_t planes,
  * Backward: du = dz * d with dz = dy * act'(y) * gain (0 where |y| >= clamp), and per (plane, 4096-element chunk)
  * the triple (sum dz*u, sum dz*noise, sum dz) in `partial` ([N*C][chunks][3] floats, pasta_mod_bias_act_bwd_workspace
  * bytes), from which the caller forms dd[n,c], dstrength and db[c]. */
-int pasta_mod_bias_act(const float* u, const float* d, const float* noise, const float* strength, const float* b, float* y,
-                       int N, int C, int64_t HW, int noise_per_sample, int act, float alpha, float gain, float clamp,
+int pasta_mod_bias_act(const void* u, const float* d, const float* noise, const float* strength, const float* b, void* y,
+                       int dtype, int N, int C, int64_t HW, int noise_per_sample, int act, float alpha, float gain, float clamp,
                        void* stream);
 int64_t pasta_mod_bias_act_bwd_workspace(int N, int C, int64_t HW);
-int pasta_mod_bias_act_bwd(const float* dy, const float* y, const float* u, const float* d, const float* noise, float* du,
-                           float* partial, int N, int C, int64_t HW, int noise_per_sample, int act, float alpha, float gain,
+int pasta_mod_bias_act_bwd(const void* dy, const void* y, const void* u, const float* d, const float* noise, void* du,
+                           float* partial, int dtype, int N, int C, int64_t HW, int noise_per_sample, int act, float alpha, float gain,
                            float clamp, void* stream);
 
 /* ------------------------------------------------------------------------- *
@@ -235,13 +237,13 @@ int pasta_mod_bias_act_bwd(const float* dy, const float* y, const float* u, cons
  * single convolution with the concatenated conv_gamma / conv_beta weights: C = channels of x, gb_stride / dgb_stride = the
  * distance in elements between consecutive samples of gamma (dgamma), 0 = C * HW (separate contiguous tensors).
  * ------------------------------------------------------------------------- */
-int pasta_spade_norm(const float* x, const float* gamma, const float* beta,
-                     float* out, float* stats, int64_t planes, int64_t HW,
+int pasta_spade_norm(const void* x, const void* gamma, const void* beta,
+                     void* out, float* stats, int dtype, int64_t planes, int64_t HW,
                      float eps, int act, float gain, float clamp, int C, int64_t gb_stride, void* stream);
-int pasta_spade_norm_bwd(const float* dout, const float* x, const float* gamma,
-                         const float* stats, float* dx, float* dgamma,
-                         float* dbeta, int64_t planes, int64_t HW,
-                         const float* beta, int act, float gain, float clamp, int C, int64_t gb_stride, int64_t dgb_stride,
+int pasta_spade_norm_bwd(const void* dout, const void* x, const void* gamma,
+                         const float* stats, void* dx, void* dgamma,
+                         void* dbeta, int dtype, int64_t planes, int64_t HW,
+                         const void* beta, int act, float gain, float clamp, int C, int64_t gb_stride, int64_t dgb_stride,
                          void* stream);
 
 /* ------------------------------------------------------------------------- *

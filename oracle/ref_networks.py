@@ -45,7 +45,13 @@ def conv2d_layer(sd, p, x, activation='linear', up=1, down=1, conv_clamp=None, g
     k = w.shape[2]
     w = w * (1 / np.sqrt(w.shape[1] * k * k))
     b = sd.get(p + '.bias')
-    x = R.conv2d_resample(x, w.to(x.dtype), f=_filter(), up=up, down=down, padding=k // 2, flip_weight=(up == 1))
+    # 16-bit storage: without upsampling the convolution is the last step and the HIP path applies bias / activation in its
+    # epilogue, so nothing is rounded in between
+    R.CONV_OUTPUT_ROUNDED = (up != 1)
+    try:
+        x = R.conv2d_resample(x, w.to(x.dtype), f=_filter(), up=up, down=down, padding=k // 2, flip_weight=(up == 1))
+    finally:
+        R.CONV_OUTPUT_ROUNDED = True
     act_gain = R.ACT_DEFAULTS[activation][1] * gain
     act_clamp = conv_clamp * gain if conv_clamp is not None else None
     return R.bias_act(x, b.to(x.dtype) if b is not None else None, act=activation, gain=act_gain, clamp=act_clamp)
@@ -112,7 +118,7 @@ def resblock(sd, p, x, activation='relu', down=1):
     y = conv2d_layer(sd, p + '.skip', x, down=down, gain=np.sqrt(0.5))
     x = conv2d_layer(sd, p + '.conv0', x, activation=activation, down=down)
     x = conv2d_layer(sd, p + '.conv1', x, activation=activation, gain=np.sqrt(0.5))
-    return y + x
+    return R.q(y + x)
 
 def const_encoder(sd, p, pose, n_downsampling=6):
     """ConstEncoderNetwork, networks.py:560-579 (n_downsampling = 6 at 256)."""
@@ -123,8 +129,8 @@ def const_encoder(sd, p, pose, n_downsampling=6):
 
 def dense(sd, p, x):
     """Dense: per-pixel Linear -> InstanceNorm2d -> LeakyReLU(0.01), networks.py:594-611."""
-    out = F.linear(x.permute(0, 2, 3, 1), sd[p + '.linear.weight'], sd[p + '.linear.bias']).permute(0, 3, 1, 2)
-    return F.leaky_relu(F.instance_norm(out, eps=1e-5), 0.01)
+    out = R.q(F.linear(x.permute(0, 2, 3, 1), R.qw(sd[p + '.linear.weight']), sd[p + '.linear.bias']).permute(0, 3, 1, 2))
+    return R.q(F.leaky_relu(R.q(F.instance_norm(out, eps=1e-5)), 0.01))
 
 def style_encoder(sd, p, c, retain, feat_levels=4):
     """StyleEncoderNetworkV16.forward, networks.py:4872-4883 (four feature levels at 256)."""
@@ -139,7 +145,7 @@ def style_encoder(sd, p, c, retain, feat_levels=4):
         x = dense(sd, f'{p}.model.{idx}', x)
         x = conv2d_layer(sd, f'{p}.model.{idx + 1}', x, down=(2 if stage < 3 else 1))
         idx += 2
-    x = x.mean(dim=[2, 3])
+    x = R.q(x.mean(dim=[2, 3]))
     return fc(sd, p + '.fc', x), feats
 
 #----------------------------------------------------------------------------
@@ -151,7 +157,7 @@ def spade_norm_block(sd, p, x, feat):
     actv = torch.relu(spade_conv2d_layer(sd, p + '.conv_mlp', feat, no_act=True))
     gamma = spade_conv2d_layer(sd, p + '.conv_gamma', actv, no_act=True)
     beta = spade_conv2d_layer(sd, p + '.conv_beta', actv, no_act=True)
-    return normalized * (1 + gamma) + beta
+    return R.q(normalized * (1 + gamma) + beta)
 
 def spade_resblock(sd, p, x, feat, conv_clamp=None):
     """Spade_ResBlockV2.forward, networks.py:5264-5273 (the block is built without conv_clamp)."""
@@ -159,7 +165,7 @@ def spade_resblock(sd, p, x, feat, conv_clamp=None):
     y = spade_conv2d_layer(sd, p + '.skip', spade_norm_block(sd, p + '.spade_skip', x, feat), gain=np.sqrt(0.5))
     x = spade_conv2d_layer(sd, p + '.conv0', spade_norm_block(sd, p + '.spade0', x, feat))
     x = spade_conv2d_layer(sd, p + '.conv1', spade_norm_block(sd, p + '.spade1', x, feat), gain=np.sqrt(0.5))
-    return y + x
+    return R.q(y + x)
 
 def get_spade_feat(sd, p, mask_256, denorm_mask, denorm_input, spade_resolution=128):
     """SynthesisNetworkFull.get_spade_feat, networks.py:5777-5800 (the fill count ``128 * 128`` is the SPADE plane)."""
@@ -168,7 +174,7 @@ def get_spade_feat(sd, p, mask_256, denorm_mask, denorm_input, spade_resolution=
     denorm_mask_128 = (F.interpolate(denorm_mask, scale_factor=0.5) > 0.9).float()
     valid = ((mask_128 + denorm_mask_128) == 2.0).float()
     res_mask = mask_128 - valid
-    x = denorm_input * mask_256 - (1 - mask_256)
+    x = R.q(denorm_input * mask_256 - (1 - mask_256))
     x = conv2d_layer(sd, p + '.spade_encoder.0', x, activation='relu')
     x = resblock(sd, p + '.spade_encoder.1', x)
     feat = resblock(sd, p + '.spade_encoder.2', x, down=2)
@@ -176,7 +182,9 @@ def get_spade_feat(sd, p, mask_256, denorm_mask, denorm_input, spade_resolution=
     mask_sum = valid.sum(dim=(2, 3), keepdim=True)
     ok = (mask_sum > 10).float()
     mask_sum = mask_sum * ok + (spade_resolution * spade_resolution) * (1 - ok)
-    return feat * (1 - res_mask) + (feat_sum / mask_sum) * res_mask
+    if R.STORAGE is None:
+        return feat * (1 - res_mask) + (feat_sum / mask_sum) * res_mask
+    return R.q(feat * (1 - res_mask)) + R.q((feat_sum / mask_sum) * res_mask)     # two 16-bit tensors, added in 16-bit: exact (disjoint supports)
 
 #----------------------------------------------------------------------------
 # Generator.
@@ -192,7 +200,8 @@ def synthesis_block_full(sd, p, x, img, ws, pose_feat, cat_feat, res, first, con
         if x.shape[2] > 16:
             x = conv2d_layer(sd, p + '.merge_conv', torch.cat([x, cat_feat[str(x.shape[2])]], dim=1))
     if img is not None:
-        img = R.upsample2d(img, _filter())
+        with R.fp32_region():           # the running image is fp32 in every storage mode (networks.py:5713-5716)
+            img = R.upsample2d(img, _filter())
     y, parsing = torgb_full(sd, p + '.torgb', x, next(wi), conv_clamp=conv_clamp, fused_modconv=fused_modconv)
     img = img + y if img is not None else y
     return x, img, parsing
@@ -229,6 +238,7 @@ def generator_full(sd, z, c, retain, pose, du_in, dl_in, du_mask, dl_mask, img_r
                    mapping_layers=1, noise_mode='const', fused_modconv=False):
     """GeneratorFull.forward, networks.py:5866-5881."""
     log2 = int(np.log2(img_resolution))
+    pose, c, retain = R.q(pose), R.q(c), R.q(retain)       # 16-bit storage: the encoders' inputs are stored in it as well
     pose_feat = const_encoder(sd, 'const_encoding', pose, n_downsampling=log2 - 2)
     code, feats = style_encoder(sd, 'style_encoding', c, retain, feat_levels=log2 - 4)
     num_ws = 2 * int(np.log2(img_resolution)) - 2      # 1 + 2*(blocks-1) convs + the last ToRGB
@@ -263,7 +273,8 @@ def _block_v18(sd, p, x, img, ws, pose_feat, cat_feat, first, conv_clamp, noise_
         if x.shape[2] > 16:
             x = conv2d_layer(sd, p + '.merge_conv', torch.cat([x, cat_feat[str(x.shape[2])]], dim=1))
     if img is not None:
-        img = R.upsample2d(img, _filter())
+        with R.fp32_region():           # the running image is fp32 in every storage mode (networks.py:5713-5716)
+            img = R.upsample2d(img, _filter())
     y, um, lm = torgb_v18(sd, p + '.torgb', x, next(wi), conv_clamp=conv_clamp, fused_modconv=fused_modconv)
     img = img + y if img is not None else y
     return x, img, um, lm
@@ -318,16 +329,17 @@ def discriminator(sd, img, c, img_resolution=256, conv_clamp=256, mapping_layers
     for res in [2 ** i for i in range(int(np.log2(img_resolution)), 2, -1)]:
         p = f'b{res}'
         if res == img_resolution:
-            x = conv2d_layer(sd, p + '.fromrgb', img, activation='lrelu', conv_clamp=conv_clamp)
+            x = conv2d_layer(sd, p + '.fromrgb', R.q(img), activation='lrelu', conv_clamp=conv_clamp)
         y = conv2d_layer(sd, p + '.skip', x, down=2, gain=np.sqrt(0.5))
         x = conv2d_layer(sd, p + '.conv0', x, activation='lrelu', conv_clamp=conv_clamp)
         x = conv2d_layer(sd, p + '.conv1', x, activation='lrelu', down=2, conv_clamp=conv_clamp, gain=np.sqrt(0.5))
-        x = y + x
-    cmap = mapping(sd, 'mapping', None, c, mapping_layers, None, z_dim=0, c_dim=c.shape[1])
-    x = minibatch_std(x)
-    x = conv2d_layer(sd, 'b4.conv', x, activation='lrelu', conv_clamp=conv_clamp)
-    x = fc(sd, 'b4.fc', x.flatten(1), activation='lrelu')
-    x = fc(sd, 'b4.out', x)
-    return (x * cmap).sum(dim=1, keepdim=True) * (1 / np.sqrt(cmap.shape[1]))
+        x = R.q(y + x)
+    with R.fp32_region():               # the epilogue always computes in fp32 (networks.py:1060)
+        cmap = mapping(sd, 'mapping', None, c, mapping_layers, None, z_dim=0, c_dim=c.shape[1])
+        x = minibatch_std(x)
+        x = conv2d_layer(sd, 'b4.conv', x, activation='lrelu', conv_clamp=conv_clamp)
+        x = fc(sd, 'b4.fc', x.flatten(1), activation='lrelu')
+        x = fc(sd, 'b4.out', x)
+        return (x * cmap).sum(dim=1, keepdim=True) * (1 / np.sqrt(cmap.shape[1]))
 
 #----------------------------------------------------------------------------

@@ -56,6 +56,34 @@ def setup_filter(f, normalize=True, flip_filter=False, gain=1, separable=None):
 # work has the reference's op composition; tests/test_oracle_golden.py checks both against the fixtures.
 FIR_AS_DEPTHWISE_CONV = False
 
+# 16-bit activation storage (BASELINE config 5 and the reference's fp16 blocks), emulated on fp32 tensors: with STORAGE set
+# to torch.bfloat16 / torch.float16 every tensor an operator hands to the next one is rounded to that type and widened
+# again (`q`), and convolution weights are rounded once (`qw`).  Products of two such values are exact in fp32 and sums
+# are fp32, which is the arithmetic of the HIP path in 16-bit storage (one matrix-core product per multiply-add, fp32
+# accumulation, one rounding on the way out).  The casts are differentiable, so gradients are rounded at the same points.
+# None (default): every function below is the plain fp32 restatement, bit for bit.
+STORAGE = None
+
+def q(x):
+    return x if STORAGE is None else x.to(STORAGE).to(x.dtype)
+
+def qw(w):
+    return w if STORAGE is None else w.to(STORAGE).to(w.dtype)
+
+import contextlib
+
+@contextlib.contextmanager
+def fp32_region():
+    """Inside: no storage rounding (the parts of a 16-bit model that stay fp32: image accumulation, discriminator epilogue)."""
+    global STORAGE
+    keep, STORAGE = STORAGE, None
+    try:
+        yield
+    finally:
+        STORAGE = keep
+
+CONV_OUTPUT_ROUNDED = True      # False while a caller emulates a convolution whose epilogue (bias, activation) is fused
+
 def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):
     """Zero-stuff, pad/crop, FIR, decimate.  upfirdn2d.py:169-208 (the reference specification)."""
     upx, upy = _pair(up)
@@ -81,7 +109,7 @@ def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):
         for a in range(fh):
             for b in range(fw):
                 y = y + taps[a, b] * z[:, :, a:a + oh, b:b + ow]
-    return y[:, :, ::downy, ::downx] * gain
+    return q(y[:, :, ::downy, ::downx] * gain)
 
 def filter2d(x, f, padding=0, flip_filter=False, gain=1):
     """upfirdn2d.py:272-304"""
@@ -140,7 +168,7 @@ def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None):
         x = x * gain
     if clamp is not None and clamp >= 0:
         x = x.clamp(-clamp, clamp)
-    return x
+    return q(x)
 
 #----------------------------------------------------------------------------
 # fma  (torch_utils/ops/fma.py:15-16)
@@ -155,9 +183,10 @@ def _conv(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True
     """conv2d_resample.py:31-54: conv2d is a correlation; flip_weight=False asks for a true convolution."""
     if not flip_weight:
         w = w.flip([2, 3])
-    if transpose:
-        return F.conv_transpose2d(x, w, stride=stride, padding=padding, groups=groups)
-    return F.conv2d(x, w, stride=stride, padding=padding, groups=groups)
+    w = qw(w)
+    y = F.conv_transpose2d(x, w, stride=stride, padding=padding, groups=groups) if transpose else \
+        F.conv2d(x, w, stride=stride, padding=padding, groups=groups)
+    return q(y) if CONV_OUTPUT_ROUNDED else y
 
 def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False, fast=True):
     """conv2d_resample.py:59-154.  ``fast=True`` takes the same branch the reference takes (needed for a
@@ -217,7 +246,7 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
     wmod = weight[None] * styles.reshape(n, 1, ic, 1, 1)                      # :65-66
     dcoefs = (wmod.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt() if demodulate else None   # :68
     if not fused_modconv:                                                     # :72-82
-        x = x * styles.to(x.dtype).reshape(n, ic, 1, 1)
+        x = q(x * styles.to(x.dtype).reshape(n, ic, 1, 1))
         x = conv2d_resample(x, weight.to(x.dtype), f=resample_filter, up=up, down=down, padding=padding, flip_weight=flip_weight)
         if demodulate:
             x = x * dcoefs.to(x.dtype).reshape(n, oc, 1, 1)

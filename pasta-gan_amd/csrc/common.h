@@ -43,6 +43,34 @@ template <>        __device__ __forceinline__ void st<__half>(__half* p, float v
 template <>        __device__ __forceinline__ float ld<__bf16>(const __bf16* p)              { return (float)(*p); }
 template <>        __device__ __forceinline__ void st<__bf16>(__bf16* p, float v)            { *p = (__bf16)v; }
 
+// Four consecutive elements (pointer aligned to the four-pack) as fp32, and back: one 16-byte or 8-byte access.
+template <class T> __device__ __forceinline__ float4 ld4(const T* p) { return make_float4(ld<T>(p), ld<T>(p + 1), ld<T>(p + 2), ld<T>(p + 3)); }
+template <>        __device__ __forceinline__ float4 ld4<float>(const float* p) { return *(const float4*)p; }
+template <>        __device__ __forceinline__ float4 ld4<__bf16>(const __bf16* p) {
+    const uint2 r = *(const uint2*)p;
+    return make_float4(__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xffff0000u),
+                       __builtin_bit_cast(float, r.y << 16), __builtin_bit_cast(float, r.y & 0xffff0000u));
+}
+template <>        __device__ __forceinline__ float4 ld4<__half>(const __half* p) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const h4 h = *(const h4*)p;
+    return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+template <class T> __device__ __forceinline__ void st4(T* p, float4 v) { st<T>(p, v.x); st<T>(p + 1, v.y); st<T>(p + 2, v.z); st<T>(p + 3, v.w); }
+template <>        __device__ __forceinline__ void st4<float>(float* p, float4 v) { *(float4*)p = v; }
+template <>        __device__ __forceinline__ void st4<__bf16>(__bf16* p, float4 v) {
+    typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 f = {v.x, v.y, v.z, v.w};
+    *(b4*)p = __builtin_convertvector(f, b4);
+}
+template <>        __device__ __forceinline__ void st4<__half>(__half* p, float4 v) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 f = {v.x, v.y, v.z, v.w};
+    *(h4*)p = __builtin_convertvector(f, h4);
+}
+
 // V elements moved as one 16-byte (or narrower) access.
 template <class T, int V> struct alignas(sizeof(T) * V) Pack { T v[V]; };
 

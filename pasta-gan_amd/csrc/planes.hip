@@ -32,28 +32,25 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // y[plane, hw] = x[plane, hw] * a[plane] + b[(per_sample ? n : 0), hw]
 // grid.x = chunks of a plane, grid.y = planes (strided).  16-byte accesses when HW % 4 == 0.
 
-template <int V>
-__global__ __launch_bounds__(256) void scale_add_kernel(const float* __restrict__ x, const float* __restrict__ a,
-                                                        const float* __restrict__ b, float* __restrict__ y,
+// T = storage type of x, b and y (float, __half, __bf16); the scales a are fp32, the arithmetic is fp32.
+template <class T, int V>
+__global__ __launch_bounds__(256) void scale_add_kernel(const T* __restrict__ x, const float* __restrict__ a,
+                                                        const T* __restrict__ b, T* __restrict__ y,
                                                         int64_t planes, int C, int64_t HW, int b_per_sample) {
-    typedef Pack<float, V> P;
     const int64_t hwv = HW / V;
     for (int64_t plane = blockIdx.y; plane < planes; plane += gridDim.y) {
         const float s = a ? a[plane] : 1.f;
-        const P* xp = (const P*)(x + plane * HW);
-        P* yp = (P*)(y + plane * HW);
-        const P* bp = b ? (const P*)(b + (b_per_sample ? (plane / C) * HW : 0)) : nullptr;
+        const T* xp = x + plane * HW;
+        T* yp = y + plane * HW;
+        const T* bp = b ? b + (b_per_sample ? (plane / C) * HW : 0) : nullptr;
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hwv; i += (int64_t)gridDim.x * 256) {
-            P v = xp[i];
-            if (bp) {
-                P w = bp[i];
-#pragma unroll
-                for (int k = 0; k < V; k++) v.v[k] = fmaf(v.v[k], s, w.v[k]);
+            if constexpr (V == 4) {
+                float4 v = ld4<T>(xp + 4 * i);
+                const float4 w = bp ? ld4<T>(bp + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                st4<T>(yp + 4 * i, make_float4(fmaf(v.x, s, w.x), fmaf(v.y, s, w.y), fmaf(v.z, s, w.z), fmaf(v.w, s, w.w)));
             } else {
-#pragma unroll
-                for (int k = 0; k < V; k++) v.v[k] *= s;
+                st<T>(yp + i, fmaf(ld<T>(xp + i), s, bp ? ld<T>(bp + i) : 0.f));
             }
-            yp[i] = v;
         }
     }
 }
@@ -61,23 +58,22 @@ __global__ __launch_bounds__(256) void scale_add_kernel(const float* __restrict_
 //------------------------------------------------------------------------------------
 // out[plane] = sum_hw p*q (q may be null).  One workgroup per plane, fixed summation order.
 
-__global__ __launch_bounds__(256) void plane_dot_kernel(const float* __restrict__ p, const float* __restrict__ q,
+template <class T>
+__global__ __launch_bounds__(256) void plane_dot_kernel(const T* __restrict__ p, const T* __restrict__ q,
                                                         float* __restrict__ out, int64_t planes, int64_t HW) {
     __shared__ float red[4];
     for (int64_t plane = blockIdx.x; plane < planes; plane += gridDim.x) {
-        const float* pp = p + plane * HW;
-        const float* qp = q ? q + plane * HW : nullptr;
+        const T* pp = p + plane * HW;
+        const T* qp = q ? q + plane * HW : nullptr;
         float acc = 0.f;
         if ((HW & 3) == 0) {
-            const float4* p4 = (const float4*)pp;
-            const float4* q4 = (const float4*)qp;
             for (int64_t i = threadIdx.x; i < HW / 4; i += 256) {
-                float4 a = p4[i];
-                if (qp) { float4 b = q4[i]; acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+                float4 a = ld4<T>(pp + 4 * i);
+                if (qp) { float4 b = ld4<T>(qp + 4 * i); acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
                 else acc += a.x + a.y + a.z + a.w;
             }
         } else {
-            for (int64_t i = threadIdx.x; i < HW; i += 256) acc += qp ? pp[i] * qp[i] : pp[i];
+            for (int64_t i = threadIdx.x; i < HW; i += 256) acc += qp ? ld<T>(pp + i) * ld<T>(qp + i) : ld<T>(pp + i);
         }
         float t = block_sum<256>(acc, red);
         if (threadIdx.x == 0) out[plane] = t;
@@ -89,9 +85,9 @@ __global__ __launch_bounds__(256) void plane_dot_kernel(const float* __restrict_
 // EPT*1024 floats (EPT = 16 is the 128x128 plane of the generator) it lives in registers
 // between the statistics and the apply pass, otherwise later passes re-read it through L2.
 
-template <int EPT>   // EPT == 0: generic loops
-__global__ __launch_bounds__(1024) void spade_norm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* __restrict__ out,
+template <class T, int EPT>   // EPT == 0: generic loops; T = storage type of x, gamma, beta, out (statistics and arithmetic: fp32)
+__global__ __launch_bounds__(1024) void spade_norm_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
+                                                          const T* __restrict__ beta, T* __restrict__ out,
                                                           float* __restrict__ stats, int64_t planes, int64_t HW, float eps,
                                                           int act, float gain, float clamp, int C, int64_t gb_ns) {
     __shared__ float red[16];
@@ -102,7 +98,7 @@ __global__ __launch_bounds__(1024) void spade_norm_kernel(const float* __restric
     };
     const int tid = threadIdx.x;
     for (int64_t plane = blockIdx.x; plane < planes; plane += gridDim.x) {
-        const float* xp = x + plane * HW;
+        const T* xp = x + plane * HW;
         const float inv = 1.f / (float)HW;
         // gamma / beta may be the two channel halves of one [N, 2C, H, W] tensor: sample stride gb_ns instead of C * HW
         const int64_t gb = (plane / C) * gb_ns + (plane % C) * HW;
@@ -111,7 +107,7 @@ __global__ __launch_bounds__(1024) void spade_norm_kernel(const float* __restric
             float4 r[EPT / 4];
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < EPT / 4; k++) { r[k] = ((const float4*)xp)[k * 1024 + tid]; s += r[k].x + r[k].y + r[k].z + r[k].w; }
+            for (int k = 0; k < EPT / 4; k++) { r[k] = ld4<T>(xp + 4 * (k * 1024 + tid)); s += r[k].x + r[k].y + r[k].z + r[k].w; }
             mean = block_sum<1024>(s, red) * inv;
             float q = 0.f;
 #pragma unroll
@@ -123,25 +119,25 @@ __global__ __launch_bounds__(1024) void spade_norm_kernel(const float* __restric
 #pragma unroll
             for (int k = 0; k < EPT / 4; k++) {
                 const int64_t i = k * 1024 + tid;
-                float4 g = gamma ? ((const float4*)(gamma + gb))[i] : make_float4(0, 0, 0, 0);
-                float4 b = beta ? ((const float4*)(beta + gb))[i] : make_float4(0, 0, 0, 0);
+                float4 g = gamma ? ld4<T>(gamma + gb + 4 * i) : make_float4(0, 0, 0, 0);
+                float4 b = beta ? ld4<T>(beta + gb + 4 * i) : make_float4(0, 0, 0, 0);
                 float4 o;
                 o.x = post(fmaf((r[k].x - mean) * rstd, 1.f + g.x, b.x));
                 o.y = post(fmaf((r[k].y - mean) * rstd, 1.f + g.y, b.y));
                 o.z = post(fmaf((r[k].z - mean) * rstd, 1.f + g.z, b.z));
                 o.w = post(fmaf((r[k].w - mean) * rstd, 1.f + g.w, b.w));
-                ((float4*)(out + plane * HW))[i] = o;
+                st4<T>(out + plane * HW + 4 * i, o);
             }
         } else {
             float s = 0.f;
-            for (int64_t i = tid; i < HW; i += 1024) s += xp[i];
+            for (int64_t i = tid; i < HW; i += 1024) s += ld<T>(xp + i);
             mean = block_sum<1024>(s, red) * inv;
             float q = 0.f;
-            for (int64_t i = tid; i < HW; i += 1024) { float d = xp[i] - mean; q += d * d; }
+            for (int64_t i = tid; i < HW; i += 1024) { float d = ld<T>(xp + i) - mean; q += d * d; }
             rstd = rsqrtf(block_sum<1024>(q, red) * inv + eps);
             for (int64_t i = tid; i < HW; i += 1024) {
-                float g = gamma ? gamma[gb + i] : 0.f, b = beta ? beta[gb + i] : 0.f;
-                out[plane * HW + i] = post(fmaf((xp[i] - mean) * rstd, 1.f + g, b));
+                float g = gamma ? ld<T>(gamma + gb + i) : 0.f, b = beta ? ld<T>(beta + gb + i) : 0.f;
+                st<T>(out + plane * HW + i, post(fmaf((ld<T>(xp + i) - mean) * rstd, 1.f + g, b)));
             }
         }
         if (tid == 0 && stats) { stats[2 * plane] = mean; stats[2 * plane + 1] = rstd; }
@@ -151,12 +147,12 @@ __global__ __launch_bounds__(1024) void spade_norm_kernel(const float* __restric
 // Backward.  xhat = (x-mean)*rstd, t = dout*(1+gamma):
 //   dgamma = dout*xhat, dbeta = dout, dx = rstd*(t - mean(t) - xhat*mean(t*xhat)).
 // dgamma/dbeta/dx may each be null (not needed).
-template <int EPT>
-__global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x,
-                                                              const float* __restrict__ gamma, const float* __restrict__ stats,
-                                                              float* __restrict__ dx, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, int64_t planes, int64_t HW,
-                                                              const float* __restrict__ beta, int act, float gain, float clamp,
+template <class T, int EPT>
+__global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ x,
+                                                              const T* __restrict__ gamma, const float* __restrict__ stats,
+                                                              T* __restrict__ dx, T* __restrict__ dgamma,
+                                                              T* __restrict__ dbeta, int64_t planes, int64_t HW,
+                                                              const T* __restrict__ beta, int act, float gain, float clamp,
                                                               int C, int64_t gb_ns, int64_t dgb_ns) {
     __shared__ float red[16];
     // gradient through the optional relu * gain / clamp of the forward: v = x_hat * (1 + gamma) + beta is recomputed
@@ -180,10 +176,10 @@ __global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const float* __res
 #pragma unroll
             for (int k = 0; k < EPT / 4; k++) {
                 const int64_t i = k * 1024 + tid;
-                float4 xv = ((const float4*)(x + base))[i];
-                float4 dv = ((const float4*)(dout + base))[i];
-                float4 gv = gamma ? ((const float4*)(gamma + gb))[i] : make_float4(0, 0, 0, 0);
-                float4 bv = (act == 2 && beta) ? ((const float4*)(beta + gb))[i] : make_float4(0, 0, 0, 0);
+                float4 xv = ld4<T>(x + base + 4 * i);
+                float4 dv = ld4<T>(dout + base + 4 * i);
+                float4 gv = gamma ? ld4<T>(gamma + gb + 4 * i) : make_float4(0, 0, 0, 0);
+                float4 bv = (act == 2 && beta) ? ld4<T>(beta + gb + 4 * i) : make_float4(0, 0, 0, 0);
                 const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w}, bs[4] = {bv.x, bv.y, bv.z, bv.w};
                 float ds[4] = {dv.x, dv.y, dv.z, dv.w};
                 float dg[4];
@@ -196,8 +192,8 @@ __global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const float* __res
                     dg[j] = ds[j] * h;
                     s1 += tt; s2 += tt * h;
                 }
-                if (dgamma) ((float4*)(dgamma + dgb))[i] = make_float4(dg[0], dg[1], dg[2], dg[3]);
-                if (dbeta) ((float4*)(dbeta + dgb))[i] = make_float4(ds[0], ds[1], ds[2], ds[3]);
+                if (dgamma) st4<T>(dgamma + dgb + 4 * i, make_float4(dg[0], dg[1], dg[2], dg[3]));
+                if (dbeta) st4<T>(dbeta + dgb + 4 * i, make_float4(ds[0], ds[1], ds[2], ds[3]));
             }
             if (dx) {
                 const float m1 = block_sum<1024>(s1, red) * inv, m2 = block_sum<1024>(s2, red) * inv;
@@ -208,26 +204,28 @@ __global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const float* __res
                     o.y = rstd * (t[k * 4 + 1] - m1 - xh[k * 4 + 1] * m2);
                     o.z = rstd * (t[k * 4 + 2] - m1 - xh[k * 4 + 2] * m2);
                     o.w = rstd * (t[k * 4 + 3] - m1 - xh[k * 4 + 3] * m2);
-                    ((float4*)(dx + base))[k * 1024 + tid] = o;
+                    st4<T>(dx + base + 4 * (k * 1024 + tid), o);
                 }
             }
         } else {
             float s1 = 0.f, s2 = 0.f;
             for (int64_t i = tid; i < HW; i += 1024) {
-                float h = (x[base + i] - mean) * rstd;
-                float d = pre(dout[base + i], h, gamma ? gamma[gb + i] : 0.f, (act == 2 && beta) ? beta[gb + i] : 0.f);
-                float tt = d * (1.f + (gamma ? gamma[gb + i] : 0.f));
+                float h = (ld<T>(x + base + i) - mean) * rstd;
+                const float gi = gamma ? ld<T>(gamma + gb + i) : 0.f;
+                float d = pre(ld<T>(dout + base + i), h, gi, (act == 2 && beta) ? ld<T>(beta + gb + i) : 0.f);
+                float tt = d * (1.f + gi);
                 s1 += tt; s2 += tt * h;
-                if (dgamma) dgamma[dgb + i] = d * h;
-                if (dbeta) dbeta[dgb + i] = d;
+                if (dgamma) st<T>(dgamma + dgb + i, d * h);
+                if (dbeta) st<T>(dbeta + dgb + i, d);
             }
             if (dx) {
                 const float m1 = block_sum<1024>(s1, red) * inv, m2 = block_sum<1024>(s2, red) * inv;
                 for (int64_t i = tid; i < HW; i += 1024) {
-                    float h = (x[base + i] - mean) * rstd;
-                    float d = pre(dout[base + i], h, gamma ? gamma[gb + i] : 0.f, (act == 2 && beta) ? beta[gb + i] : 0.f);
-                    float tt = d * (1.f + (gamma ? gamma[gb + i] : 0.f));
-                    dx[base + i] = rstd * (tt - m1 - h * m2);
+                    float h = (ld<T>(x + base + i) - mean) * rstd;
+                    const float gi = gamma ? ld<T>(gamma + gb + i) : 0.f;
+                    float d = pre(ld<T>(dout + base + i), h, gi, (act == 2 && beta) ? ld<T>(beta + gb + i) : 0.f);
+                    float tt = d * (1.f + gi);
+                    st<T>(dx + base + i, rstd * (tt - m1 - h * m2));
                 }
             }
         }
@@ -251,31 +249,32 @@ __device__ __forceinline__ float mba_fwd(float u, float d, float nz, float b, in
     return v;
 }
 
-__global__ __launch_bounds__(256) void mod_bias_act_kernel(const float* __restrict__ u, const float* __restrict__ d,
+template <class T>      // storage type of u and y; d, noise, strength and b are fp32
+__global__ __launch_bounds__(256) void mod_bias_act_kernel(const T* __restrict__ u, const float* __restrict__ d,
                                                            const float* __restrict__ noise, const float* __restrict__ strength,
-                                                           const float* __restrict__ b, float* __restrict__ y, int C, int64_t HW,
+                                                           const float* __restrict__ b, T* __restrict__ y, int C, int64_t HW,
                                                            int noise_per_sample, int act, float alpha, float gain, float clamp) {
     const int64_t plane = blockIdx.x;
     const int n = (int)(plane / C), c = (int)(plane - (int64_t)n * C);
     const float dv = d ? d[plane] : 1.f, bv = b ? b[c] : 0.f, ns = noise ? strength[0] : 0.f;
-    const float* up = u + plane * HW;
+    const T* up = u + plane * HW;
     const float* np_ = noise ? noise + (noise_per_sample ? (int64_t)n * HW : 0) : nullptr;
-    float* yp = y + plane * HW;
+    T* yp = y + plane * HW;
     const int64_t i0 = (int64_t)blockIdx.y * MBA_CHUNK, i1 = i0 + MBA_CHUNK < HW ? i0 + MBA_CHUNK : HW;
     if ((HW & 3) == 0) {
         for (int64_t i = i0 + 4 * threadIdx.x; i < i1; i += 1024) {
-            const float4 uv = *(const float4*)(up + i);
+            const float4 uv = ld4<T>(up + i);
             const float4 nv = np_ ? *(const float4*)(np_ + i) : make_float4(0, 0, 0, 0);
             float4 o;
             o.x = mba_fwd(uv.x, dv, nv.x * ns, bv, act, alpha, gain, clamp);
             o.y = mba_fwd(uv.y, dv, nv.y * ns, bv, act, alpha, gain, clamp);
             o.z = mba_fwd(uv.z, dv, nv.z * ns, bv, act, alpha, gain, clamp);
             o.w = mba_fwd(uv.w, dv, nv.w * ns, bv, act, alpha, gain, clamp);
-            *(float4*)(yp + i) = o;
+            st4<T>(yp + i, o);
         }
     } else {
         for (int64_t i = i0 + threadIdx.x; i < i1; i += 256)
-            yp[i] = mba_fwd(up[i], dv, np_ ? np_[i] * ns : 0.f, bv, act, alpha, gain, clamp);
+            st<T>(yp + i, mba_fwd(ld<T>(up + i), dv, np_ ? np_[i] * ns : 0.f, bv, act, alpha, gain, clamp));
     }
 }
 
@@ -286,36 +285,37 @@ __device__ __forceinline__ float mba_dz(float dy, float y, int act, float alpha,
     return g;
 }
 
-__global__ __launch_bounds__(256) void mod_bias_act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                               const float* __restrict__ u, const float* __restrict__ d,
-                                                               const float* __restrict__ noise, float* __restrict__ du,
+template <class T>      // storage type of dy, y, u and du
+__global__ __launch_bounds__(256) void mod_bias_act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                               const T* __restrict__ u, const float* __restrict__ d,
+                                                               const float* __restrict__ noise, T* __restrict__ du,
                                                                float* __restrict__ partial, int C, int64_t HW, int chunks,
                                                                int noise_per_sample, int act, float alpha, float gain, float clamp) {
     __shared__ float red[4];
     const int64_t plane = blockIdx.x;
     const int n = (int)(plane / C);
     const float dv = d ? d[plane] : 1.f;
-    const float* dyp = dy + plane * HW; const float* yp = y + plane * HW; const float* up = u + plane * HW;
+    const T* dyp = dy + plane * HW; const T* yp = y + plane * HW; const T* up = u + plane * HW;
     const float* np_ = noise ? noise + (noise_per_sample ? (int64_t)n * HW : 0) : nullptr;
-    float* dup = du + plane * HW;
+    T* dup = du + plane * HW;
     const int64_t i0 = (int64_t)blockIdx.y * MBA_CHUNK, i1 = i0 + MBA_CHUNK < HW ? i0 + MBA_CHUNK : HW;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     if ((HW & 3) == 0) {
         for (int64_t i = i0 + 4 * threadIdx.x; i < i1; i += 1024) {
-            const float4 gv = *(const float4*)(dyp + i), yv = *(const float4*)(yp + i), uv = *(const float4*)(up + i);
+            const float4 gv = ld4<T>(dyp + i), yv = ld4<T>(yp + i), uv = ld4<T>(up + i);
             const float4 nv = np_ ? *(const float4*)(np_ + i) : make_float4(0, 0, 0, 0);
             const float z0 = mba_dz(gv.x, yv.x, act, alpha, gain, clamp), z1 = mba_dz(gv.y, yv.y, act, alpha, gain, clamp);
             const float z2 = mba_dz(gv.z, yv.z, act, alpha, gain, clamp), z3 = mba_dz(gv.w, yv.w, act, alpha, gain, clamp);
             s0 += z0 * uv.x + z1 * uv.y + z2 * uv.z + z3 * uv.w;
             s1 += z0 * nv.x + z1 * nv.y + z2 * nv.z + z3 * nv.w;
             s2 += z0 + z1 + z2 + z3;
-            *(float4*)(dup + i) = make_float4(z0 * dv, z1 * dv, z2 * dv, z3 * dv);
+            st4<T>(dup + i, make_float4(z0 * dv, z1 * dv, z2 * dv, z3 * dv));
         }
     } else {
         for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
-            const float z = mba_dz(dyp[i], yp[i], act, alpha, gain, clamp);
-            s0 += z * up[i]; s1 += np_ ? z * np_[i] : 0.f; s2 += z;
-            dup[i] = z * dv;
+            const float z = mba_dz(ld<T>(dyp + i), ld<T>(yp + i), act, alpha, gain, clamp);
+            s0 += z * ld<T>(up + i); s1 += np_ ? z * np_[i] : 0.f; s2 += z;
+            st<T>(dup + i, z * dv);
         }
     }
     s0 = block_sum<256>(s0, red); s1 = block_sum<256>(s1, red); s2 = block_sum<256>(s2, red);
@@ -327,7 +327,16 @@ __global__ __launch_bounds__(256) void mod_bias_act_bwd_kernel(const float* __re
 
 }  // namespace pasta
 
-extern "C" int pasta_scale_add(const float* x, const float* a, const float* b, float* y, int N, int C, int64_t HW,
+// runs LAUNCH_(T) with T the storage type of dtype code `dtype` (PASTA_F32 / _F16 / _BF16)
+#define PASTA_BY_DTYPE(dtype, what, LAUNCH_)                                                             \
+    switch (dtype) {                                                                                     \
+        case PASTA_F32: { LAUNCH_(float); break; }                                                       \
+        case PASTA_F16: { LAUNCH_(__half); break; }                                                      \
+        case PASTA_BF16: { LAUNCH_(__bf16); break; }                                                     \
+        default: return ::pasta::fail(what ": unsupported dtype code %d", dtype);                        \
+    }
+
+extern "C" int pasta_scale_add(const void* x, const float* a, const void* b, void* y, int dtype, int N, int C, int64_t HW,
                                int b_per_sample, void* stream) {
     using namespace pasta;
     PASTA_CHECK(x && y, "scale_add: null pointer");
@@ -338,18 +347,23 @@ extern "C" int pasta_scale_add(const float* x, const float* a, const float* b, f
     int gx = (int)(ceil_div64(per_plane, 256) < 64 ? ceil_div64(per_plane, 256) : 64);
     int gy = (int)(planes < 65535 ? planes : 65535);
     hipStream_t s = (hipStream_t)stream;
-    if (vec) hipLaunchKernelGGL((scale_add_kernel<4>), dim3(gx, gy), dim3(256), 0, s, x, a, b, y, planes, C, HW, b_per_sample);
-    else     hipLaunchKernelGGL((scale_add_kernel<1>), dim3(gx, gy), dim3(256), 0, s, x, a, b, y, planes, C, HW, b_per_sample);
+#define PASTA_L(T)                                                                                                                         \
+    if (vec) hipLaunchKernelGGL((scale_add_kernel<T, 4>), dim3(gx, gy), dim3(256), 0, s, (const T*)x, a, (const T*)b, (T*)y, planes, C, HW, b_per_sample); \
+    else     hipLaunchKernelGGL((scale_add_kernel<T, 1>), dim3(gx, gy), dim3(256), 0, s, (const T*)x, a, (const T*)b, (T*)y, planes, C, HW, b_per_sample)
+    PASTA_BY_DTYPE(dtype, "scale_add", PASTA_L)
+#undef PASTA_L
     return launch_status("scale_add");
 }
 
-extern "C" int pasta_plane_dot(const float* p, const float* q, float* out, int64_t planes, int64_t HW, void* stream) {
+extern "C" int pasta_plane_dot(const void* p, const void* q, float* out, int dtype, int64_t planes, int64_t HW, void* stream) {
     using namespace pasta;
     PASTA_CHECK(p && out, "plane_dot: null pointer");
     PASTA_CHECK(planes >= 1 && HW >= 1, "plane_dot: empty tensor");
     PASTA_CHECK((((uintptr_t)p | (uintptr_t)q) & 15) == 0 || (HW & 3) != 0, "plane_dot: operands must be 16-byte aligned");
     int grid = (int)(planes < 65535 ? planes : 65535);
-    hipLaunchKernelGGL(plane_dot_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, q, out, planes, HW);
+#define PASTA_L(T) hipLaunchKernelGGL(plane_dot_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)p, (const T*)q, out, planes, HW)
+    PASTA_BY_DTYPE(dtype, "plane_dot", PASTA_L)
+#undef PASTA_L
     return launch_status("plane_dot");
 }
 
@@ -403,7 +417,7 @@ __global__ __launch_bounds__(256) void nan_to_num_multi_kernel(NanToNumTable tab
     }
 }
 
-extern "C" int pasta_spade_norm(const float* x, const float* gamma, const float* beta, float* out, float* stats,
+extern "C" int pasta_spade_norm(const void* x, const void* gamma, const void* beta, void* out, float* stats, int dtype,
                                 int64_t planes, int64_t HW, float eps, int act, float gain, float clamp, int C, int64_t gb_stride,
                                 void* stream) {
     using namespace pasta;
@@ -416,14 +430,19 @@ extern "C" int pasta_spade_norm(const float* x, const float* gamma, const float*
     int grid = (int)(planes < 65535 ? planes : 65535);
     hipStream_t s = (hipStream_t)stream;
     const bool al = (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out) & 15) == 0 && gb_ns % 4 == 0;
-    if (HW == 16384 && al) hipLaunchKernelGGL((spade_norm_kernel<16>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, stats, planes, HW, eps, act, gain, clamp, C, gb_ns);
-    else if (HW == 4096 && al) hipLaunchKernelGGL((spade_norm_kernel<4>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, stats, planes, HW, eps, act, gain, clamp, C, gb_ns);
-    else hipLaunchKernelGGL((spade_norm_kernel<0>), dim3(grid), dim3(1024), 0, s, x, gamma, beta, out, stats, planes, HW, eps, act, gain, clamp, C, gb_ns);
+#define PASTA_ARGS(T) (const T*)x, (const T*)gamma, (const T*)beta, (T*)out, stats, planes, HW, eps, act, gain, clamp, C, gb_ns
+#define PASTA_L(T)                                                                                                        \
+    if (HW == 16384 && al) hipLaunchKernelGGL((spade_norm_kernel<T, 16>), dim3(grid), dim3(1024), 0, s, PASTA_ARGS(T));  \
+    else if (HW == 4096 && al) hipLaunchKernelGGL((spade_norm_kernel<T, 4>), dim3(grid), dim3(1024), 0, s, PASTA_ARGS(T)); \
+    else hipLaunchKernelGGL((spade_norm_kernel<T, 0>), dim3(grid), dim3(1024), 0, s, PASTA_ARGS(T))
+    PASTA_BY_DTYPE(dtype, "spade_norm", PASTA_L)
+#undef PASTA_L
+#undef PASTA_ARGS
     return launch_status("spade_norm");
 }
 
-extern "C" int pasta_spade_norm_bwd(const float* dout, const float* x, const float* gamma, const float* stats, float* dx,
-                                    float* dgamma, float* dbeta, int64_t planes, int64_t HW, const float* beta, int act, float gain,
+extern "C" int pasta_spade_norm_bwd(const void* dout, const void* x, const void* gamma, const float* stats, void* dx,
+                                    void* dgamma, void* dbeta, int dtype, int64_t planes, int64_t HW, const void* beta, int act, float gain,
                                     float clamp, int C, int64_t gb_stride, int64_t dgb_stride, void* stream) {
     using namespace pasta;
     PASTA_CHECK(dout && x && stats, "spade_norm_bwd: null pointer");
@@ -437,14 +456,19 @@ extern "C" int pasta_spade_norm_bwd(const float* dout, const float* x, const flo
     hipStream_t s = (hipStream_t)stream;
     const bool al = (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dout | (uintptr_t)dx | (uintptr_t)dgamma | (uintptr_t)dbeta | (uintptr_t)beta) & 15) == 0 &&
                     gb_ns % 4 == 0 && dgb_ns % 4 == 0;
-    if (HW == 16384 && al) hipLaunchKernelGGL((spade_norm_bwd_kernel<16>), dim3(grid), dim3(1024), 0, s, dout, x, gamma, stats, dx, dgamma, dbeta, planes, HW, beta, act, gain, clamp, C, gb_ns, dgb_ns);
-    else if (HW == 4096 && al) hipLaunchKernelGGL((spade_norm_bwd_kernel<4>), dim3(grid), dim3(1024), 0, s, dout, x, gamma, stats, dx, dgamma, dbeta, planes, HW, beta, act, gain, clamp, C, gb_ns, dgb_ns);
-    else hipLaunchKernelGGL((spade_norm_bwd_kernel<0>), dim3(grid), dim3(1024), 0, s, dout, x, gamma, stats, dx, dgamma, dbeta, planes, HW, beta, act, gain, clamp, C, gb_ns, dgb_ns);
+#define PASTA_ARGS(T) (const T*)dout, (const T*)x, (const T*)gamma, stats, (T*)dx, (T*)dgamma, (T*)dbeta, planes, HW, (const T*)beta, act, gain, clamp, C, gb_ns, dgb_ns
+#define PASTA_L(T)                                                                                                            \
+    if (HW == 16384 && al) hipLaunchKernelGGL((spade_norm_bwd_kernel<T, 16>), dim3(grid), dim3(1024), 0, s, PASTA_ARGS(T));  \
+    else if (HW == 4096 && al) hipLaunchKernelGGL((spade_norm_bwd_kernel<T, 4>), dim3(grid), dim3(1024), 0, s, PASTA_ARGS(T)); \
+    else hipLaunchKernelGGL((spade_norm_bwd_kernel<T, 0>), dim3(grid), dim3(1024), 0, s, PASTA_ARGS(T))
+    PASTA_BY_DTYPE(dtype, "spade_norm_bwd", PASTA_L)
+#undef PASTA_L
+#undef PASTA_ARGS
     return launch_status("spade_norm_bwd");
 }
 
-extern "C" int pasta_mod_bias_act(const float* u, const float* d, const float* noise, const float* strength, const float* b, float* y,
-                                  int N, int C, int64_t HW, int noise_per_sample, int act, float alpha, float gain, float clamp,
+extern "C" int pasta_mod_bias_act(const void* u, const float* d, const float* noise, const float* strength, const float* b, void* y,
+                                  int dtype, int N, int C, int64_t HW, int noise_per_sample, int act, float alpha, float gain, float clamp,
                                   void* stream) {
     using namespace pasta;
     PASTA_CHECK(u && y, "mod_bias_act: null pointer");
@@ -454,8 +478,10 @@ extern "C" int pasta_mod_bias_act(const float* u, const float* d, const float* n
     PASTA_CHECK(((HW & 3) != 0) || ((((uintptr_t)u | (uintptr_t)y | (uintptr_t)noise) & 15) == 0), "mod_bias_act: pointers must be 16-byte aligned");
     const int64_t chunks = (HW + MBA_CHUNK - 1) / MBA_CHUNK;
     PASTA_CHECK(chunks <= 65535 && (int64_t)N * C <= INT32_MAX, "mod_bias_act: tensor too large");
-    hipLaunchKernelGGL(mod_bias_act_kernel, dim3((unsigned)(N * C), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, u, d, noise, strength, b, y,
-                       C, HW, noise_per_sample, act, alpha, gain, clamp);
+#define PASTA_L(T) hipLaunchKernelGGL(mod_bias_act_kernel<T>, dim3((unsigned)(N * C), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, (const T*)u, d, noise, \
+                                      strength, b, (T*)y, C, HW, noise_per_sample, act, alpha, gain, clamp)
+    PASTA_BY_DTYPE(dtype, "mod_bias_act", PASTA_L)
+#undef PASTA_L
     return launch_status("mod_bias_act");
 }
 
@@ -464,8 +490,8 @@ extern "C" int64_t pasta_mod_bias_act_bwd_workspace(int N, int C, int64_t HW) {
     return (int64_t)N * C * ((HW + pasta::MBA_CHUNK - 1) / pasta::MBA_CHUNK) * 3 * (int64_t)sizeof(float);
 }
 
-extern "C" int pasta_mod_bias_act_bwd(const float* dy, const float* y, const float* u, const float* d, const float* noise, float* du,
-                                      float* partial, int N, int C, int64_t HW, int noise_per_sample, int act, float alpha, float gain,
+extern "C" int pasta_mod_bias_act_bwd(const void* dy, const void* y, const void* u, const float* d, const float* noise, void* du,
+                                      float* partial, int dtype, int N, int C, int64_t HW, int noise_per_sample, int act, float alpha, float gain,
                                       float clamp, void* stream) {
     using namespace pasta;
     PASTA_CHECK(dy && y && u && du && partial, "mod_bias_act_bwd: null pointer");
@@ -475,8 +501,10 @@ extern "C" int pasta_mod_bias_act_bwd(const float* dy, const float* y, const flo
                 "mod_bias_act_bwd: pointers must be 16-byte aligned");
     const int64_t chunks = (HW + MBA_CHUNK - 1) / MBA_CHUNK;
     PASTA_CHECK(chunks <= 65535 && (int64_t)N * C <= INT32_MAX, "mod_bias_act_bwd: tensor too large");
-    hipLaunchKernelGGL(mod_bias_act_bwd_kernel, dim3((unsigned)(N * C), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, dy, y, u, d, noise, du,
-                       partial, C, HW, (int)chunks, noise_per_sample, act, alpha, gain, clamp);
+#define PASTA_L(T) hipLaunchKernelGGL(mod_bias_act_bwd_kernel<T>, dim3((unsigned)(N * C), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (const T*)y, \
+                                      (const T*)u, d, noise, (T*)du, partial, C, HW, (int)chunks, noise_per_sample, act, alpha, gain, clamp)
+    PASTA_BY_DTYPE(dtype, "mod_bias_act_bwd", PASTA_L)
+#undef PASTA_L
     return launch_status("mod_bias_act_bwd");
 }
 

@@ -154,15 +154,15 @@ ABI = {
     'pasta_conv2d':       (ctypes.c_int, [_c_ptr] * 5 + [ctypes.POINTER(ConvDesc), _c_ptr, _c_i64, _c_ptr]),
     'pasta_conv2d_ex':    (ctypes.c_int, [_c_ptr] * 5 + [ctypes.POINTER(ConvEpilogue), ctypes.POINTER(ConvDesc), _c_ptr, _c_i64, _c_ptr]),
     'pasta_conv2d_wgrad': (ctypes.c_int, [_c_ptr] * 3 + [ctypes.POINTER(ConvDesc), _c_ptr, _c_i64, _c_ptr]),
-    'pasta_scale_add':    (ctypes.c_int, [_c_ptr] * 4 + [ctypes.c_int, ctypes.c_int, _c_i64, ctypes.c_int, _c_ptr]),
-    'pasta_plane_dot':    (ctypes.c_int, [_c_ptr] * 3 + [_c_i64, _c_i64, _c_ptr]),
-    'pasta_mod_bias_act': (ctypes.c_int, [_c_ptr] * 6 + [ctypes.c_int, ctypes.c_int, _c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+    'pasta_scale_add':    (ctypes.c_int, [_c_ptr] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i64, ctypes.c_int, _c_ptr]),
+    'pasta_plane_dot':    (ctypes.c_int, [_c_ptr] * 3 + [ctypes.c_int, _c_i64, _c_i64, _c_ptr]),
+    'pasta_mod_bias_act': (ctypes.c_int, [_c_ptr] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                           ctypes.c_float, ctypes.c_float, _c_ptr]),
     'pasta_mod_bias_act_bwd_workspace': (_c_i64, [ctypes.c_int, ctypes.c_int, _c_i64]),
-    'pasta_mod_bias_act_bwd': (ctypes.c_int, [_c_ptr] * 7 + [ctypes.c_int, ctypes.c_int, _c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+    'pasta_mod_bias_act_bwd': (ctypes.c_int, [_c_ptr] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                               ctypes.c_float, ctypes.c_float, _c_ptr]),
-    'pasta_spade_norm':   (ctypes.c_int, [_c_ptr] * 5 + [_c_i64, _c_i64, _c_f32, ctypes.c_int, _c_f32, _c_f32, ctypes.c_int, _c_i64, _c_ptr]),
-    'pasta_spade_norm_bwd': (ctypes.c_int, [_c_ptr] * 7 + [_c_i64, _c_i64, _c_ptr, ctypes.c_int, _c_f32, _c_f32, ctypes.c_int, _c_i64, _c_i64, _c_ptr]),
+    'pasta_spade_norm':   (ctypes.c_int, [_c_ptr] * 5 + [ctypes.c_int, _c_i64, _c_i64, _c_f32, ctypes.c_int, _c_f32, _c_f32, ctypes.c_int, _c_i64, _c_ptr]),
+    'pasta_spade_norm_bwd': (ctypes.c_int, [_c_ptr] * 7 + [ctypes.c_int, _c_i64, _c_i64, _c_ptr, ctypes.c_int, _c_f32, _c_f32, ctypes.c_int, _c_i64, _c_i64, _c_ptr]),
     'pasta_ada_matrices': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, ctypes.c_int, ctypes.c_int, _c_ptr, ctypes.POINTER(AdaConfig)] +
                                          [ctypes.c_int] * 4 + [_c_f32, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     'pasta_ada_theta':    (ctypes.c_int, [_c_ptr, _c_i64, ctypes.POINTER(_c_f32), ctypes.POINTER(_c_f32), _c_ptr, _c_ptr]),

@@ -20,41 +20,43 @@ def fma(a, b, c): # => a * b + c
 
 def _plane_pattern(a, b, c):
     """True when (a, b, c) is the demodulate-and-add-noise pattern the HIP kernels cover."""
-    if not (a.device.type == 'cuda' and a.dtype == torch.float32 and a.ndim == 4 and a.is_contiguous()):
+    if not (a.device.type == 'cuda' and a.dtype in _native.DTYPE_CODE and a.dtype != torch.float64 and a.ndim == 4 and a.is_contiguous()):
         return False
     n, ch, h, w = a.shape
-    if b.dtype != torch.float32 or tuple(b.shape) != (n, ch, 1, 1):
+    if b.dtype not in (a.dtype, torch.float32) or tuple(b.shape) != (n, ch, 1, 1):
         return False
-    if c.dtype != torch.float32 or tuple(c.shape) not in ((n, 1, h, w), (h, w), (1, 1, h, w)):
+    if c.dtype != a.dtype or tuple(c.shape) not in ((n, 1, h, w), (h, w), (1, 1, h, w)):
         return False
     return a.numel() > 0
 
 def scale_planes(x, s, noise=None):
-    """x[n,c,:,:] * s[n,c] (+ noise broadcast over channels) in one pass; fp32 NCHW on the GPU."""
+    """x[n,c,:,:] * s[n,c] (+ noise broadcast over channels) in one pass; NCHW fp32 / fp16 / bf16 on the GPU (the scales
+    are fp32, the noise has x's type)."""
     _native.require_gpu(x, 'scale_add')
     n, ch, h, w = x.shape
     x = x.contiguous()
-    s = s.reshape(n * ch).contiguous() if s is not None else None
+    s = s.reshape(n * ch).float().contiguous() if s is not None else None
     per_sample = 0
     if noise is not None:
         per_sample = int(noise.ndim == 4 and noise.shape[0] == n and n > 1)
-        noise = noise.contiguous()
+        noise = noise.to(x.dtype).contiguous()
     y = torch.empty_like(x)
     with torch.cuda.device(x.device):
-        st = _native.lib().pasta_scale_add(_native.ptr(x), _native.ptr(s), _native.ptr(noise), _native.ptr(y),
+        st = _native.lib().pasta_scale_add(_native.ptr(x), _native.ptr(s), _native.ptr(noise), _native.ptr(y), _native.dtype_code(x, 'scale_add'),
                                            n, ch, h * w, per_sample, _native.stream())
     _native.check(st)
     return y
 
 def plane_dot(p, q=None):
-    """out[n,c] = sum_hw p*q (or sum_hw p); fp32 NCHW on the GPU, fixed summation order."""
+    """out[n,c] = sum_hw p*q (or sum_hw p) as fp32; NCHW fp32 / fp16 / bf16 on the GPU, fixed summation order."""
     _native.require_gpu(p, 'plane_dot')
     n, ch, h, w = p.shape
     p = p.contiguous()
-    q = q.contiguous() if q is not None else None
+    q = q.to(p.dtype).contiguous() if q is not None else None
     out = torch.empty([n, ch], dtype=torch.float32, device=p.device)
     with torch.cuda.device(p.device):
-        st = _native.lib().pasta_plane_dot(_native.ptr(p), _native.ptr(q), _native.ptr(out), n * ch, h * w, _native.stream())
+        st = _native.lib().pasta_plane_dot(_native.ptr(p), _native.ptr(q), _native.ptr(out), _native.dtype_code(p, 'plane_dot'), n * ch, h * w,
+                                           _native.stream())
     _native.check(st)
     return out
 
@@ -74,11 +76,11 @@ class _FusedMultiplyAdd(torch.autograd.Function): # a * b + c
     def backward(ctx, dout):
         a, b = ctx.saved_tensors
         da = db = dc = None
-        fast = ctx.fast and dout.dtype == torch.float32 and not torch.is_grad_enabled()
+        fast = ctx.fast and dout.dtype == a.dtype and not torch.is_grad_enabled()
         if ctx.needs_input_grad[0]:
             da = scale_planes(dout, b) if fast else _unbroadcast(dout * b, a.shape)
         if ctx.needs_input_grad[1]:
-            db = plane_dot(dout, a).reshape(b.shape) if fast else _unbroadcast(dout * a, b.shape)
+            db = plane_dot(dout, a).reshape(b.shape).to(b.dtype) if fast else _unbroadcast(dout * a, b.shape)
         if ctx.needs_input_grad[2]:
             dc = _unbroadcast(dout, ctx.c_shape)
         return da, db, dc

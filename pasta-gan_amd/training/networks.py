@@ -42,12 +42,14 @@ class _ScalePlanes(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = fma.scale_planes(dy, s)
         if ctx.needs_input_grad[1]:
-            ds = fma.plane_dot(dy, x).reshape(s.shape)
+            ds = fma.plane_dot(dy, x).reshape(s.shape).to(s.dtype)
         return dx, ds
 
+_HIP_DTYPES = (torch.float32, torch.float16, torch.bfloat16)      # activation storage types of the fused plane kernels
+
 def scale_planes(x, s):
-    """x * s.reshape(N, C, 1, 1) in one pass (fp32 NCHW on the GPU); other dtypes use a broadcast multiply."""
-    if x.dtype == torch.float32 and x.device.type == 'cuda' and x.ndim == 4 and x.numel() > 0:
+    """x * s.reshape(N, C, 1, 1) in one pass (NCHW fp32 / fp16 / bf16 on the GPU, fp32 scales); otherwise a broadcast multiply."""
+    if x.dtype in _HIP_DTYPES and x.device.type == 'cuda' and x.ndim == 4 and x.numel() > 0:
         return _ScalePlanes.apply(x, s.to(torch.float32).reshape(x.shape[0], x.shape[1]))
     return x * s.to(x.dtype).reshape(x.shape[0], -1, 1, 1)
 
@@ -64,7 +66,7 @@ class _SpadeModulate(torch.autograd.Function):
         fused = beta is None
         if fused:
             assert gamma.shape == (n, 2 * c, h, w)
-            beta_ptr, gstride = gamma.data_ptr() + 4 * c * h * w, 2 * c * h * w
+            beta_ptr, gstride = gamma.data_ptr() + x.element_size() * c * h * w, 2 * c * h * w
         else:
             beta = beta.contiguous()
             beta_ptr, gstride = beta.data_ptr(), 0
@@ -73,7 +75,7 @@ class _SpadeModulate(torch.autograd.Function):
         act, gain, clamp = post                     # (2, gain, clamp): relu * gain with clamp on the way out; (0, 1, -1): none
         with torch.cuda.device(x.device):
             st = _native.lib().pasta_spade_norm(_native.ptr(x), _native.ptr(gamma), beta_ptr, _native.ptr(out),
-                                                _native.ptr(stats), n * c, h * w, float(eps), act, float(gain), float(clamp),
+                                                _native.ptr(stats), _native.dtype_code(x, 'spade_norm'), n * c, h * w, float(eps), act, float(gain), float(clamp),
                                                 c, gstride, _native.stream())
         _native.check(st)
         ctx.save_for_backward(x, gamma, stats, beta if (act == 2 and not fused) else None)
@@ -90,12 +92,13 @@ class _SpadeModulate(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         lib = _native.lib()
         if ctx.fused:       # gamma | beta and their gradients as channel halves of one tensor each
-            half = 4 * c * h * w
+            half = x.element_size() * c * h * w
             dgb = torch.empty_like(gamma) if ctx.needs_input_grad[1] else None
             if dx is not None or dgb is not None:
                 with torch.cuda.device(x.device):
                     st = lib.pasta_spade_norm_bwd(_native.ptr(dout), _native.ptr(x), _native.ptr(gamma), _native.ptr(stats), _native.ptr(dx),
-                                                  _native.ptr(dgb), dgb.data_ptr() + half if dgb is not None else None, n * c, h * w,
+                                                  _native.ptr(dgb), dgb.data_ptr() + half if dgb is not None else None,
+                                                  _native.dtype_code(x, 'spade_norm_bwd'), n * c, h * w,
                                                   gamma.data_ptr() + half, act, float(gain), float(clamp), c, 2 * c * h * w, 2 * c * h * w,
                                                   _native.stream())
                 _native.check(st)
@@ -111,7 +114,7 @@ class _SpadeModulate(torch.autograd.Function):
             with torch.cuda.device(x.device):
                 st = lib.pasta_spade_norm_bwd(_native.ptr(dout), _native.ptr(x), _native.ptr(gamma), _native.ptr(stats),
                                               _native.ptr(dx), _native.ptr(dgamma), _native.ptr(dbeta if act == 2 else None),
-                                              n * c, h * w, _native.ptr(beta), act, float(gain), float(clamp), c, 0, 0, _native.stream())
+                                              _native.dtype_code(x, 'spade_norm_bwd'), n * c, h * w, _native.ptr(beta), act, float(gain), float(clamp), c, 0, 0, _native.stream())
             _native.check(st)
         return dx, dgamma, (dbeta if ctx.needs_input_grad[2] else None), None, None
 
@@ -120,8 +123,8 @@ def spade_modulate(x, gamma, beta, eps=1e-5, relu_gain=None, clamp=None):
     in the same pass (the activation of the Spade_Conv2dLayer that consumes the result).  ``beta=None``: ``gamma`` holds
     gamma | beta as the two channel halves of a [N, 2C, H, W] tensor."""
     _native.require_gpu(x, 'spade_modulate')
-    if x.dtype != torch.float32:
-        raise RuntimeError('spade_modulate: float32 only (the generator runs in fp32, networks.py:5747-5748)')
+    if x.dtype not in _HIP_DTYPES or gamma.dtype != x.dtype or (beta is not None and beta.dtype != x.dtype):
+        raise RuntimeError('spade_modulate: x, gamma and beta must share one of float32 / float16 / bfloat16')
     post = (0, 1.0, -1.0) if relu_gain is None else (2, float(relu_gain), float(clamp if clamp is not None else -1))
     return _SpadeModulate.apply(x, gamma, beta, eps, post)
 
@@ -145,7 +148,7 @@ class _ModBiasAct(torch.autograd.Function):
         y = torch.empty_like(u)
         with torch.cuda.device(u.device):
             st = _native.lib().pasta_mod_bias_act(_native.ptr(u), _native.ptr(d), _native.ptr(noise), _native.ptr(strength), _native.ptr(b),
-                                                  _native.ptr(y), n, c, h * w, per_sample, act_idx, float(alpha), float(gain), float(clamp),
+                                                  _native.ptr(y), _native.dtype_code(u, 'mod_bias_act'), n, c, h * w, per_sample, act_idx, float(alpha), float(gain), float(clamp),
                                                   _native.stream())
         _native.check(st)
         ctx.save_for_backward(u, d, noise, y)
@@ -164,7 +167,7 @@ class _ModBiasAct(torch.autograd.Function):
         part = torch.empty([lib.pasta_mod_bias_act_bwd_workspace(n, c, h * w) // 4], dtype=torch.float32, device=u.device)
         with torch.cuda.device(u.device):
             st = lib.pasta_mod_bias_act_bwd(_native.ptr(dy), _native.ptr(y), _native.ptr(u), _native.ptr(d), _native.ptr(noise), _native.ptr(du),
-                                            _native.ptr(part), n, c, h * w, ctx.per_sample, act_idx, float(alpha), float(gain), float(clamp),
+                                            _native.ptr(part), _native.dtype_code(u, 'mod_bias_act_bwd'), n, c, h * w, ctx.per_sample, act_idx, float(alpha), float(gain), float(clamp),
                                             _native.stream())
         _native.check(st)
         sums = part.reshape(n, c, -1, 3).sum(dim=2)                    # [N, C, 3]: sum dz*u, sum dz*noise, sum dz
@@ -179,7 +182,7 @@ def mod_bias_act(u, dcoefs, noise, strength, bias, act='lrelu', alpha=None, gain
     First-order differentiable (the generator takes no double backward)."""
     _native.require_gpu(u, 'mod_bias_act')
     spec = bias_act.activation_funcs[act]
-    assert act in ('linear', 'lrelu') and u.dtype == torch.float32
+    assert act in ('linear', 'lrelu') and u.dtype in _HIP_DTYPES
     cfg = (spec.cuda_idx, float(alpha if alpha is not None else spec.def_alpha), float(gain if gain is not None else spec.def_gain),
            float(clamp if clamp is not None else -1))
     return _ModBiasAct.apply(u, dcoefs, noise, strength, bias, cfg)
@@ -207,12 +210,27 @@ def _scaled_act(activation, gain, conv_clamp):
     """Activation gain and clamp of a layer invoked with an extra ``gain``; the clamp scales with it (networks.py:176-177)."""
     return bias_act.activation_funcs[activation].def_gain * gain, (None if conv_clamp is None else conv_clamp * gain)
 
-def _hip_fp32(x):
-    return x.dtype == torch.float32 and x.device.type == 'cuda'
+def _hip_act(x):
+    """Is ``x`` an activation tensor the fused HIP kernels take (fp32, or 16-bit storage: fp16 / bf16)?"""
+    return x.dtype in _HIP_DTYPES and x.device.type == 'cuda'
 
-def _block_dtype(use_fp16, channels_last, force_fp32):
+def _master_weight(weight, x):
+    """The weight operand for a convolution over ``x``: 16-bit activations on the GPU meet the fp32 master directly (the
+    packing kernel of the convolution rounds it to the operand type -- what ``weight.to(x.dtype)`` does in the reference,
+    networks.py:171, without a cast kernel and without a 16-bit weight-gradient detour); otherwise ``weight.to(x.dtype)``."""
+    return weight if (x.device.type == 'cuda' and x.dtype != torch.float32) else weight.to(x.dtype)
+
+def _as_dtype(name):
+    """'float16' / 'bfloat16' / torch dtype / None -> torch dtype or None"""
+    if name is None or isinstance(name, torch.dtype):
+        return name
+    dtype = getattr(torch, str(name))
+    assert dtype in (torch.float16, torch.bfloat16, torch.float32)
+    return None if dtype == torch.float32 else dtype
+
+def _block_dtype(use_fp16, channels_last, force_fp32, half_dtype=torch.float16):
     half = use_fp16 and not force_fp32
-    return (torch.float16 if half else torch.float32), (torch.channels_last if channels_last and not force_fp32 else torch.contiguous_format)
+    return (half_dtype if half else torch.float32), (torch.channels_last if channels_last and not force_fp32 else torch.contiguous_format)
 
 #----------------------------------------------------------------------------
 # Modulated convolution.
@@ -226,7 +244,7 @@ def _modulate_and_convolve(x, weight, styles, up, down, padding, resample_filter
     """Shared-weight form of the modulated convolution up to, not including, the demodulation (networks.py:72-76):
     returns conv(x * s) and the demodulation coefficients (None without demodulation)."""
     dcoefs = _demodulation(weight, styles) if demodulate else None
-    y = conv2d_resample.conv2d_resample(x=scale_planes(x, styles), w=weight.to(x.dtype), f=resample_filter, up=up, down=down,
+    y = conv2d_resample.conv2d_resample(x=scale_planes(x, styles), w=_master_weight(weight, x), f=resample_filter, up=up, down=down,
                                         padding=padding, flip_weight=flip_weight)
     return y, dcoefs
 
@@ -361,10 +379,7 @@ class _FilteredConv(torch.nn.Module):
                 self.register_buffer('bias', bias)
 
     def _resample_args(self, x):
-        # 16-bit activations on the GPU meet the fp32 master weight directly: the convolution's packing kernel rounds it to
-        # the operand type (what `self.weight.to(x.dtype)` does in the reference, networks.py:171, without the cast kernel)
-        w = self.weight if (x.device.type == 'cuda' and x.dtype != torch.float32) else self.weight.to(x.dtype)
-        return dict(w=w, f=self.resample_filter, up=self.up, down=self.down, padding=self.padding,
+        return dict(w=_master_weight(self.weight, x), f=self.resample_filter, up=self.up, down=self.down, padding=self.padding,
                     flip_weight=(self.up == 1), wgain=self.weight_gain)     # up: the transposed convolution wants true-convolution taps
 
 @persistence.persistent_class
@@ -439,7 +454,7 @@ class SynthesisLayer(_StyledConv):
         unit = self._unit_noise(x, noise_mode)
         act_gain, act_clamp = _scaled_act(self.activation, gain, self.conv_clamp)
         conv = dict(up=self.up, padding=self.padding, resample_filter=self.resample_filter, flip_weight=(self.up == 1))
-        if not fused_modconv and _hip_fp32(x) and self.activation in ('linear', 'lrelu'):
+        if not fused_modconv and _hip_act(x) and self.activation in ('linear', 'lrelu'):
             # training: demodulation, noise, bias, activation and clamp are ONE pass over the convolution's output
             u, dcoefs = _modulate_and_convolve(x, self.weight, styles, down=1, demodulate=True, **conv)
             return mod_bias_act(u, dcoefs, unit, (None if unit is None else self.noise_strength), self.bias, act=self.activation,
@@ -568,7 +583,7 @@ class Dense(nn.Module):
         self.linear = nn.Linear(in_channels, out_channels)
 
     def forward(self, x):
-        if _hip_fp32(x):
+        if _hip_act(x):
             y = conv2d_gradfix.conv2d_bias_act(x, self.linear.weight[:, :, None, None], self.linear.bias)
         else:
             y = self.linear(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
@@ -595,7 +610,7 @@ class StyleEncoderNetworkV16(nn.Module):
         for layer in self.feat_enc:
             const_input = layer(const_input)
             pyramid.append(const_input)
-        code = self.fc(self.model(x).flatten(1))
+        code = self.fc(self.model(x).flatten(1).float())           # the style code and everything downstream of it: fp32
         return code, pyramid
 
 #----------------------------------------------------------------------------
@@ -614,7 +629,7 @@ class Spade_Norm_Block(torch.nn.Module):
 
     def _twin_convs(self, actv):
         g, b = self.conv_gamma, self.conv_beta
-        return (actv.dtype == torch.float32 and g.weight.shape == b.weight.shape and g.bias is None and b.bias is None
+        return (actv.dtype in _HIP_DTYPES and g.weight.shape == b.weight.shape and g.bias is None and b.bias is None
                 and (g.up, g.down, g.padding, g.weight_gain) == (b.up, b.down, b.padding, b.weight_gain) and g.up == g.down == 1)
 
     def forward(self, x, denorm_feats, post_act=None):
@@ -688,6 +703,7 @@ class _PoseStyleBlock(torch.nn.Module):
         self.in_channels, self.w_dim, self.resolution, self.img_channels = in_channels, w_dim, resolution, img_channels
         self.is_last, self.architecture, self.use_fp16 = is_last, architecture, use_fp16
         self.channels_last = bool(use_fp16 and fp16_channels_last)
+        self.half_dtype = torch.float16         # storage type of a use_fp16 block (the synthesis network may set bfloat16)
         _attach_filter(self, resample_filter)
         styled = dict(w_dim=w_dim, resolution=resolution, conv_clamp=conv_clamp, channels_last=self.channels_last, **layer_kwargs)
         first = (in_channels == 0)
@@ -711,7 +727,7 @@ class _PoseStyleBlock(torch.nn.Module):
     def forward(self, x, img, ws, pose_feature, cat_feat, force_fp32=False, fused_modconv=None, **layer_kwargs):
         misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
         latents = list(ws.unbind(dim=1))
-        dtype, memory_format = _block_dtype(self.use_fp16, self.channels_last, force_fp32)
+        dtype, memory_format = _block_dtype(self.use_fp16, self.channels_last, force_fp32, getattr(self, 'half_dtype', torch.float16))
         if fused_modconv is None:       # per-sample weights only outside training, and in fp16 only for a single sample
             fused_modconv = (not self.training) and (dtype == torch.float32 or int(x.shape[0]) == 1)
         styled = dict(fused_modconv=fused_modconv, **layer_kwargs)
@@ -775,18 +791,26 @@ class _PatchRoutedSynthesis(torch.nn.Module):
     block_class = None
     block_kwargs_extra = staticmethod(lambda style: dict())
 
-    def _build(self, w_dim, img_resolution, img_channels, channel_base, channel_max, block_kwargs):
+    def _build(self, w_dim, img_resolution, img_channels, channel_base, channel_max, block_kwargs, act_dtype=None):
         assert img_resolution >= 8 and img_resolution & (img_resolution - 1) == 0
         self.w_dim, self.img_resolution, self.img_channels = w_dim, img_resolution, img_channels
+        # Own extension (BASELINE config 5): ``act_dtype`` = 'bfloat16' / 'float16' stores every activation of the synthesis
+        # network in that type (convolutions: one matrix-core product, fp32 accumulation; demodulation coefficients, styles,
+        # instance-norm statistics, noise strength, bias and the output images stay fp32).  None = the reference's behaviour:
+        # every block computes in fp32 whatever num_fp16_res says (networks.py:5747-5748).
+        self.act_dtype = _as_dtype(act_dtype)
         self.img_resolution_log2 = int(np.log2(img_resolution))
         self.block_resolutions = [2 ** k for k in range(2, self.img_resolution_log2 + 1)]
         width = {res: min(channel_base // res, channel_max) for res in self.block_resolutions}
         top, below = self.block_resolutions[-1], self.block_resolutions[-2]
         self.spade_resolution = below
 
-        def block(res, style):          # every block of the generator computes in fp32 (networks.py:5747-5748)
-            return self.block_class(width[res // 2] if res > 4 else 0, width[res], w_dim=w_dim, resolution=res, img_channels=img_channels,
-                                    is_last=(res == top), use_fp16=False, **self.block_kwargs_extra(style), **block_kwargs)
+        def block(res, style):          # every block of the generator computes in fp32 (networks.py:5747-5748) unless act_dtype is set
+            b = self.block_class(width[res // 2] if res > 4 else 0, width[res], w_dim=w_dim, resolution=res, img_channels=img_channels,
+                                 is_last=(res == top), use_fp16=(self.act_dtype is not None), **self.block_kwargs_extra(style), **block_kwargs)
+            if self.act_dtype is not None:
+                b.half_dtype = self.act_dtype
+            return b
         self.num_ws = 0
         for res in self.block_resolutions:
             b = block(res, True)
@@ -815,12 +839,15 @@ class _PatchRoutedSynthesis(torch.nn.Module):
         covered_s = (halve(denorm_mask) > 0.9).to(dt)
         valid = ((region_s + covered_s) == 2.0).to(dt)
         hole = region_s - valid
-        feat = self.spade_encoder(denorm_input * region - (1 - region))
-        total = (feat * valid).sum(dim=(2, 3), keepdim=True)
+        act = getattr(self, 'act_dtype', None) or dt
+        feat = self.spade_encoder((denorm_input * region - (1 - region)).to(act))
+        total = (feat.float() * valid).sum(dim=(2, 3), keepdim=True)
         count = valid.sum(dim=(2, 3), keepdim=True)
         enough = (count > 10).to(dt)
         count = count * enough + float(self.spade_resolution ** 2) * (1 - enough)
-        return feat * (1 - hole) + (total / count) * hole
+        if feat.dtype == dt:
+            return feat * (1 - hole) + (total / count) * hole
+        return (feat * (1 - hole).to(act) + ((total / count) * hole).to(act))
 
     def _regions(self, heads):
         """(upper, lower) garment regions at image resolution from the last block's extra ToRGB outputs."""
@@ -835,7 +862,7 @@ class _PatchRoutedSynthesis(torch.nn.Module):
             b = getattr(self, f'b{res}')
             rows = ws.narrow(1, start, b.num_conv + b.num_torgb)      # a block's ToRGB shares the next block's first latent
             start += b.num_conv
-            x, img, *heads = b(x, img, rows, pose_feat, cat_feat, force_fp32=True, **block_kwargs)
+            x, img, *heads = b(x, img, rows, pose_feat, cat_feat, force_fp32=(self.act_dtype is None), **block_kwargs)
             if res == self.spade_resolution:
                 keep = (x.clone(), img.clone())                         # later blocks update both in place
         return img, heads, keep, rows
@@ -848,7 +875,7 @@ class _PatchRoutedSynthesis(torch.nn.Module):
         for i in (1, 2, 3):
             x = getattr(self, f'spade_b{self.spade_resolution}_{i}')(x, feat)
         texture = getattr(self, f'texture_b{self.img_resolution}')
-        return texture(x, img_below, top_rows, pose_feat, cat_feat, force_fp32=True, **block_kwargs)[1]
+        return texture(x, img_below, top_rows, pose_feat, cat_feat, force_fp32=(self.act_dtype is None), **block_kwargs)[1]
 
 @persistence.persistent_class
 class SynthesisNetworkFull(_PatchRoutedSynthesis):
@@ -857,9 +884,9 @@ class SynthesisNetworkFull(_PatchRoutedSynthesis):
     block_class = SynthesisBlockFull
     block_kwargs_extra = staticmethod(lambda style: dict(is_style=style))
 
-    def __init__(self, w_dim, img_resolution, img_channels, channel_base=32768, channel_max=512, num_fp16_res=0, **block_kwargs):
+    def __init__(self, w_dim, img_resolution, img_channels, channel_base=32768, channel_max=512, num_fp16_res=0, act_dtype=None, **block_kwargs):
         super().__init__()
-        self._build(w_dim, img_resolution, img_channels, channel_base, channel_max, block_kwargs)
+        self._build(w_dim, img_resolution, img_channels, channel_base, channel_max, block_kwargs, act_dtype)
 
     def _regions(self, heads):
         label = heads[0].detach().argmax(dim=1, keepdim=True)           # softmax is monotone: argmax of the logits (:5826)
@@ -876,9 +903,9 @@ class SynthesisNetworkV18(_PatchRoutedSynthesis):
     Returns (img, finetune_img, upper_mask, lower_mask)."""
     block_class = SynthesisBlockV18
 
-    def __init__(self, w_dim, img_resolution, img_channels, channel_base=32768, channel_max=512, num_fp16_res=0, **block_kwargs):
+    def __init__(self, w_dim, img_resolution, img_channels, channel_base=32768, channel_max=512, num_fp16_res=0, act_dtype=None, **block_kwargs):
         super().__init__()
-        self._build(w_dim, img_resolution, img_channels, channel_base, channel_max, block_kwargs)
+        self._build(w_dim, img_resolution, img_channels, channel_base, channel_max, block_kwargs, act_dtype)
 
     def _regions(self, heads):
         return heads[0], heads[1]
@@ -908,6 +935,9 @@ class _TryOnGenerator(torch.nn.Module):
 
     def forward(self, z, c, retain, pose, denorm_upper_input, denorm_lower_input, denorm_upper_mask, denorm_lower_mask,
                 truncation_psi=1, truncation_cutoff=None, **synthesis_kwargs):
+        act = getattr(self.synthesis, 'act_dtype', None)
+        if act is not None:             # 16-bit activation storage (own extension): the encoders run in it as well
+            pose, c, retain = pose.to(act), c.to(act), retain.to(act)
         pose_feat = self.const_encoding(pose)
         code, pyramid = self.style_encoding(c, retain)
         ws = self.mapping(z, code, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
@@ -947,6 +977,7 @@ class DiscriminatorBlock(torch.nn.Module):
         self.in_channels, self.resolution, self.img_channels = in_channels, resolution, img_channels
         self.first_layer_idx, self.architecture, self.use_fp16 = first_layer_idx, architecture, use_fp16
         self.channels_last = bool(use_fp16 and fp16_channels_last)
+        self.half_dtype = torch.float16         # storage type of a use_fp16 block (Discriminator(half_dtype=...) may set bfloat16)
         _attach_filter(self, resample_filter)
         # Freeze-D: layers are numbered through the whole discriminator; those below ``freeze_layers`` hold buffers
         plan = []
@@ -963,7 +994,7 @@ class DiscriminatorBlock(torch.nn.Module):
         self.num_layers = len(plan)
 
     def forward(self, x, img, force_fp32=False):
-        dtype, memory_format = _block_dtype(self.use_fp16, self.channels_last, force_fp32)
+        dtype, memory_format = _block_dtype(self.use_fp16, self.channels_last, force_fp32, getattr(self, 'half_dtype', torch.float16))
         if x is not None:
             misc.assert_shape(x, [None, self.in_channels, self.resolution, self.resolution])
             x = x.to(dtype=dtype, memory_format=memory_format)
@@ -1038,7 +1069,7 @@ class Discriminator(torch.nn.Module):
     """Residual StyleGAN2 discriminator, projection-conditioned on the style code (networks.py:1084-1139).  The
     ``num_fp16_res`` highest resolutions compute in fp16 (none when 0)."""
     def __init__(self, c_dim, img_resolution, img_channels, architecture='resnet', channel_base=32768, channel_max=512,
-                 num_fp16_res=0, conv_clamp=None, cmap_dim=None, block_kwargs={}, mapping_kwargs={}, epilogue_kwargs={}):
+                 num_fp16_res=0, conv_clamp=None, cmap_dim=None, block_kwargs={}, mapping_kwargs={}, epilogue_kwargs={}, half_dtype='float16'):
         super().__init__()
         self.c_dim, self.img_resolution, self.img_channels = c_dim, img_resolution, img_channels
         self.img_resolution_log2 = int(np.log2(img_resolution))
@@ -1054,6 +1085,7 @@ class Discriminator(torch.nn.Module):
         for res in self.block_resolutions:
             blk = DiscriminatorBlock(width[res] if res < img_resolution else 0, width[res], width[res // 2], resolution=res,
                                      first_layer_idx=layer_idx, use_fp16=(res >= first_fp16), **block_kwargs, **shared)
+            blk.half_dtype = _as_dtype(half_dtype) or torch.float16       # own extension: 'bfloat16' for BASELINE config 5
             setattr(self, f'b{res}', blk)
             layer_idx += blk.num_layers
         if c_dim > 0:

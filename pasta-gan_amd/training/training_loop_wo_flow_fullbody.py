@@ -49,17 +49,22 @@ def augment_options(aug='ada', augpipe='bgc', p=None, target=None):
         opts.ada_target = 0.6 if target is None else float(target)
     return opts
 
-def fashion_config(channel_base=16384, d_fp16_res=0, mbstd_group_size=4):
+def fashion_config(channel_base=16384, d_fp16_res=0, mbstd_group_size=4, img_resolution=256, act_dtype=None):
     """G/D/optimiser/loss options of ``--cfg fashion`` (train_wo_flow_fullbody.py:166-215, train.sh:3-10); augmentation
-    off (``cfg.update(augment_options(...))`` turns it on)."""
-    G_kwargs = dnnlib.EasyDict(class_name='training.networks.GeneratorFull', z_dim=0, c_dim=512, w_dim=512, img_resolution=256,
+    off (``cfg.update(augment_options(...))`` turns it on).  ``act_dtype`` ('bfloat16' / 'float16'; BASELINE config 5):
+    16-bit activation storage in the generator's synthesis network and encoders and in every discriminator block."""
+    G_kwargs = dnnlib.EasyDict(class_name='training.networks.GeneratorFull', z_dim=0, c_dim=512, w_dim=512, img_resolution=img_resolution,
                                img_channels=3, mapping_kwargs=dnnlib.EasyDict(num_layers=1),
                                synthesis_kwargs=dnnlib.EasyDict(channel_base=channel_base, channel_max=512, num_fp16_res=3,
                                                                 conv_clamp=256, use_noise=True))
-    D_kwargs = dnnlib.EasyDict(class_name='training.networks.Discriminator', c_dim=512, img_resolution=256, img_channels=3,
+    D_kwargs = dnnlib.EasyDict(class_name='training.networks.Discriminator', c_dim=512, img_resolution=img_resolution, img_channels=3,
                                channel_base=channel_base, channel_max=512, num_fp16_res=d_fp16_res, conv_clamp=256,
                                block_kwargs=dnnlib.EasyDict(), mapping_kwargs=dnnlib.EasyDict(),
                                epilogue_kwargs=dnnlib.EasyDict(mbstd_group_size=mbstd_group_size))
+    if act_dtype is not None:
+        G_kwargs.synthesis_kwargs.act_dtype = act_dtype
+        D_kwargs.half_dtype = act_dtype
+        D_kwargs.num_fp16_res = int(np.log2(img_resolution)) - 2      # every block b<R> .. b8
     opt = dnnlib.EasyDict(class_name='torch.optim.Adam', lr=0.002, betas=[0, 0.99], eps=1e-8)
     loss_kwargs = dnnlib.EasyDict(class_name='training.loss_wo_flow_fullbody.StyleGAN2Loss', r1_gamma=10, l1_weight=40,
                                   vgg_weight=0, contextual_weight=0, pl_weight=0, mask_weight=20)
