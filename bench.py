@@ -345,6 +345,10 @@ def main():
                     "(fused_modconv, grouped convolution), const noise; reports generated images/sec and the HBM roofline of upfirdn2d")
     ap.add_argument('--res', type=int, default=None, choices=[256, 512], help="--mode infer: 256 = GeneratorV18 (test.py's class, parity pinned); "
                     "512 (default) = the resolution-generalised GeneratorFull standing in for test_512.py's unreleased class (parity unpinned)")
+    ap.add_argument('--storage', default='f32', choices=['f32', 'bf16', 'f16'], help="activation storage (BASELINE config 5 = bf16): 16-bit tensors in "
+                    "HBM for the generator's synthesis network and encoders and every discriminator block, one matrix-core product per multiply-add, "
+                    "fp32 accumulation, demodulation, statistics and images.  Reduced precision: reported as such, never the headline")
+    ap.add_argument('--train-res', type=int, default=256, choices=[256, 512], help='--mode train: 512 = the resolution-generalised model (config 5: 512x320, batch 8/GPU)')
     ap.add_argument('--d-fp16-res', type=int, default=0, help="discriminator blocks of the N highest resolutions store and multiply in fp16 "
                     "(networks.py:1107-1120).  The reference's train script sets 4 (train_wo_flow_fullbody.py:195-196); the headline keeps 0 = "
                     "everything fp32-equivalent, which is what the parity oracle (the reference's force_fp32 CPU path) computes")
@@ -396,14 +400,15 @@ def main():
     if args.mode == 'infer':
         assert world == 1, '--mode infer is a single-GPU measurement (replicas only: nothing is exchanged)'
         return run_infer(args, device)
-    cfg = fashion_config(mbstd_group_size=min(args.batch_gpu, 4), d_fp16_res=args.d_fp16_res)      # train_wo_flow_fullbody.py:184: mbstd = min(batch_gpu, 4)
+    act = {'f32': None, 'bf16': 'bfloat16', 'f16': 'float16'}[args.storage]
+    cfg = fashion_config(mbstd_group_size=min(args.batch_gpu, 4), d_fp16_res=args.d_fp16_res, img_resolution=args.train_res, act_dtype=act)      # train_wo_flow_fullbody.py:184: mbstd = min(batch_gpu, 4)
     from training.training_loop_wo_flow_fullbody import augment_options
     cfg.update(augment_options(aug=args.aug, augpipe='bgc', p=args.aug_p))
     if args.vgg_weight > 0:
         cfg.loss_kwargs.vgg_weight = args.vgg_weight
         cfg.loss_kwargs.vgg_random_init = True
     step = TrainingStep(device, cfg=cfg, num_gpus=world, rank=rank, batch_size=args.batch_gpu * world, batch_gpu=args.batch_gpu, ddp_mode=args.ddp_mode)
-    data = SyntheticFullBodyBatch(args.batch_gpu, device, seed=rank)
+    data = SyntheticFullBodyBatch(args.batch_gpu, device, seed=rank, res=args.train_res)
     meter = ConvMeter(lib)
     if not args.no_meter:
         conv2d_gradfix.launch_hook = meter
@@ -445,13 +450,16 @@ def main():
     if rank == 0:
         images = args.steps * args.batch_gpu * world
         out = {
-            'metric': 'training images/sec at 256x192 (tensor 256x256), batch 16 per GPU',
+            'metric': 'training images/sec at 256x192 (tensor 256x256), batch 16 per GPU' if args.train_res == 256 else
+                      f'training images/sec at 512x320 (tensor 512x512), batch {args.batch_gpu} per GPU',
             'value': round(images / dt, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1000 * dt / args.steps, 2), 'host_issue_ms_per_step': round(1000 * host_dt / args.steps, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'bf16x3': 'f32 storage, split-bf16 x3 products (reduced: allow_tf32 counterpart)', 'bf16': 'f32 storage, bf16 operands (reduced: mixed precision)'}.get(conv2d_gradfix.conv_math, 'f32') +
-                     (f'; discriminator b256..b{256 >> (args.d_fp16_res - 1)} in fp16 storage and products (reduced: the reference train script\'s mixed precision)' if args.d_fp16_res > 0 else ''), 'conv_math': conv2d_gradfix.conv_math, 'data': 'synthetic', 'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
-            'config': {'workload': 'BASELINE config 2: full training_loop step (Gmain+Dmain every iter, Dreg/16, Greg/4, Adam, EMA), '
-                                   'GeneratorFull+Discriminator cfg=fashion 256x256, batch 16/GPU, ' + ('G and D in fp32, ' if args.d_fp16_res == 0 else f'G in fp32, D num_fp16_res={args.d_fp16_res}, ') +
+                     (f'; discriminator b256..b{256 >> (args.d_fp16_res - 1)} in fp16 storage and products (reduced: the reference train script\'s mixed precision)' if args.d_fp16_res > 0 else '') +
+                     (f'; {args.storage} ACTIVATION STORAGE in G and D, one {args.storage} matrix-core product per multiply-add, fp32 accumulation / demodulation / statistics (reduced: BASELINE config 5, tolerance in tests/test_storage16_gpu.py)' if act else ''), 'conv_math': conv2d_gradfix.conv_math, 'data': 'synthetic', 'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            'config': {'workload': ('BASELINE config 2' if args.train_res == 256 and act is None else 'BASELINE config 5 (one GPU of it)' if act else 'config 2 at 512') +
+                                   ': full training_loop step (Gmain+Dmain every iter, Dreg/16, Greg/4, Adam, EMA), '
+                                   f'GeneratorFull+Discriminator cfg=fashion {args.train_res}x{args.train_res}, batch {args.batch_gpu}/GPU, ' + ('G and D in fp32, ' if args.d_fp16_res == 0 else f'G in fp32, D num_fp16_res={args.d_fp16_res}, ') +
                                    ('vgg_weight=0 (weights unavailable)' if args.vgg_weight <= 0 else f'vgg_weight={args.vgg_weight:g} with random-init VGG-19') + (', no ADA' if args.aug == 'noaug' else f', ADA pipeline bgc ({args.aug}, p0={args.aug_p:g})') + ', random-init weights; timed iterations ' + f'{args.warmup}..{args.warmup + args.steps - 1}',
                        'global_batch': args.batch_gpu * world, 'parallelism': f'dp{world} ({transport})'},
         }

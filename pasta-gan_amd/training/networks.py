@@ -729,7 +729,7 @@ class _PoseStyleBlock(torch.nn.Module):
         latents = list(ws.unbind(dim=1))
         dtype, memory_format = _block_dtype(self.use_fp16, self.channels_last, force_fp32, getattr(self, 'half_dtype', torch.float16))
         if fused_modconv is None:       # per-sample weights only outside training, and in fp16 only for a single sample
-            fused_modconv = (not self.training) and (dtype == torch.float32 or int(x.shape[0]) == 1)
+            fused_modconv = (not self.training) and (dtype == torch.float32 or int(ws.shape[0]) == 1)
         styled = dict(fused_modconv=fused_modconv, **layer_kwargs)
 
         if self.in_channels == 0:
@@ -755,6 +755,7 @@ class _PoseStyleBlock(torch.nn.Module):
         if self.num_torgb:
             rgb, *extras = self.torgb(x, latents.pop(0), fused_modconv=fused_modconv)
             rgb = rgb.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+            extras = [e if e is None else e.to(torch.float32) for e in extras]          # every output of the network is fp32
             img = rgb if img is None else img.add_(rgb)
         return (x, img, *extras)
 
