@@ -57,16 +57,19 @@ class ConvMeter:
         self.enabled = False
         self.only = None
         self._family = {}          # descriptor fields -> (family, kernels): one plan call per distinct launch
+        self.iteration = 0         # set by the caller before every step
+        self.counts = {}           # iteration -> {family: kernel launches}: counted always (no events), for the PMC cross-check
 
     def __call__(self, kind, desc, launch):
-        if not self.enabled:
-            return launch()
         import ctypes
         key = (kind, desc.N, desc.C_in, desc.H, desc.W, desc.C_out, desc.OH, desc.OW, desc.kh, desc.kw, desc.stride, desc.pad_h, desc.pad_w,
-               desc.groups, desc.transposed, desc.math)
+               desc.groups, desc.transposed, desc.math, desc.io_dtype)
         hit = self._family.get(key)
-        if hit is not None and self.only is not None and hit[0] not in self.only:
-            return launch()
+        if hit is not None:
+            c = self.counts.setdefault(self.iteration, {})
+            c[hit[0]] = c.get(hit[0], 0) + hit[1]
+            if not self.enabled or (self.only is not None and hit[0] not in self.only):
+                return launch()
         g = desc.groups
         macs = desc.N * desc.C_out * (desc.C_in // g) * desc.kh * desc.kw
         macs *= (desc.H * desc.W) if desc.transposed else (desc.OH * desc.OW)
@@ -81,8 +84,11 @@ class ConvMeter:
             self.lib.pasta_conv2d_wgrad_plan(ctypes.byref(desc), ctypes.byref(which))
             family = WGRAD_NAMES[which.value]
             kernels = 1
-        self._family[key] = (family, kernels)
-        if self.only is not None and family not in self.only:
+        if hit is None:
+            self._family[key] = (family, kernels)
+            c = self.counts.setdefault(self.iteration, {})
+            c[family] = c.get(family, 0) + kernels
+        if not self.enabled or (self.only is not None and family not in self.only):
             return launch()
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
@@ -112,18 +118,31 @@ class ConvMeter:
         return sorted(((k, v[0], v[1], v[2] / (v[1] * 1e-3) / 1e12) for k, v in tab.items()), key=lambda r: -r[2])
 
 
-def pmc_traffic(kernel_family):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/r*_pmc.json; separate
-    --pmc runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950). None if absent."""
+def pmc_traffic(kernel_family, expected_launches):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/r*_pmc.json: separate
+    --pmc runs of ``bench.py --steps 1 --warmup 1 --no-cpu-baseline``, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for gfx950).  The figure is only reported when the profile is of THIS code: the kernel must have been launched there
+    exactly as often as this run launches it in the same two iterations (iteration 0 with every phase + one plain
+    iteration).  Returns (bytes per launch or None, file name or the reason for None)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json')))
     if not files:
-        return None, None
+        return None, 'no profiles/r*_pmc.json'
     want = kernel_family.replace(' ', '')
+    name_ = os.path.basename(files[-1])
     for name, v in json.load(open(files[-1])).items():
+        if name.startswith('_'):
+            continue
         if want in name.replace(' ', ''):
-            return float(v['hbm_bytes_corrected']), os.path.basename(files[-1])
-    return None, None
+            if expected_launches is None:
+                return None, f'{name_}: launch count of this run unknown (needs --warmup >= 2 with the meter on)'
+            if int(v['launches']) != int(expected_launches):
+                return None, (f'{name_} is stale: it holds {int(v["launches"])} launches of this kernel over two iterations, this code makes '
+                              f'{int(expected_launches)}')
+            return float(v['hbm_bytes_corrected']), name_
+    return None, f'{name_}: kernel not in the profile'
+
+
 
 
 def host_threads():
@@ -352,6 +371,8 @@ def main():
     ap.add_argument('--d-fp16-res', type=int, default=0, help="discriminator blocks of the N highest resolutions store and multiply in fp16 "
                     "(networks.py:1107-1120).  The reference's train script sets 4 (train_wo_flow_fullbody.py:195-196); the headline keeps 0 = "
                     "everything fp32-equivalent, which is what the parity oracle (the reference's force_fp32 CPU path) computes")
+    ap.add_argument('--no-variants', action='store_true', help='skip the two reduced-precision side measurements (fp16 discriminator blocks as in '
+                    'the reference train script; bf16 activation storage = BASELINE config 5) that a default single-GPU run appends as `also_measured`')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-meter', action='store_true', help='do not bracket convolution launches with events')
     ap.add_argument('--by-shape', action='store_true', help='also print a per-shape convolution table to stderr')
@@ -422,6 +443,7 @@ def main():
     survey = None
     for it in range(args.warmup):
         meter.enabled = (not args.no_meter) and it == args.warmup - 1
+        meter.iteration = it
         step.run(data)
     torch.cuda.synchronize()
     if meter.enabled:
@@ -433,7 +455,8 @@ def main():
     meter.enabled = not args.no_meter
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for it in range(args.steps):
+        meter.iteration = args.warmup + it
         step.run(data)
     host_dt = time.perf_counter() - t0        # when the host had issued everything (no sync inside the loop)
     torch.cuda.synchronize()
@@ -468,7 +491,10 @@ def main():
             dom = max(fam.items(), key=lambda kv: kv[1]['ms'])
             name, f = dom
             achieved = f['flops'] / (f['ms'] * 1e-3) / 1e12
-            traffic, src = pmc_traffic(name)
+            # launches of this kernel in iteration 0 (every phase) + one plain iteration = what the PMC command executes
+            plain = next((i for i in sorted(meter.counts) if i > 0 and i % 4 != 0), None)
+            expected = (meter.counts.get(0, {}).get(name, 0) + meter.counts[plain].get(name, 0)) if (0 in meter.counts and plain is not None) else None
+            traffic, src = pmc_traffic(name, expected)
             if name in (*bf16x6_names().values(), *bf16x6_rows_names().values(), WGRAD_NAMES[2], WGRAD_NAMES[3], WGRAD_NAMES[4]):
                 # six (three, one) bf16 MFMA products per multiply-add: the matrix pipes execute that multiple of the algorithmic FLOPs
                 nprod = {'bf16x3': 3, 'bf16': 1}.get(conv2d_gradfix.conv_math, 6)
@@ -498,6 +524,31 @@ def main():
         if args.by_shape:
             for shape, calls, ms, tf in meter.by_shape()[:args.by_shape_top]:
                 print(f'{str(shape):70s} calls/step={calls / args.steps:6.1f} ms/step={ms / args.steps:8.2f} TF/s={tf:7.1f}', file=sys.stderr)
+        headline_cfg = args.mode == 'train' and act is None and args.d_fp16_res == 0 and args.train_res == 256 and args.conv_math in (None, 'default')
+        if world == 1 and headline_cfg and not args.no_variants and args.aug == 'noaug' and args.vgg_weight <= 0:
+            # Side measurements, AFTER the headline's timed region and never part of `value`: the same step at the precision the
+            # reference's own train script uses for D, and in 16-bit activation storage (BASELINE config 5 at this resolution).
+            del step
+            torch.cuda.empty_cache()
+            out['also_measured'] = {}
+            for tag, kw, note in [('d_fp16_res_4', dict(d_fp16_res=4), 'D blocks b256..b32 in fp16 storage + products as train_wo_flow_fullbody.py:195-196 sets them; G fp32-equivalent; '
+                                                                        'parity: reference fixture, tests/test_fullwidth.py (2e-2)'),
+                                  ('storage_bf16', dict(act_dtype='bfloat16'), 'bf16 activation storage in G and D (BASELINE config 5 arithmetic at 256x256, batch 16); '
+                                                                               'parity: oracle in the same storage type, tests/test_storage16_gpu.py')]:
+                vcfg = fashion_config(mbstd_group_size=min(args.batch_gpu, 4), **kw)
+                vstep = TrainingStep(device, cfg=vcfg, num_gpus=1, rank=0, batch_size=args.batch_gpu, batch_gpu=args.batch_gpu)
+                for _ in range(2):
+                    vstep.run(data)
+                torch.cuda.synchronize()
+                tv = time.perf_counter()
+                for _ in range(16):
+                    vstep.run(data)
+                torch.cuda.synchronize()
+                tv = time.perf_counter() - tv
+                out['also_measured'][tag] = {'value': round(16 * args.batch_gpu / tv, 3), 'unit': 'images/sec', 'ms_per_step': round(1000 * tv / 16, 2),
+                                             'steps': 16, 'warmup': 2, 'precision': 'REDUCED relative to the headline', 'note': note}
+                del vstep
+                torch.cuda.empty_cache()
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

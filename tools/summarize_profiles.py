@@ -75,6 +75,11 @@ def main():
                     continue
                 w.writerow([k, n, f'{fk:.0f}', f'{wk:.0f}', f'{corrected:.0f}', f'{util:.1f}'])
                 summary[k] = dict(launches=n, fetch_kb=fk, write_kb=wk, hbm_bytes_corrected=corrected, mfma_util_percent=util)
+        import subprocess
+        commit = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], cwd=ROOT, stdout=subprocess.PIPE, text=True).stdout.strip()
+        summary['_meta'] = dict(commit=commit, command='python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-meter --no-variants',
+                                iterations='0 (every phase) and 1 (Gmain + Dmain): `launches` is over these two',
+                                note='bench.py reports roofline.traffic from this file only when its own launch count for the two iterations matches')
         json.dump(summary, open(os.path.join(out, f'{a.tag}_pmc.json'), 'w'), indent=1)
         print('pmc summary for %d kernels' % len(summary))
 
