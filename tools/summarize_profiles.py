@@ -32,6 +32,7 @@ def main():
     ap.add_argument('--pmc')
     ap.add_argument('--pmc-prefix', default='pmc_')
     ap.add_argument('--steps', type=int, default=5, help='steps (warm-up included) the stats run executed')
+    ap.add_argument('--sq', help='directory of the SQ counter pass (wave-cycle breakdown) -> <tag>_sq_stalls.csv')
     a = ap.parse_args()
     out = os.path.join(ROOT, 'profiles')
     os.makedirs(out, exist_ok=True)
@@ -82,6 +83,31 @@ def main():
                                 note='bench.py reports roofline.traffic from this file only when its own launch count for the two iterations matches')
         json.dump(summary, open(os.path.join(out, f'{a.tag}_pmc.json'), 'w'), indent=1)
         print('pmc summary for %d kernels' % len(summary))
+    if a.sq:
+        sq_stalls(a.tag, a.sq, out)
+        print('sq stall summary written')
+
+
+def sq_stalls(tag, directory, out):
+    f = glob.glob(os.path.join(directory, '*', '*_counter_collection.csv'))[0]
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    n = collections.defaultdict(int)
+    for r in csv.DictReader(open(f)):
+        per[r['Kernel_Name']][r['Counter_Name']] += float(r['Counter_Value'])
+        if r['Counter_Name'] == 'SQ_WAVE_CYCLES':
+            n[r['Kernel_Name']] += 1
+    names = ['SQ_ACTIVE_INST_ANY', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_WAIT_INST_LDS', 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE', 'SQ_INSTS_VALU']
+    with open(os.path.join(out, f'{tag}_sq_stalls.csv'), 'w', newline='') as fh:
+        w = csv.writer(fh)
+        w.writerow(['kernel', 'launches', 'wave_cycles_per_launch'] + [x + '/SQ_WAVE_CYCLES' for x in names[:4]] +
+                   ['SQ_LDS_BANK_CONFLICT/SQ_LDS_IDX_ACTIVE', 'SQ_INSTS_VALU_per_launch'])
+        for k in sorted(per, key=lambda k: -per[k]['SQ_WAVE_CYCLES']):
+            wc = per[k]['SQ_WAVE_CYCLES']
+            if wc <= 0 or wc < 0.002 * max(v['SQ_WAVE_CYCLES'] for v in per.values()):
+                continue
+            lds = per[k]['SQ_LDS_IDX_ACTIVE']
+            w.writerow([k, n[k], f'{wc / max(n[k], 1):.0f}'] + [f'{per[k][x] / wc:.3f}' for x in names[:4]] +
+                       [f'{per[k]["SQ_LDS_BANK_CONFLICT"] / lds:.3f}' if lds > 0 else '', f'{per[k]["SQ_INSTS_VALU"] / max(n[k], 1):.0f}'])
 
 
 if __name__ == '__main__':
