@@ -276,9 +276,12 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
         # brought to unit max-norm first (networks.py:57-59)
         weight = weight * (_fan_in_gain(i, np.sqrt(kh * kw)) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
         styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)
-    if fused_modconv:
+    if fused_modconv and not (_hip_act(x) and o < 128):
         y = _per_sample_convolve(x, weight, styles, up, down, padding, resample_filter, demodulate, flip_weight)
         return y if noise is None else y.add_(noise)
+    # (fused_modconv with fewer than 128 output channels on the GPU: the N groups of the per-sample-weight form would each
+    # fill a quarter or less of a 128-row matrix tile -- 45..73 TFLOP/s measured on the 32- and 64-channel layers of the 512
+    # generator -- so the algebraically identical shared-weight form below runs instead; same result to fp32 rounding)
     y, dcoefs = _modulate_and_convolve(x, weight, styles, up, down, padding, resample_filter, demodulate, flip_weight)
     if dcoefs is None:
         return y if noise is None else y.add_(noise.to(y.dtype))
