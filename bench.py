@@ -33,13 +33,14 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 matrix peak
 PEAK_HBM_GBS = 8000.0
 # kernel names as rocprofv3 prints them (without blanks); the last template argument = bf16 pieces per operand
 # (3 = the default six-product arithmetic, 2 = bf16x3, 1 = bf16)
+STORAGE_IO = 0        # pasta_conv_desc.io_dtype of the run (0 f32, 1 f16, 3 bf16): part of the kernel names, sets the product count
 def _np():
     from torch_utils.ops import conv2d_gradfix
-    return {'bf16x3': 2, 'bf16': 1}.get(conv2d_gradfix.conv_math, 3)
+    return 1 if STORAGE_IO else {'bf16x3': 2, 'bf16': 1}.get(conv2d_gradfix.conv_math, 3)
 def bf16x6_names():
-    return {0: f'conv_fwd_bf16x6_kernel<128,128,3,{_np()}>', 1: f'conv_fwd_bf16x6_kernel<64,256,2,{_np()}>'}
+    return {0: f'conv_fwd_bf16x6_kernel<128,128,3,{_np()},{STORAGE_IO}>', 1: f'conv_fwd_bf16x6_kernel<64,256,2,{_np()},{STORAGE_IO}>'}
 def bf16x6_rows_names():
-    return {0: f'conv_fwd_rows_bf16x6_kernel<128,128,2,1,{_np()}>', 1: f'conv_fwd_rows_bf16x6_kernel<64,256,2,1,{_np()}>'}
+    return {0: f'conv_fwd_rows_bf16x6_kernel<128,128,2,1,{_np()},{STORAGE_IO}>', 1: f'conv_fwd_rows_bf16x6_kernel<64,256,2,1,{_np()},{STORAGE_IO}>'}
 
 TILE_NAMES = {0: 'conv_fwd_kernel<128,128,2,2,8,4>', 1: 'conv_fwd_kernel<64,256,2,2,8,4>',
               2: 'conv_fwd_kernel<32,256,1,2,8>', 3: 'conv_fwd_kernel<64,64,1,1,8>'}
@@ -422,6 +423,8 @@ def main():
         assert world == 1, '--mode infer is a single-GPU measurement (replicas only: nothing is exchanged)'
         return run_infer(args, device)
     act = {'f32': None, 'bf16': 'bfloat16', 'f16': 'float16'}[args.storage]
+    global STORAGE_IO
+    STORAGE_IO = {'f32': 0, 'bf16': 3, 'f16': 1}[args.storage]
     cfg = fashion_config(mbstd_group_size=min(args.batch_gpu, 4), d_fp16_res=args.d_fp16_res, img_resolution=args.train_res, act_dtype=act)      # train_wo_flow_fullbody.py:184: mbstd = min(batch_gpu, 4)
     from training.training_loop_wo_flow_fullbody import augment_options
     cfg.update(augment_options(aug=args.aug, augpipe='bgc', p=args.aug_p))
@@ -497,7 +500,7 @@ def main():
             traffic, src = pmc_traffic(name, expected)
             if name in (*bf16x6_names().values(), *bf16x6_rows_names().values(), WGRAD_NAMES[2], WGRAD_NAMES[3], WGRAD_NAMES[4]):
                 # six (three, one) bf16 MFMA products per multiply-add: the matrix pipes execute that multiple of the algorithmic FLOPs
-                nprod = {'bf16x3': 3, 'bf16': 1}.get(conv2d_gradfix.conv_math, 6)
+                nprod = 1 if STORAGE_IO else {'bf16x3': 3, 'bf16': 1}.get(conv2d_gradfix.conv_math, 6)
                 peak = PEAK_BF16_MFMA_TFLOPS / nprod
                 note = ('split-bf16: %s products from %d x v_mfma_f32_32x32x16_bf16, fp32 accumulate; peak = 2500 TFLOP/s '
                         'dense bf16 / %d; executed bf16 rate = %d x achieved = %.0f TFLOP/s = %.1f%% of 2.5 PFLOP/s' %

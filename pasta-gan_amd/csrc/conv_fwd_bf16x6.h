@@ -332,6 +332,14 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
 // pixels; the B
 // image is double-buffered per stage, the A image per step.  Control flow around memory operations is static as in
 // the base kernel.
+// Schedules (PASTA_ROWS_PIPE selects; all bit-compatible in their results up to the order of the six products):
+//   1 (default)  below.   0: weights fetched and stored within one step.
+//   2  register diet, three workgroups per CU (157 VGPRs): +2-4 % on the 128^2 SPADE layers, -4 % at 64^2 and 32^2.
+//   3  weights straight to registers, one barrier per stage instead of per step, half the LDS traffic: +-0 %.
+// Round-2 finding (profiles/r2_ablation_rows.txt): three workgroups per CU, a third of the barriers,
+// half of the LDS traffic -- none of it moves the kernel, while removing either operand's global loads in a timing-only
+// build gains 20-24 %.  The kernel behaves as power / clock limited at ~1.25-1.3 PFLOP/s of executed bf16 MFMA (the
+// guide's tuned 256^2 GEMM template reaches 1.32-1.47 on random operands): what remains is energy per product, not schedule.
 // PIPE = 1 (default): the weights of a step are fetched TWO steps ahead into one of two register sets and stored to LDS a
 // full step later, so the store never waits for an L2 round trip (+1.5 % on the 128 x 128 x 128 layers; PIPE = 0 fetches
 // and stores within one step).  Also measured and dropped: reading the next step's fragments during the current step's
@@ -349,8 +357,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     constexpr int SLOTS = BN + 16;                      // up to 8 segments with two halo slots each
     constexpr int ABUF = APT * 256 * 8, BSEG = SLOTS * 8, BBUF = 2 * NP * BSEG;      // bf16 elements
     extern __shared__ __attribute__((aligned(16))) __bf16 rows_smem[];
-    __bf16* const As = rows_smem;                       // [2][ABUF]
-    __bf16* const Bs = rows_smem + 2 * ABUF;            // [2][BBUF]
+    __bf16* const As = rows_smem;                       // [2][ABUF]  (PIPE 3: the weights never enter LDS)
+    __bf16* const Bs = rows_smem + (PIPE == 3 ? 0 : 2 * ABUF);            // [2][BBUF]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -596,9 +604,148 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
         __syncthreads();
     };
 
+    // Register diet (PIPE == 2, launched at THREE workgroups per CU: <= 168 VGPRs):
+    //  * fragments are read one operand at a time, in an order in which consecutive product groups share an operand:
+    //    (a3,b1) (a2,b1) (a2,b2) (a1,b2) (a1,b3) (a1,b1): seven operand reads (fourteen ds_read_b128) instead of six pairs
+    //    held at once -- 24 fragment registers live instead of 48.  The order of the six products within a chunk is free:
+    //    the accumulator already holds the sum over all earlier chunks;
+    //  * the split runs piece by piece with the residuals kept IN the staging registers, each piece stored as soon as it is
+    //    complete: 4 packed registers live instead of 12;
+    //  * the weights are fetched and stored within one step (one register set: PIPE 0's schedule).
+    auto split_piece = [&](float* b, const int* nvalid, uint32_t (&q)[BPT][4], bool first) {
+#pragma unroll
+        for (int i = 0; i < BPT; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float v0 = b[8 * i + 2 * j], v1 = b[8 * i + 2 * j + 1];
+                if (first && nvalid[i] < 8) {
+                    v0 = 2 * j < nvalid[i] ? v0 : 0.f;
+                    v1 = 2 * j + 1 < nvalid[i] ? v1 : 0.f;
+                }
+                const uint32_t w = io_pack2<IO>(v0, v1);
+                q[i][j] = w;
+                v0 -= __builtin_bit_cast(float, w << 16);
+                v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
+                PASTA_KEEP_SCALAR(v0);
+                b[8 * i + 2 * j] = v0; b[8 * i + 2 * j + 1] = v1;
+            }
+    };
+    auto store_piece = [&](int buf, int slot, int hbase, int piece, const uint32_t (&q)[BPT][4]) {
+#pragma unroll
+        for (int i = 0; i < BPT; i++) {
+            __bf16* bd = Bs + buf * BBUF + ((hbase + i) * SLOTS + slot) * 8 + piece * 2 * BSEG;
+            *(uint4*)(bd) = make_uint4(q[i][0], q[i][1], q[i][2], q[i][3]);
+        }
+    };
+    auto step_diet = [&](const int TAP, const int abuf, const int bbuf) {
+        if (TAP == 2) next_a_stage();
+        if (TAP == 0) { load_b(); load_a(1); } else { load_a(TAP == 1 ? 2 : 0); }
+        const int off = p.rows_rev ? 2 - TAP : TAP;
+        const __bf16* A_ = As + abuf * ABUF;
+        const __bf16* B_ = Bs + bbuf * BBUF;
+        bf16x8 fa[WMT], fb[WNT];
+        auto lda = [&](int pc) {
+#pragma unroll
+            for (int a = 0; a < WMT; a++) fa[a] = *(const bf16x8*)&A_[((pc * 2 + hl) * BM + (wm * WMT + a) * 32 + jl) * 8];
+        };
+        auto ldb = [&](int pc) {
+#pragma unroll
+            for (int b = 0; b < WNT; b++) fb[b] = *(const bf16x8*)&B_[((pc * 2 + hl) * SLOTS + fslot[b] + off) * 8];
+        };
+        auto mm = [&]() {
+#pragma unroll
+            for (int a = 0; a < WMT; a++)
+#pragma unroll
+                for (int b = 0; b < WNT; b++) acc[a][b] = io_mfma<IO>(fa[a], fb[b], acc[a][b]);
+        };
+        const bool mine = TAP == 1 || (TAP == 2 && wave == h_owner);
+        float* const sb = TAP == 1 ? mb : hb;
+        const int* const sv = TAP == 1 ? m_nvalid : h_nvalid;
+        const int sslot = TAP == 1 ? m_slot : h_slot, shalf = TAP == 1 ? half0 : h_half;
+        uint32_t q[BPT][4];
+        if constexpr (NP == 3) {
+            lda(2); ldb(0); mm();                                   // a3 b1
+            if (mine) { split_piece(sb, sv, q, true); store_piece(bbuf ^ 1, sslot, shalf, 0, q); }
+            lda(1); mm();                                           // a2 b1
+            ldb(1); mm();                                           // a2 b2
+            if (mine) { split_piece(sb, sv, q, false); store_piece(bbuf ^ 1, sslot, shalf, 1, q); }
+            lda(0); mm();                                           // a1 b2
+            ldb(2); mm();                                           // a1 b3
+            if (mine) { split_piece(sb, sv, q, false); store_piece(bbuf ^ 1, sslot, shalf, 2, q); }
+            store_a(abuf ^ 1, 0);
+            ldb(0); mm();                                           // a1 b1
+        }
+        __syncthreads();
+    };
+
+    // Weights straight to registers (PIPE == 3).  The packed weight chunk is already in fragment order -- [piece][k-half]
+    // [row][8 bf16]: the 64 lanes of a fragment read 2 x 512 contiguous bytes -- so each wave fetches ITS OWN A fragments
+    // from global memory (L2 / L1 resident: every workgroup of an output-channel tile reads the same 885 KB per layer) one
+    // step ahead, into the register set the previous step has just finished with.  The A operand never touches LDS: no
+    // ds_write / ds_read for it, half the LDS footprint, and -- the point -- the workgroup barrier is needed only where
+    // the B image changes hands, once per STAGE (72 MFMAs) instead of once per step (24).
+    bf16x8 ar0[WMT][3], ar1[WMT][3];
+    auto load_a_frags = [&](int tap_i, bf16x8 (&dst)[WMT][3]) {
+        const __bf16* wt = (tap_i == 0 ? a_w0 : tap_i == 1 ? a_w1 : a_w2) + (int64_t)a_cc * a_chunk;
+#pragma unroll
+        for (int pc = 0; pc < NP; pc++)
+#pragma unroll
+            for (int a = 0; a < WMT; a++)
+                dst[a][pc] = *(const bf16x8*)(wt + ((int64_t)(pc * 2 + hl) * p.Og_pad + o_blk + (wm * WMT + a) * 32 + jl) * 8);
+    };
+#ifndef PASTA_ABLATE
+#define PASTA_ABLATE 0          // timing-only builds (results are garbage): 1 = no activation loads, 2 = no split / LDS stores of B, 4 = no weight loads, 8 = no MFMAs
+#endif
+    auto step_areg = [&](const int TAP, const int bbuf, bf16x8 (&cur)[WMT][3], bf16x8 (&nxt)[WMT][3]) {
+        if (TAP == 2) next_a_stage();
+        if (TAP == 0 && !(PASTA_ABLATE & 1)) load_b();
+        if (!(PASTA_ABLATE & 4)) load_a_frags(TAP == 0 ? 1 : TAP == 1 ? 2 : 0, nxt);
+        // The fetches above are for the NEXT step.  Left alone, the scheduler sinks each of them to just in front of its
+        // first use to save registers (s_waitcnt vmcnt(1) / vmcnt(0) between the MFMAs of the next step: an L2 round trip
+        // per fragment); the scheduling barrier keeps them here, a whole step ahead.
+        __builtin_amdgcn_sched_barrier(0);
+        const int off = p.rows_rev ? 2 - TAP : TAP;
+        const __bf16* B_ = Bs + bbuf * BBUF;
+        bf16x8 fb[WNT];
+        auto ldb = [&](int pc) {
+#pragma unroll
+            for (int b = 0; b < WNT; b++) fb[b] = *(const bf16x8*)&B_[((pc * 2 + hl) * SLOTS + fslot[b] + off) * 8];
+        };
+        auto mm = [&](int pa) {
+            if (PASTA_ABLATE & 8) {
+#pragma unroll
+                for (int b = 0; b < WNT; b++) asm volatile("" :: "v"(fb[b]));
+#pragma unroll
+                for (int a = 0; a < WMT; a++) asm volatile("" :: "v"(cur[a][pa]));
+                return;
+            }
+#pragma unroll
+            for (int a = 0; a < WMT; a++)
+#pragma unroll
+                for (int b = 0; b < WNT; b++) acc[a][b] = io_mfma<IO>(cur[a][pa], fb[b], acc[a][b]);
+        };
+        const bool mine = !(PASTA_ABLATE & 2) && (TAP == 1 || (TAP == 2 && wave == h_owner));
+        float* const sb = TAP == 1 ? mb : hb;
+        const int* const sv = TAP == 1 ? m_nvalid : h_nvalid;
+        const int sslot = TAP == 1 ? m_slot : h_slot, shalf = TAP == 1 ? half0 : h_half;
+        uint32_t q[BPT][4];
+        if constexpr (NP == 3) {
+            ldb(0); mm(2);                                          // a3 b1
+            if (mine) { split_piece(sb, sv, q, true); store_piece(bbuf ^ 1, sslot, shalf, 0, q); }
+            mm(1);                                                  // a2 b1
+            ldb(1); mm(1);                                          // a2 b2
+            if (mine) { split_piece(sb, sv, q, false); store_piece(bbuf ^ 1, sslot, shalf, 1, q); }
+            mm(0);                                                  // a1 b2
+            ldb(2); mm(0);                                          // a1 b3
+            if (mine) { split_piece(sb, sv, q, false); store_piece(bbuf ^ 1, sslot, shalf, 2, q); }
+            ldb(0); mm(0);                                          // a1 b1
+        }
+        if (TAP == 2) __syncthreads();                              // the B image of the next stage is complete, this one is free
+    };
+
     // prologue: stage 0 of this K slice entirely, and the weights of its first tap
     load_b();
-    load_a(0);
+    if (PIPE != 3) load_a(0);
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -611,9 +758,23 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
             for (int i = 0; i < BPT; i++) split_pair(hb, h_nvalid, i, j);
         store_q(0, h_slot, h_half);
     }
-    store_a(0);
+    if (PIPE != 3) store_a(0);
     if (PIPE == 1) load_a(1, 1);                     // weights of step 1: stored by step 0
+    if (PIPE == 3) load_a_frags(0, ar0);             // fragments of step 0
     __syncthreads();
+    if constexpr (PIPE == 3) {
+        static_assert(NP == 3, "the weights-in-registers schedule exists for the six-product arithmetic");
+        for (int s = 0; s < nstages; s += 2) {
+            step_areg(0, 0, ar0, ar1); step_areg(1, 0, ar1, ar0); step_areg(2, 0, ar0, ar1);
+            step_areg(0, 1, ar1, ar0); step_areg(1, 1, ar0, ar1); step_areg(2, 1, ar1, ar0);
+        }
+    } else if constexpr (PIPE == 2) {
+        static_assert(NP == 3, "the register-diet schedule exists for the six-product arithmetic");
+        for (int s = 0; s < nstages; s += 2) {
+            step_diet(0, 0, 0); step_diet(1, 1, 0); step_diet(2, 0, 0);
+            step_diet(0, 1, 1); step_diet(1, 0, 1); step_diet(2, 1, 1);
+        }
+    } else
     // two stages (six steps) per trip: the B image alternates per stage, the A image per step; an odd stage count runs
     // one all-zero stage
     for (int s = 0; s < nstages; s += 2) {
@@ -666,13 +827,28 @@ static void launch_fwd_bf16_np(const ConvFwdParams& q, dim3 grid, hipStream_t s)
         if (!attr_set) {
             if constexpr (IO == IO_F32)
                 (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 0, NP, IO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if constexpr (IO == IO_F32 && NP == 3)
+                (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 3, 2, NP, IO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP, IO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             const char* e = getenv("PASTA_ROWS_PIPE");
-            if (e) pipe = e[0] != '0';
+            if (e) pipe = e[0] - '0';
             attr_set = true;
         }
+        if constexpr (IO == IO_F32 && NP == 3) {
+            if (pipe == 2) { hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 3, 2, NP, IO>), grid, dim3(256), lds, s, q); return; }
+            if (pipe == 3) {
+                constexpr size_t lds3 = (size_t)(2 * 2 * NP * (BN + 16) * 8) * sizeof(__bf16);       // the B images only
+                static bool attr3 = false;
+                if (!attr3) {
+                    (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 3, NP, IO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+                    attr3 = true;
+                }
+                hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 3, NP, IO>), grid, dim3(256), lds3, s, q);
+                return;
+            }
+        }
         if constexpr (IO == IO_F32) {
-            if (pipe != 1) { hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 0, NP, IO>), grid, dim3(256), lds, s, q); return; }
+            if (pipe == 0) { hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 0, NP, IO>), grid, dim3(256), lds, s, q); return; }
         }
         hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP, IO>), grid, dim3(256), lds, s, q);
         return;

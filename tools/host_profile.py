@@ -22,11 +22,13 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--top', type=int, default=45)
     ap.add_argument('--sort', default='tottime')
+    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--act-dtype', default=None)
     args = ap.parse_args()
     from training.training_loop_wo_flow_fullbody import TrainingStep, SyntheticFullBodyBatch, fashion_config
     dev = torch.device('cuda', 0)
-    step = TrainingStep(dev, cfg=fashion_config(), batch_size=16, batch_gpu=16)
-    data = SyntheticFullBodyBatch(16, dev, seed=0)
+    step = TrainingStep(dev, cfg=fashion_config(act_dtype=args.act_dtype, mbstd_group_size=min(args.batch, 4)), batch_size=args.batch, batch_gpu=args.batch)
+    data = SyntheticFullBodyBatch(args.batch, dev, seed=0)
     for _ in range(2):
         step.run(data)
     torch.cuda.synchronize()
