@@ -534,8 +534,9 @@ def main():
             del step
             torch.cuda.empty_cache()
             out['also_measured'] = {}
-            for tag, kw, note in [('d_fp16_res_4', dict(d_fp16_res=4), 'D blocks b256..b32 in fp16 storage + products as train_wo_flow_fullbody.py:195-196 sets them; G fp32-equivalent; '
-                                                                        'parity: reference fixture, tests/test_fullwidth.py (2e-2)'),
+            for tag, kw, note in [('d_fp16_res_3', dict(d_fp16_res=3), 'D blocks b256..b64 in fp16 storage + products: num_fp16_res = 3, conv_clamp = 256 as train_wo_flow_fullbody.py:195-196 sets them '
+                                                                        '(GeneratorFull forces its blocks to fp32, networks.py:2307,2331): the reference script\'s default precision; '
+                                                                        'parity: reference fixture with num_fp16_res = 4, tests/test_fullwidth.py (2e-2)'),
                                   ('storage_bf16', dict(act_dtype='bfloat16'), 'bf16 activation storage in G and D (BASELINE config 5 arithmetic at 256x256, batch 16); '
                                                                                'parity: oracle in the same storage type, tests/test_storage16_gpu.py')]:
                 vcfg = fashion_config(mbstd_group_size=min(args.batch_gpu, 4), **kw)

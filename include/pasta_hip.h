@@ -169,7 +169,10 @@ int pasta_conv2d(const void* x, const float* w, void* y,      /* x, y: elements 
                  void* stream);
 
 /* Optional fused epilogue of pasta_conv2d_ex: after the output scale,
- *   y = clamp(act(y + bias[c]) * gain)      -- Conv2dLayer's bias_act (training/networks.py:176-178), forward only
+ *   y = clamp(act(y + noise * noise_strength[0] + res + bias[c]) * gain)
+ * -- Conv2dLayer's bias_act (training/networks.py:176-178) and, with oscale = the demodulation coefficients and the noise
+ * operand, the whole tail of SynthesisLayer (networks.py:77-82, 313-314: x * dcoefs + noise, bias_act) in the convolution's
+ * own epilogue; forward only (the training path keeps pasta_mod_bias_act, whose backward needs the convolution output).
  * act: 1 linear, 2 relu, 3 lrelu (bias_act.py:24-26); bias NULL = none; clamp < 0 = none. */
 typedef struct pasta_conv_epilogue {
     const float* bias;            /* [C_out] or NULL */
@@ -181,6 +184,9 @@ typedef struct pasta_conv_epilogue {
                                      torch.cat (networks.py:5690-5693) as two 1x1 convolutions, and the SPADE block's
                                      y + conv(x) (:5273) -- it is time-neutral (+0.4 % / 0.0 %), so the networks keep the
                                      reference's formulation and the operand stays an option of the operator. */
+    const float* noise;           /* fp32 [OH*OW] (noise_per_sample 0) or [N][OH*OW] (1), or NULL */
+    const float* noise_strength;  /* device scalar (SynthesisLayer.noise_strength); required with noise */
+    int32_t noise_per_sample;
 } pasta_conv_epilogue;
 
 /* pasta_conv2d with the epilogue above (ep NULL = plain pasta_conv2d). */
@@ -189,16 +195,31 @@ int pasta_conv2d_ex(const void* x, const float* w, void* y,
                     const pasta_conv_desc* d, void* workspace, int64_t workspace_bytes,
                     void* stream);
 
+/* Modulated convolution in its per-sample-weight form (networks.py:84-94, the `fused_modconv` branch test.py runs):
+ * d describes the grouped convolution the reference launches (groups = N samples, C_in = N*I, C_out = N*O, x viewed as
+ * [1, N*I, H, W]); w is the ONE shared weight [O, I, kh, kw] ([I, O, kh, kw] when d->transposed).  The weight-packing
+ * kernel forms each group's operand  w[o,i,:] * styles[n,i] * dcoefs[n,o]  on its way into the staging layout, so the
+ * [N, O, I, kh, kw] tensor of the reference and the passes that build it do not exist (dcoefs NULL = no demodulation;
+ * pasta_demod_coefs computes them).  Forward only. */
+int pasta_conv2d_modulated(const void* x, const float* w, const float* styles, const float* dcoefs, void* y,
+                           const pasta_conv_epilogue* ep, const pasta_conv_desc* d, void* workspace,
+                           int64_t workspace_bytes, void* stream);
+
 /* dw = d(conv)/dw given x and dy (same descriptor as the forward); x, dy: elements of d->io_dtype, dw: fp32. */
 int pasta_conv2d_wgrad(const void* x, const void* dy, float* dw,
                        const pasta_conv_desc* d, void* workspace,
                        int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
- * Modulated-convolution helpers (training/networks.py:36-94).  The demodulation
- * coefficients themselves are an [N,I]x[I,O] product of squared styles and
- * squared-weight sums, left to the host's BLAS (tiny).
+ * Modulated-convolution helpers (training/networks.py:36-94).
  * ------------------------------------------------------------------------- */
+/* Demodulation coefficients (networks.py:65-68):
+ *   d[n,o] = rsqrt(sum_{i,k} (w[o,i,k] * styles[n,i])^2 + eps),  w: [O,I,KK] fp32, styles: [N,I] fp32, d: [N,O] fp32.
+ * One workgroup per output channel, tap-summed squared weights in LDS, wavefront-shuffle reduction over I (I <= 4096);
+ * the reference's per-sample weight tensor [N,O,I,kh,kw] is never formed. */
+int pasta_demod_coefs(const float* w, const float* styles, float* d, int N, int O, int I, int KK,
+                      float eps, void* stream);
+
 /* y[n,c,h,w] = x[n,c,h,w] * a[n,c] + (b ? b[n,0,h,w] : 0)   fma.py:15 with the
  * broadcast shapes modulated_conv2d uses (a: [N,C], b: [N,HW] or [HW], or NULL) */
 /* (this and the following plane kernels: `dtype` = storage type of the activation tensors -- PASTA_F32, PASTA_F16 or

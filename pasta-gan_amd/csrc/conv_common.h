@@ -85,6 +85,12 @@ template <int IO> __device__ __forceinline__ f32x16 io_mfma(bf16x8_t a, bf16x8_t
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
 }
 
+// accumulator -> output value: demodulation scale and noise as mod_bias_act_kernel rounds them (fma(acc, d, noise * strength)),
+// residual, then bias / activation / gain / clamp.  d = 1 and nz = 0 leave the accumulator bit-identical.
+__device__ __forceinline__ float conv_scale_noise(float v, const float* osb, int o, float nz) {
+    return osb ? fmaf(v, osb[o], nz) : v + nz;
+}
+
 // Parameters of the forward-type kernels (conv2d, conv_transpose2d and both input gradients).
 struct ConvFwdParams {
     const float* x; const float* wp; float* y;         // x, y (and res): elements of type `io` behind these pointers
@@ -103,6 +109,9 @@ struct ConvFwdParams {
     int bf16x6;                           // weights packed as split-bf16 pieces, run conv_fwd_bf16x6_kernel
     const float* bias;                    // fused epilogue (pasta_conv_epilogue); act == 0: none
     const float* res;                     // [N, Cout, OH, OW] added before bias / activation, or null
+    const float* noise;                   // [OH*OW] or [N][OH*OW] fp32, times noise_strength[0], added after the output scale (SynthesisLayer), or null
+    const float* noise_strength;
+    int noise_ps;                         // noise is per sample
     int act;
     float alpha, gain, clamp;
     int tap_dy[MAX_TAPS], tap_dx[MAX_TAPS], tap_slab[MAX_TAPS];     // int so that a wave-uniform index reads them with s_load_dword

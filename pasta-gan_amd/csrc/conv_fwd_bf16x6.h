@@ -29,7 +29,8 @@ __device__ __forceinline__ void split3(float v, __bf16& a, __bf16& b, __bf16& c)
 // [g][tap][chunk of 16 channels][piece 3][half 2][O_pad][8]
 __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int G, int Ig,
                                                                 int Og, int Ig_pad, int Og_pad, int kh, int kw, int transposed,
-                                                                int flip, float wscale, int f16) {
+                                                                int flip, float wscale, int f16, const float* __restrict__ mod_s,
+                                                                const float* __restrict__ mod_d) {
     const int64_t total = (int64_t)G * kh * kw * Ig_pad * Og_pad;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int j = (int)(idx & 7);
@@ -44,9 +45,13 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __r
         if (i < Ig && o < Og) {
             int ty = t / kw, tx = t - ty * kw;
             if (flip) { ty = kh - 1 - ty; tx = kw - 1 - tx; }
-            const int64_t src = transposed ? (((int64_t)(g * Ig + i) * Og + o) * kh + ty) * kw + tx
-                                           : (((int64_t)(g * Og + o) * Ig + i) * kh + ty) * kw + tx;
+            // mod_s: ONE weight of a single group, shared by all groups, modulated per group (= sample) on the way:
+            // w[o,i] * s[g,i] (* d[g,o]) rounded in this order, as networks.py:65-68, 84-86 forms its per-sample weights
+            const int gs = mod_s ? 0 : g;
+            const int64_t src = transposed ? (((int64_t)(gs * Ig + i) * Og + o) * kh + ty) * kw + tx
+                                           : (((int64_t)(gs * Og + o) * Ig + i) * kh + ty) * kw + tx;
             v = w[src] * wscale;
+            if (mod_s) { v *= mod_s[(int64_t)g * Ig + i]; if (mod_d) v *= mod_d[(int64_t)g * Og + o]; }
         }
         __bf16 p1, p2, p3;
         split3(v, p1, p2, p3);
@@ -63,7 +68,10 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __r
 // mid*hi: ~2^-16 relative, PASTA_MATH_BF16X3), 1 = one product (plain bf16 operands, PASTA_MATH_BF16).  The packed
 // weights always hold three pieces; NP < 3 fetches and stages the leading ones only.
 // IO = storage type of x / y / res (conv_common.h): 16-bit storage runs NP = 1 on the matching matrix-core type.
-template <int BM, int BN, int OCC, int NP, int IO = IO_F32>      // (128, 128): waves 2 x 2;  (64, 256): waves 1 x 4; each wave 64 rows x 64 pixels
+// ISC: the activations are multiplied by p.iscale[n, channel] (the styles of a modulated convolution, networks.py:74) on
+// their way from the fetch registers to the split -- x * s rounded to fp32 exactly as a separate scaling pass would, so
+// the modulated activation tensor never exists in HBM.
+template <int BM, int BN, int OCC, int NP, int IO = IO_F32, bool ISC = false>      // (128, 128): waves 2 x 2;  (64, 256): waves 1 x 4; each wave 64 rows x 64 pixels
 __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams p) {
     static_assert(IO == IO_F32 || NP == 1, "16-bit storage: the element is the operand, one product");
     constexpr unsigned ES = io_size<IO>::value;
@@ -127,8 +135,9 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     // The loop body is free of data-dependent control flow around its memory operations: every step issues the same
     // loads and stores (past the end of the K range they re-read valid addresses and the activations are zeroed), so
     // that the s_waitcnt counters the compiler derives let a fetch stay in flight for a whole step.
-    struct Stage { float b[8 * BPT]; int nvalid[BPT]; };
+    struct Stage { float b[8 * BPT]; float sc[ISC ? 8 * BPT : 1]; int nvalid[BPT]; };
     Stage st0, st1;
+    const float* const isb = ISC ? p.iscale + (int64_t)n_in * p.Cin + (int64_t)g * p.Ig : nullptr;
     float4 areg0, areg1, areg2;         // APT of them are used (scalars: an array here is not kept in registers)
     int ld_t = c_first / NC, ld_cc = c_first - ld_t * NC, ld_left = nchunks;
     bool ld_ok = false;
@@ -155,6 +164,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
             for (int j = 0; j < 8; j++) {
                 const unsigned coff = (unsigned)(c0 + j < last ? c0 + j : last) * (unsigned)HW * ES;    // scalar
                 st.b[8 * i + j] = io_ld<IO>(xbytes, ld_pix + coff);
+                if constexpr (ISC) st.sc[8 * i + j] = isb[c0 + j < last ? c0 + j : last];
             }
             st.nvalid[i] = (ld_ok && real) ? p.Ig - c0 : 0;     // elements j < nvalid are real
         }
@@ -188,6 +198,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     auto split_pair = [&](const Stage& st, int i, int j) {
         float v0 = st.b[8 * i + 2 * j], v1 = st.b[8 * i + 2 * j + 1];
+        if constexpr (ISC) { v0 *= st.sc[8 * i + 2 * j]; v1 *= st.sc[8 * i + 2 * j + 1]; }
         if (st.nvalid[i] < 8) {                  // border pixel or channel tail
             v0 = 2 * j < st.nvalid[i] ? v0 : 0.f;
             v1 = 2 * j + 1 < st.nvalid[i] ? v1 : 0.f;
@@ -290,6 +301,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     }
 
     const int OHW = p.OH * p.OW;
+    const bool has_noise = p.noise && p.ksplit == 1;
+    const float nstr = has_noise ? p.noise_strength[0] : 0.f;
 #pragma unroll
     for (int b = 0; b < WNT; b++) {
         const int64_t pix = pix_blk + (wn * WNT + b) * 32 + jl;
@@ -297,7 +310,9 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
         const int n = (int)(pix / (P * Q));
         const int rem = (int)(pix - (int64_t)n * P * Q);
         const int pp = rem / Q, qq = rem - pp * Q;
-        const int64_t yoff = ((int64_t)n * p.Cout + (int64_t)g * p.Og) * OHW + (oy0 + pp * p.osy) * p.OW + ox0 + qq * p.osx;
+        const int plane_off = (oy0 + pp * p.osy) * p.OW + ox0 + qq * p.osx;
+        const int64_t yoff = ((int64_t)n * p.Cout + (int64_t)g * p.Og) * OHW + plane_off;
+        const float nz = has_noise ? p.noise[(p.noise_ps ? (int64_t)n * OHW : 0) + plane_off] * nstr : 0.f;
         float* pb = p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW + yoff : nullptr;      // K slices: fp32 partial sums
         const bool has_res = p.res && p.ksplit == 1;
         const float* osb = (p.oscale && p.ksplit == 1) ? p.oscale + (int64_t)n * p.Cout + (int64_t)g * p.Og : nullptr;
@@ -308,7 +323,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
                 const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
                 if (o < p.Og) {
                     float v = acc[a][b][r];
-                    if (osb) v *= osb[o];
+                    v = conv_scale_noise(v, osb, o, nz);
                     if (has_res) v += io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES);
                     if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
                     if (pb) pb[(int64_t)o * OHW] = v;
@@ -344,9 +359,10 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
 // full step later, so the store never waits for an L2 round trip (+1.5 % on the 128 x 128 x 128 layers; PIPE = 0 fetches
 // and stores within one step).  Also measured and dropped: reading the next step's fragments during the current step's
 // MFMAs (two fragment sets, 236-256 VGPRs) -- no change, the other workgroup of the CU already covers that latency.
-template <int BM, int BN, int OCC, int PIPE, int NP, int IO = IO_F32>
+template <int BM, int BN, int OCC, int PIPE, int NP, int IO = IO_F32, bool ISC = false>     // ISC: as in conv_fwd_bf16x6_kernel
 __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdParams p) {
     static_assert(IO == IO_F32 || NP == 1, "16-bit storage: the element is the operand, one product");
+    static_assert(!ISC || PIPE <= 1, "the input scale is staged by the default schedules only");
     constexpr unsigned ES = io_size<IO>::value;
     constexpr int WMT = 2, WNT = 2, KC = 16;
     constexpr int WAVES_N = BN / 64;
@@ -419,6 +435,9 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     };
     set_row(b_dy);
     float mb[8 * BPT], hb[8 * BPT];
+    float msc[ISC ? 8 * BPT : 1], hsc[ISC ? 8 * BPT : 1];           // ISC: the input scales of the channels in mb / hb
+    const float* const m_isb = ISC ? p.iscale + (int64_t)n_in * p.Cin + (int64_t)g * p.Ig : nullptr;
+    const float* const h_isb = ISC ? p.iscale + (int64_t)h_n * p.Cin + (int64_t)g * p.Ig : nullptr;
     int m_nvalid[BPT], h_nvalid[BPT];
     int h_owner = 0;                                 // the wave that stages the halo pixels of the stage in flight
     auto load_b = [&]() {
@@ -431,8 +450,10 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
             for (int i = 0; i < BPT; i++) {
                 const int c0 = cc * KC + (h_half + i) * 8;
 #pragma unroll
-                for (int j = 0; j < 8; j++)
+                for (int j = 0; j < 8; j++) {
                     hb[8 * i + j] = io_ld<IO>(xbytes, h_pix + (unsigned)(c0 + j < last ? c0 + j : last) * (unsigned)HW * ES);
+                    if constexpr (ISC) hsc[8 * i + j] = h_isb[c0 + j < last ? c0 + j : last];
+                }
                 h_nvalid[i] = (h_ok && real) ? p.Ig - c0 : 0;
             }
         }
@@ -443,6 +464,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
             for (int j = 0; j < 8; j++) {
                 const unsigned coff = (unsigned)(c0 + j < last ? c0 + j : last) * (unsigned)HW * ES;    // scalar
                 mb[8 * i + j] = io_ld<IO>(xbytes, m_pix + coff);
+                if constexpr (ISC) msc[8 * i + j] = m_isb[c0 + j < last ? c0 + j : last];
             }
             m_nvalid[i] = (m_ok && real) ? p.Ig - c0 : 0;
         }
@@ -498,8 +520,9 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     uint32_t q1[BPT][4], q2[BPT][4], q3[BPT][4];
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    auto split_pair = [&](const float* b, const int* nvalid, int i, int j) {
+    auto split_pair = [&](const float* b, const int* nvalid, int i, int j, const float* sc = nullptr) {
         float v0 = b[8 * i + 2 * j], v1 = b[8 * i + 2 * j + 1];
+        if constexpr (ISC) { v0 *= sc[8 * i + 2 * j]; v1 *= sc[8 * i + 2 * j + 1]; }
         if (nvalid[i] < 8) {
             v0 = 2 * j < nvalid[i] ? v0 : 0.f;
             v1 = 2 * j + 1 < nvalid[i] ? v1 : 0.f;
@@ -584,8 +607,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
         _Pragma("unroll") for (int a = 0; a < WMT; a++) _Pragma("unroll") for (int b = 0; b < WNT; b++)          \
             acc[a][b] = io_mfma<IO>(f.a[a][PA], f.b[b][PB], acc[a][b]); }
 #define PASTA_SPLIT(J)                                                                                         \
-        if (TAP == 1) { _Pragma("unroll") for (int i = 0; i < BPT; i++) split_pair(mb, m_nvalid, i, J); }        \
-        if (TAP == 2 && wave == h_owner) { _Pragma("unroll") for (int i = 0; i < BPT; i++) split_pair(hb, h_nvalid, i, J); }
+        if (TAP == 1) { _Pragma("unroll") for (int i = 0; i < BPT; i++) split_pair(mb, m_nvalid, i, J, msc); }   \
+        if (TAP == 2 && wave == h_owner) { _Pragma("unroll") for (int i = 0; i < BPT; i++) split_pair(hb, h_nvalid, i, J, hsc); }
         PASTA_MM(2, 0)
         PASTA_SPLIT(0)
         PASTA_MM(0, 2)
@@ -749,13 +772,13 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
-        for (int i = 0; i < BPT; i++) split_pair(mb, m_nvalid, i, j);
+        for (int i = 0; i < BPT; i++) split_pair(mb, m_nvalid, i, j, msc);
     store_q(0, m_slot, half0);
     if (wave == h_owner) {
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
-            for (int i = 0; i < BPT; i++) split_pair(hb, h_nvalid, i, j);
+            for (int i = 0; i < BPT; i++) split_pair(hb, h_nvalid, i, j, hsc);
         store_q(0, h_slot, h_half);
     }
     if (PIPE != 3) store_a(0);
@@ -783,13 +806,17 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     }
 
     const int OHW = p.OH * p.OW;
+    const bool has_noise = p.noise && p.ksplit == 1;
+    const float nstr = has_noise ? p.noise_strength[0] : 0.f;
 #pragma unroll
     for (int b = 0; b < WNT; b++) {
         const int64_t pix = pix_blk + (wn * WNT + b) * 32 + jl;
         const int n = (int)(pix / (P * Q));
         const int rem = (int)(pix - (int64_t)n * P * Q);
         const int pp = rem / Q, qq = rem - pp * Q;
-        const int64_t yoff = ((int64_t)n * p.Cout + (int64_t)g * p.Og) * OHW + (oy0 + pp * p.osy) * p.OW + ox0 + qq * p.osx;
+        const int plane_off = (oy0 + pp * p.osy) * p.OW + ox0 + qq * p.osx;
+        const int64_t yoff = ((int64_t)n * p.Cout + (int64_t)g * p.Og) * OHW + plane_off;
+        const float nz = has_noise ? p.noise[(p.noise_ps ? (int64_t)n * OHW : 0) + plane_off] * nstr : 0.f;
         float* pb = p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW + yoff : nullptr;      // K slices: fp32 partial sums
         const bool has_res = p.res && p.ksplit == 1;
         const float* osb = (p.oscale && p.ksplit == 1) ? p.oscale + (int64_t)n * p.Cout + (int64_t)g * p.Og : nullptr;
@@ -800,7 +827,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
                 const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
                 if (o < p.Og) {
                     float v = acc[a][b][r];
-                    if (osb) v *= osb[o];
+                    v = conv_scale_noise(v, osb, o, nz);
                     if (has_res) v += io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES);
                     if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
                     if (pb) pb[(int64_t)o * OHW] = v;
@@ -856,6 +883,24 @@ static void launch_fwd_bf16_np(const ConvFwdParams& q, dim3 grid, hipStream_t s)
     hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<BM, BN, (BN == 256 ? 2 : 3), NP, IO>), grid, dim3(256), 0, s, q);     // <= 64 KB of LDS: two or three workgroups per CU
 }
 
+// The same two kernels with the input scale in the staging (fp32 storage, six products: the no-grad forward of a modulated
+// convolution; other arithmetics keep the separate scaling pass).
+template <int BM, int BN>
+static void launch_fwd_bf16_isc(const ConvFwdParams& q, dim3 grid, hipStream_t s) {
+    if (q.rows && q.ncls == 1 && rows_tile_ok(q.cls[0].P, q.cls[0].Q, BN)) {
+        constexpr int APT = (2 * 3 * BM + 255) / 256;
+        constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 2 * 3 * (BN + 16) * 8) * sizeof(__bf16);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, 3, IO_F32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, 3, IO_F32, true>), grid, dim3(256), lds, s, q);
+        return;
+    }
+    hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<BM, BN, 2, 3, IO_F32, true>), grid, dim3(256), 0, s, q);
+}
+
 template <int BM, int BN>
 static void launch_fwd_bf16x6(const ConvFwdParams& p, hipStream_t s) {
     ConvFwdParams q = p;
@@ -868,7 +913,8 @@ static void launch_fwd_bf16x6(const ConvFwdParams& p, hipStream_t s) {
     tiles *= p.ncls;
     dim3 grid((unsigned)tiles, q.o_tiles * q.ksplit, p.G);
     // p.bf16x6 = number of bf16 pieces per operand (3: six products, 2: three, 1: one)
-    if (p.io == IO_BF16)    launch_fwd_bf16_np<BM, BN, 1, IO_BF16>(q, grid, s);       // 16-bit storage: always one product
+    if (p.iscale)           launch_fwd_bf16_isc<BM, BN>(q, grid, s);                  // fp32 storage, six products (the caller checked)
+    else if (p.io == IO_BF16)    launch_fwd_bf16_np<BM, BN, 1, IO_BF16>(q, grid, s);       // 16-bit storage: always one product
     else if (p.io == IO_F16) launch_fwd_bf16_np<BM, BN, 1, IO_F16>(q, grid, s);
     else if (p.bf16x6 == 1) launch_fwd_bf16_np<BM, BN, 1, IO_F32>(q, grid, s);
     else if (p.bf16x6 == 2) launch_fwd_bf16_np<BM, BN, 2, IO_F32>(q, grid, s);

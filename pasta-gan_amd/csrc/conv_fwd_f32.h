@@ -10,7 +10,8 @@ namespace pasta {
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int G, int Ig,
                                                            int Og, int Ig_pad, int Og_pad, int kh, int kw, int transposed,
-                                                           int flip, float wscale) {
+                                                           int flip, float wscale, const float* __restrict__ mod_s,
+                                                           const float* __restrict__ mod_d) {
     const int64_t total = (int64_t)G * kh * kw * Ig_pad * Og_pad;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         int o = (int)(idx % Og_pad);
@@ -22,9 +23,13 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
         if (i < Ig && o < Og) {
             int ty = t / kw, tx = t - ty * kw;
             if (flip) { ty = kh - 1 - ty; tx = kw - 1 - tx; }
-            int64_t src = transposed ? (((int64_t)(g * Ig + i) * Og + o) * kh + ty) * kw + tx
-                                     : (((int64_t)(g * Og + o) * Ig + i) * kh + ty) * kw + tx;
+            // mod_s: ONE weight of a single group, shared by all groups, modulated per group (= sample) on the way:
+            // w[o,i] * s[g,i] (* d[g,o]) rounded in this order, as networks.py:65-68, 84-86 forms its per-sample weights
+            const int gs = mod_s ? 0 : g;
+            const int64_t src = transposed ? (((int64_t)(gs * Ig + i) * Og + o) * kh + ty) * kw + tx
+                                           : (((int64_t)(gs * Og + o) * Ig + i) * kh + ty) * kw + tx;
             v = w[src] * wscale;
+            if (mod_s) { v *= mod_s[(int64_t)g * Ig + i]; if (mod_d) v *= mod_d[(int64_t)g * Og + o]; }
         }
         wp[idx] = v;
     }
@@ -172,6 +177,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_kernel(ConvFwdParams p) {
 
     // ---- epilogue: registers -> NCHW, rows = channels, lanes = consecutive pixels.
     const int OHW = p.OH * p.OW;
+    const bool has_noise = p.noise && p.ksplit == 1;
+    const float nstr = has_noise ? p.noise_strength[0] : 0.f;
 #pragma unroll
     for (int b = 0; b < WNT; b++) {
         const int64_t pix = pix_blk + (wn * WNT + b) * 32 + jl;
@@ -179,7 +186,9 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_kernel(ConvFwdParams p) {
         const int n = (int)(pix / (p.P * p.Q));
         const int rem = (int)(pix - (int64_t)n * p.P * p.Q);
         const int pp = rem / p.Q, qq = rem - pp * p.Q;
-        const int64_t yoff = ((int64_t)n * p.Cout + (int64_t)g * p.Og) * OHW + (p.oy0 + pp * p.osy) * p.OW + p.ox0 + qq * p.osx;
+        const int plane_off = (p.oy0 + pp * p.osy) * p.OW + p.ox0 + qq * p.osx;
+        const int64_t yoff = ((int64_t)n * p.Cout + (int64_t)g * p.Og) * OHW + plane_off;
+        const float nz = has_noise ? p.noise[(p.noise_ps ? (int64_t)n * OHW : 0) + plane_off] * nstr : 0.f;
         float* yb = (p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW : p.y) + yoff;
         const float* rb = (p.res && p.ksplit == 1) ? p.res + yoff : nullptr;
         const float* osb = (p.oscale && p.ksplit == 1) ? p.oscale + (int64_t)n * p.Cout + (int64_t)g * p.Og : nullptr;
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_kernel(ConvFwdParams p) {
                 const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
                 if (o < p.Og) {
                     float v = acc[a][b][r];
-                    if (osb) v *= osb[o];
+                    v = conv_scale_noise(v, osb, o, nz);
                     if (rb) v += rb[(int64_t)o * OHW];
                     if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
                     yb[(int64_t)o * OHW] = v;

@@ -61,7 +61,9 @@ template <int IO>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, void* __restrict__ y,
                                                             const float* __restrict__ oscale, int64_t numel, int ohw, int ksplit,
                                                             const float* __restrict__ bias, int cout, int act, float alpha, float gain,
-                                                            float clamp, const void* __restrict__ res) {
+                                                            float clamp, const void* __restrict__ res, const float* __restrict__ noise,
+                                                            const float* __restrict__ noise_strength, int noise_ps) {
+    const float nstr = noise ? noise_strength[0] : 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
         float v = 0.f;
         int k = 0;
@@ -72,7 +74,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         }
         for (; k < ksplit; k++) v += partial[(int64_t)k * numel + i];
         const int64_t nc = i / ohw;
-        if (oscale) v *= oscale[nc];
+        const float nz = noise ? noise[(noise_ps ? (nc / cout) * (int64_t)ohw : 0) + (i - nc * ohw)] * nstr : 0.f;
+        v = conv_scale_noise(v, oscale ? oscale + nc : nullptr, 0, nz);
         if (res) v += io_ld1<IO>((const char*)res + i * io_size<IO>::value);
         if (act) v = conv_epilogue(v, bias ? bias[nc % cout] : 0.f, act, alpha, gain, clamp);
         io_st<IO>(y, i, v);
@@ -91,6 +94,9 @@ static int64_t fwd_lattice_pixels(const pasta_conv_desc* d) {
 static int math_pieces(int math) { return math == PASTA_MATH_BF16 ? 1 : math == PASTA_MATH_BF16X3 ? 2 : 3; }
 
 struct FwdPlan { FwdTile tile; int ksplit; int bf16x6; };
+
+// Do the split-bf16 kernels of this launch take the input scale (modulation) in their staging code?
+static bool isc_in_staging(const pasta_conv_desc* d) { return d->io_dtype == PASTA_F32 && math_pieces(d->math) == 3; }
 
 static FwdPlan plan_fwd(const pasta_conv_desc* d) {
     const int Og = d->C_out / d->groups, Ig = d->C_in / d->groups;
@@ -226,7 +232,7 @@ extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int has_iscale, int* 
     using namespace pasta;
     if (int e = check_desc(d, "conv2d_plan")) return e;
     const FwdPlan f = plan_fwd(d);
-    const bool sb = f.bf16x6 && !has_iscale;
+    const bool sb = f.bf16x6 && (!has_iscale || isc_in_staging(d));
     if (d->io_dtype != PASTA_F32 && !sb) return fail("conv2d: no 16-bit-storage kernel for this shape (fewer than 16 input channels per group, at most 32 "
                                                       "output channels, or an input scale): convert the tensors to fp32 for this launch");
     if (tile) *tile = (int)f.tile;
@@ -246,12 +252,32 @@ extern "C" int pasta_conv2d(const void* x, const float* w, void* y, const float*
     return pasta_conv2d_ex(x, w, y, iscale, oscale, nullptr, d, workspace, workspace_bytes, stream);
 }
 
+namespace pasta {
+static int conv2d_run(const void* x, const float* w, void* y, const float* iscale, const float* oscale,
+                      const pasta_conv_epilogue* ep, const pasta_conv_desc* d, void* workspace, int64_t workspace_bytes,
+                      void* stream, const float* wmod_s, const float* wmod_d);
+}
+
 extern "C" int pasta_conv2d_ex(const void* x, const float* w, void* y, const float* iscale, const float* oscale,
                                const pasta_conv_epilogue* ep, const pasta_conv_desc* d, void* workspace, int64_t workspace_bytes,
                                void* stream) {
+    return pasta::conv2d_run(x, w, y, iscale, oscale, ep, d, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+extern "C" int pasta_conv2d_modulated(const void* x, const float* w, const float* styles, const float* dcoefs, void* y,
+                                      const pasta_conv_epilogue* ep, const pasta_conv_desc* d, void* workspace, int64_t workspace_bytes,
+                                      void* stream) {
     using namespace pasta;
+    PASTA_CHECK(styles, "conv2d_modulated: null styles");
+    return conv2d_run(x, w, y, nullptr, nullptr, ep, d, workspace, workspace_bytes, stream, styles, dcoefs);
+}
+
+int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscale, const float* oscale,
+                      const pasta_conv_epilogue* ep, const pasta_conv_desc* d, void* workspace, int64_t workspace_bytes,
+                      void* stream, const float* wmod_s, const float* wmod_d) {
     if (int e = check_desc(d, "conv2d")) return e;
     PASTA_CHECK(!ep || (ep->act >= 1 && ep->act <= 3), "conv2d: fused epilogue supports act 1..3 (linear, relu, lrelu), got %d", ep ? ep->act : 0);
+    PASTA_CHECK(!ep || !ep->noise || ep->noise_strength, "conv2d: noise without noise_strength");
     PASTA_CHECK(x && w && y, "conv2d: null pointer");
     const int64_t need = pasta_conv2d_workspace(d);
     PASTA_CHECK(workspace && workspace_bytes >= need, "conv2d: workspace of %lld bytes needed, %lld given", (long long)need, (long long)workspace_bytes);
@@ -269,10 +295,12 @@ extern "C" int pasta_conv2d_ex(const void* x, const float* w, void* y, const flo
     p.KK = d->kh * d->kw;
     p.bias = ep ? ep->bias : nullptr; p.act = ep ? ep->act : 0; p.res = ep ? (const float*)ep->res : nullptr;
     p.alpha = ep ? ep->alpha : 0.f; p.gain = ep ? ep->gain : 1.f; p.clamp = ep ? ep->clamp : -1.f;
+    p.noise = ep ? ep->noise : nullptr; p.noise_strength = ep ? ep->noise_strength : nullptr; p.noise_ps = ep ? ep->noise_per_sample : 0;
     p.ksplit = plan.ksplit;
     p.o_tiles = 1;
     p.partial = (float*)workspace + round_up((int)(((int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad * 3 + 1) / 2), 4);
-    p.bf16x6 = (plan.bf16x6 && !iscale) ? math_pieces(d->math) : 0;     // bf16 pieces per operand; 0 = fp32 kernel
+    // bf16 pieces per operand; 0 = fp32 kernel.  An input scale rides in the staging of the six-product fp32-storage kernels only.
+    p.bf16x6 = (plan.bf16x6 && (!iscale || isc_in_staging(d))) ? math_pieces(d->math) : 0;
     p.io = d->io_dtype;
     if (p.io != IO_F32) {
         PASTA_CHECK(p.bf16x6, "conv2d: no 16-bit-storage kernel for this shape (pasta_conv2d_plan tells beforehand)");
@@ -287,10 +315,10 @@ extern "C" int pasta_conv2d_ex(const void* x, const float* w, void* y, const flo
         if (blocks > 4096) blocks = 4096;
         if (p.bf16x6)
             hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, (__bf16*)workspace, p.G, p.Ig, p.Og,
-                               p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip, wscale, p.io == IO_F16 ? 1 : 0);
+                               p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip, wscale, p.io == IO_F16 ? 1 : 0, wmod_s, wmod_d);
         else
             hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, (float*)workspace, p.G, p.Ig, p.Og,
-                               p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip, wscale);
+                               p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip, wscale, wmod_s, wmod_d);
     }
 
     if (!d->transposed) {
@@ -346,7 +374,7 @@ extern "C" int pasta_conv2d_ex(const void* x, const float* w, void* y, const flo
         int64_t blocks = ceil_div64(numel, 256);
         if (blocks > 2048) blocks = 2048;
 #define PASTA_SK(IO_) hipLaunchKernelGGL(splitk_reduce_kernel<IO_>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)p.partial, (void*)y, oscale, numel, \
-                                         d->OH * d->OW, p.ksplit, p.bias, d->C_out, p.act, p.alpha, p.gain, p.clamp, (const void*)p.res)
+                                         d->OH * d->OW, p.ksplit, p.bias, d->C_out, p.act, p.alpha, p.gain, p.clamp, (const void*)p.res, p.noise, p.noise_strength, p.noise_ps)
         if (p.io == IO_BF16) PASTA_SK(IO_BF16); else if (p.io == IO_F16) PASTA_SK(IO_F16); else PASTA_SK(IO_F32);
 #undef PASTA_SK
     }

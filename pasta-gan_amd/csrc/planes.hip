@@ -325,6 +325,36 @@ __global__ __launch_bounds__(256) void mod_bias_act_bwd_kernel(const T* __restri
     }
 }
 
+//------------------------------------------------------------------------------------
+// Demodulation coefficients of the modulated convolution (networks.py:65-68):
+//   d[n,o] = rsqrt(sum_{i,k} (w[o,i,k] * s[n,i])^2 + eps) = rsqrt(sum_i s[n,i]^2 * W2[o,i] + eps),  W2[o,i] = sum_k w[o,i,k]^2.
+// One workgroup per output channel: the tap-summed squared weights of the channel are formed once in LDS (the [N,O,I,k,k]
+// per-sample weight tensor of the reference never exists), then each wave takes samples in turn and reduces over the
+// input channels with wavefront shuffles.
+
+constexpr int DEMOD_MAX_I = 4096;
+
+__global__ __launch_bounds__(256) void demod_coefs_kernel(const float* __restrict__ w, const float* __restrict__ s, float* __restrict__ d,
+                                                          int N, int O, int I, int KK, float eps) {
+    __shared__ float w2[DEMOD_MAX_I];
+    const int o = blockIdx.x;
+    const float* wo = w + (int64_t)o * I * KK;
+    for (int i = threadIdx.x; i < I; i += 256) {
+        float t = 0.f;
+        for (int k = 0; k < KK; k++) { const float v = wo[(int64_t)i * KK + k]; t += v * v; }
+        w2[i] = t;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int n = wave; n < N; n += 4) {
+        const float* sn = s + (int64_t)n * I;
+        float t = 0.f;
+        for (int i = lane; i < I; i += 64) { const float v = sn[i]; t += v * v * w2[i]; }
+        t = wave_sum(t);
+        if (lane == 0) d[(int64_t)n * O + o] = rsqrtf(t + eps);
+    }
+}
+
 }  // namespace pasta
 
 // runs LAUNCH_(T) with T the storage type of dtype code `dtype` (PASTA_F32 / _F16 / _BF16)
@@ -365,6 +395,15 @@ extern "C" int pasta_plane_dot(const void* p, const void* q, float* out, int dty
     PASTA_BY_DTYPE(dtype, "plane_dot", PASTA_L)
 #undef PASTA_L
     return launch_status("plane_dot");
+}
+
+extern "C" int pasta_demod_coefs(const float* w, const float* styles, float* d, int N, int O, int I, int KK, float eps, void* stream) {
+    using namespace pasta;
+    PASTA_CHECK(w && styles && d, "demod_coefs: null pointer");
+    PASTA_CHECK(N >= 1 && O >= 1 && I >= 1 && KK >= 1, "demod_coefs: empty tensor");
+    PASTA_CHECK(I <= DEMOD_MAX_I, "demod_coefs: %d input channels, at most %d", I, DEMOD_MAX_I);
+    hipLaunchKernelGGL(demod_coefs_kernel, dim3(O), dim3(256), 0, (hipStream_t)stream, w, styles, d, N, O, I, KK, eps);
+    return launch_status("demod_coefs");
 }
 
 //------------------------------------------------------------------------------------

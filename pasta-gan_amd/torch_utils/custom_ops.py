@@ -122,7 +122,8 @@ class ConvDesc(ctypes.Structure):
 
 class ConvEpilogue(ctypes.Structure):
     """Mirror of ``pasta_conv_epilogue`` (include/pasta_hip.h)."""
-    _fields_ = [('bias', _c_ptr), ('act', _c_i32), ('alpha', _c_f32), ('gain', _c_f32), ('clamp', _c_f32), ('res', _c_ptr)]
+    _fields_ = [('bias', _c_ptr), ('act', _c_i32), ('alpha', _c_f32), ('gain', _c_f32), ('clamp', _c_f32), ('res', _c_ptr),
+                ('noise', _c_ptr), ('noise_strength', _c_ptr), ('noise_per_sample', _c_i32)]
 
 class AdaConfig(ctypes.Structure):
     """Mirror of ``pasta_ada_config`` (include/pasta_hip.h)."""
@@ -154,6 +155,8 @@ ABI = {
     'pasta_conv2d':       (ctypes.c_int, [_c_ptr] * 5 + [ctypes.POINTER(ConvDesc), _c_ptr, _c_i64, _c_ptr]),
     'pasta_conv2d_ex':    (ctypes.c_int, [_c_ptr] * 5 + [ctypes.POINTER(ConvEpilogue), ctypes.POINTER(ConvDesc), _c_ptr, _c_i64, _c_ptr]),
     'pasta_conv2d_wgrad': (ctypes.c_int, [_c_ptr] * 3 + [ctypes.POINTER(ConvDesc), _c_ptr, _c_i64, _c_ptr]),
+    'pasta_conv2d_modulated': (ctypes.c_int, [_c_ptr] * 5 + [ctypes.POINTER(ConvEpilogue), ctypes.POINTER(ConvDesc), _c_ptr, _c_i64, _c_ptr]),
+    'pasta_demod_coefs':  (ctypes.c_int, [_c_ptr] * 3 + [ctypes.c_int] * 4 + [_c_f32, _c_ptr]),
     'pasta_scale_add':    (ctypes.c_int, [_c_ptr] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i64, ctypes.c_int, _c_ptr]),
     'pasta_plane_dot':    (ctypes.c_int, [_c_ptr] * 3 + [ctypes.c_int, _c_i64, _c_i64, _c_ptr]),
     'pasta_mod_bias_act': (ctypes.c_int, [_c_ptr] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_float,

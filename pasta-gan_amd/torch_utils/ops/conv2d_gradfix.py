@@ -95,26 +95,30 @@ launch_hook = None
 def _f32(t):
     return t if t.dtype == torch.float32 else t.float()
 
-def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None):
+def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, noise=None):
     """y = conv(x * iscale[n,c]) * oscale[n,c'] through ``pasta_conv2d_ex``; fp32 accumulation.  fp32 tensors run the
     split-bf16 (fp32-equivalent) or fp32 matrix-core kernels; fp16 / bf16 tensors stay 16-bit in HBM where a kernel exists
     (``_native16``) and are converted for the launch otherwise.
     ``epilogue`` = (bias or None, act code 1..3, alpha, gain, clamp[, residual or None]) fuses Conv2dLayer's bias_act into the
-    store; the residual ([N, C_out, OH, OW]) is added to the convolution before the bias."""
+    store; the residual ([N, C_out, OH, OW]) is added to the convolution before the bias.
+    ``noise`` = (plane(s) [OH, OW] or [N, 1, OH, OW] fp32, strength scalar tensor): added after ``oscale`` (needs ``epilogue``).
+    ``wmod`` = (styles [G, I], dcoefs [G, O] or None): ``w`` is ONE group's weight shared by all ``cfg.groups`` groups and
+    modulated per group by the packing kernel (``pasta_conv2d_modulated``)."""
     _native.require_gpu(x, 'conv2d')
     if x.ndim != 4 or w.ndim != 4:
         raise RuntimeError('conv2d: x and w must be rank 4')
     out_dtype = x.dtype
     w = _f32(w).contiguous()
     kh, kw = w.shape[2], w.shape[3]
+    shared = cfg.groups if wmod is not None else 1        # the weight tensor holds one group
     if cfg.transposed:
-        if w.shape[0] != x.shape[1]:
+        if w.shape[0] * shared != x.shape[1]:
             raise RuntimeError(f'conv_transpose2d: weight {tuple(w.shape)} does not match input channels {x.shape[1]}')
         c_out = w.shape[1] * cfg.groups
     else:
         if w.shape[1] * cfg.groups != x.shape[1]:
             raise RuntimeError(f'conv2d: weight {tuple(w.shape)} does not match input channels {x.shape[1]} (groups={cfg.groups})')
-        c_out = w.shape[0]
+        c_out = w.shape[0] * shared
     oh, ow = _out_hw(cfg, x.shape[2], x.shape[3], kh, kw)
     if oh < 1 or ow < 1:
         raise RuntimeError('conv2d: output must be at least 1x1')
@@ -146,13 +150,32 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None):
             res = res.to(io).contiguous()
             if res.shape != y.shape:
                 raise RuntimeError(f'conv2d: residual {tuple(res.shape)} does not match the output {tuple(y.shape)}')
+        nz = nstr = None
+        if noise is not None:
+            nz, nstr = _f32(noise[0]).contiguous(), _f32(noise[1]).reshape(1).contiguous()
+            if nz.numel() not in (oh * ow, x.shape[0] * oh * ow):
+                raise RuntimeError(f'conv2d: noise {tuple(nz.shape)} is neither one {oh}x{ow} plane nor one per sample')
         ep = custom_ops.ConvEpilogue(bias=bias.data_ptr() if bias is not None else None, act=int(act_code), alpha=float(alpha),
-                                     gain=float(gain), clamp=float(clamp), res=res.data_ptr() if res is not None else None)
+                                     gain=float(gain), clamp=float(clamp), res=res.data_ptr() if res is not None else None,
+                                     noise=nz.data_ptr() if nz is not None else None, noise_strength=nstr.data_ptr() if nz is not None else None,
+                                     noise_per_sample=int(nz is not None and nz.numel() != oh * ow))
+    elif noise is not None:
+        raise RuntimeError('conv2d: the noise operand is part of the fused epilogue')
+    if wmod is not None:
+        assert iscale is None and oscale is None
+        mod_s = _f32(wmod[0]).contiguous()
+        mod_d = _f32(wmod[1]).contiguous() if wmod[1] is not None else None
+        assert mod_s.numel() == x.shape[1] and (mod_d is None or mod_d.numel() == c_out)
     def launch():
         with torch.cuda.device(x.device):
-            st = lib.pasta_conv2d_ex(_native.ptr(x), _native.ptr(w), _native.ptr(y), _native.ptr(iscale), _native.ptr(oscale),
-                                     ctypes.byref(ep) if ep is not None else None, ctypes.byref(desc), _native.ptr(work),
-                                     work.numel() * 4, _native.stream())
+            if wmod is not None:
+                st = lib.pasta_conv2d_modulated(_native.ptr(x), _native.ptr(w), _native.ptr(mod_s), _native.ptr(mod_d), _native.ptr(y),
+                                                ctypes.byref(ep) if ep is not None else None, ctypes.byref(desc), _native.ptr(work),
+                                                work.numel() * 4, _native.stream())
+            else:
+                st = lib.pasta_conv2d_ex(_native.ptr(x), _native.ptr(w), _native.ptr(y), _native.ptr(iscale), _native.ptr(oscale),
+                                         ctypes.byref(ep) if ep is not None else None, ctypes.byref(desc), _native.ptr(work),
+                                         work.numel() * 4, _native.stream())
         _native.check(st)
     if launch_hook is None:
         launch()
@@ -285,6 +308,87 @@ def conv2d_bias_act(input, weight, bias=None, stride=1, padding=0, groups=1, act
     if residual is not None:
         y = y + residual
     return ba.bias_act(y, bias, act=act, alpha=alpha, gain=gain, clamp=clamp)
+
+def modulated_conv2d_forward(x, weight, styles, dcoefs=None, stride=1, padding=0, transposed=False, per_sample=False, tail=None):
+    """FORWARD-ONLY modulated convolution (networks.py:36-94) in one launch -- no autograd graph is recorded; the training
+    path keeps its differentiable pieces.  ``x`` [N,I,H,W], ``weight`` [O,I,kh,kw] ([I,O,kh,kw] when ``transposed``),
+    ``styles`` [N,I], ``dcoefs`` [N,O] or None.
+
+    ``per_sample=False``: ``conv(x * styles) * dcoefs`` with the shared weight.  fp32 tensors: the styles ride in the
+    kernel's activation staging (``iscale``), no modulated copy of ``x`` is written; 16-bit tensors are scaled by a pass of
+    their own first.  ``per_sample=True``: the reference's grouped form (groups = N), each sample's weights
+    ``w * styles[n] * dcoefs[n]`` formed by the weight-packing kernel.
+    ``tail`` = dict(noise=unit plane(s) or None, strength=scalar tensor, bias, act, alpha, gain, clamp): the rest of
+    SynthesisLayer / ToRGBLayer -- ``+ noise * strength``, bias, activation, gain, clamp -- in the convolution's epilogue
+    (act in FUSABLE_ACTS).  Without ``tail`` the plain (for ``per_sample``: demodulated) convolution is returned and
+    ``dcoefs`` of the shared form must be applied by the caller (an upsampling layer filters first)."""
+    from . import bias_act as ba
+    from . import fma
+    assert not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, weight, styles, dcoefs))), \
+        'modulated_conv2d_forward records no graph'
+    n, o = int(x.shape[0]), int(weight.shape[1] if transposed else weight.shape[0])
+    sh, sw = _pair(stride)
+    ph, pw = _pair(padding)
+    assert sh == sw
+    epilogue = noise = None
+    if tail is not None:
+        spec = ba.activation_funcs[tail['act']]
+        assert tail['act'] in FUSABLE_ACTS
+        bias = tail.get('bias')
+        if bias is not None and per_sample:
+            bias = bias.repeat(n)                       # the grouped launch has N * O output channels
+        epilogue = (bias, spec.cuda_idx, float(tail['alpha'] if tail.get('alpha') is not None else spec.def_alpha),
+                    float(tail['gain'] if tail.get('gain') is not None else spec.def_gain),
+                    float(tail['clamp'] if tail.get('clamp') is not None else -1))
+        if tail.get('noise') is not None:
+            noise = (tail['noise'], tail['strength'])
+    if per_sample:
+        if noise is not None and noise[0].numel() != noise[0].shape[-1] * noise[0].shape[-2]:
+            raise NotImplementedError('modulated_conv2d_forward: per-sample noise with per-sample weights')
+        cfg = _Cfg((bool(transposed), sh, ph, pw, 0, 0, n, 1.0))
+        y = _launch_conv(x.reshape(1, -1, *x.shape[2:]), weight, cfg, epilogue=epilogue, wmod=(styles, dcoefs), noise=noise)
+        return y.reshape(n, o, *y.shape[2:])
+    cfg = _Cfg((bool(transposed), sh, ph, pw, 0, 0, 1, 1.0))
+    if x.dtype != torch.float32:
+        x, styles = fma.scale_planes(x, styles), None
+    if tail is None:
+        return _launch_conv(x, weight, cfg, iscale=styles)
+    return _launch_conv(x, weight, cfg, iscale=styles, oscale=dcoefs, epilogue=epilogue, noise=noise)
+
+def demod_coefs(weight, styles):
+    """``rsqrt(sum_{i,kh,kw} (weight[o,i] * styles[n,i])^2 + 1e-8)`` [N, O] (networks.py:65-68) by ``pasta_demod_coefs``: one
+    workgroup per output channel, wavefront-shuffle reduction; differentiable to any order (the backward is written in
+    differentiable torch operations on the small [N,I] / [O,I] matrices)."""
+    return _DemodCoefs.apply(weight, styles)
+
+class _DemodCoefs(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight, styles):
+        _native.require_gpu(weight, 'demod_coefs')
+        o, i = int(weight.shape[0]), int(weight.shape[1])
+        n = int(styles.shape[0])
+        assert styles.shape == (n, i)
+        w32, s32 = _f32(weight).contiguous(), _f32(styles).contiguous()
+        d = torch.empty([n, o], dtype=torch.float32, device=weight.device)
+        with torch.cuda.device(weight.device):
+            _native.check(_native.lib().pasta_demod_coefs(_native.ptr(w32), _native.ptr(s32), _native.ptr(d), n, o, i,
+                                                          int(weight[0, 0].numel()), 1e-8, _native.stream()))
+        ctx.save_for_backward(weight, styles, d)
+        return d.to(styles.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        weight, styles, d = ctx.saved_tensors
+        if torch.is_grad_enabled():         # a graph of this backward is being recorded: d has to be a function of the inputs again
+            d = _DemodCoefs.apply(weight, styles).to(torch.float32)
+        # d = q^-1/2, q[n,o] = sum_i s[n,i]^2 W2[o,i] + eps, W2 = sum_taps w^2
+        dq = -0.5 * g.to(torch.float32) * d * d * d
+        ds = dw = None
+        if ctx.needs_input_grad[1]:
+            ds = (2 * styles * (dq @ weight.square().sum(dim=[2, 3]).to(torch.float32))).to(styles.dtype)
+        if ctx.needs_input_grad[0]:
+            dw = (2 * weight * (dq.t() @ styles.square().to(torch.float32))[:, :, None, None]).to(weight.dtype)
+        return dw, ds
 
 class _ConvWgradHip(torch.autograd.Function):
     @staticmethod

@@ -19,11 +19,15 @@ from .upfirdn2d import _get_filter_size
 def _get_weight_shape(w):
     return [int(sz) for sz in w.shape]
 
-def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True, wgain=1.0):
+def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True, wgain=1.0, modulation=None):
     """Dispatch to ``conv2d`` / ``conv_transpose2d``. Both are correlations, so a true convolution
     (``flip_weight=False``) mirrors the taps first."""
     if not flip_weight:
         w = w.flip([2, 3])
+    if modulation is not None:      # forward-only modulated convolution: (styles, dcoefs or None, per_sample)
+        assert groups == 1 and wgain == 1.0
+        return conv2d_gradfix.modulated_conv2d_forward(x, w, modulation[0], modulation[1], stride=stride, padding=padding, transposed=transpose,
+                                                       per_sample=modulation[2])
     if transpose:
         return conv2d_gradfix.conv_transpose2d(x, w, stride=stride, padding=padding, groups=groups, wgain=wgain)
     return conv2d_gradfix.conv2d(x, w, stride=stride, padding=padding, groups=groups, wgain=wgain)
@@ -65,12 +69,15 @@ def conv2d_resample_bias_act(x, w, b=None, f=None, up=1, down=1, padding=0, grou
 
 #----------------------------------------------------------------------------
 
-def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False, wgain=1.0):
+def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False, wgain=1.0, modulation=None):
     """Convolve ``x`` [N,C,H,W] with ``w`` [O,C//groups,kh,kw], upsampling by ``up`` before and/or
     downsampling by ``down`` after, low-pass filtered with ``f`` (from ``upfirdn2d.setup_filter``).
 
     ``padding`` is relative to the upsampled image (int, [x, y] or [x0, x1, y0, y1]).
-    ``flip_weight=True`` is correlation (``torch.nn.functional.conv2d``), ``False`` convolution."""
+    ``flip_weight=True`` is correlation (``torch.nn.functional.conv2d``), ``False`` convolution.
+    ``modulation`` (extension, forward only, groups == 1) = (styles [N,I], dcoefs [N,O] or None, per_sample): the dense
+    convolution of the decomposition is ``conv2d_gradfix.modulated_conv2d_forward`` -- styles in the kernel's staging
+    (shared weight; dcoefs are then left to the caller) or styles and dcoefs in the weight packing (per-sample weights)."""
     assert isinstance(x, torch.Tensor) and x.ndim == 4
     assert isinstance(w, torch.Tensor) and w.ndim == 4 and (w.dtype == x.dtype or w.dtype == torch.float32)    # fp32 master weights may meet 16-bit activations
     assert f is None or (isinstance(f, torch.Tensor) and f.ndim in [1, 2] and f.dtype == torch.float32)
@@ -98,17 +105,17 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
     # 1x1 kernel, downsampling: decimate first, then mix channels on the small image.
     if pointwise and down > 1 and up == 1:
         x = upfirdn2d.upfirdn2d(x=x, f=f, down=down, padding=pad, flip_filter=flip_filter)
-        return _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight, wgain=wgain)
+        return _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight, wgain=wgain, modulation=modulation)
 
     # 1x1 kernel, upsampling: mix channels on the small image, then interpolate.
     if pointwise and up > 1 and down == 1:
-        x = _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight, wgain=wgain)
+        x = _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight, wgain=wgain, modulation=modulation)
         return upfirdn2d.upfirdn2d(x=x, f=f, up=up, padding=pad, gain=up ** 2, flip_filter=flip_filter)
 
     # Downsampling only: low-pass at full resolution, strided convolution.
     if down > 1 and up == 1:
         x = upfirdn2d.upfirdn2d(x=x, f=f, padding=pad, flip_filter=flip_filter)
-        return _conv2d_wrapper(x=x, w=w, stride=down, groups=groups, flip_weight=flip_weight, wgain=wgain)
+        return _conv2d_wrapper(x=x, w=w, stride=down, groups=groups, flip_weight=flip_weight, wgain=wgain, modulation=modulation)
 
     # Upsampling (optionally followed by downsampling): transposed strided convolution, then low-pass.
     if up > 1:
@@ -124,7 +131,7 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
         py1 -= kh - up
         pxt = max(min(-px0, -px1), 0)
         pyt = max(min(-py0, -py1), 0)
-        x = _conv2d_wrapper(x=x, w=w, stride=up, padding=[pyt, pxt], groups=groups, transpose=True, flip_weight=(not flip_weight), wgain=wgain)
+        x = _conv2d_wrapper(x=x, w=w, stride=up, padding=[pyt, pxt], groups=groups, transpose=True, flip_weight=(not flip_weight), wgain=wgain, modulation=modulation)
         x = upfirdn2d.upfirdn2d(x=x, f=f, padding=[px0 + pxt, px1 + pxt, py0 + pyt, py1 + pyt], gain=up ** 2, flip_filter=flip_filter)
         if down > 1:
             x = upfirdn2d.upfirdn2d(x=x, f=f, down=down, flip_filter=flip_filter)
@@ -132,11 +139,11 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
 
     # No resampling and symmetric non-negative padding: a plain convolution.
     if up == 1 and down == 1 and px0 == px1 and py0 == py1 and px0 >= 0 and py0 >= 0:
-        return _conv2d_wrapper(x=x, w=w, padding=[py0, px0], groups=groups, flip_weight=flip_weight, wgain=wgain)
+        return _conv2d_wrapper(x=x, w=w, padding=[py0, px0], groups=groups, flip_weight=flip_weight, wgain=wgain, modulation=modulation)
 
     # Anything else: pad/upsample, convolve, downsample as three separate steps.
     x = upfirdn2d.upfirdn2d(x=x, f=(f if up > 1 else None), up=up, padding=pad, gain=up ** 2, flip_filter=flip_filter)
-    x = _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight, wgain=wgain)
+    x = _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight, wgain=wgain, modulation=modulation)
     if down > 1:
         x = upfirdn2d.upfirdn2d(x=x, f=f, down=down, flip_filter=flip_filter)
     return x

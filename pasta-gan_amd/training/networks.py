@@ -236,9 +236,35 @@ def _block_dtype(use_fp16, channels_last, force_fp32, half_dtype=torch.float16):
 # Modulated convolution.
 
 def _demodulation(weight, styles):
-    """rsqrt(sum_{i,kh,kw} (w[o,i] s[n,i])^2 + 1e-8) as a [N, O] matrix product of the squared styles with the tap-summed
-    squared weights: the per-sample weight tensor [N,O,I,k,k] of networks.py:65-68 is never formed."""
+    """rsqrt(sum_{i,kh,kw} (w[o,i] s[n,i])^2 + 1e-8) [N, O]: the per-sample weight tensor [N,O,I,k,k] of networks.py:65-68 is
+    never formed.  On the GPU one kernel (``pasta_demod_coefs``: a workgroup per output channel, wavefront-shuffle
+    reduction over the input channels); elsewhere a matrix product of the squared styles with the tap-summed squared weights."""
+    if weight.device.type == 'cuda' and weight.dtype == torch.float32 and styles.dtype == torch.float32 and weight.shape[1] <= 4096:
+        return conv2d_gradfix.demod_coefs(weight, styles)
     return torch.rsqrt(styles.square() @ weight.square().sum(dim=[2, 3]).t() + 1e-8)
+
+def _forward_only(*tensors):
+    """No graph will be recorded for an operation on these tensors: the one-launch forward kernels may run."""
+    return not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors))
+
+def _styled_conv_forward(x, weight, styles, *, up=1, padding=0, resample_filter=None, flip_weight=True, demodulate=True, per_sample=False,
+                         noise=None, strength=None, bias=None, act='linear', gain=None, clamp=None):
+    """Forward-only SynthesisLayer / ToRGBLayer body (networks.py:36-94, 302-314): modulation in the convolution's activation
+    staging (shared weight) or weight packing (``per_sample``: the reference's fused_modconv form); demodulation, noise,
+    bias, activation and clamp in its epilogue.  An upsampling layer filters between the two, so its tail is one pass of
+    ``mod_bias_act`` after the filter.  ``noise`` = unit-variance plane(s) before the learnt ``strength``."""
+    if x.dtype == torch.float16 and demodulate:           # networks.py:57-59
+        weight = weight * (_fan_in_gain(weight.shape[1], np.sqrt(weight[0, 0].numel())) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
+        styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)
+    dcoefs = _demodulation(weight, styles) if demodulate else None
+    if up == 1:
+        w = weight if flip_weight else weight.flip([2, 3])
+        tail = dict(noise=noise, strength=strength, bias=bias, act=act, gain=gain, clamp=clamp)
+        return conv2d_gradfix.modulated_conv2d_forward(x, w, styles, dcoefs, padding=padding, per_sample=per_sample, tail=tail)
+    u = conv2d_resample.conv2d_resample(x=x, w=weight, f=resample_filter, up=up, padding=padding, flip_weight=flip_weight,
+                                        modulation=(styles, dcoefs, per_sample))
+    with torch.no_grad():
+        return mod_bias_act(u, (None if per_sample else dcoefs), noise, strength, bias, act=act, gain=gain, clamp=clamp)
 
 def _modulate_and_convolve(x, weight, styles, up, down, padding, resample_filter, demodulate, flip_weight):
     """Shared-weight form of the modulated convolution up to, not including, the demodulation (networks.py:72-76):
@@ -457,6 +483,12 @@ class SynthesisLayer(_StyledConv):
         unit = self._unit_noise(x, noise_mode)
         act_gain, act_clamp = _scaled_act(self.activation, gain, self.conv_clamp)
         conv = dict(up=self.up, padding=self.padding, resample_filter=self.resample_filter, flip_weight=(self.up == 1))
+        if _hip_act(x) and self.activation in ('linear', 'lrelu') and _forward_only(x, styles, self.weight, self.bias) and \
+                not (fused_modconv and unit is not None and unit.ndim == 4 and self.weight.shape[0] >= 128):
+            # no graph: the whole layer is the convolution launch (+ the filter and one tail pass when upsampling)
+            return _styled_conv_forward(x, self.weight, styles, **conv, per_sample=(fused_modconv and self.weight.shape[0] >= 128), noise=unit,
+                                        strength=(None if unit is None else self.noise_strength), bias=self.bias, act=self.activation,
+                                        gain=act_gain, clamp=act_clamp)
         if not fused_modconv and _hip_act(x) and self.activation in ('linear', 'lrelu'):
             # training: demodulation, noise, bias, activation and clamp are ONE pass over the convolution's output
             u, dcoefs = _modulate_and_convolve(x, self.weight, styles, down=1, demodulate=True, **conv)
@@ -485,6 +517,8 @@ class _StyledHeads(_StyledConv):
         """-> (image, [head outputs in declaration order])"""
         styles = self.affine(w) * self.weight_gain
         def run(weight, bias, act):
+            if _hip_act(x) and act in conv2d_gradfix.FUSABLE_ACTS and _forward_only(x, styles, weight, bias):
+                return _styled_conv_forward(x, weight, styles, demodulate=False, bias=bias, act=act, clamp=self.conv_clamp)
             y = modulated_conv2d(x=x, weight=weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
             return bias_act.bias_act(y, bias.to(y.dtype), act=act, clamp=self.conv_clamp)
         linear = [s for s, _c, act in self._heads if act == 'linear']
