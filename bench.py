@@ -37,10 +37,13 @@ STORAGE_IO = 0        # pasta_conv_desc.io_dtype of the run (0 f32, 1 f16, 3 bf1
 def _np():
     from torch_utils.ops import conv2d_gradfix
     return 1 if STORAGE_IO else {'bf16x3': 2, 'bf16': 1}.get(conv2d_gradfix.conv_math, 3)
-def bf16x6_names():
-    return {0: f'conv_fwd_bf16x6_kernel<128,128,3,{_np()},{STORAGE_IO}>', 1: f'conv_fwd_bf16x6_kernel<64,256,2,{_np()},{STORAGE_IO}>'}
-def bf16x6_rows_names():
-    return {0: f'conv_fwd_rows_bf16x6_kernel<128,128,2,1,{_np()},{STORAGE_IO}>', 1: f'conv_fwd_rows_bf16x6_kernel<64,256,2,1,{_np()},{STORAGE_IO}>'}
+def bf16x6_names():         # template arguments as rocprofv3 prints them: <BM, BN, OCC, pieces, storage, input scale in the staging>
+    return {0: f'conv_fwd_bf16x6_kernel<128,128,3,{_np()},{STORAGE_IO},false>', 1: f'conv_fwd_bf16x6_kernel<64,256,2,{_np()},{STORAGE_IO},false>'}
+def bf16x6_rows_names():    # <BM, BN, OCC, schedule, pieces, storage, input scale, parity pairs>
+    return {0: f'conv_fwd_rows_bf16x6_kernel<128,128,2,1,{_np()},{STORAGE_IO},false,false>',
+            1: f'conv_fwd_rows_bf16x6_kernel<64,256,2,1,{_np()},{STORAGE_IO},false,false>'}
+def bf16x6_pair_names():    # stride-2 conv_transpose2d on the row-reuse kernel's parity-pair mode (+ its remainder launch)
+    return {0: 'conv_fwd_rows_bf16x6_kernel<128,128,2,2,3,0,false,true>', 1: 'conv_fwd_rows_bf16x6_kernel<64,256,2,2,3,0,false,true>'}
 
 TILE_NAMES = {0: 'conv_fwd_kernel<128,128,2,2,8,4>', 1: 'conv_fwd_kernel<64,256,2,2,8,4>',
               2: 'conv_fwd_kernel<32,256,1,2,8>', 3: 'conv_fwd_kernel<64,64,1,1,8>'}
@@ -78,7 +81,7 @@ class ConvMeter:
             tile, ksplit, math, launches, kernel = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
             self.lib.pasta_conv2d_plan(ctypes.byref(desc), 0, ctypes.byref(tile), ctypes.byref(ksplit), ctypes.byref(math), ctypes.byref(launches),
                                        ctypes.byref(kernel))      # has_iscale = 0: the networks never pass iscale
-            family = {0: TILE_NAMES, 1: bf16x6_names(), 2: bf16x6_rows_names()}[kernel.value][tile.value]
+            family = {0: TILE_NAMES, 1: bf16x6_names(), 2: bf16x6_rows_names(), 3: bf16x6_pair_names()}[kernel.value][tile.value]
             kernels = launches.value
         else:
             which = ctypes.c_int()

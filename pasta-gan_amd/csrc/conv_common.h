@@ -122,6 +122,9 @@ struct ConvFwdParams {
     // conv_fwd_rows_bf16x6_kernel (3-wide stride-1 lattices): smallest horizontal tap offset, and whether the three
     // taps of a kernel row are stored with descending offsets (input-gradient launches)
     int rows, rows_d0, rows_rev;
+    // parity-pair mode of the row-reuse kernel (stride-2 conv_transpose2d): B-image offset of tap c, and whether the
+    // two-tap column (taps 0 and 2) is the odd output column
+    int pair_off[3], pair_bx;
 };
 
 // Tile choice.  O_pad multiple returned so that the caller can pack weights accordingly.

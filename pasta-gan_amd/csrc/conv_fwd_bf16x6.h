@@ -359,10 +359,20 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
 // full step later, so the store never waits for an L2 round trip (+1.5 % on the 128 x 128 x 128 layers; PIPE = 0 fetches
 // and stores within one step).  Also measured and dropped: reading the next step's fragments during the current step's
 // MFMAs (two fragment sets, 236-256 VGPRs) -- no change, the other workgroup of the CU already covers that latency.
-template <int BM, int BN, int OCC, int PIPE, int NP, int IO = IO_F32, bool ISC = false>     // ISC: as in conv_fwd_bf16x6_kernel
+// PAIR (stride-2 conv_transpose2d, 3x3: every upsampling layer and the input gradient of every stride-2 convolution): the
+// lattice is the INPUT plane, a workgroup owns one vertical output parity a and BOTH horizontal parities of its pixels.
+// The kernel row r (r = a + pad mod 2: one or two rows per a) is a stage as above; of its three taps, c = 0 and c = 2 belong
+// to the output column 2q + (pad & 1) (input offsets dx, dx - 1), c = 1 to the other column -- two accumulator sets, the same
+// B image (offsets p.pair_off[c]).  Against one launch per parity class: the K loop of a workgroup is three or six taps
+// long instead of one to four, the input is fetched and split once per row instead of once per tap, and an output row
+// leaves as whole 8-byte pairs (2q, 2q + 1) instead of every second float.  Runs on the register-diet schedule (PIPE 2),
+// which leaves room for the second accumulator set.  Outputs beyond 2H x 2W (one row / column when OH = 2H + 1) are a
+// small launch of conv_fwd_bf16x6_kernel over remainder lattices.
+template <int BM, int BN, int OCC, int PIPE, int NP, int IO = IO_F32, bool ISC = false, bool PAIR = false>     // ISC: as in conv_fwd_bf16x6_kernel
 __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdParams p) {
     static_assert(IO == IO_F32 || NP == 1, "16-bit storage: the element is the operand, one product");
     static_assert(!ISC || PIPE <= 1, "the input scale is staged by the default schedules only");
+    static_assert(!PAIR || (PIPE == 2 && !ISC), "the parity-pair mode runs on the register-diet schedule");
     constexpr unsigned ES = io_size<IO>::value;
     constexpr int WMT = 2, WNT = 2, KC = 16;
     constexpr int WAVES_N = BN / 64;
@@ -381,9 +391,17 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     const int g = blockIdx.z;
     const int ks = blockIdx.y / p.o_tiles;
     const int o_blk = (blockIdx.y - ks * p.o_tiles) * BM;
-    const int P = p.cls[0].P, Q = p.cls[0].Q, oy0 = p.cls[0].oy0, ox0 = p.cls[0].ox0, T = p.cls[0].T;
+    int cls_i = 0;
+    unsigned tile_x = blockIdx.x;
+    if constexpr (PAIR) {                               // first half of the grid: the vertical parity with two kernel rows
+        const unsigned per = gridDim.x >> 1;
+        cls_i = blockIdx.x >= per ? 1 : 0;
+        tile_x = blockIdx.x - (unsigned)cls_i * per;
+    }
+    const int P = p.cls[cls_i].P, Q = p.cls[cls_i].Q, oy0 = p.cls[cls_i].oy0, ox0 = p.cls[cls_i].ox0, T = p.cls[cls_i].T;
+    const int tap0 = PAIR ? p.cls[cls_i].tap0 : 0;
     const int KH = T / 3;
-    const int64_t pix_blk = (int64_t)blockIdx.x * BN;   // the host guarantees full tiles inside one image
+    const int64_t pix_blk = (int64_t)tile_x * BN;       // the host guarantees full tiles inside one image
     const int HW = p.H * p.W;
     const int NC = p.Ig_pad / KC;
     const int stages_all = KH * NC;
@@ -426,7 +444,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     bool m_ok = false, h_ok = false;
     unsigned m_pix = xb_off, h_pix = hb_off;
     auto set_row = [&](int dyi) {
-        const int dy = p.tap_dy[__builtin_amdgcn_readfirstlane(3 * dyi)];
+        const int dy = p.tap_dy[__builtin_amdgcn_readfirstlane(tap0 + 3 * dyi)];
         const int iy = py + dy, hy = h_py + dy;
         m_ok = (unsigned)iy < (unsigned)p.H && (unsigned)m_cx < (unsigned)p.W;
         m_pix = m_ok ? xb_off + (unsigned)(iy * p.W + m_cx) * ES : xb_off;
@@ -478,7 +496,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     int a_dy = b_dy, a_cc = b_cc;
     const __bf16* a_w0 = wb; const __bf16* a_w1 = wb; const __bf16* a_w2 = wb;
     auto set_a_row = [&](int dyi) {
-        const int t = __builtin_amdgcn_readfirstlane(3 * dyi);
+        const int t = __builtin_amdgcn_readfirstlane(tap0 + 3 * dyi);
         a_w0 = wb + (int64_t)p.tap_slab[t] * NC * a_chunk;
         a_w1 = wb + (int64_t)p.tap_slab[t + 1] * NC * a_chunk;
         a_w2 = wb + (int64_t)p.tap_slab[t + 2] * NC * a_chunk;
@@ -559,12 +577,13 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     };
 
     f32x16 acc[WMT][WNT];
+    f32x16 acc2[WMT][WNT];                           // PAIR: the output column of tap c = 1
 #pragma unroll
     for (int a = 0; a < WMT; a++)
 #pragma unroll
         for (int b = 0; b < WNT; b++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+            for (int r = 0; r < 16; r++) { acc[a][b][r] = 0.f; if constexpr (PAIR) acc2[a][b][r] = 0.f; }
 
     const int hl = lane >> 5, jl = lane & 31;
     int fslot[WNT];                                  // slot of this lane's pixel of B fragment b, for tap offset 0
@@ -663,7 +682,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     auto step_diet = [&](const int TAP, const int abuf, const int bbuf) {
         if (TAP == 2) next_a_stage();
         if (TAP == 0) { load_b(); load_a(1); } else { load_a(TAP == 1 ? 2 : 0); }
-        const int off = p.rows_rev ? 2 - TAP : TAP;
+        const int off = PAIR ? p.pair_off[TAP] : p.rows_rev ? 2 - TAP : TAP;
         const __bf16* A_ = As + abuf * ABUF;
         const __bf16* B_ = Bs + bbuf * BBUF;
         bf16x8 fa[WMT], fb[WNT];
@@ -679,7 +698,10 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
 #pragma unroll
             for (int a = 0; a < WMT; a++)
 #pragma unroll
-                for (int b = 0; b < WNT; b++) acc[a][b] = io_mfma<IO>(fa[a], fb[b], acc[a][b]);
+                for (int b = 0; b < WNT; b++) {
+                    if (PAIR && TAP == 1) acc2[a][b] = io_mfma<IO>(fa[a], fb[b], acc2[a][b]);
+                    else acc[a][b] = io_mfma<IO>(fa[a], fb[b], acc[a][b]);
+                }
         };
         const bool mine = TAP == 1 || (TAP == 2 && wave == h_owner);
         float* const sb = TAP == 1 ? mb : hb;
@@ -806,6 +828,31 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     }
 
     const int OHW = p.OH * p.OW;
+    if constexpr (PAIR) {
+        // (p, q) of the input lattice -> output row 2p + a, columns 2q and 2q + 1: one 8-byte store per lane
+        struct __attribute__((packed, aligned(4))) Pair { float even, odd; };
+#pragma unroll
+        for (int b = 0; b < WNT; b++) {
+            const int64_t pix = pix_blk + (wn * WNT + b) * 32 + jl;
+            const int n = (int)(pix / (P * Q));
+            const int rem = (int)(pix - (int64_t)n * P * Q);
+            const int pp = rem / Q, qq = rem - pp * Q;
+            const int64_t yoff = ((int64_t)n * p.Cout + (int64_t)g * p.Og) * OHW + (oy0 + 2 * pp) * p.OW + 2 * qq;
+#pragma unroll
+            for (int a = 0; a < WMT; a++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
+                    if (o < p.Og) {
+                        Pair v;
+                        v.even = p.pair_bx ? acc2[a][b][r] : acc[a][b][r];
+                        v.odd = p.pair_bx ? acc[a][b][r] : acc2[a][b][r];
+                        *(Pair*)(p.y + yoff + (int64_t)o * OHW) = v;
+                    }
+                }
+        }
+        return;
+    }
     const bool has_noise = p.noise && p.ksplit == 1;
     const float nstr = has_noise ? p.noise_strength[0] : 0.f;
 #pragma unroll
@@ -919,6 +966,24 @@ static void launch_fwd_bf16x6(const ConvFwdParams& p, hipStream_t s) {
     else if (p.bf16x6 == 1) launch_fwd_bf16_np<BM, BN, 1, IO_F32>(q, grid, s);
     else if (p.bf16x6 == 2) launch_fwd_bf16_np<BM, BN, 2, IO_F32>(q, grid, s);
     else                    launch_fwd_bf16_np<BM, BN, 3, IO_F32>(q, grid, s);
+}
+
+// Parity-pair launch of the row-reuse kernel (see its PAIR note): p.cls[0..1] are the two vertical parities over the input
+// lattice, tap tables per class, p.pair_off / p.pair_bx / p.rows_d0 set by the caller.
+template <int BM, int BN>
+static void launch_fwd_pair(const ConvFwdParams& p, hipStream_t s) {
+    ConvFwdParams q = p;
+    q.o_tiles = (p.Og + BM - 1) / BM;
+    const int64_t tiles = (int64_t)p.N * p.cls[0].P * p.cls[0].Q / BN;
+    dim3 grid((unsigned)(2 * tiles), q.o_tiles, p.G);
+    constexpr int APT = (2 * 3 * BM + 255) / 256;
+    constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 2 * 3 * (BN + 16) * 8) * sizeof(__bf16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 2, 3, IO_F32, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 2, 3, IO_F32, false, true>), grid, dim3(256), lds, s, q);
 }
 
 // Do the T taps at table positions [0, T) form rows of three horizontally adjacent offsets (ascending or descending)?

@@ -228,6 +228,8 @@ extern "C" int pasta_conv2d_tile(const pasta_conv_desc* d) {
     return (int)plan_fwd(d).tile;
 }
 
+namespace pasta { static bool pair_launch_ok(const pasta_conv_desc* d, int pieces, int ksplit, FwdTile tile, bool plain); }
+
 extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int has_iscale, int* tile, int* ksplit, int* math, int* launches, int* kernel) {
     using namespace pasta;
     if (int e = check_desc(d, "conv2d_plan")) return e;
@@ -238,11 +240,13 @@ extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int has_iscale, int* 
     if (tile) *tile = (int)f.tile;
     if (ksplit) *ksplit = f.ksplit;
     if (math) *math = !sb ? PASTA_MATH_F32 : d->io_dtype != PASTA_F32 ? PASTA_MATH_BF16 : d->math == PASTA_MATH_BF16X3 ? PASTA_MATH_BF16X3 : d->math == PASTA_MATH_BF16 ? PASTA_MATH_BF16 : PASTA_MATH_BF16X6;
-    if (launches) *launches = !d->transposed ? 1 : merged_classes(d, sb) ? 1 : (d->stride < d->OH ? d->stride : d->OH) * (d->stride < d->OW ? d->stride : d->OW);
+    const bool pair = sb && pair_launch_ok(d, math_pieces(d->math), f.ksplit, f.tile, !has_iscale);
+    if (launches) *launches = !d->transposed ? 1 : pair ? 1 + (d->OH > 2 * d->H || d->OW > 2 * d->W ? 1 : 0) : merged_classes(d, sb) ? 1 :
+                              (d->stride < d->OH ? d->stride : d->OH) * (d->stride < d->OW ? d->stride : d->OW);
     if (kernel) {
         // the lattice of a stride-1 launch is the output plane itself, its taps kh rows of kw adjacent offsets
         const bool rows = sb && d->stride == 1 && d->kw == 3 && rows_tile_ok(d->OH, d->OW, f.tile == T128x128 ? 128 : 256);
-        *kernel = !sb ? 0 : rows ? 2 : 1;
+        *kernel = !sb ? 0 : pair ? 3 : rows ? 2 : 1;
     }
     return 0;
 }
@@ -253,6 +257,108 @@ extern "C" int pasta_conv2d(const void* x, const float* w, void* y, const float*
 }
 
 namespace pasta {
+// Stride-2 3x3 conv_transpose2d whose output covers the doubled input plane (OH = 2H or 2H + 1): the parity-pair mode of
+// the row-reuse kernel (conv_fwd_bf16x6.h) when the launch is the plain six-product fp32 convolution.
+static bool pair_launch_ok(const pasta_conv_desc* d, int pieces, int ksplit, FwdTile tile, bool plain) {
+    static const bool enabled = !(getenv("PASTA_T2_PAIR") && getenv("PASTA_T2_PAIR")[0] == '0');
+    if (!enabled || !d->transposed || d->stride != 2 || d->kh != 3 || d->kw != 3 || d->pad_h != d->pad_w || d->pad_h > 1) return false;
+    if (pieces != 3 || d->io_dtype != PASTA_F32 || !plain || ksplit != 1) return false;
+    if (d->OH < 2 * d->H || d->OH > 2 * d->H + 1 || d->OW < 2 * d->W || d->OW > 2 * d->W + 1) return false;
+    if (tile != T128x128 && tile != T64x256) return false;
+    // Measured (profiles/r2_conv_pairs.txt): onto 2H x 2W outputs (no remainder) the pair kernel is 1.4x the per-class launch at
+    // every size; with the remainder row / column it wins where the main launch outlasts the remainder's K loop (a few
+    // dozen workgroups, 0.1 - 0.3 ms of serial latency however little they compute): input planes of 128 x 128 and larger.
+    const bool remainder = d->OH > 2 * d->H || d->OW > 2 * d->W;
+    if (remainder && (int64_t)d->H * d->W < 128 * 128 && !(getenv("PASTA_T2_PAIR") && getenv("PASTA_T2_PAIR")[0] == '2')) return false;
+    return rows_tile_ok(d->H, d->W, tile == T128x128 ? 128 : 256);
+}
+
+// A second stream per device for work that is independent of the caller's stream for the length of one call (fork and
+// join with events inside the call: the caller sees one stream-ordered operation).
+struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool tried = false; };
+static SideStream* side_stream() {
+    static SideStream table[32];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+    SideStream& t = table[dev];
+    if (!t.tried) {
+        t.tried = true;
+        const char* e = getenv("PASTA_SIDE_STREAM");
+        if (!(e && e[0] == '0') && hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking) == hipSuccess) {
+            if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&t.join, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(t.stream); t.stream = nullptr; }
+        } else t.stream = nullptr;
+    }
+    return t.stream ? &t : nullptr;
+}
+
+static void launch_transposed_pairs(const pasta_conv_desc* d, const ConvFwdParams& base, FwdTile tile, hipStream_t s) {
+    const int pad = d->pad_h, H = d->H, W = d->W;
+    // remainder: output row 2H and / or column 2W, as lattices of conv_fwd_bf16x6_kernel.  A few dozen workgroups whose K
+    // loops are as long as anyone's (0.1 - 0.2 ms of latency for 1 % of the work): they run on the side stream, under the
+    // main launch.
+    const bool xrow = d->OH == 2 * H + 1, xcol = d->OW == 2 * W + 1;
+    SideStream* side = nullptr;
+    if (xrow || xcol) {
+        ConvFwdParams q = base;
+        q.rows = 0; q.ncls = 0;
+        int ntap = 0;
+        auto add_class = [&](int a, int b, int P, int Q, int oy0, int ox0, int py_shift, int px_shift) {
+            const int tap0 = ntap;
+            for (int r = 0; r < 3; r++) {
+                if (posmod(a + pad - r, 2) != 0) continue;
+                if (py_shift && floordiv(a + pad - r, 2) + py_shift >= H) continue;       // reads below the last input row: zero for the whole class
+                for (int c = 0; c < 3; c++) {
+                    if (posmod(b + pad - c, 2) != 0) continue;
+                    if (px_shift && floordiv(b + pad - c, 2) + px_shift >= W) continue;   // right of the last input column
+                    q.tap_dy[ntap] = floordiv(a + pad - r, 2) + py_shift;
+                    q.tap_dx[ntap] = floordiv(b + pad - c, 2) + px_shift;
+                    q.tap_slab[ntap] = r * 3 + c;
+                    ntap++;
+                }
+            }
+            q.cls[q.ncls++] = {P, Q, oy0, ox0, ntap - tap0, tap0};
+        };
+        if (xrow) {                                           // oy = 2H (a = 0, p = H): every column
+            add_class(0, 0, 1, (d->OW + 1) / 2, 2 * H, 0, H, 0);
+            add_class(0, 1, 1, d->OW / 2, 2 * H, 1, H, 0);
+        }
+        if (xcol) {                                           // ox = 2W (b = 0, q = W): the rows below 2H
+            add_class(0, 0, H, 1, 0, 2 * W, 0, W);
+            add_class(1, 0, H, 1, 1, 2 * W, 0, W);
+        }
+        side = side_stream();
+        if (side && (hipEventRecord(side->fork, s) != hipSuccess || hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess)) side = nullptr;
+        dispatch_fwd(tile, q, side ? side->stream : s);
+        if (side && hipEventRecord(side->join, side->stream) != hipSuccess) { (void)hipStreamSynchronize(side->stream); side = nullptr; }
+    }
+    ConvFwdParams p = base;
+    // main lattice: (p, q) of the input plane -> outputs (2p + a, 2q + b), a, b in {0, 1}
+    p.ncls = 2; p.rows = 1; p.rows_rev = 0;
+    p.pair_bx = pad & 1;                                  // the column with two taps (c = 0, 2)
+    const int dx0 = (p.pair_bx + pad) / 2;                // input offset of tap c = 0; tap c = 2 reads one pixel to its left
+    const int dx1 = floordiv((1 - p.pair_bx) + pad - 1, 2);
+    p.rows_d0 = dx0 - 1;
+    p.pair_off[0] = 1; p.pair_off[1] = dx1 - p.rows_d0; p.pair_off[2] = 0;
+    for (int k = 0; k < 2; k++) {
+        const int a = k == 0 ? (pad & 1) : 1 - (pad & 1);          // class 0: the parity with two kernel rows
+        int nt = 0;
+        for (int r = 0; r < 3; r++) {
+            if (posmod(a + pad - r, 2) != 0) continue;
+            for (int c = 0; c < 3; c++) {
+                p.tap_dy[6 * k + nt] = floordiv(a + pad - r, 2);
+                p.tap_dx[6 * k + nt] = 0;
+                p.tap_slab[6 * k + nt] = r * 3 + c;
+                nt++;
+            }
+        }
+        p.cls[k] = {H, W, a, 0, nt, 6 * k};
+    }
+    if (tile == T128x128) launch_fwd_pair<128, 128>(p, s); else launch_fwd_pair<64, 256>(p, s);
+
+    if (side) (void)hipStreamWaitEvent(s, side->join, 0);
+}
+
 static int conv2d_run(const void* x, const float* w, void* y, const float* iscale, const float* oscale,
                       const pasta_conv_epilogue* ep, const pasta_conv_desc* d, void* workspace, int64_t workspace_bytes,
                       void* stream, const float* wmod_s, const float* wmod_d);
@@ -337,6 +443,10 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
         // input row = pp + (a + pad - r)/u.
         const int u = d->stride;
         p.osy = u; p.osx = u; p.isy = 1; p.isx = 1;
+        if (pair_launch_ok(d, p.bf16x6, p.ksplit, tile, !iscale && !oscale && !ep)) {
+            launch_transposed_pairs(d, p, tile, s);
+            return launch_status("conv2d");
+        }
         const bool merged = merged_classes(d, p.bf16x6 != 0);
         int ntap = 0;
         p.ncls = 0;
