@@ -10,4 +10,11 @@ python3 tools/bench_hbm_ops.py > gpurun_out/r2_hbm_microbench.txt 2>/dev/null
 python3 tools/bench_conv.py --reps 10 > gpurun_out/r2_conv_microbench.txt 2>/dev/null
 ./tools/microbench/mfma_shape > gpurun_out/r2_mfma_shape.txt 2>&1
 python3 tools/phase_times.py > gpurun_out/r2_phase_times.txt 2>&1 || true
-echo BATCH DONE
+echo BATCH1 DONE
+# round-2 additions: the inference workload's per-kernel times, the chip's power / clock under the dominant kernel
+export TMPDIR=/tmp
+rm -rf gpurun_out/r2_infer512_stats
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2_infer512_stats -- python3 bench.py --mode infer --res 512 --no-cpu-baseline --steps 20 --warmup 2 > gpurun_out/r2_infer512_stats.log 2>&1
+find gpurun_out/r2_infer512_stats -name "*.csv" ! -name "*kernel_stats.csv" -delete
+bash tools/power_probe.sh "spade 256" > /dev/null 2>&1; cp gpurun_out/power_probe.txt gpurun_out/r2_power_probe.txt
+echo BATCH2 DONE
