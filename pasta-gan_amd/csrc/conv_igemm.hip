@@ -26,6 +26,7 @@
 //     second kernel that also writes PyTorch's [.., .., kh, kw] layout (bitwise reproducible).
 //
 // C/D fragment map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
+#include <mutex>
 #include "conv_common.h"
 #include "conv_fwd_f32.h"
 #include "conv_fwd_bf16x6.h"
@@ -276,6 +277,7 @@ static bool pair_launch_ok(const pasta_conv_desc* d, int pieces, int ksplit, Fwd
 // A second stream per device for work that is independent of the caller's stream for the length of one call (fork and
 // join with events inside the call: the caller sees one stream-ordered operation).
 struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool tried = false; };
+static std::mutex side_mutex;          // held from the fork to the join of one call: the stream and its events are shared by the host threads
 static SideStream* side_stream() {
     static SideStream table[32];
     int dev = 0;
@@ -299,6 +301,7 @@ static void launch_transposed_pairs(const pasta_conv_desc* d, const ConvFwdParam
     // main launch.
     const bool xrow = d->OH == 2 * H + 1, xcol = d->OW == 2 * W + 1;
     SideStream* side = nullptr;
+    std::unique_lock<std::mutex> lock(side_mutex, std::defer_lock);
     if (xrow || xcol) {
         ConvFwdParams q = base;
         q.rows = 0; q.ncls = 0;
@@ -327,6 +330,7 @@ static void launch_transposed_pairs(const pasta_conv_desc* d, const ConvFwdParam
             add_class(0, 0, H, 1, 0, 2 * W, 0, W);
             add_class(1, 0, H, 1, 1, 2 * W, 0, W);
         }
+        lock.lock();
         side = side_stream();
         if (side && (hipEventRecord(side->fork, s) != hipSuccess || hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess)) side = nullptr;
         dispatch_fwd(tile, q, side ? side->stream : s);
