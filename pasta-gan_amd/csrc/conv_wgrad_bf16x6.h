@@ -39,41 +39,56 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
     const char* const Sg = (const char*)p.S + ((int64_t)g * p.Ag + a_blk) * PQ * ES;
     const char* const Lg = (const char*)p.L + ((int64_t)g * p.Bg + b_blk) * PQ * ES;       // LH == P, LW == Q for this kernel
 
-    // staging roles (fixed): S unit = (channel a, group of 8 pixels); L units = (channel b, halo row, group of 8 columns)
+    // Chunk order: down a 32-pixel column block of one image (chunk -> n, column block qb, row pp, pp fastest).  The L halo
+    // of chunk (pp) is image rows pp-1 .. pp+1; the three rows live in a ring in LDS (row y in slot y mod 3), so going from pp
+    // to pp+1 fetches, splits and stores ONE new row (pp+2's predecessor pp+1 is already there) instead of three: a third of
+    // the L traffic and of the staging work of a row-major order.  Rows pp-1 and pp are primed where a column block or a
+    // K slice begins.
+    // staging roles (fixed): S unit = (channel a, group of 8 pixels); L row units = (channel b, group of 8 columns): 320 per row
     const int s_a = tid >> 2, s_grp = tid & 3;
     const bool s_ch_ok = a_blk + s_a < p.Ag;
-    int l_b[4], l_row[4], l_grp[4];
-    bool l_ch_ok[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int v = tid + 256 * j;                // 960 units
-        l_b[j] = v / 15;
-        const int rg = v - l_b[j] * 15;
-        l_row[j] = rg / 5; l_grp[j] = rg - l_row[j] * 5;
-        l_ch_ok[j] = v < 960 && b_blk + l_b[j] < p.Bg;
-    }
+    const int l_b0 = tid / 5, l_g0 = tid - l_b0 * 5;                    // unit tid
+    const int l_b1 = (256 + tid) / 5, l_g1 = (256 + tid) - l_b1 * 5;    // unit 256 + tid (threads 0..63)
+    const bool l_ok0 = b_blk + l_b0 < p.Bg, l_ok1 = tid < 64 && b_blk + l_b1 < p.Bg;
 
-    float4 sreg[2], lreg[4][2];
-    unsigned vmask = 0;                              // validity of the 10 sixteen-byte halves held in registers
-    auto fetch = [&](int ch) {
-        const int row = ch / p.qblocks, qb = ch - row * p.qblocks;
-        const int n = row / p.P, pp = row - n * p.P, q0 = qb * 32;
-        vmask = 0;
+    float4 sreg[2], lreg[2][2];
+    unsigned vmask = 0;                              // validity of the 6 sixteen-byte halves held in registers
+    auto decode = [&](int ch, int& n, int& qb, int& pp) {
+        const int per_img = p.P * p.qblocks;
+        n = ch / per_img;
+        const int rem = ch - n * per_img;
+        qb = rem / p.P; pp = rem - qb * p.P;
+    };
+    // one L row (image row ly of sample n, columns q0 - 4 .. q0 + 36) into r[0..1]; returns the validity bits of its four halves
+    auto fetch_row = [&](int n, int q0, int ly, float4 (&r)[2][2]) -> unsigned {
+        unsigned m = 0;
+        const bool rowok = (unsigned)ly < (unsigned)p.P;
         {
-            const char* sp = Sg + ((int64_t)n * p.SC * PQ + (int64_t)s_a * PQ + pp * p.Q + q0 + 8 * s_grp) * ES;
-            if (s_ch_ok) {
-                sreg[0] = io_ld4<IO>(sp); sreg[1] = io_ld4<IO>(sp + 4 * ES);
-                vmask |= 3u;
-            }
+            const int lx = q0 - 4 + 8 * l_g0;
+            const char* lp = Lg + ((int64_t)n * p.LC * PQ + (int64_t)l_b0 * PQ + ly * p.Q + lx) * ES;
+            if (rowok && l_ok0 && lx >= 0 && lx + 4 <= p.Q) { r[0][0] = io_ld4<IO>(lp); m |= 1u; }
+            if (rowok && l_ok0 && lx + 4 >= 0 && lx + 8 <= p.Q) { r[0][1] = io_ld4<IO>(lp + 4 * ES); m |= 2u; }
         }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int ly = pp + l_row[j] - 1, lx = q0 - 4 + 8 * l_grp[j];
-            const bool rok = l_ch_ok[j] && (unsigned)ly < (unsigned)p.P;
-            const char* lp = Lg + ((int64_t)n * p.LC * PQ + (int64_t)l_b[j] * PQ + ly * p.Q + lx) * ES;
-            if (rok && lx >= 0 && lx + 4 <= p.Q) { lreg[j][0] = io_ld4<IO>(lp); vmask |= 4u << (2 * j); }
-            if (rok && lx + 4 >= 0 && lx + 8 <= p.Q) { lreg[j][1] = io_ld4<IO>(lp + 4 * ES); vmask |= 8u << (2 * j); }
+        {
+            const int lx = q0 - 4 + 8 * l_g1;
+            const char* lp = Lg + ((int64_t)n * p.LC * PQ + (int64_t)l_b1 * PQ + ly * p.Q + lx) * ES;
+            if (rowok && l_ok1 && lx >= 0 && lx + 4 <= p.Q) { r[1][0] = io_ld4<IO>(lp); m |= 4u; }
+            if (rowok && l_ok1 && lx + 4 >= 0 && lx + 8 <= p.Q) { r[1][1] = io_ld4<IO>(lp + 4 * ES); m |= 8u; }
         }
+        return m;
+    };
+    // prefetch of chunk ch: its S pixels and the ONE L row the ring does not hold yet (pp + 1)
+    auto fetch = [&](int ch) {
+        int n, qb, pp;
+        decode(ch, n, qb, pp);
+        const int q0 = qb * 32;
+        vmask = 0;
+        const char* sp = Sg + ((int64_t)n * p.SC * PQ + (int64_t)s_a * PQ + pp * p.Q + q0 + 8 * s_grp) * ES;
+        if (s_ch_ok) {
+            sreg[0] = io_ld4<IO>(sp); sreg[1] = io_ld4<IO>(sp + 4 * ES);
+            vmask |= 3u;
+        }
+        vmask |= fetch_row(n, q0, pp + 1, lreg) << 2;
     };
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -103,14 +118,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
         if constexpr (NP >= 2) *(uint4*)(dst + piece_stride) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
         if constexpr (NP >= 3) *(uint4*)(dst + 2 * piece_stride) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
     };
-    auto stash = [&]() {
-        split_store(sreg[0], sreg[1], vmask & 1u, vmask & 2u, Ss + s_a * SP + 8 * s_grp, S_PIECE);
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (tid + 256 * j < 960)
-                split_store(lreg[j][0], lreg[j][1], vmask & (4u << (2 * j)), vmask & (8u << (2 * j)),
-                            Ls + (l_b[j] * 3 + l_row[j]) * LP + 8 * l_grp[j], L_PIECE);
+    // one L row from registers into ring slot `slot`
+    auto stash_row = [&](const float4 (&r)[2][2], unsigned m, int slot) {
+        split_store(r[0][0], r[0][1], m & 1u, m & 2u, Ls + (l_b0 * 3 + slot) * LP + 8 * l_g0, L_PIECE);
+        if (tid < 64) split_store(r[1][0], r[1][1], m & 4u, m & 8u, Ls + (l_b1 * 3 + slot) * LP + 8 * l_g1, L_PIECE);
     };
+    auto slot_of = [](int y) { return (y + 3) % 3; };       // y >= -1
 
     f32x16 acc[9];
 #pragma unroll
@@ -122,10 +135,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
     const int c_end = (int)((int64_t)p.chunks_total * (ks + 1) / p.ksplit);
     if (c_begin < c_end) fetch(c_begin);
     for (int ch = c_begin; ch < c_end; ch++) {
+        int n_c, qb_c, pp_c;
+        decode(ch, n_c, qb_c, pp_c);
         __syncthreads();                  // the previous chunk's fragment reads are done
-        stash();
+        if (pp_c == 0 || ch == c_begin) { // a column block or this K slice begins: rows pp-1 and pp are not in the ring yet
+            float4 t[2][2];
+            unsigned m = fetch_row(n_c, qb_c * 32, pp_c - 1, t);
+            stash_row(t, m, slot_of(pp_c - 1));
+            m = fetch_row(n_c, qb_c * 32, pp_c, t);
+            stash_row(t, m, slot_of(pp_c));
+        }
+        split_store(sreg[0], sreg[1], vmask & 1u, vmask & 2u, Ss + s_a * SP + 8 * s_grp, S_PIECE);
+        stash_row(lreg, vmask >> 2, slot_of(pp_c + 1));
         __syncthreads();
         if (ch + 1 < c_end) fetch(ch + 1);
+        const int slot0 = slot_of(pp_c - 1);          // ring slot of halo row 0; rows 1, 2 follow cyclically
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             bf16x8 af[3];
@@ -135,11 +159,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
             for (int pb = NP - 1; pb >= 0; pb--) {  // B pieces from the smallest to the largest
 #pragma unroll
                 for (int row = 0; row < 3; row++) {
-                    const __bf16* lb = &Ls[pb * L_PIECE + ((wb * 32 + jl) * 3 + row) * LP + 16 * s + 8 * hl];
+                    const int slot = slot0 + row >= 3 ? slot0 + row - 3 : slot0 + row;
+                    const __bf16* lb = &Ls[pb * L_PIECE + ((wb * 32 + jl) * 3 + slot) * LP + 16 * s + 8 * hl];
                     // Only dwords 1..6 are used and the compiler narrows the two reads to ds_read2_b64 + ds_read2_b32, whose
                     // 32-bank rule makes the 60-dword lane stride conflict 2-way (SQ_LDS_BANK_CONFLICT = half of this kernel's
-                    // LDS cycles).  Forcing whole ds_read_b128 (PASTA_KEEP_WHOLE) removes the conflicts but costs two more live
-                    // registers per read in a kernel that sits at 250 of 256: it spills and runs 12 % slower (measured).
+                    // LDS cycles).  Forcing whole ds_read_b128 (PASTA_KEEP_WHOLE) removes the conflicts; measured twice: round 1
+                    // (250 of 256 registers) it spilled and ran 12 % slower, round 2 (with the row ring's smaller staging state it
+                    // fits: 252 registers, no scratch) it runs 1 - 3 % slower than the narrowed reads
+                    // (profiles/r2_wgrad_ring.txt) -- the conflicts are not what limits this kernel.
                     const uint4 b0 = *(const uint4*)lb, b1 = *(const uint4*)(lb + 8);
                     const uint32_t d[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
                     uint4 w[3];
