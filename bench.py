@@ -81,7 +81,8 @@ class ConvMeter:
             tile, ksplit, math, launches, kernel = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
             self.lib.pasta_conv2d_plan(ctypes.byref(desc), 0, ctypes.byref(tile), ctypes.byref(ksplit), ctypes.byref(math), ctypes.byref(launches),
                                        ctypes.byref(kernel))      # has_iscale = 0: the networks never pass iscale
-            family = {0: TILE_NAMES, 1: bf16x6_names(), 2: bf16x6_rows_names(), 3: bf16x6_pair_names()}[kernel.value][tile.value]
+            family = {0: TILE_NAMES, 1: bf16x6_names(), 2: bf16x6_rows_names(), 3: bf16x6_pair_names(),
+                      4: {0: 'conv_fwd_rows2d_bf16x6_kernel<128,128,4>'}, 5: {0: 'conv_fwd_rows2d_bf16x6_kernel<128,128,2>'}}[kernel.value][tile.value]
             kernels = launches.value
         else:
             which = ctypes.c_int()
@@ -501,7 +502,7 @@ def main():
             plain = next((i for i in sorted(meter.counts) if i > 0 and i % 4 != 0), None)
             expected = (meter.counts.get(0, {}).get(name, 0) + meter.counts[plain].get(name, 0)) if (0 in meter.counts and plain is not None) else None
             traffic, src = pmc_traffic(name, expected)
-            if name in (*bf16x6_names().values(), *bf16x6_rows_names().values(), WGRAD_NAMES[2], WGRAD_NAMES[3], WGRAD_NAMES[4]):
+            if 'bf16x6' in name:        # every split-bf16 kernel family (forward-type base / row / pair / 2-D, the three weight gradients)
                 # six (three, one) bf16 MFMA products per multiply-add: the matrix pipes execute that multiple of the algorithmic FLOPs
                 nprod = 1 if STORAGE_IO else {'bf16x3': 3, 'bf16': 1}.get(conv2d_gradfix.conv_math, 6)
                 peak = PEAK_BF16_MFMA_TFLOPS / nprod

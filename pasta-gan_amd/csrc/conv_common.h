@@ -122,6 +122,7 @@ struct ConvFwdParams {
     // conv_fwd_rows_bf16x6_kernel (3-wide stride-1 lattices): smallest horizontal tap offset, and whether the three
     // taps of a kernel row are stored with descending offsets (input-gradient launches)
     int rows, rows_d0, rows_rev;
+    int rows_y0;                          // conv_fwd_rows2d_bf16x6_kernel: smallest vertical tap offset
     // parity-pair mode of the row-reuse kernel (stride-2 conv_transpose2d): B-image offset of tap c, and whether the
     // two-tap column (taps 0 and 2) is the odd output column
     int pair_off[3], pair_bx;

@@ -1,0 +1,334 @@
+// Two-dimensional pixel tiles for the row-reuse forward kernel (fp32 storage, six products).  Included by conv_igemm.hip.
+#pragma once
+#include "conv_fwd_bf16x6.h"
+
+namespace pasta {
+
+//------------------------------------------------------------------------------------
+// conv_fwd_rows_bf16x6_kernel fetches, splits and stores one input row per (kernel row dy, 16-channel chunk): three rows of
+// staging work per output row, and the output rows above and below (other workgroups) stage the same input rows again.
+// Here a pixel tile is R output rows x SEG = BN / R columns, and the B image of a chunk is the R + 2 input rows the tile
+// touches (one halo column on either side): (R + 2) / R rows of staging per output row instead of 3 -- 1.5 for R = 4 --
+// with the same 9 x 24 MFMAs per chunk and wave.  (The weight gradient gained 8 - 17 % from the same reuse, and the
+// timing-only ablation of the row kernel puts the activation fetch + split + LDS stores at a quarter of its time.)
+//   B image: [piece][k-half][slot][8 bf16], slot = i * (SEG + 2) + j for image row i (input row p0 + ymin + i) and image
+//            column j (input column q0 + d0 + j).  The fragment of tap (dy, dx) for the 32 pixels of tile row r starts at
+//            slot (r + dy - ymin) * (SEG + 2) + (dx - d0) + 32 * (column block of the fragment).
+//   Staging: the 2 * SLOTS (slot, k-half) units of the next chunk are dealt round-robin to the threads (2 units each for
+//            R = 4, SEG = 32); unit k is fetched at step 3k of the current chunk and split + stored at step 3k + 3 (four units of the
+//            64 x 256 tile: steps 2k and 2k + 2), so at most two eight-register sets are in flight and every fetch has two
+//            or three steps (48 - 72 MFMAs) to land.
+//   Weights: per step (tap) as in the row kernel, fetched two steps ahead into one of two register sets.
+// One loop trip = two chunks = 18 steps, so that every buffer index is a literal and the control flow around memory
+// operations is static (the s_waitcnt counters then let a fetch stay in flight across steps).
+template <int BM, int BN, int R>
+__global__ __launch_bounds__(256, 2) void conv_fwd_rows2d_bf16x6_kernel(ConvFwdParams p) {
+    constexpr int NP = 3, IO = IO_F32;
+    constexpr unsigned ES = 4;
+    constexpr int WMT = 2, WNT = 2, KC = 16;
+    constexpr int WAVES_N = BN / 64;
+    static_assert((BM / 64) * WAVES_N == 4, "four waves per workgroup");
+    constexpr int SEG = BN / R, SW = SEG + 2, SLOTS = (R + 2) * SW;
+    static_assert(SEG % 32 == 0, "a fragment's 32 pixels lie in one tile row");
+    constexpr int UNITS = 2 * SLOTS, UPT = (UNITS + 255) / 256;          // (slot, k-half) staging units; per thread
+    static_assert(UPT <= 4, "at most four staging units per thread and chunk");
+    // unit k of the next chunk is fetched at step LSTEP(k) and split + stored at step TSTEP(k)
+    constexpr int USTRIDE = UPT <= 3 ? 3 : 2;
+    constexpr int AUNITS = 2 * NP * BM, APT = (AUNITS + 255) / 256;
+    constexpr int ABUF = APT * 256 * 8, BSEG = SLOTS * 8, BBUF = 2 * NP * BSEG;      // bf16 elements
+    extern __shared__ __attribute__((aligned(16))) __bf16 rows2d_smem[];
+    __bf16* const As = rows2d_smem;                     // [2][ABUF]
+    __bf16* const Bs = rows2d_smem + 2 * ABUF;          // [2][BBUF]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int g = blockIdx.z;
+    const int ks = blockIdx.y / p.o_tiles;
+    const int o_blk = (blockIdx.y - ks * p.o_tiles) * BM;
+    const int P = p.cls[0].P, Q = p.cls[0].Q;
+    const int HW = p.H * p.W;
+    const int NC = p.Ig_pad / KC;
+    const int c_first = (int)((int64_t)NC * ks / p.ksplit);
+    const int nchunks = (int)((int64_t)NC * (ks + 1) / p.ksplit) - c_first;
+    // tile -> (image, row block, column block)
+    const int cblocks = Q / SEG, tpi = (P / R) * cblocks;
+    const int n_img = blockIdx.x / tpi;
+    const int t_in = blockIdx.x - n_img * tpi;
+    const int p0 = (t_in / cblocks) * R, q0 = (t_in % cblocks) * SEG;
+    const int ymin = p.rows_y0, d0 = p.rows_d0;
+
+    const char* const xbytes = (const char*)p.x;
+    const unsigned xb_off = (unsigned)(((int64_t)n_img * p.Cin + (int64_t)g * p.Ig) * HW) * ES;
+    const __bf16* wb = (const __bf16*)p.wp + (int64_t)g * p.KK * NC * 6 * p.Og_pad * 8;
+    const int64_t a_chunk = (int64_t)6 * p.Og_pad * 8;             // bf16 elements of one packed 16-channel chunk
+
+    // ---- staging units of this thread: unit u = tid + 256 k -> (slot, k-half); pixel byte offset (channel 0) and validity
+    unsigned u_pix[UPT];
+    bool u_ok[UPT];
+    int u_half[UPT], u_lds[UPT];
+#pragma unroll
+    for (int k = 0; k < UPT; k++) {
+        const int u = tid + 256 * k;
+        const int half = u >= SLOTS ? 1 : 0;
+        int slot = u - half * SLOTS;
+        const bool real = u < UNITS;
+        slot = real ? slot : 0;
+        const int i = slot / SW, j = slot - i * SW;
+        const int y = p0 + ymin + i, x = q0 + d0 + j;
+        u_ok[k] = real && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        u_pix[k] = u_ok[k] ? xb_off + (unsigned)(y * p.W + x) * ES : xb_off;
+        u_half[k] = half;
+        u_lds[k] = real ? (half * SLOTS + slot) * 8 : -1;           // element offset inside a piece of the B image; -1: no unit
+    }
+
+    float sb0[8], sb1[8];                               // the two staging register sets
+    int nv0 = 0, nv1 = 0;                               // valid channels of the set (0: pixel outside / chunk past the end)
+    auto load_unit = [&](int k, int cc, bool real_chunk, float (&sb)[8], int& nv) {
+        const int c0 = cc * KC + u_half[k] * 8;
+        const int last = p.Ig - 1;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int c = c0 + j < last ? c0 + j : last;
+            sb[j] = *(const float*)(xbytes + u_pix[k] + (unsigned)c * (unsigned)HW * ES);
+        }
+        nv = (u_ok[k] && real_chunk) ? p.Ig - c0 : 0;
+    };
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    uint32_t q1[4], q2[4], q3[4];
+    auto split_pair = [&](const float (&sb)[8], int nv, int j) {
+        float v0 = sb[2 * j], v1 = sb[2 * j + 1];
+        if (nv < 8) {
+            v0 = 2 * j < nv ? v0 : 0.f;
+            v1 = 2 * j + 1 < nv ? v1 : 0.f;
+        }
+        f32x2 v = {v0, v1};
+        uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        q1[j] = w;
+        v0 -= __builtin_bit_cast(float, w << 16);
+        v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
+        PASTA_KEEP_SCALAR(v0);
+        v = f32x2{v0, v1};
+        w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        q2[j] = w;
+        v0 -= __builtin_bit_cast(float, w << 16);
+        v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
+        PASTA_KEEP_SCALAR(v0);
+        v = f32x2{v0, v1};
+        q3[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    };
+    auto store_unit = [&](int k, int bbuf) {
+        if (u_lds[k] >= 0) {
+            __bf16* bd = Bs + bbuf * BBUF + u_lds[k];
+            *(uint4*)(bd) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+            *(uint4*)(bd + 2 * BSEG) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+            *(uint4*)(bd + 4 * BSEG) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+        }
+    };
+
+    // ---- weights: tap slabs and the fetch position (two steps ahead of the multiplication)
+    const __bf16* wtap[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) wtap[t] = wb + (int64_t)p.tap_slab[t] * NC * a_chunk;
+    float4 areg0, areg1, areg2, breg0, breg1, breg2;
+    auto load_a = [&](int tap, int cc, int set) {              // tap and set are literals at every call
+        const int ccl = cc < NC ? cc : NC - 1;          // past the end of the K range (or of an empty slice): a valid address, unused data
+        const __bf16* wt = wtap[tap] + (int64_t)ccl * a_chunk;
+        auto unit = [&](int j) {
+            int e = tid + 256 * j;
+            if (256 * (j + 1) > AUNITS) e = e < AUNITS ? e : AUNITS - 1;
+            const int seg = e / BM, within = e - seg * BM;
+            return *(const float4*)(wt + ((int64_t)seg * p.Og_pad + o_blk + within) * 8);
+        };
+        if (set == 0) { areg0 = unit(0); if (APT > 1) areg1 = unit(1); if (APT > 2) areg2 = unit(2); }
+        else          { breg0 = unit(0); if (APT > 1) breg1 = unit(1); if (APT > 2) breg2 = unit(2); }
+    };
+    auto store_a = [&](int buf, int set) {
+        __bf16* d = As + buf * ABUF;
+        *(float4*)&d[tid * 8] = set ? breg0 : areg0;
+        if (APT > 1) *(float4*)&d[(tid + 256) * 8] = set ? breg1 : areg1;
+        if (APT > 2) *(float4*)&d[(tid + 512) * 8] = set ? breg2 : areg2;
+    };
+
+    f32x16 acc[WMT][WNT];
+#pragma unroll
+    for (int a = 0; a < WMT; a++)
+#pragma unroll
+        for (int b = 0; b < WNT; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    const int hl = lane >> 5, jl = lane & 31;
+    int fslot[WNT];                                  // slot of this lane's pixel of B fragment b for the tap (ymin, d0)
+#pragma unroll
+    for (int b = 0; b < WNT; b++) {
+        const int t = (wn * WNT + b) * 32 + jl;
+        const int r = t / SEG, c = t - r * SEG;
+        fslot[b] = r * SW + c;
+    }
+    // slot offset of tap t = 3 * dyi + dxi: (dy - ymin) rows, (dx - d0) columns (scalars)
+    int toff[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) toff[t] = (p.tap_dy[t] - ymin) * SW + (p.tap_dx[t] - d0);
+
+    struct Frag { bf16x8 a[WMT][3], b[WNT][3]; };
+    auto read_frag = [&](Frag& f, int abuf, int bbuf, int off) {
+        const __bf16* A_ = As + abuf * ABUF;
+        const __bf16* B_ = Bs + bbuf * BBUF;
+#define PASTA_LDA(PC) { _Pragma("unroll") for (int a = 0; a < WMT; a++) f.a[a][PC] = *(const bf16x8*)&A_[(((PC) * 2 + hl) * BM + (wm * WMT + a) * 32 + jl) * 8]; }
+#define PASTA_LDB(PC) { _Pragma("unroll") for (int b = 0; b < WNT; b++) f.b[b][PC] = *(const bf16x8*)&B_[(((PC) * 2 + hl) * SLOTS + fslot[b] + off) * 8]; }
+        PASTA_LDA(2) PASTA_LDB(0) PASTA_LDA(0) PASTA_LDB(2) PASTA_LDA(1) PASTA_LDB(1)
+#undef PASTA_LDA
+#undef PASTA_LDB
+    };
+
+    // One step = one tap of one chunk: 24 MFMAs in six groups.  S (0..8: tap within the chunk) and PAR (parity of the chunk
+    // within the trip) are literals; cc = the chunk being multiplied.
+    //   weights:  step g = 9 * chunk + S multiplies A buffer g & 1, stores the weights of step g + 1 (fetched by step g - 1
+    //             into register set (g + 1) & 1) and fetches those of step g + 2 into set g & 1.
+    //   staging:  unit k of chunk cc + 1 is fetched at step 3k into set k & 1 and split + stored at step 3k + 3 (the last
+    //             one at step 8 when it would fall off the chunk).
+    auto step = [&](const int S, const int PAR, int cc) {
+        const int gpar = (PAR * 9 + S) & 1;              // parity of the global step index within the trip (18 steps: even)
+        const bool next_real = cc + 1 < c_first + nchunks;
+        // fetches first: they are the oldest outstanding loads when the split of a later step waits for them
+        if (S + 2 < 9) load_a(S + 2, cc, gpar); else load_a(S + 2 - 9, cc + 1, gpar);
+#pragma unroll
+        for (int k = 0; k < UPT; k++)
+            if (S == USTRIDE * k) {
+                if ((k & 1) == 0) load_unit(k, cc + 1 < c_first + nchunks ? cc + 1 : cc, next_real, sb0, nv0);
+                else              load_unit(k, cc + 1 < c_first + nchunks ? cc + 1 : cc, next_real, sb1, nv1);
+            }
+        // which unit is split and stored in this step (literal): k with 3k + 3 == S, or the last unit at S == 8
+        constexpr int NOUNIT = -1;
+        int ku = NOUNIT;
+#pragma unroll
+        for (int k = 0; k < UPT; k++)
+            if (S == (USTRIDE * (k + 1) < 8 ? USTRIDE * (k + 1) : 8)) ku = k;
+        Frag f;
+        read_frag(f, gpar, PAR, toff[S]);
+#define PASTA_MM(PA, PB)                                                                                       \
+        { _Pragma("unroll") for (int a = 0; a < WMT; a++) _Pragma("unroll") for (int b = 0; b < WNT; b++)        \
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][PA], f.b[b][PB], acc[a][b], 0, 0, 0); }
+#define PASTA_SPLIT(J) if (ku != NOUNIT) { if ((ku & 1) == 0) split_pair(sb0, nv0, J); else split_pair(sb1, nv1, J); }
+        PASTA_MM(2, 0)
+        PASTA_SPLIT(0)
+        PASTA_MM(0, 2)
+        PASTA_SPLIT(1)
+        PASTA_MM(1, 1)
+        PASTA_SPLIT(2)
+        PASTA_MM(1, 0)
+        PASTA_SPLIT(3)
+        PASTA_MM(0, 1)
+        if (ku != NOUNIT) store_unit(ku, PAR ^ 1);
+        store_a(gpar ^ 1, gpar ^ 1);
+        PASTA_MM(0, 0)
+#undef PASTA_MM
+#undef PASTA_SPLIT
+        __syncthreads();
+    };
+
+    // prologue: the whole B image of the first chunk and the weights of its first two taps
+    load_a(0, c_first, 0);
+#pragma unroll
+    for (int k = 0; k < UPT; k++) {
+        load_unit(k, c_first, nchunks > 0, sb0, nv0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) split_pair(sb0, nv0, j);
+        store_unit(k, 0);
+    }
+    store_a(0, 0);
+    load_a(1, c_first, 1);                           // stored by step 0
+    __syncthreads();
+    for (int c = 0; c < nchunks; c += 2) {           // an odd count runs one all-zero chunk (its fetches re-read valid addresses)
+        const int cc = c_first + c;
+        step(0, 0, cc); step(1, 0, cc); step(2, 0, cc); step(3, 0, cc); step(4, 0, cc); step(5, 0, cc); step(6, 0, cc); step(7, 0, cc); step(8, 0, cc);
+        step(0, 1, cc + 1); step(1, 1, cc + 1); step(2, 1, cc + 1); step(3, 1, cc + 1); step(4, 1, cc + 1); step(5, 1, cc + 1); step(6, 1, cc + 1); step(7, 1, cc + 1); step(8, 1, cc + 1);
+    }
+
+    const int OHW = p.OH * p.OW;
+    const bool has_noise = p.noise && p.ksplit == 1;
+    const float nstr = has_noise ? p.noise_strength[0] : 0.f;
+#pragma unroll
+    for (int b = 0; b < WNT; b++) {
+        const int t = (wn * WNT + b) * 32 + jl;
+        const int r = t / SEG, c = t - r * SEG;
+        const int plane_off = (p0 + r) * p.OW + q0 + c;             // stride-1 lattice: the output plane itself
+        const int64_t yoff = ((int64_t)n_img * p.Cout + (int64_t)g * p.Og) * OHW + plane_off;
+        const float nz = has_noise ? p.noise[(p.noise_ps ? (int64_t)n_img * OHW : 0) + plane_off] * nstr : 0.f;
+        float* pb = p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW + yoff : nullptr;
+        const bool has_res = p.res && p.ksplit == 1;
+        const float* osb = (p.oscale && p.ksplit == 1) ? p.oscale + (int64_t)n_img * p.Cout + (int64_t)g * p.Og : nullptr;
+#pragma unroll
+        for (int a = 0; a < WMT; a++)
+#pragma unroll
+            for (int r16 = 0; r16 < 16; r16++) {
+                const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r16, lane);
+                if (o < p.Og) {
+                    float v = acc[a][b][r16];
+                    v = conv_scale_noise(v, osb, o, nz);
+                    if (has_res) v += p.res[yoff + (int64_t)o * OHW];
+                    if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
+                    if (pb) pb[(int64_t)o * OHW] = v;
+                    else p.y[yoff + (int64_t)o * OHW] = v;
+                }
+            }
+    }
+}
+
+// Is the 2-D tile applicable: 3x3 stride-1 lattice (9 taps in 3 rows of 3, any order), planes divisible into R x (BN / R) tiles.
+template <int BN, int R>
+static bool rows2d_tile_ok(int P, int Q) {
+    constexpr int SEG = BN / R;
+    return P % R == 0 && Q % SEG == 0;
+}
+
+template <int BM, int BN, int R>
+static void launch_fwd_rows2d(const ConvFwdParams& p, hipStream_t s) {
+    ConvFwdParams q = p;
+    q.o_tiles = (p.Og + BM - 1) / BM;
+    constexpr int SEG = BN / R, SLOTS = (R + 2) * (SEG + 2);
+    constexpr int APT = (2 * 3 * BM + 255) / 256;
+    constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 2 * 3 * SLOTS * 8) * sizeof(__bf16);
+    const int64_t tiles = (int64_t)p.N * (p.cls[0].P / R) * (p.cls[0].Q / SEG);
+    dim3 grid((unsigned)tiles, q.o_tiles * q.ksplit, p.G);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_fwd_rows2d_bf16x6_kernel<BM, BN, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_fwd_rows2d_bf16x6_kernel<BM, BN, R>), grid, dim3(256), lds, s, q);
+}
+
+// Rows per 2-D tile for a P x Q lattice on the 128 x 128 tile: 4 (32-column segments), else 2 (64 columns), else 0 = the row
+// kernel.  PASTA_ROWS2D=0 keeps the row kernel, =2 prefers two-row tiles (A/B measurements).
+// (64 x 256 tiles: the double-buffered B image of R = 4 -- 6 rows x 66 columns -- is 76 KB, one workgroup per CU; they keep the row kernel.)
+static int rows2d_rows(int P, int Q) {
+    static const int mode = getenv("PASTA_ROWS2D") ? atoi(getenv("PASTA_ROWS2D")) : 4;
+    if (mode == 0) return 0;
+    if (mode != 2 && rows2d_tile_ok<128, 4>(P, Q)) return 4;
+    return rows2d_tile_ok<128, 2>(P, Q) ? 2 : 0;
+}
+
+// The plain six-product fp32 launch of a 3x3 stride-1 lattice on 2-D tiles, if the plane divides into them.
+template <int BM, int BN>
+static bool try_fwd_rows2d(const ConvFwdParams& p, hipStream_t s) {
+    if constexpr (BN != 128) return false;
+    if ( !p.rows || p.ncls != 1 || p.cls[0].T != 9 || p.bf16x6 != 3 || p.io != IO_F32 || p.iscale) return false;
+    int ymin = p.tap_dy[0], ymax = p.tap_dy[0], xmin = p.tap_dx[0], xmax = p.tap_dx[0];
+    for (int t = 1; t < 9; t++) {
+        ymin = p.tap_dy[t] < ymin ? p.tap_dy[t] : ymin; ymax = p.tap_dy[t] > ymax ? p.tap_dy[t] : ymax;
+        xmin = p.tap_dx[t] < xmin ? p.tap_dx[t] : xmin; xmax = p.tap_dx[t] > xmax ? p.tap_dx[t] : xmax;
+    }
+    if (ymax - ymin != 2 || xmax - xmin != 2 || xmin != p.rows_d0) return false;
+    ConvFwdParams q = p;
+    q.rows_y0 = ymin;
+    if constexpr (BN == 128) {
+        const int R = rows2d_rows(p.cls[0].P, p.cls[0].Q);
+        if (R == 4) { launch_fwd_rows2d<BM, BN, 4>(q, s); return true; }
+        if (R == 2) { launch_fwd_rows2d<BM, BN, 2>(q, s); return true; }
+    }
+    return false;
+}
+
+}  // namespace pasta

@@ -30,6 +30,7 @@
 #include "conv_common.h"
 #include "conv_fwd_f32.h"
 #include "conv_fwd_bf16x6.h"
+#include "conv_fwd_rows2d_bf16x6.h"
 #include "conv_wgrad_f32.h"
 #include "conv_wgrad_bf16x6.h"
 
@@ -42,11 +43,11 @@ static int fwd_ipad(int Ig, FwdTile t) { return (Ig <= 4 && t == T64x256) ? 4 : 
 static void dispatch_fwd(FwdTile t, const ConvFwdParams& p, hipStream_t s) {
     switch (t) {
         case T128x128:
-            if (p.bf16x6) { launch_fwd_bf16x6<128, 128>(p, s); break; }
+            if (p.bf16x6) { if (!try_fwd_rows2d<128, 128>(p, s)) launch_fwd_bf16x6<128, 128>(p, s); break; }
             launch_fwd<128, 128, 2, 2, FWD_KC, 4>(p, s);        // 4 waves/SIMD: 99-112 TFLOP/s vs 95-104 at 3
             break;
         case T64x256:
-            if (p.bf16x6) { launch_fwd_bf16x6<64, 256>(p, s); break; }
+            if (p.bf16x6) { if (!try_fwd_rows2d<64, 256>(p, s)) launch_fwd_bf16x6<64, 256>(p, s); break; }
             if (p.Ig_pad == 4) launch_fwd<64, 256, 2, 2, 4>(p, s);      // RGB stems: 4-channel K chunks
             else launch_fwd<64, 256, 2, 2, FWD_KC, 4>(p, s);
             break;
@@ -247,7 +248,9 @@ extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int has_iscale, int* 
     if (kernel) {
         // the lattice of a stride-1 launch is the output plane itself, its taps kh rows of kw adjacent offsets
         const bool rows = sb && d->stride == 1 && d->kw == 3 && rows_tile_ok(d->OH, d->OW, f.tile == T128x128 ? 128 : 256);
-        *kernel = !sb ? 0 : pair ? 3 : rows ? 2 : 1;
+        const bool rows2d = rows && d->kh == 3 && f.tile == T128x128 && !has_iscale && math_pieces(d->math) == 3 && d->io_dtype == PASTA_F32 &&
+                            rows2d_rows(d->OH, d->OW) > 0;
+        *kernel = !sb ? 0 : pair ? 3 : rows2d ? (rows2d_rows(d->OH, d->OW) == 4 ? 4 : 5) : rows ? 2 : 1;
     }
     return 0;
 }

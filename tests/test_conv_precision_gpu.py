@@ -87,7 +87,7 @@ def test_split_bf16_gradients_match_fp32_accuracy():
 @pytest.mark.parametrize('n,cin,cout,hw', [(9, 32, 48, 32), (2, 16, 136, 64), (1, 24, 40, 128), (1, 16, 64, 256), (3, 48, 64, 64), (2, 32, 130, 128),
                                            (4, 64, 128, 32), (2, 20, 200, 96)])
 def test_row_reuse_kernel_every_tiling(n, cin, cout, hw):
-    """conv_fwd_rows_bf16x6_kernel on every (tile, row-segment) combination: 128- and 256-pixel tiles made of 1, 2, 4
+    """conv_fwd_rows_bf16x6_kernel / conv_fwd_rows2d_bf16x6_kernel on every (tile, row-segment) combination: 128- and 256-pixel tiles made of 1, 2, 4
     or 8 row segments, image borders on all sides, channel tails; forward (ascending taps) and input gradient
     (descending taps) against torch's CPU convolution.  The last case (96-pixel rows) must fall back to the base kernel."""
     import ctypes
@@ -110,7 +110,8 @@ def test_row_reuse_kernel_every_tiling(n, cin, cout, hw):
                                transposed=0, flip=0, math=0)
     kernel = ctypes.c_int()
     custom_ops.get_plugin().pasta_conv2d_plan(ctypes.byref(desc), 0, None, None, None, None, ctypes.byref(kernel))
-    assert kernel.value == (1 if hw == 96 else 2)
+    # 96-pixel rows: base kernel (1); more than 64 output channels (128 x 128 tile): the 2-D tiles of four rows (4); else the row kernel (2)
+    assert kernel.value == (1 if hw == 96 else 4 if cout > 64 else 2)
 
 
 @pytest.mark.parametrize('transposed,n,cin,cout,hw,pad', [(False, 2, 40, 72, 65, 0), (False, 2, 64, 64, 64, 1), (False, 1, 24, 130, 129, 0),
@@ -244,7 +245,8 @@ def test_plan_reports_the_reduced_modes():
         tile, ks, math, launches, kernel = (ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int())
         _native.check(lib.pasta_conv2d_plan(ctypes.byref(d), 0, ctypes.byref(tile), ctypes.byref(ks), ctypes.byref(math),
                                             ctypes.byref(launches), ctypes.byref(kernel)))
-        assert math.value == code and kernel.value == 2       # the row-reuse kernel in every split mode
+        # the row-reuse family in every split mode: its 2-D tiles (4) for the six-product arithmetic, the row kernel (2) for the reduced ones
+        assert math.value == code and kernel.value == (4 if mode == 'bf16x6' else 2)
 
 
 # ---- edge of the split-bf16 operand range ------------------------------------------------------------------------------
