@@ -150,7 +150,7 @@ int pasta_conv2d_tile(const pasta_conv_desc* d);
  * grid), *kernel = 0 conv_fwd_kernel (fp32 MFMA), 1 conv_fwd_bf16x6_kernel, 2 conv_fwd_rows_bf16x6_kernel (split-bf16 with
  * row reuse: 3-wide stride-1 kernels on planes whose rows are a multiple of 32 pixels), 3 the same kernel's parity-pair
  * mode (3x3 stride-2 conv_transpose2d onto 2H(+1) x 2W(+1) outputs: one launch over the input lattice + one small
- * launch of kernel 1 for the last row / column), 4 / 5 conv_fwd_rows2d_bf16x6_kernel<128,128,R> with R = 4 / 2 output rows per
+ * launch of kernel 1 for the last row / column), 4 / 5 / 6 conv_fwd_rows2d_bf16x6_kernel<128,128,4>, <128,128,2>, <64,256,8>: R output rows per
  * pixel tile (3x3 stride-1 lattices on the 128 x 128 tile whose planes divide into R x 128/R tiles: the R + 2 input rows of a
  * tile are staged once per 16-channel chunk).  Any out pointer may be NULL. */
 int pasta_conv2d_plan(const pasta_conv_desc* d, int has_iscale, int* tile, int* ksplit, int* math, int* launches, int* kernel);

@@ -302,7 +302,6 @@ static void launch_fwd_rows2d(const ConvFwdParams& p, hipStream_t s) {
 
 // Rows per 2-D tile for a P x Q lattice on the 128 x 128 tile: 4 (32-column segments), else 2 (64 columns), else 0 = the row
 // kernel.  PASTA_ROWS2D=0 keeps the row kernel, =2 prefers two-row tiles (A/B measurements).
-// (64 x 256 tiles: the double-buffered B image of R = 4 -- 6 rows x 66 columns -- is 76 KB, one workgroup per CU; they keep the row kernel.)
 static int rows2d_rows(int P, int Q) {
     static const int mode = getenv("PASTA_ROWS2D") ? atoi(getenv("PASTA_ROWS2D")) : 4;
     if (mode == 0) return 0;
@@ -310,10 +309,14 @@ static int rows2d_rows(int P, int Q) {
     return rows2d_tile_ok<128, 2>(P, Q) ? 2 : 0;
 }
 
+static bool rows2d_rows256(int P, int Q) {
+    static const int mode = getenv("PASTA_ROWS2D") ? atoi(getenv("PASTA_ROWS2D")) : 4;
+    return mode != 0 && mode != 1 && rows2d_tile_ok<256, 8>(P, Q);          // PASTA_ROWS2D=1: 2-D tiles for the 128 x 128 tile only
+}
+
 // The plain six-product fp32 launch of a 3x3 stride-1 lattice on 2-D tiles, if the plane divides into them.
 template <int BM, int BN>
 static bool try_fwd_rows2d(const ConvFwdParams& p, hipStream_t s) {
-    if constexpr (BN != 128) return false;
     if ( !p.rows || p.ncls != 1 || p.cls[0].T != 9 || p.bf16x6 != 3 || p.io != IO_F32 || p.iscale) return false;
     int ymin = p.tap_dy[0], ymax = p.tap_dy[0], xmin = p.tap_dx[0], xmax = p.tap_dx[0];
     for (int t = 1; t < 9; t++) {
@@ -327,6 +330,9 @@ static bool try_fwd_rows2d(const ConvFwdParams& p, hipStream_t s) {
         const int R = rows2d_rows(p.cls[0].P, p.cls[0].Q);
         if (R == 4) { launch_fwd_rows2d<BM, BN, 4>(q, s); return true; }
         if (R == 2) { launch_fwd_rows2d<BM, BN, 2>(q, s); return true; }
+    } else {
+        // 64 x 256 tile: 8 rows x 32 columns (B image 10 x 34 slots, 65 KB double-buffered + 16 KB of weights: two workgroups per CU, just)
+        if (rows2d_rows256(p.cls[0].P, p.cls[0].Q)) { launch_fwd_rows2d<BM, BN, 8>(q, s); return true; }
     }
     return false;
 }

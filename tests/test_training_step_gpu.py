@@ -137,7 +137,10 @@ def test_merged_discriminator_pass_equals_separate_passes():
     g_sep = torch.autograd.grad(sum((a * x).sum() for a, x in zip(sep, w)), imgs)
     g_mer = torch.autograd.grad(sum((a * x).sum() for a, x in zip(mer, w)), imgs)
     for a, b in zip(g_sep, g_mer):
-        assert rel_err(b, a) < 1e-4
+        # the two ways take different launch plans (K slices at 8 images, none at 24), each fp32-accurate to ~1e-6 per convolution
+        # (measured against fp64: rms 7e-7 sliced / 1e-6 unsliced at 512 channels); through 14 layers and their lrelu masks the
+        # image gradients (magnitude 1e-15 with these weights) of the two differ by 0.7e-4 .. 1.4e-4 of their maximum
+        assert rel_err(b, a) < 3e-4
 
 
 def test_ada_controller_moves_p_like_the_reference():
