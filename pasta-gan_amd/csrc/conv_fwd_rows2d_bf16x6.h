@@ -1,4 +1,4 @@
-// Two-dimensional pixel tiles for the row-reuse forward kernel (fp32 storage, six products).  Included by conv_igemm.hip.
+// Two-dimensional pixel tiles for the row-reuse forward kernel.  Included by conv_igemm.hip.
 #pragma once
 #include "conv_fwd_bf16x6.h"
 
@@ -21,10 +21,11 @@ namespace pasta {
 //   Weights: per step (tap) as in the row kernel, fetched two steps ahead into one of two register sets.
 // One loop trip = two chunks = 18 steps, so that every buffer index is a literal and the control flow around memory
 // operations is static (the s_waitcnt counters then let a fetch stay in flight across steps).
-template <int BM, int BN, int R>
+// NP / IO as in conv_fwd_bf16x6_kernel: bf16 pieces per operand and the storage type of x / y / res.
+template <int BM, int BN, int R, int NP = 3, int IO = IO_F32>
 __global__ __launch_bounds__(256, 2) void conv_fwd_rows2d_bf16x6_kernel(ConvFwdParams p) {
-    constexpr int NP = 3, IO = IO_F32;
-    constexpr unsigned ES = 4;
+    static_assert(IO == IO_F32 || NP == 1, "16-bit storage: the element is the operand, one product");
+    constexpr unsigned ES = io_size<IO>::value;
     constexpr int WMT = 2, WNT = 2, KC = 16;
     constexpr int WAVES_N = BN / 64;
     static_assert((BM / 64) * WAVES_N == 4, "four waves per workgroup");
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_rows2d_bf16x6_kernel(ConvFwdP
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int c = c0 + j < last ? c0 + j : last;
-            sb[j] = *(const float*)(xbytes + u_pix[k] + (unsigned)c * (unsigned)HW * ES);
+            sb[j] = io_ld<IO>(xbytes, u_pix[k] + (unsigned)c * (unsigned)HW * ES);
         }
         nv = (u_ok[k] && real_chunk) ? p.Ig - c0 : 0;
     };
@@ -103,26 +104,30 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_rows2d_bf16x6_kernel(ConvFwdP
             v1 = 2 * j + 1 < nv ? v1 : 0.f;
         }
         f32x2 v = {v0, v1};
-        uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        uint32_t w = io_pack2<IO>(v0, v1);
         q1[j] = w;
-        v0 -= __builtin_bit_cast(float, w << 16);
-        v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
-        PASTA_KEEP_SCALAR(v0);
-        v = f32x2{v0, v1};
-        w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-        q2[j] = w;
-        v0 -= __builtin_bit_cast(float, w << 16);
-        v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
-        PASTA_KEEP_SCALAR(v0);
-        v = f32x2{v0, v1};
-        q3[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        if constexpr (NP >= 2) {
+            v0 -= __builtin_bit_cast(float, w << 16);
+            v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
+            PASTA_KEEP_SCALAR(v0);
+            v = f32x2{v0, v1};
+            w = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+            q2[j] = w;
+        }
+        if constexpr (NP >= 3) {
+            v0 -= __builtin_bit_cast(float, w << 16);
+            v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
+            PASTA_KEEP_SCALAR(v0);
+            v = f32x2{v0, v1};
+            q3[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        }
     };
     auto store_unit = [&](int k, int bbuf) {
         if (u_lds[k] >= 0) {
             __bf16* bd = Bs + bbuf * BBUF + u_lds[k];
             *(uint4*)(bd) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
-            *(uint4*)(bd + 2 * BSEG) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
-            *(uint4*)(bd + 4 * BSEG) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+            if constexpr (NP >= 2) *(uint4*)(bd + 2 * BSEG) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+            if constexpr (NP >= 3) *(uint4*)(bd + 4 * BSEG) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
         }
     };
 
@@ -175,8 +180,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_rows2d_bf16x6_kernel(ConvFwdP
     auto read_frag = [&](Frag& f, int abuf, int bbuf, int off) {
         const __bf16* A_ = As + abuf * ABUF;
         const __bf16* B_ = Bs + bbuf * BBUF;
-#define PASTA_LDA(PC) { _Pragma("unroll") for (int a = 0; a < WMT; a++) f.a[a][PC] = *(const bf16x8*)&A_[(((PC) * 2 + hl) * BM + (wm * WMT + a) * 32 + jl) * 8]; }
-#define PASTA_LDB(PC) { _Pragma("unroll") for (int b = 0; b < WNT; b++) f.b[b][PC] = *(const bf16x8*)&B_[(((PC) * 2 + hl) * SLOTS + fslot[b] + off) * 8]; }
+#define PASTA_LDA(PC) if constexpr ((PC) < NP) { _Pragma("unroll") for (int a = 0; a < WMT; a++) f.a[a][PC] = *(const bf16x8*)&A_[(((PC) * 2 + hl) * BM + (wm * WMT + a) * 32 + jl) * 8]; }
+#define PASTA_LDB(PC) if constexpr ((PC) < NP) { _Pragma("unroll") for (int b = 0; b < WNT; b++) f.b[b][PC] = *(const bf16x8*)&B_[(((PC) * 2 + hl) * SLOTS + fslot[b] + off) * 8]; }
         PASTA_LDA(2) PASTA_LDB(0) PASTA_LDA(0) PASTA_LDB(2) PASTA_LDA(1) PASTA_LDB(1)
 #undef PASTA_LDA
 #undef PASTA_LDB
@@ -208,8 +213,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_rows2d_bf16x6_kernel(ConvFwdP
         Frag f;
         read_frag(f, gpar, PAR, toff[S]);
 #define PASTA_MM(PA, PB)                                                                                       \
-        { _Pragma("unroll") for (int a = 0; a < WMT; a++) _Pragma("unroll") for (int b = 0; b < WNT; b++)        \
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][PA], f.b[b][PB], acc[a][b], 0, 0, 0); }
+        if constexpr ((PA) + (PB) < NP) {                                                                        \
+        _Pragma("unroll") for (int a = 0; a < WMT; a++) _Pragma("unroll") for (int b = 0; b < WNT; b++)          \
+            acc[a][b] = io_mfma<IO>(f.a[a][PA], f.b[b][PB], acc[a][b]); }
 #define PASTA_SPLIT(J) if (ku != NOUNIT) { if ((ku & 1) == 0) split_pair(sb0, nv0, J); else split_pair(sb1, nv1, J); }
         PASTA_MM(2, 0)
         PASTA_SPLIT(0)
@@ -267,10 +273,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_rows2d_bf16x6_kernel(ConvFwdP
                 if (o < p.Og) {
                     float v = acc[a][b][r16];
                     v = conv_scale_noise(v, osb, o, nz);
-                    if (has_res) v += p.res[yoff + (int64_t)o * OHW];
+                    if (has_res) v += io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES);
                     if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
                     if (pb) pb[(int64_t)o * OHW] = v;
-                    else p.y[yoff + (int64_t)o * OHW] = v;
+                    else io_st<IO>(p.y, yoff + (int64_t)o * OHW, v);
                 }
             }
     }
@@ -283,25 +289,35 @@ static bool rows2d_tile_ok(int P, int Q) {
     return P % R == 0 && Q % SEG == 0;
 }
 
+template <int BM, int BN, int R, int NP, int IO>
+static void launch_fwd_rows2d_np(const ConvFwdParams& q, dim3 grid, hipStream_t s) {
+    constexpr int SEG = BN / R, SLOTS = (R + 2) * (SEG + 2);
+    constexpr int APT = (2 * NP * BM + 255) / 256;
+    constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 2 * NP * SLOTS * 8) * sizeof(__bf16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_fwd_rows2d_bf16x6_kernel<BM, BN, R, NP, IO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_fwd_rows2d_bf16x6_kernel<BM, BN, R, NP, IO>), grid, dim3(256), lds, s, q);
+}
+
 template <int BM, int BN, int R>
 static void launch_fwd_rows2d(const ConvFwdParams& p, hipStream_t s) {
     ConvFwdParams q = p;
     q.o_tiles = (p.Og + BM - 1) / BM;
-    constexpr int SEG = BN / R, SLOTS = (R + 2) * (SEG + 2);
-    constexpr int APT = (2 * 3 * BM + 255) / 256;
-    constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 2 * 3 * SLOTS * 8) * sizeof(__bf16);
+    constexpr int SEG = BN / R;
     const int64_t tiles = (int64_t)p.N * (p.cls[0].P / R) * (p.cls[0].Q / SEG);
     dim3 grid((unsigned)tiles, q.o_tiles * q.ksplit, p.G);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_fwd_rows2d_bf16x6_kernel<BM, BN, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((conv_fwd_rows2d_bf16x6_kernel<BM, BN, R>), grid, dim3(256), lds, s, q);
+    if (p.io == IO_BF16)     launch_fwd_rows2d_np<BM, BN, R, 1, IO_BF16>(q, grid, s);     // 16-bit storage: one product
+    else if (p.io == IO_F16) launch_fwd_rows2d_np<BM, BN, R, 1, IO_F16>(q, grid, s);
+    else if (p.bf16x6 == 1)  launch_fwd_rows2d_np<BM, BN, R, 1, IO_F32>(q, grid, s);
+    else if (p.bf16x6 == 2)  launch_fwd_rows2d_np<BM, BN, R, 2, IO_F32>(q, grid, s);
+    else                     launch_fwd_rows2d_np<BM, BN, R, 3, IO_F32>(q, grid, s);
 }
 
 // Rows per 2-D tile for a P x Q lattice on the 128 x 128 tile: 4 (32-column segments), else 2 (64 columns), else 0 = the row
-// kernel.  PASTA_ROWS2D=0 keeps the row kernel, =2 prefers two-row tiles (A/B measurements).
+// kernel.  PASTA_ROWS2D=0 keeps the row kernel, =2 prefers two-row tiles, =1 keeps the 64 x 256 tile on the row kernel (A/B measurements).
 static int rows2d_rows(int P, int Q) {
     static const int mode = getenv("PASTA_ROWS2D") ? atoi(getenv("PASTA_ROWS2D")) : 4;
     if (mode == 0) return 0;
@@ -317,7 +333,7 @@ static bool rows2d_rows256(int P, int Q) {
 // The plain six-product fp32 launch of a 3x3 stride-1 lattice on 2-D tiles, if the plane divides into them.
 template <int BM, int BN>
 static bool try_fwd_rows2d(const ConvFwdParams& p, hipStream_t s) {
-    if ( !p.rows || p.ncls != 1 || p.cls[0].T != 9 || p.bf16x6 != 3 || p.io != IO_F32 || p.iscale) return false;
+    if (!p.rows || p.ncls != 1 || p.cls[0].T != 9 || !p.bf16x6 || p.iscale) return false;        // every arithmetic and storage type; an input scale keeps the row kernel
     int ymin = p.tap_dy[0], ymax = p.tap_dy[0], xmin = p.tap_dx[0], xmax = p.tap_dx[0];
     for (int t = 1; t < 9; t++) {
         ymin = p.tap_dy[t] < ymin ? p.tap_dy[t] : ymin; ymax = p.tap_dy[t] > ymax ? p.tap_dy[t] : ymax;

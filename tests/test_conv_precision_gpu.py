@@ -250,8 +250,9 @@ def test_plan_reports_the_reduced_modes():
         tile, ks, math, launches, kernel = (ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int())
         _native.check(lib.pasta_conv2d_plan(ctypes.byref(d), 0, ctypes.byref(tile), ctypes.byref(ks), ctypes.byref(math),
                                             ctypes.byref(launches), ctypes.byref(kernel)))
-        # the row-reuse family in every split mode: its 2-D tiles (4) for the six-product arithmetic, the row kernel (2) for the reduced ones
-        assert math.value == code and kernel.value == (4 if mode == 'bf16x6' else 2)
+        # the row-reuse family in every split mode: its 2-D tiles of four rows (4), or the row kernel (2) under PASTA_ROWS2D=0
+        import os
+        assert math.value == code and kernel.value == (2 if os.environ.get('PASTA_ROWS2D') == '0' else 4)
 
 
 # ---- edge of the split-bf16 operand range ------------------------------------------------------------------------------
