@@ -82,8 +82,8 @@ class ConvMeter:
             self.lib.pasta_conv2d_plan(ctypes.byref(desc), 0, ctypes.byref(tile), ctypes.byref(ksplit), ctypes.byref(math), ctypes.byref(launches),
                                        ctypes.byref(kernel))      # has_iscale = 0: the networks never pass iscale
             family = {0: TILE_NAMES, 1: bf16x6_names(), 2: bf16x6_rows_names(), 3: bf16x6_pair_names(),
-                      4: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,128,4,{_np()},{STORAGE_IO}>'}, 5: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,128,2,{_np()},{STORAGE_IO}>'},
-                      6: {1: f'conv_fwd_rows2d_bf16x6_kernel<64,256,8,{_np()},{STORAGE_IO}>'}}[kernel.value][tile.value]     # <BM, BN, rows per tile, pieces, storage>
+                      4: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,128,4,{_np()},{STORAGE_IO},false>'}, 5: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,128,2,{_np()},{STORAGE_IO},false>'},
+                      6: {1: f'conv_fwd_rows2d_bf16x6_kernel<64,256,8,{_np()},{STORAGE_IO},false>'}}[kernel.value][tile.value]     # <BM, BN, rows per tile, pieces, storage, input scale>
             kernels = launches.value
         else:
             which = ctypes.c_int()

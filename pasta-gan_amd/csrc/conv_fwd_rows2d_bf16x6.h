@@ -22,9 +22,11 @@ namespace pasta {
 // One loop trip = two chunks = 18 steps, so that every buffer index is a literal and the control flow around memory
 // operations is static (the s_waitcnt counters then let a fetch stay in flight across steps).
 // NP / IO as in conv_fwd_bf16x6_kernel: bf16 pieces per operand and the storage type of x / y / res.
-template <int BM, int BN, int R, int NP = 3, int IO = IO_F32>
+// ISC: p.iscale[n, channel] (the styles of a modulated convolution) multiplied onto the activations between fetch and split.
+template <int BM, int BN, int R, int NP = 3, int IO = IO_F32, bool ISC = false>
 __global__ __launch_bounds__(256, 2) void conv_fwd_rows2d_bf16x6_kernel(ConvFwdParams p) {
     static_assert(IO == IO_F32 || NP == 1, "16-bit storage: the element is the operand, one product");
+    static_assert(!ISC || (NP == 3 && IO == IO_F32), "the input scale rides in the six-product fp32 staging");
     constexpr unsigned ES = io_size<IO>::value;
     constexpr int WMT = 2, WNT = 2, KC = 16;
     constexpr int WAVES_N = BN / 64;
@@ -83,22 +85,26 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_rows2d_bf16x6_kernel(ConvFwdP
     }
 
     float sb0[8], sb1[8];                               // the two staging register sets
+    float sc0[ISC ? 8 : 1], sc1[ISC ? 8 : 1];           // ISC: the input scales of their channels
+    const float* const isb = ISC ? p.iscale + (int64_t)n_img * p.Cin + (int64_t)g * p.Ig : nullptr;
     int nv0 = 0, nv1 = 0;                               // valid channels of the set (0: pixel outside / chunk past the end)
-    auto load_unit = [&](int k, int cc, bool real_chunk, float (&sb)[8], int& nv) {
+    auto load_unit = [&](int k, int cc, bool real_chunk, float (&sb)[8], float (&sc)[ISC ? 8 : 1], int& nv) {
         const int c0 = cc * KC + u_half[k] * 8;
         const int last = p.Ig - 1;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int c = c0 + j < last ? c0 + j : last;
             sb[j] = io_ld<IO>(xbytes, u_pix[k] + (unsigned)c * (unsigned)HW * ES);
+            if constexpr (ISC) sc[j] = isb[c];
         }
         nv = (u_ok[k] && real_chunk) ? p.Ig - c0 : 0;
     };
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     uint32_t q1[4], q2[4], q3[4];
-    auto split_pair = [&](const float (&sb)[8], int nv, int j) {
+    auto split_pair = [&](const float (&sb)[8], const float (&sc)[ISC ? 8 : 1], int nv, int j) {
         float v0 = sb[2 * j], v1 = sb[2 * j + 1];
+        if constexpr (ISC) { v0 *= sc[2 * j]; v1 *= sc[2 * j + 1]; }
         if (nv < 8) {
             v0 = 2 * j < nv ? v0 : 0.f;
             v1 = 2 * j + 1 < nv ? v1 : 0.f;
@@ -201,8 +207,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_rows2d_bf16x6_kernel(ConvFwdP
 #pragma unroll
         for (int k = 0; k < UPT; k++)
             if (S == USTRIDE * k) {
-                if ((k & 1) == 0) load_unit(k, cc + 1 < c_first + nchunks ? cc + 1 : cc, next_real, sb0, nv0);
-                else              load_unit(k, cc + 1 < c_first + nchunks ? cc + 1 : cc, next_real, sb1, nv1);
+                if ((k & 1) == 0) load_unit(k, cc + 1 < c_first + nchunks ? cc + 1 : cc, next_real, sb0, sc0, nv0);
+                else              load_unit(k, cc + 1 < c_first + nchunks ? cc + 1 : cc, next_real, sb1, sc1, nv1);
             }
         // which unit is split and stored in this step (literal): k with 3k + 3 == S, or the last unit at S == 8
         constexpr int NOUNIT = -1;
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_rows2d_bf16x6_kernel(ConvFwdP
         if constexpr ((PA) + (PB) < NP) {                                                                        \
         _Pragma("unroll") for (int a = 0; a < WMT; a++) _Pragma("unroll") for (int b = 0; b < WNT; b++)          \
             acc[a][b] = io_mfma<IO>(f.a[a][PA], f.b[b][PB], acc[a][b]); }
-#define PASTA_SPLIT(J) if (ku != NOUNIT) { if ((ku & 1) == 0) split_pair(sb0, nv0, J); else split_pair(sb1, nv1, J); }
+#define PASTA_SPLIT(J) if (ku != NOUNIT) { if ((ku & 1) == 0) split_pair(sb0, sc0, nv0, J); else split_pair(sb1, sc1, nv1, J); }
         PASTA_MM(2, 0)
         PASTA_SPLIT(0)
         PASTA_MM(0, 2)
@@ -238,9 +244,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_rows2d_bf16x6_kernel(ConvFwdP
     load_a(0, c_first, 0);
 #pragma unroll
     for (int k = 0; k < UPT; k++) {
-        load_unit(k, c_first, nchunks > 0, sb0, nv0);
+        load_unit(k, c_first, nchunks > 0, sb0, sc0, nv0);
 #pragma unroll
-        for (int j = 0; j < 4; j++) split_pair(sb0, nv0, j);
+        for (int j = 0; j < 4; j++) split_pair(sb0, sc0, nv0, j);
         store_unit(k, 0);
     }
     store_a(0, 0);
@@ -289,17 +295,17 @@ static bool rows2d_tile_ok(int P, int Q) {
     return P % R == 0 && Q % SEG == 0;
 }
 
-template <int BM, int BN, int R, int NP, int IO>
+template <int BM, int BN, int R, int NP, int IO, bool ISC = false>
 static void launch_fwd_rows2d_np(const ConvFwdParams& q, dim3 grid, hipStream_t s) {
     constexpr int SEG = BN / R, SLOTS = (R + 2) * (SEG + 2);
     constexpr int APT = (2 * NP * BM + 255) / 256;
     constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 2 * NP * SLOTS * 8) * sizeof(__bf16);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_fwd_rows2d_bf16x6_kernel<BM, BN, R, NP, IO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv_fwd_rows2d_bf16x6_kernel<BM, BN, R, NP, IO, ISC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_fwd_rows2d_bf16x6_kernel<BM, BN, R, NP, IO>), grid, dim3(256), lds, s, q);
+    hipLaunchKernelGGL((conv_fwd_rows2d_bf16x6_kernel<BM, BN, R, NP, IO, ISC>), grid, dim3(256), lds, s, q);
 }
 
 template <int BM, int BN, int R>
@@ -309,7 +315,8 @@ static void launch_fwd_rows2d(const ConvFwdParams& p, hipStream_t s) {
     constexpr int SEG = BN / R;
     const int64_t tiles = (int64_t)p.N * (p.cls[0].P / R) * (p.cls[0].Q / SEG);
     dim3 grid((unsigned)tiles, q.o_tiles * q.ksplit, p.G);
-    if (p.io == IO_BF16)     launch_fwd_rows2d_np<BM, BN, R, 1, IO_BF16>(q, grid, s);     // 16-bit storage: one product
+    if (p.iscale)            launch_fwd_rows2d_np<BM, BN, R, 3, IO_F32, true>(q, grid, s);   // fp32 storage, six products (the caller checked)
+    else if (p.io == IO_BF16) launch_fwd_rows2d_np<BM, BN, R, 1, IO_BF16>(q, grid, s);     // 16-bit storage: one product
     else if (p.io == IO_F16) launch_fwd_rows2d_np<BM, BN, R, 1, IO_F16>(q, grid, s);
     else if (p.bf16x6 == 1)  launch_fwd_rows2d_np<BM, BN, R, 1, IO_F32>(q, grid, s);
     else if (p.bf16x6 == 2)  launch_fwd_rows2d_np<BM, BN, R, 2, IO_F32>(q, grid, s);
@@ -333,7 +340,7 @@ static bool rows2d_rows256(int P, int Q) {
 // The plain six-product fp32 launch of a 3x3 stride-1 lattice on 2-D tiles, if the plane divides into them.
 template <int BM, int BN>
 static bool try_fwd_rows2d(const ConvFwdParams& p, hipStream_t s) {
-    if (!p.rows || p.ncls != 1 || p.cls[0].T != 9 || !p.bf16x6 || p.iscale) return false;        // every arithmetic and storage type; an input scale keeps the row kernel
+    if (!p.rows || p.ncls != 1 || p.cls[0].T != 9 || !p.bf16x6) return false;        // every arithmetic and storage type (an input scale implies fp32 storage, six products)
     int ymin = p.tap_dy[0], ymax = p.tap_dy[0], xmin = p.tap_dx[0], xmax = p.tap_dx[0];
     for (int t = 1; t < 9; t++) {
         ymin = p.tap_dy[t] < ymin ? p.tap_dy[t] : ymin; ymax = p.tap_dy[t] > ymax ? p.tap_dy[t] : ymax;

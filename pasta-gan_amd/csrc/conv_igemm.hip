@@ -248,7 +248,7 @@ extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int has_iscale, int* 
     if (kernel) {
         // the lattice of a stride-1 launch is the output plane itself, its taps kh rows of kw adjacent offsets
         const bool rows = sb && d->stride == 1 && d->kw == 3 && rows_tile_ok(d->OH, d->OW, f.tile == T128x128 ? 128 : 256);
-        const bool plain6 = sb && d->stride == 1 && d->kw == 3 && d->kh == 3 && !has_iscale;
+        const bool plain6 = sb && d->stride == 1 && d->kw == 3 && d->kh == 3;
         const bool rows2d = plain6 && f.tile == T128x128 && rows2d_rows(d->OH, d->OW) > 0;
         const bool rows2d_256 = plain6 && f.tile == T64x256 && rows2d_rows256(d->OH, d->OW);
         *kernel = !sb ? 0 : pair ? 3 : rows2d ? (rows2d_rows(d->OH, d->OW) == 4 ? 4 : 5) : rows2d_256 ? 6 : rows ? 2 : 1;
