@@ -105,7 +105,10 @@ static FwdPlan plan_fwd(const pasta_conv_desc* d) {
     const int64_t npix = fwd_lattice_pixels(d);
     const bool sb = (d->math != PASTA_MATH_F32 || d->io_dtype != PASTA_F32) && Ig >= 16 && (int64_t)d->N * d->C_in * d->H * d->W < (1ll << 30);
     FwdPlan f;
-    if (Og <= 32) f.tile = T32x256;                                   // ToRGB / parsing heads: HBM-bound, few rows
+    // ToRGB / parsing heads (<= 16 output channels): HBM-bound, few rows, fp32 MFMA.  17..32 output channels (the 512^2 block of the
+    // 512 generator) take the 64-row split-bf16 tile half empty: 80 (fp32 storage) / 175 (16-bit) TFLOP/s effective against 55 on the
+    // fp32 tile, and 16-bit tensors are not converted for the launch.
+    if (Og <= 32 && !(sb && Og > 16 && npix > 8192)) f.tile = T32x256;
     else if (npix <= 8192) f.tile = (sb && Og > 64) ? T128x128 : T64x64;     // 4..16 pixel layers: K is sliced to fill the chip
     else if (Og <= 64) f.tile = T64x256;
     else f.tile = T128x128;
