@@ -77,13 +77,17 @@ class ConvMeter:
         g = desc.groups
         macs = desc.N * desc.C_out * (desc.C_in // g) * desc.kh * desc.kw
         macs *= (desc.H * desc.W) if desc.transposed else (desc.OH * desc.OW)
-        if kind == 'conv':
+        if kind in ('conv', 'conv_isc'):
+            isc = kind == 'conv_isc'           # forward-only modulated convolutions: the styles ride in the kernel's staging
             tile, ksplit, math, launches, kernel = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-            self.lib.pasta_conv2d_plan(ctypes.byref(desc), 0, ctypes.byref(tile), ctypes.byref(ksplit), ctypes.byref(math), ctypes.byref(launches),
-                                       ctypes.byref(kernel))      # has_iscale = 0: the networks never pass iscale
+            self.lib.pasta_conv2d_plan(ctypes.byref(desc), int(isc), ctypes.byref(tile), ctypes.byref(ksplit), ctypes.byref(math), ctypes.byref(launches),
+                                       ctypes.byref(kernel))
             family = {0: TILE_NAMES, 1: bf16x6_names(), 2: bf16x6_rows_names(), 3: bf16x6_pair_names(),
                       4: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,128,4,{_np()},{STORAGE_IO},false>'}, 5: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,128,2,{_np()},{STORAGE_IO},false>'},
                       6: {1: f'conv_fwd_rows2d_bf16x6_kernel<64,256,8,{_np()},{STORAGE_IO},false>'}}[kernel.value][tile.value]     # <BM, BN, rows per tile, pieces, storage, input scale>
+            if isc and kernel.value != 0:       # the instance with the input scale: same family, another template argument (rocprofv3 names)
+                family = {1: family.replace(',3,3,0,false>', ',2,3,0,true>'), 2: family.replace(',false,false>', ',true,false>')}.get(
+                    kernel.value, family.replace(',false>', ',true>'))
             kernels = launches.value
         else:
             which = ctypes.c_int()

@@ -180,7 +180,7 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, 
     if launch_hook is None:
         launch()
     else:
-        launch_hook('conv', desc, launch)
+        launch_hook('conv' if iscale is None else 'conv_isc', desc, launch)      # 'conv_isc': the launch passes an input scale (another kernel instance)
     return y.to(out_dtype)
 
 def _launch_wgrad(x, dy, cfg, w_shape, out_dtype=None):
