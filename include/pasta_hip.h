@@ -307,6 +307,27 @@ int pasta_affine_sample_adjoint(const float* dy, const float* theta, float* dx, 
 int pasta_nan_to_num_multi(float* const* ptrs, const int64_t* numels, int n, float nan, float posinf, float neginf,
                            void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Body-part patch pipeline (training/dataset.py:838-927 `normalize`,
+ * which the reference runs on the host through cv2.warpPerspective, ~28 warps per sample).
+ * uint8 HWC images; bilinear interpolation in OpenCV's fixed point (1/32-pixel source
+ * coordinates, 2^15 weights).  OpenCV is unavailable where this was built: the arithmetic is
+ * held bit for bit to oracle/ref_patches.py's restatement of the published algorithm, parity
+ * with cv2 itself is UNPINNED.
+ * ------------------------------------------------------------------------- */
+/* dst[b] = cv2.warpPerspective(src[src_index ? src_index[b] : b], M_b, (dw, dh), INTER_LINEAR, border) for b < B.
+ * src: [*, sh, sw, C] uint8, dst: [B, dh, dw, C]; minv: [B][9] doubles = the INVERTED matrices (destination -> source,
+ * what cv2 forms first); valid (optional, [B]): 0 writes zeros; border: 0 = BORDER_CONSTANT (0), 1 = BORDER_REPLICATE. */
+int pasta_warp_perspective_u8(const uint8_t* src, const int32_t* src_index, const double* minv, const uint8_t* valid,
+                              uint8_t* dst, int B, int sh, int sw, int dh, int dw, int C, int border, void* stream);
+
+/* dataset.py:884-888 / 894-898 for N samples x P parts in one pass: out[n] starts black; for k = 0..P-1 with valid[n][k]:
+ * where channel 0 of warpPerspective(masks[n][k], BORDER_CONSTANT) is 255, the pixel becomes warpPerspective(patches[n][k]).
+ * patches, masks: [N, P, ph, pw, 3] uint8; minv: [N][P][9] doubles (destination -> patch); out: [N, H, W, 3];
+ * part_mask (optional): [N, P, H, W] receives each part's 0 / 1 mask (the reference keeps those of the four arm parts). */
+int pasta_patch_composite_u8(const uint8_t* patches, const uint8_t* masks, const double* minv, const uint8_t* valid,
+                             uint8_t* out, uint8_t* part_mask, int N, int P, int ph, int pw, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

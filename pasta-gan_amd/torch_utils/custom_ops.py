@@ -174,6 +174,8 @@ ABI = {
     'pasta_affine_sample': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64] + [ctypes.c_int] * 5 + [_c_ptr]),
     'pasta_affine_sample_adjoint': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64] + [ctypes.c_int] * 5 + [_c_ptr]),
     'pasta_nan_to_num_multi': (ctypes.c_int, [ctypes.POINTER(_c_ptr), ctypes.POINTER(_c_i64), ctypes.c_int, _c_f32, _c_f32, _c_f32, _c_ptr]),
+    'pasta_warp_perspective_u8': (ctypes.c_int, [_c_ptr] * 5 + [ctypes.c_int] * 7 + [_c_ptr]),
+    'pasta_patch_composite_u8': (ctypes.c_int, [_c_ptr] * 6 + [ctypes.c_int] * 6 + [_c_ptr]),
 }
 
 def get_plugin(module_name='pasta_hip', sources=None, **build_kwargs):
