@@ -237,28 +237,59 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
     const char* const Sg = (const char*)p.S + ((int64_t)g * p.Ag + a_blk) * PQ * ES;
     const char* const Lg = (const char*)p.L + ((int64_t)g * p.Bg + b_blk) * LHW * ES;
 
-    // staging roles (fixed): S unit = (channel a, group of 8 pixels), threads 0..127; L units = (channel b, halo row,
-    // group of 8 columns), 960 of them
+    // Chunk order as in the stride-1 kernel: down a 16-pixel column block of one image.  The halo of chunk pp is L rows
+    // 2pp - pad + {0, 1, 2}; its last row is the first row of chunk pp + 1, so with the rows in a ring in LDS (row y in slot
+    // y mod 3) a chunk fetches, splits and stores TWO new rows instead of three; the first row is primed where a column block
+    // or a K slice begins.
+    // staging roles (fixed): S unit = (channel a, group of 8 pixels), threads 0..127; L row units = (channel b, group of 8
+    // columns), 320 per row: unit v = tid + 256 j < 640 belongs to new row 1 + v / 320
     const int s_a = tid >> 1, s_grp = tid & 1;
     const bool s_on = tid < 128 && a_blk + s_a < p.Ag;
-    int l_b[4], l_row[4], l_grp[4];
-    bool l_ch_ok[4];
+    int l_b[3], l_grp[3], l_k[3];
+    bool l_ch_ok[3];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < 3; j++) {
         const int v = tid + 256 * j;
-        l_b[j] = v / 15;
-        const int rg = v - l_b[j] * 15;
-        l_row[j] = rg / 5; l_grp[j] = rg - l_row[j] * 5;
-        l_ch_ok[j] = v < 960 && b_blk + l_b[j] < p.Bg;
+        l_k[j] = v >= 320 ? 2 : 1;
+        const int u = v - (l_k[j] - 1) * 320;
+        l_b[j] = u / 5; l_grp[j] = u - l_b[j] * 5;
+        l_ch_ok[j] = v < 640 && b_blk + l_b[j] < p.Bg;
     }
+    // the priming row (k = 0): unit tid, and unit 256 + tid for the first 64 threads
+    const int p_b0 = tid / 5, p_g0 = tid - p_b0 * 5, p_b1 = (256 + tid) / 5, p_g1 = (256 + tid) - p_b1 * 5;
 
     float4 sreg[2];
-    float lreg[4][8];
-    unsigned lmask = 0;                              // validity bit of each of the 32 halo elements held in registers
+    float lreg[3][8];
+    unsigned lmask = 0;                              // validity bit of each of the 24 halo elements held in registers
     bool s_ok = false;
+    auto decode = [&](int ch, int& n, int& qb, int& pp) {
+        const int per_img = p.P * p.qblocks;
+        n = ch / per_img;
+        const int rem = ch - n * per_img;
+        qb = rem / p.P; pp = rem - qb * p.P;
+    };
+    // eight consecutive elements of L row ly of channel b (sample n) from column lx on; returns their validity bits
+    auto fetch_unit = [&](int n, int ly, int lx, int b, bool ch_ok, float (&r)[8]) -> unsigned {
+        const bool rok = ch_ok && (unsigned)ly < (unsigned)p.LH;
+        const char* lp = Lg + ((int64_t)n * p.LC * LHW + (int64_t)b * LHW + ly * p.LW + lx) * ES;
+        int first = lx < 0 ? -lx : 0, last = p.LW - lx < 8 ? p.LW - lx : 8;
+        if (!rok || last < 0) last = 0;
+        if (first > last) first = last;
+        const unsigned m = ((1u << last) - 1u) & ~((1u << first) - 1u);
+        if (m == 0xffu) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) r[e] = io_ld1<IO>(lp + e * ES);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if ((m >> e) & 1u) r[e] = io_ld1<IO>(lp + e * ES);
+        }
+        return m;
+    };
     auto fetch = [&](int ch) {
-        const int row = ch / p.qblocks, qb = ch - row * p.qblocks;
-        const int n = row / p.P, pp = row - n * p.P, q0 = qb * 16;
+        int n, qb, pp;
+        decode(ch, n, qb, pp);
+        const int q0 = qb * 16;
         s_ok = s_on;
         if (s_on) {
             const char* sp = Sg + ((int64_t)n * p.SC * PQ + (int64_t)s_a * PQ + pp * p.Q + q0 + 8 * s_grp) * ES;
@@ -266,24 +297,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
         }
         lmask = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int ly = 2 * pp + l_row[j] - p.pad_h, lx = 2 * q0 - 4 + 8 * l_grp[j];
-            const bool rok = l_ch_ok[j] && (unsigned)ly < (unsigned)p.LH;
-            const char* lp = Lg + ((int64_t)n * p.LC * LHW + (int64_t)l_b[j] * LHW + ly * p.LW + lx) * ES;
-            int first = lx < 0 ? -lx : 0, last = p.LW - lx < 8 ? p.LW - lx : 8;
-            if (!rok || last < 0) last = 0;
-            if (first > last) first = last;
-            const unsigned m = ((1u << last) - 1u) & ~((1u << first) - 1u);
-            if (m == 0xffu) {
-#pragma unroll
-                for (int e = 0; e < 8; e++) lreg[j][e] = io_ld1<IO>(lp + e * ES);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; e++)
-                    if ((m >> e) & 1u) lreg[j][e] = io_ld1<IO>(lp + e * ES);
-            }
-            lmask |= m << (8 * j);
-        }
+        for (int j = 0; j < 3; j++)
+            lmask |= fetch_unit(n, 2 * pp + l_k[j] - p.pad_h, 2 * q0 - 4 + 8 * l_grp[j], l_b[j], l_ch_ok[j], lreg[j]) << (8 * j);
     };
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -316,14 +331,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
                                  s_ok ? sreg[1].x : 0.f, s_ok ? sreg[1].y : 0.f, s_ok ? sreg[1].z : 0.f, s_ok ? sreg[1].w : 0.f};
             split_store(sv, Ss + s_a * SP + 8 * s_grp, S_PIECE);
         }
+    };
+    auto slot_of = [](int y) { return (y + 3) % 3; };       // y >= -1
+    // one staged L unit (eight elements, validity bits m) into ring slot `slot`
+    auto stash_unit = [&](const float (&r)[8], unsigned m, int b, int grp, int slot) {
+        float lv[8];
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (tid + 256 * j < 960) {
-                float lv[8];
-#pragma unroll
-                for (int e = 0; e < 8; e++) lv[e] = ((lmask >> (8 * j + e)) & 1u) ? lreg[j][e] : 0.f;
-                split_store(lv, Ls + (l_b[j] * 3 + l_row[j]) * LP + 8 * l_grp[j], L_PIECE);
-            }
+        for (int e = 0; e < 8; e++) lv[e] = ((m >> e) & 1u) ? r[e] : 0.f;
+        split_store(lv, Ls + (b * 3 + slot) * LP + 8 * grp, L_PIECE);
     };
 
     f32x16 acc[9];
@@ -336,10 +351,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
     const int c_end = (int)((int64_t)p.chunks_total * (ks + 1) / p.ksplit);
     if (c_begin < c_end) fetch(c_begin);
     for (int ch = c_begin; ch < c_end; ch++) {
+        int n_c, qb_c, pp_c;
+        decode(ch, n_c, qb_c, pp_c);
+        const int y0 = 2 * pp_c - p.pad_h;
         __syncthreads();                  // the previous chunk's fragment reads are done
+        if (pp_c == 0 || ch == c_begin) { // a column block or this K slice begins: the first halo row is not in the ring yet
+            float t[8];
+            unsigned m = fetch_unit(n_c, y0, 2 * qb_c * 16 - 4 + 8 * p_g0, p_b0, b_blk + p_b0 < p.Bg, t);
+            stash_unit(t, m, p_b0, p_g0, slot_of(y0));
+            if (tid < 64) {
+                m = fetch_unit(n_c, y0, 2 * qb_c * 16 - 4 + 8 * p_g1, p_b1, b_blk + p_b1 < p.Bg, t);
+                stash_unit(t, m, p_b1, p_g1, slot_of(y0));
+            }
+        }
         stash();
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            if (tid + 256 * j < 640) stash_unit(lreg[j], (lmask >> (8 * j)) & 0xffu, l_b[j], l_grp[j], slot_of(y0 + l_k[j]));
         __syncthreads();
         if (ch + 1 < c_end) fetch(ch + 1);
+        const int slot0 = slot_of(y0);
         bf16x8 af[3];
 #pragma unroll
         for (int pc = 0; pc < NP; pc++) af[pc] = *(const bf16x8*)&Ss[pc * S_PIECE + (wa * 32 + jl) * SP + 8 * hl];
@@ -347,7 +378,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
         for (int pb = NP - 1; pb >= 0; pb--) {      // B pieces from the smallest to the largest
 #pragma unroll
             for (int row = 0; row < 3; row++) {
-                const __bf16* lb = &Ls[pb * L_PIECE + ((wb * 32 + jl) * 3 + row) * LP + 16 * hl];
+                const int slot = slot0 + row >= 3 ? slot0 + row - 3 : slot0 + row;
+                const __bf16* lb = &Ls[pb * L_PIECE + ((wb * 32 + jl) * 3 + slot) * LP + 16 * hl];
                 uint4 b0 = *(const uint4*)lb, b1 = *(const uint4*)(lb + 8), b2 = *(const uint4*)(lb + 16);
                 PASTA_KEEP_WHOLE(b0); PASTA_KEEP_WHOLE(b1); PASTA_KEEP_WHOLE(b2);      // whole ds_read_b128 (conflict-free) instead of narrowed read2 pairs: +2 % here
                 const uint32_t d[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
