@@ -16,6 +16,7 @@ shapes (training_loop...:289-297, 425-456) directly in HBM.
 import copy
 
 import numpy as np
+import os
 import torch
 
 import dnnlib
@@ -187,6 +188,10 @@ class TrainingStep:
 
         self.phases = []
         for name, module, opt_kwargs, reg_interval in [('G', G, cfg.G_opt_kwargs, cfg.G_reg_interval), ('D', D, cfg.D_opt_kwargs, cfg.D_reg_interval)]:
+            if (device.type == 'cuda' and opt_kwargs.get('class_name') == 'torch.optim.Adam' and 'fused' not in opt_kwargs and 'foreach' not in opt_kwargs
+                    and os.environ.get('PASTA_FUSED_ADAM', '1') != '0'):
+                # the same update (torch.optim.Adam's formula) as ONE multi-tensor kernel per step instead of seven foreach passes
+                opt_kwargs = dnnlib.EasyDict(opt_kwargs, fused=True)
             if reg_interval is None:
                 opt = dnnlib.util.construct_class_by_name(params=module.parameters(), **opt_kwargs)
                 self.phases += [dnnlib.EasyDict(name=name + 'both', module=module, opt=opt, interval=1)]
