@@ -60,3 +60,67 @@ def test_generator_discriminator_ddp_two_ranks_one_gpu(ddp_mode):
         p.join(timeout=60)
     for rank, msg in results:
         assert msg == 'ok', f'rank {rank}: {msg}'
+
+
+def _rccl_worker(port, out):
+    """One rank on RCCL (torch.distributed backend 'nccl'): process-group creation bound to the device, barrier, broadcast of
+    module states, and the flat reducer's hooks + asynchronous all-reduce on the real discriminator -- everything the N-rank run
+    does except having a second GPU to talk to."""
+    for p in (PKG, ROOT, os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device('cuda', 0)
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        assert dist.get_backend() == 'nccl'
+        from training import networks
+        from training.grad_reducer import FlatGradReducer, broadcast_module_states
+        from training.training_loop_wo_flow_fullbody import fashion_config
+        torch.manual_seed(0)
+        kw = dict(fashion_config(channel_base=2048).D_kwargs)
+        kw.pop('class_name')
+        for key, value in dict(c_dim=512, img_resolution=256, img_channels=3).items():
+            kw.setdefault(key, value)
+        D = networks.Discriminator(**kw).to(dev)
+        broadcast_module_states([D])
+        dist.barrier()
+        img = torch.randn([4, 3, 256, 256], device=dev)
+        c = torch.randn([4, 512], device=dev)
+        D(img, c).sum().backward()
+        plain = [p.grad.clone() for p in D.parameters()]
+        for p in D.parameters():
+            p.grad = None
+        red = FlatGradReducer(D, world_size=1, bucket_mb=8)
+        red.begin()
+        red.arm(1)
+        D(img, c).sum().backward()
+        red.finish()
+        torch.cuda.synchronize()
+        for p, g in zip(D.parameters(), plain):
+            assert p.grad is not None and torch.equal(p.grad, g)
+        t = torch.ones([1 << 20], device=dev)
+        dist.all_reduce(t)
+        assert float(t.sum()) == float(1 << 20)
+        out.put('ok')
+    except Exception:  # noqa: BLE001
+        import traceback
+        out.put('FAIL: ' + traceback.format_exc())
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rccl_initialises_and_carries_the_flat_reducer_single_rank():
+    """RCCL on this stack with world_size 1 (the test box has one GPU): the multi-GPU run's transport, hooks and stream
+    semantics -- the bitwise gradients of a plain backward pass must come back from the buckets."""
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(31000 + os.getpid() % 2000, out))
+    p.start()
+    res = out.get(timeout=500)
+    p.join(timeout=60)
+    assert res == 'ok', res
