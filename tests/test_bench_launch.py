@@ -52,3 +52,24 @@ def test_rccl_refuses_more_ranks_than_gpus():
         pytest.skip('needs a single-GPU box')
     res = _run({'PASTA_DIST_BACKEND': 'nccl'}, '--gpus', '2', '--steps', '1', '--warmup', '1', '--no-cpu-baseline', timeout=600)
     assert res.returncode != 0 and 'needs 2 GPUs' in res.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1200)
+def test_driver_style_launch_through_torch_distributed_run():
+    """The driver's multi-GPU invocation: ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...`` -- every process is one rank (RANK / LOCAL_RANK / WORLD_SIZE from the launcher);
+    rank 0 alone prints the line.  Two ranks on the one card of the test box, gloo transport."""
+    env = dict(os.environ, PASTA_DIST_BACKEND='gloo')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        env.pop(k, None)
+    port = 23000 + os.getpid() % 2000
+    res = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                          '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1',
+                          '--batch-gpu', '4', '--no-cpu-baseline'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 8 and out['scaling'] == 'weak'
+    assert 'world_size 2' in out['config']['parallelism']
