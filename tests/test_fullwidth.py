@@ -91,7 +91,9 @@ def test_oracle_discriminator_at_full_width():
     gx, = torch.autograd.grad(logits.sum(), x, create_graph=True)
     _summary_ok(g, 'D.r1_grads', gx, TOL_FWD)
     pen = gx.square().sum([1, 2, 3])
-    assert rel_err(pen, g['D.r1_penalty']) < TOL_FWD
+    # sums of squares of 1e-11-sized gradients: 1e-4 on the host that wrote the fixture, 6e-4 on another CPU model (different
+    # convolution blocking in torch's CPU back end), so the bound is the latter's
+    assert rel_err(pen, g['D.r1_penalty']) < 2e-3
     loss = torch.nn.functional.softplus(-logits).mean() + 5.0 * pen.mean()
     grads = dict(zip(pnames, torch.autograd.grad(loss, [sd[k] for k in pnames], allow_unused=True)))
     for k in FW.GRAD_KEYS_D:
