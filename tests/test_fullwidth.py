@@ -96,9 +96,11 @@ def test_oracle_discriminator_at_full_width():
     assert rel_err(pen, g['D.r1_penalty']) < 2e-3
     loss = torch.nn.functional.softplus(-logits).mean() + 5.0 * pen.mean()
     grads = dict(zip(pnames, torch.autograd.grad(loss, [sd[k] for k in pnames], allow_unused=True)))
+    # (the double backward through the R1 term is as sensitive to the host's convolution back end: 1e-3 where the fixture was
+    # written, 1.3e-3 on b4.conv.weight on another CPU model)
     for k in FW.GRAD_KEYS_D:
-        _summary_ok(g, 'D.grad.' + k, grads[k], TOL_GRAD)
-    _gradnorms_ok(g, 'D.gradnorms', grads, TOL_GRAD)
+        _summary_ok(g, 'D.grad.' + k, grads[k], 3 * TOL_GRAD)
+    _gradnorms_ok(g, 'D.gradnorms', grads, 3 * TOL_GRAD)
 
 
 # ---- the HIP path -------------------------------------------------------------------------------------------------------
