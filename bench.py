@@ -83,11 +83,12 @@ class ConvMeter:
             self.lib.pasta_conv2d_plan(ctypes.byref(desc), int(isc), ctypes.byref(tile), ctypes.byref(ksplit), ctypes.byref(math), ctypes.byref(launches),
                                        ctypes.byref(kernel))
             family = {0: TILE_NAMES, 1: bf16x6_names(), 2: bf16x6_rows_names(), 3: bf16x6_pair_names(),
-                      4: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,128,4,{_np()},{STORAGE_IO},false>'}, 5: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,128,2,{_np()},{STORAGE_IO},false>'},
-                      6: {1: f'conv_fwd_rows2d_bf16x6_kernel<64,256,8,{_np()},{STORAGE_IO},false>'}}[kernel.value][tile.value]     # <BM, BN, rows per tile, pieces, storage, input scale>
+                      4: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,128,4,{_np()},{STORAGE_IO},false,256>'}, 5: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,128,2,{_np()},{STORAGE_IO},false,256>'},
+                      6: {1: f'conv_fwd_rows2d_bf16x6_kernel<64,256,8,{_np()},{STORAGE_IO},false,256>'},
+                      7: {0: 'conv_fwd_rows2d_bf16x6_kernel<128,256,8,3,0,false,512>'}}[kernel.value][tile.value]     # <BM, BN, rows per tile, pieces, storage, input scale, threads>
             if isc and kernel.value != 0:       # the instance with the input scale: same family, another template argument (rocprofv3 names)
                 family = {1: family.replace(',3,3,0,false>', ',2,3,0,true>'), 2: family.replace(',false,false>', ',true,false>')}.get(
-                    kernel.value, family.replace(',false>', ',true>'))
+                    kernel.value, family.replace(',false,256>', ',true,256>'))
             kernels = launches.value
         else:
             which = ctypes.c_int()

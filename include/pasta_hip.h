@@ -152,7 +152,8 @@ int pasta_conv2d_tile(const pasta_conv_desc* d);
  * mode (3x3 stride-2 conv_transpose2d onto 2H(+1) x 2W(+1) outputs: one launch over the input lattice + one small
  * launch of kernel 1 for the last row / column), 4 / 5 / 6 conv_fwd_rows2d_bf16x6_kernel<128,128,4>, <128,128,2>, <64,256,8>: R output rows per
  * pixel tile (3x3 stride-1 lattices on the 128 x 128 tile whose planes divide into R x 128/R tiles: the R + 2 input rows of a
- * tile are staged once per 16-channel chunk).  Any out pointer may be NULL. */
+ * tile are staged once per 16-channel chunk), 7 the same kernel on eight waves and a 128 x 256 tile (<128,256,8,3,0,false,512>: plain
+ * six-product fp32 launches on planes of a multiple of 8 rows).  Any out pointer may be NULL. */
 int pasta_conv2d_plan(const pasta_conv_desc* d, int has_iscale, int* tile, int* ksplit, int* math, int* launches, int* kernel);
 
 /* Same for pasta_conv2d_wgrad: *kernel = 0 conv_wgrad_kernel (fp32 MFMA, taps x 64 x 64 tiles), 1

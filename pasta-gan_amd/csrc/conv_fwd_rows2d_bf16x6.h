@@ -23,22 +23,24 @@ namespace pasta {
 // operations is static (the s_waitcnt counters then let a fetch stay in flight across steps).
 // NP / IO as in conv_fwd_bf16x6_kernel: bf16 pieces per operand and the storage type of x / y / res.
 // ISC: p.iscale[n, channel] (the styles of a modulated convolution) multiplied onto the activations between fetch and split.
-template <int BM, int BN, int R, int NP = 3, int IO = IO_F32, bool ISC = false>
-__global__ __launch_bounds__(256, 2) void conv_fwd_rows2d_bf16x6_kernel(ConvFwdParams p) {
+// NT = threads per workgroup: 256 (four waves; two workgroups per CU) or 512 (eight waves on a 128 x 256 tile, one workgroup per
+// CU: the weights of a step are fetched and stored once for 256 pixels instead of once for 128).
+template <int BM, int BN, int R, int NP = 3, int IO = IO_F32, bool ISC = false, int NT = 256>
+__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_kernel(ConvFwdParams p) {
     static_assert(IO == IO_F32 || NP == 1, "16-bit storage: the element is the operand, one product");
     static_assert(!ISC || (NP == 3 && IO == IO_F32), "the input scale rides in the six-product fp32 staging");
     constexpr unsigned ES = io_size<IO>::value;
     constexpr int WMT = 2, WNT = 2, KC = 16;
     constexpr int WAVES_N = BN / 64;
-    static_assert((BM / 64) * WAVES_N == 4, "four waves per workgroup");
+    static_assert((BM / 64) * WAVES_N == NT / 64, "one wave per 64 x 64 sub-tile");
     constexpr int SEG = BN / R, SW = SEG + 2, SLOTS = (R + 2) * SW;
     static_assert(SEG % 32 == 0, "a fragment's 32 pixels lie in one tile row");
-    constexpr int UNITS = 2 * SLOTS, UPT = (UNITS + 255) / 256;          // (slot, k-half) staging units; per thread
+    constexpr int UNITS = 2 * SLOTS, UPT = (UNITS + NT - 1) / NT;          // (slot, k-half) staging units; per thread
     static_assert(UPT <= 4, "at most four staging units per thread and chunk");
     // unit k of the next chunk is fetched at step LSTEP(k) and split + stored at step TSTEP(k)
     constexpr int USTRIDE = UPT <= 3 ? 3 : 2;
-    constexpr int AUNITS = 2 * NP * BM, APT = (AUNITS + 255) / 256;
-    constexpr int ABUF = APT * 256 * 8, BSEG = SLOTS * 8, BBUF = 2 * NP * BSEG;      // bf16 elements
+    constexpr int AUNITS = 2 * NP * BM, APT = (AUNITS + NT - 1) / NT;
+    constexpr int ABUF = APT * NT * 8, BSEG = SLOTS * 8, BBUF = 2 * NP * BSEG;      // bf16 elements
     extern __shared__ __attribute__((aligned(16))) __bf16 rows2d_smem[];
     __bf16* const As = rows2d_smem;                     // [2][ABUF]
     __bf16* const Bs = rows2d_smem + 2 * ABUF;          // [2][BBUF]
@@ -65,13 +67,13 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_rows2d_bf16x6_kernel(ConvFwdP
     const __bf16* wb = (const __bf16*)p.wp + (int64_t)g * p.KK * NC * 6 * p.Og_pad * 8;
     const int64_t a_chunk = (int64_t)6 * p.Og_pad * 8;             // bf16 elements of one packed 16-channel chunk
 
-    // ---- staging units of this thread: unit u = tid + 256 k -> (slot, k-half); pixel byte offset (channel 0) and validity
+    // ---- staging units of this thread: unit u = tid + NT k -> (slot, k-half); pixel byte offset (channel 0) and validity
     unsigned u_pix[UPT];
     bool u_ok[UPT];
     int u_half[UPT], u_lds[UPT];
 #pragma unroll
     for (int k = 0; k < UPT; k++) {
-        const int u = tid + 256 * k;
+        const int u = tid + NT * k;
         const int half = u >= SLOTS ? 1 : 0;
         int slot = u - half * SLOTS;
         const bool real = u < UNITS;
@@ -146,8 +148,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_rows2d_bf16x6_kernel(ConvFwdP
         const int ccl = cc < NC ? cc : NC - 1;          // past the end of the K range (or of an empty slice): a valid address, unused data
         const __bf16* wt = wtap[tap] + (int64_t)ccl * a_chunk;
         auto unit = [&](int j) {
-            int e = tid + 256 * j;
-            if (256 * (j + 1) > AUNITS) e = e < AUNITS ? e : AUNITS - 1;
+            int e = tid + NT * j;
+            if (NT * (j + 1) > AUNITS) e = e < AUNITS ? e : AUNITS - 1;
             const int seg = e / BM, within = e - seg * BM;
             return *(const float4*)(wt + ((int64_t)seg * p.Og_pad + o_blk + within) * 8);
         };
@@ -157,8 +159,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_rows2d_bf16x6_kernel(ConvFwdP
     auto store_a = [&](int buf, int set) {
         __bf16* d = As + buf * ABUF;
         *(float4*)&d[tid * 8] = set ? breg0 : areg0;
-        if (APT > 1) *(float4*)&d[(tid + 256) * 8] = set ? breg1 : areg1;
-        if (APT > 2) *(float4*)&d[(tid + 512) * 8] = set ? breg2 : areg2;
+        if (APT > 1) *(float4*)&d[(tid + NT) * 8] = set ? breg1 : areg1;
+        if (APT > 2) *(float4*)&d[(tid + 2 * NT) * 8] = set ? breg2 : areg2;
     };
 
     f32x16 acc[WMT][WNT];
@@ -295,17 +297,17 @@ static bool rows2d_tile_ok(int P, int Q) {
     return P % R == 0 && Q % SEG == 0;
 }
 
-template <int BM, int BN, int R, int NP, int IO, bool ISC = false>
+template <int BM, int BN, int R, int NP, int IO, bool ISC = false, int NT = 256>
 static void launch_fwd_rows2d_np(const ConvFwdParams& q, dim3 grid, hipStream_t s) {
     constexpr int SEG = BN / R, SLOTS = (R + 2) * (SEG + 2);
-    constexpr int APT = (2 * NP * BM + 255) / 256;
-    constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 2 * NP * SLOTS * 8) * sizeof(__bf16);
+    constexpr int APT = (2 * NP * BM + NT - 1) / NT;
+    constexpr size_t lds = (size_t)(2 * APT * NT * 8 + 2 * 2 * NP * SLOTS * 8) * sizeof(__bf16);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_fwd_rows2d_bf16x6_kernel<BM, BN, R, NP, IO, ISC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv_fwd_rows2d_bf16x6_kernel<BM, BN, R, NP, IO, ISC, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_fwd_rows2d_bf16x6_kernel<BM, BN, R, NP, IO, ISC>), grid, dim3(256), lds, s, q);
+    hipLaunchKernelGGL((conv_fwd_rows2d_bf16x6_kernel<BM, BN, R, NP, IO, ISC, NT>), grid, dim3(NT), lds, s, q);
 }
 
 template <int BM, int BN, int R>
@@ -326,14 +328,23 @@ static void launch_fwd_rows2d(const ConvFwdParams& p, hipStream_t s) {
 // Rows per 2-D tile for a P x Q lattice on the 128 x 128 tile: 4 (32-column segments), else 2 (64 columns), else 0 = the row
 // kernel.  PASTA_ROWS2D=0 keeps the row kernel, =2 prefers two-row tiles, =1 keeps the 64 x 256 tile on the row kernel (A/B measurements).
 static int rows2d_rows(int P, int Q) {
-    static const int mode = getenv("PASTA_ROWS2D") ? atoi(getenv("PASTA_ROWS2D")) : 4;
+    static const int mode = getenv("PASTA_ROWS2D") ? atoi(getenv("PASTA_ROWS2D")) : 8;
     if (mode == 0) return 0;
     if (mode != 2 && rows2d_tile_ok<128, 4>(P, Q)) return 4;
     return rows2d_tile_ok<128, 2>(P, Q) ? 2 : 0;
 }
 
+// Eight waves on a 128 x 256 tile (8 rows x 32 columns; plain six-product fp32 launches): the weights of a step are fetched from L2
+// and stored to LDS once for 256 pixels instead of once for 128 -- +3.7 .. 6 % over the four-wave 128 x 128 tile on every live
+// shape (profiles/r2_rows2d.txt).  A 64 x 512 tile on eight waves (the 64-channel layers) spills and is 10 % slower: not kept.
+// PASTA_ROWS2D=4 keeps the four-wave tiles.
+static bool rows2d_wide(int P, int Q) {
+    static const int mode = getenv("PASTA_ROWS2D") ? atoi(getenv("PASTA_ROWS2D")) : 8;
+    return mode == 8 && rows2d_tile_ok<256, 8>(P, Q);
+}
+
 static bool rows2d_rows256(int P, int Q) {
-    static const int mode = getenv("PASTA_ROWS2D") ? atoi(getenv("PASTA_ROWS2D")) : 4;
+    static const int mode = getenv("PASTA_ROWS2D") ? atoi(getenv("PASTA_ROWS2D")) : 8;
     return mode != 0 && mode != 1 && rows2d_tile_ok<256, 8>(P, Q);          // PASTA_ROWS2D=1: 2-D tiles for the 128 x 128 tile only
 }
 
@@ -350,6 +361,13 @@ static bool try_fwd_rows2d(const ConvFwdParams& p, hipStream_t s) {
     ConvFwdParams q = p;
     q.rows_y0 = ymin;
     if constexpr (BN == 128) {
+        if (rows2d_wide(p.cls[0].P, p.cls[0].Q) && p.bf16x6 == 3 && p.io == IO_F32 && !p.iscale) {
+            ConvFwdParams w8 = q;
+            w8.o_tiles = (p.Og + BM - 1) / BM;
+            const int64_t tiles = (int64_t)p.N * (p.cls[0].P / 8) * (p.cls[0].Q / 32);
+            launch_fwd_rows2d_np<128, 256, 8, 3, IO_F32, false, 512>(w8, dim3((unsigned)tiles, w8.o_tiles * w8.ksplit, p.G), s);
+            return true;
+        }
         const int R = rows2d_rows(p.cls[0].P, p.cls[0].Q);
         if (R == 4) { launch_fwd_rows2d<BM, BN, 4>(q, s); return true; }
         if (R == 2) { launch_fwd_rows2d<BM, BN, 2>(q, s); return true; }

@@ -254,7 +254,8 @@ extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int has_iscale, int* 
         const bool plain6 = sb && d->stride == 1 && d->kw == 3 && d->kh == 3;
         const bool rows2d = plain6 && f.tile == T128x128 && rows2d_rows(d->OH, d->OW) > 0;
         const bool rows2d_256 = plain6 && f.tile == T64x256 && rows2d_rows256(d->OH, d->OW);
-        *kernel = !sb ? 0 : pair ? 3 : rows2d ? (rows2d_rows(d->OH, d->OW) == 4 ? 4 : 5) : rows2d_256 ? 6 : rows ? 2 : 1;
+        const bool wide = rows2d && !has_iscale && math_pieces(d->math) == 3 && d->io_dtype == PASTA_F32 && rows2d_wide(d->OH, d->OW);
+        *kernel = !sb ? 0 : pair ? 3 : wide ? 7 : rows2d ? (rows2d_rows(d->OH, d->OW) == 4 ? 4 : 5) : rows2d_256 ? 6 : rows ? 2 : 1;
     }
     return 0;
 }

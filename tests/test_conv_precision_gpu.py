@@ -115,8 +115,8 @@ def test_row_reuse_kernel_every_tiling(n, cin, cout, hw):
     import os
     if os.environ.get('PASTA_ROWS2D') == '0':       # the row kernel; 96-pixel rows fall back to the base kernel
         assert kernel.value == (1 if hw == 96 else 2)
-    else:
-        assert kernel.value == (4 if cout > 64 else 6)
+    else:                                            # 128-row tiles: eight waves on 128 x 256 (7); 64-row tiles: eight-row tiles (6)
+        assert kernel.value == (7 if cout > 64 else 6)
 
 
 @pytest.mark.parametrize('transposed,n,cin,cout,hw,pad', [(False, 2, 40, 72, 65, 0), (False, 2, 64, 64, 64, 1), (False, 1, 24, 130, 129, 0),
@@ -250,9 +250,9 @@ def test_plan_reports_the_reduced_modes():
         tile, ks, math, launches, kernel = (ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int())
         _native.check(lib.pasta_conv2d_plan(ctypes.byref(d), 0, ctypes.byref(tile), ctypes.byref(ks), ctypes.byref(math),
                                             ctypes.byref(launches), ctypes.byref(kernel)))
-        # the row-reuse family in every split mode: its 2-D tiles of four rows (4), or the row kernel (2) under PASTA_ROWS2D=0
+        # the row-reuse family in every split mode: 2-D tiles (eight waves for the six-product arithmetic: 7, else four-row tiles: 4), or the row kernel (2) under PASTA_ROWS2D=0
         import os
-        assert math.value == code and kernel.value == (2 if os.environ.get('PASTA_ROWS2D') == '0' else 4)
+        assert math.value == code and kernel.value == (2 if os.environ.get('PASTA_ROWS2D') == '0' else 7 if mode == 'bf16x6' else 4)
 
 
 # ---- edge of the split-bf16 operand range ------------------------------------------------------------------------------
