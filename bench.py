@@ -64,9 +64,9 @@ class ConvMeter:
         self.iteration = 0         # set by the caller before every step
         self.counts = {}           # iteration -> {family: kernel launches}: counted always (no events), for the PMC cross-check
 
-    def __call__(self, kind, desc, launch):
+    def __call__(self, kind, desc, launch, flags=0):
         import ctypes
-        key = (kind, desc.N, desc.C_in, desc.H, desc.W, desc.C_out, desc.OH, desc.OW, desc.kh, desc.kw, desc.stride, desc.pad_h, desc.pad_w,
+        key = (kind, flags, desc.N, desc.C_in, desc.H, desc.W, desc.C_out, desc.OH, desc.OW, desc.kh, desc.kw, desc.stride, desc.pad_h, desc.pad_w,
                desc.groups, desc.transposed, desc.math, desc.io_dtype)
         hit = self._family.get(key)
         if hit is not None:
@@ -80,7 +80,7 @@ class ConvMeter:
         if kind in ('conv', 'conv_isc'):
             isc = kind == 'conv_isc'           # forward-only modulated convolutions: the styles ride in the kernel's staging
             tile, ksplit, math, launches, kernel = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-            self.lib.pasta_conv2d_plan(ctypes.byref(desc), int(isc), ctypes.byref(tile), ctypes.byref(ksplit), ctypes.byref(math), ctypes.byref(launches),
+            self.lib.pasta_conv2d_plan(ctypes.byref(desc), int(flags) | int(isc), ctypes.byref(tile), ctypes.byref(ksplit), ctypes.byref(math), ctypes.byref(launches),
                                        ctypes.byref(kernel))
             family = {0: TILE_NAMES, 1: bf16x6_names(), 2: bf16x6_rows_names(), 3: bf16x6_pair_names(),
                       4: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,128,4,{_np()},{STORAGE_IO},false,256>'}, 5: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,128,2,{_np()},{STORAGE_IO},false,256>'},
@@ -544,24 +544,28 @@ def main():
             del step
             torch.cuda.empty_cache()
             out['also_measured'] = {}
-            for tag, kw, note in [('d_fp16_res_3', dict(d_fp16_res=3), 'D blocks b256..b64 in fp16 storage + products: num_fp16_res = 3, conv_clamp = 256 as train_wo_flow_fullbody.py:195-196 sets them '
+            for tag, kw, vbatch, vres, note in [('d_fp16_res_3', dict(d_fp16_res=3), args.batch_gpu, 256, 'D blocks b256..b64 in fp16 storage + products: num_fp16_res = 3, conv_clamp = 256 as train_wo_flow_fullbody.py:195-196 sets them '
                                                                         '(GeneratorFull forces its blocks to fp32, networks.py:2307,2331): the reference script\'s default precision; '
                                                                         'parity: reference fixture with num_fp16_res = 4, tests/test_fullwidth.py (2e-2)'),
-                                  ('storage_bf16', dict(act_dtype='bfloat16'), 'bf16 activation storage in G and D (BASELINE config 5 arithmetic at 256x256, batch 16); '
-                                                                               'parity: oracle in the same storage type, tests/test_storage16_gpu.py')]:
-                vcfg = fashion_config(mbstd_group_size=min(args.batch_gpu, 4), **kw)
-                vstep = TrainingStep(device, cfg=vcfg, num_gpus=1, rank=0, batch_size=args.batch_gpu, batch_gpu=args.batch_gpu)
+                                  ('storage_bf16', dict(act_dtype='bfloat16'), args.batch_gpu, 256, 'bf16 activation storage in G and D (BASELINE config 5 arithmetic at 256x256, batch 16); '
+                                                                               'parity: oracle in the same storage type, tests/test_storage16_gpu.py'),
+                                  ('storage_bf16_512', dict(act_dtype='bfloat16', img_resolution=512), 8, 512, 'BASELINE config 5, one GPU of it: 512x320 (tensor 512x512) training step, batch 8, bf16 '
+                                                                               'activation storage with fp32 demodulation / accumulation; the 512 model is the resolution-generalised GeneratorFull '
+                                                                               '(parity UNPINNED: the reference ships no 512 class); parity vs the oracle in the same storage type: tests/test_config5_gpu.py')]:
+                vcfg = fashion_config(mbstd_group_size=min(vbatch, 4), **kw)
+                vstep = TrainingStep(device, cfg=vcfg, num_gpus=1, rank=0, batch_size=vbatch, batch_gpu=vbatch)
+                vdata = data if (vbatch, vres) == (args.batch_gpu, 256) else SyntheticFullBodyBatch(vbatch, device, seed=rank, res=vres)
                 for _ in range(2):
-                    vstep.run(data)
+                    vstep.run(vdata)
                 torch.cuda.synchronize()
                 tv = time.perf_counter()
                 for _ in range(16):
-                    vstep.run(data)
+                    vstep.run(vdata)
                 torch.cuda.synchronize()
                 tv = time.perf_counter() - tv
-                out['also_measured'][tag] = {'value': round(16 * args.batch_gpu / tv, 3), 'unit': 'images/sec', 'ms_per_step': round(1000 * tv / 16, 2),
-                                             'steps': 16, 'warmup': 2, 'precision': 'REDUCED relative to the headline', 'note': note}
-                del vstep
+                out['also_measured'][tag] = {'value': round(16 * vbatch / tv, 3), 'unit': 'images/sec', 'ms_per_step': round(1000 * tv / 16, 2),
+                                             'steps': 16, 'warmup': 2, 'batch': vbatch, 'resolution': vres, 'precision': 'REDUCED relative to the headline', 'note': note}
+                del vstep, vdata
                 torch.cuda.empty_cache()
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline()

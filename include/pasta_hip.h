@@ -144,9 +144,9 @@ int pasta_conv2d_tile(const pasta_conv_desc* d);
 
 /* The full launch plan of pasta_conv2d(_ex) for d, for reporting (bench.py attributes time and FLOPs to kernel
  * families with it): *tile as pasta_conv2d_tile, *ksplit = number of K slices (> 1: partial sums in the workspace,
- * reduced by a second kernel), *math = PASTA_MATH_F32 or PASTA_MATH_BF16X6 actually used (has_iscale != 0 says the
- * launch passes an iscale vector, which the split-bf16 kernels take in their staging for fp32 storage and six products
- * only), *launches = launches of the main kernel (conv_transpose2d: one per output parity class unless the classes share a
+ * reduced by a second kernel), *math = PASTA_MATH_F32 or PASTA_MATH_BF16X6 actually used (launch_flags = OR of PASTA_PLAN_*:
+ * what the launch will pass besides x, w, y -- an iscale vector, which the split-bf16 kernels take in their staging for fp32
+ * storage and six products only; an oscale vector; a fused epilogue.  0 / 1 keep their round-2 meaning), *launches = launches of the main kernel (conv_transpose2d: one per output parity class unless the classes share a
  * grid), *kernel = 0 conv_fwd_kernel (fp32 MFMA), 1 conv_fwd_bf16x6_kernel, 2 conv_fwd_rows_bf16x6_kernel (split-bf16 with
  * row reuse: 3-wide stride-1 kernels on planes whose rows are a multiple of 32 pixels), 3 the same kernel's parity-pair
  * mode (3x3 stride-2 conv_transpose2d onto 2H(+1) x 2W(+1) outputs: one launch over the input lattice + one small
@@ -154,7 +154,10 @@ int pasta_conv2d_tile(const pasta_conv_desc* d);
  * pixel tile (3x3 stride-1 lattices on the 128 x 128 tile whose planes divide into R x 128/R tiles: the R + 2 input rows of a
  * tile are staged once per 16-channel chunk), 7 the same kernel on eight waves and a 128 x 256 tile (<128,256,8,3,0,false,512>: plain
  * six-product fp32 launches on planes of a multiple of 8 rows).  Any out pointer may be NULL. */
-int pasta_conv2d_plan(const pasta_conv_desc* d, int has_iscale, int* tile, int* ksplit, int* math, int* launches, int* kernel);
+#define PASTA_PLAN_ISCALE   1
+#define PASTA_PLAN_OSCALE   2
+#define PASTA_PLAN_EPILOGUE 4
+int pasta_conv2d_plan(const pasta_conv_desc* d, int launch_flags, int* tile, int* ksplit, int* math, int* launches, int* kernel);
 
 /* Same for pasta_conv2d_wgrad: *kernel = 0 conv_wgrad_kernel (fp32 MFMA, taps x 64 x 64 tiles), 1
  * conv_wgrad_smallcin_kernel (<= 8 input channels: (channel, tap) pairs as GEMM columns), 2

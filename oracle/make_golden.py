@@ -1,6 +1,6 @@
 """Generate tests/golden/*.npz by running the REFERENCE itself (build container only).
 
-    python oracle/make_golden.py [--ref /root/reference] [--only ops|layers|primitives|models|fullwidth|loss|augment|snapshot]
+    python oracle/make_golden.py [--ref /root/reference] [--only ops|layers|primitives|models|fullwidth|fullwidth_r1|loss|augment|snapshot]
 
 The reference is imported read-only from ``--ref`` (never copied): op level as is, model level
 with the two harness accommodations SURVEY.md F1/F4 describe (cwd = reference root,
@@ -253,6 +253,9 @@ if __name__ == '__main__':
     if args.only in ('all', 'fullwidth'):
         from make_golden_fullwidth import gen_fullwidth
         gen_fullwidth(args.ref, import_reference_networks)
+    if args.only in ('all', 'fullwidth_r1'):
+        from make_golden_fullwidth_r1 import gen_fullwidth_r1
+        gen_fullwidth_r1(args.ref, import_reference_networks)
     if args.only == 'snapshot':       # own process: it blanks the reference's module-source capture before importing its networks
         from make_golden_snapshot import gen_snapshot
         gen_snapshot(args.ref, import_reference_networks)

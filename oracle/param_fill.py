@@ -16,8 +16,19 @@ def _wave(name, numel, scale):
     return (v * scale).astype(np.float32)
 
 
-def fill_module(module):
-    """Overwrite every parameter and buffer of ``module`` in place (resample filters are left alone)."""
+def _normal(name, numel, scale):
+    """Standard-normal values that depend only on (tensor name, element index): numpy's legacy MT19937 stream seeded by the
+    CRC of the name (stable across numpy versions and platforms by numpy's compatibility guarantee for RandomState)."""
+    return (np.random.RandomState(zlib.crc32(name.encode())).standard_normal(numel) * scale).astype(np.float32)
+
+
+def fill_module(module, kind='wave'):
+    """Overwrite every parameter and buffer of ``module`` in place (resample filters are left alone).
+    ``kind='wave'``: smooth closed form (sums over wide layers largely cancel: a full-width discriminator filled this way
+    barely depends on its image).  ``kind='normal'``: unit-variance pseudo-random weights, the statistics of the
+    reference's own initialisation (``torch.randn`` weights, networks.py:149), so signals and gradients keep O(1) size
+    through 512-channel layers -- used where a derivative with respect to the IMAGE must be non-degenerate (R1)."""
+    gen = _wave if kind == 'wave' else _normal
     with torch.no_grad():
         for name, t in list(module.named_parameters()) + list(module.named_buffers()):
             if name.endswith('resample_filter') or name.endswith('w_avg') or t.numel() == 0:
@@ -25,10 +36,12 @@ def fill_module(module):
             if name.endswith('noise_strength'):
                 t.fill_(0.1)
                 continue
-            scale = 0.9
+            scale = 0.9 if kind == 'wave' else 1.0
+            if kind == 'normal' and '.'.join(name.split('.')[-3:-1]).startswith('mapping.fc') and name.endswith('weight'):
+                scale = 100.0       # mapping layers run at lr_multiplier 0.01: the reference initialises them as randn / 0.01 (networks.py:108)
             if name.endswith('bias') or name.endswith('bias1'):
                 scale = 0.1
-            t.copy_(torch.from_numpy(_wave(name, t.numel(), scale)).reshape(t.shape))
+            t.copy_(torch.from_numpy(gen(name, t.numel(), scale)).reshape(t.shape))
     return module
 
 

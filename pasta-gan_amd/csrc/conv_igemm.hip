@@ -233,11 +233,19 @@ extern "C" int pasta_conv2d_tile(const pasta_conv_desc* d) {
     return (int)plan_fwd(d).tile;
 }
 
-namespace pasta { static bool pair_launch_ok(const pasta_conv_desc* d, int pieces, int ksplit, FwdTile tile, bool plain); }
+namespace pasta {
+static bool pair_launch_ok(const pasta_conv_desc* d, int pieces, int ksplit, FwdTile tile, bool plain);
+// The parity-pair kernel carries no scales and no epilogue: ONE predicate for the planner and the launch.
+static inline bool pair_plain(int launch_flags) { return launch_flags == 0; }
+static inline int launch_flags_of(const float* iscale, const float* oscale, const pasta_conv_epilogue* ep) {
+    return (iscale ? PASTA_PLAN_ISCALE : 0) | (oscale ? PASTA_PLAN_OSCALE : 0) | (ep ? PASTA_PLAN_EPILOGUE : 0);
+}
+}
 
-extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int has_iscale, int* tile, int* ksplit, int* math, int* launches, int* kernel) {
+extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int launch_flags, int* tile, int* ksplit, int* math, int* launches, int* kernel) {
     using namespace pasta;
     if (int e = check_desc(d, "conv2d_plan")) return e;
+    const bool has_iscale = (launch_flags & PASTA_PLAN_ISCALE) != 0;
     const FwdPlan f = plan_fwd(d);
     const bool sb = f.bf16x6 && (!has_iscale || isc_in_staging(d));
     if (d->io_dtype != PASTA_F32 && !sb) return fail("conv2d: no 16-bit-storage kernel for this shape (fewer than 16 input channels per group, at most 32 "
@@ -245,7 +253,7 @@ extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int has_iscale, int* 
     if (tile) *tile = (int)f.tile;
     if (ksplit) *ksplit = f.ksplit;
     if (math) *math = !sb ? PASTA_MATH_F32 : d->io_dtype != PASTA_F32 ? PASTA_MATH_BF16 : d->math == PASTA_MATH_BF16X3 ? PASTA_MATH_BF16X3 : d->math == PASTA_MATH_BF16 ? PASTA_MATH_BF16 : PASTA_MATH_BF16X6;
-    const bool pair = sb && pair_launch_ok(d, math_pieces(d->math), f.ksplit, f.tile, !has_iscale);
+    const bool pair = sb && pair_launch_ok(d, math_pieces(d->math), f.ksplit, f.tile, pair_plain(launch_flags));
     if (launches) *launches = !d->transposed ? 1 : pair ? 1 + (d->OH > 2 * d->H || d->OW > 2 * d->W ? 1 : 0) : merged_classes(d, sb) ? 1 :
                               (d->stride < d->OH ? d->stride : d->OH) * (d->stride < d->OW ? d->stride : d->OW);
     if (kernel) {
@@ -455,7 +463,7 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
         // input row = pp + (a + pad - r)/u.
         const int u = d->stride;
         p.osy = u; p.osx = u; p.isy = 1; p.isx = 1;
-        if (pair_launch_ok(d, p.bf16x6, p.ksplit, tile, !iscale && !oscale && !ep)) {
+        if (pair_launch_ok(d, p.bf16x6, p.ksplit, tile, pair_plain(launch_flags_of(iscale, oscale, ep)))) {
             launch_transposed_pairs(d, p, tile, s);
             return launch_status("conv2d");
         }

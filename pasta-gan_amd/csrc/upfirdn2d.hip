@@ -189,6 +189,8 @@ __global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p,
             const bool ex = rem_x && tile_x == tiles_x - 1 && tx == BX - 1;
             const bool ey = rem_y && tile_y == tiles_y - 1 && ty == BY - 1;
             auto one = [&](int yy, int xx) {          // output (yy, xx) relative to the tile origin
+                // the OTHER dimension may end inside this tile (non-square planes: 20 x 33 on 32 x 32 tiles)
+                if (tile_y * TOH + yy >= p.outH || tile_x * TOW + xx >= p.outW) return;
                 float v = 0.f;
 #pragma unroll
                 for (int jy = 0; jy < FH; jy++)

@@ -38,8 +38,10 @@ _cached_plugins = dict()
 def _sources():
     return sorted(os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith('.hip'))
 
-def _digest(sources):
+def _digest(sources, extra_flags=()):
     h = hashlib.md5()
+    # the compile flags are part of what the library IS: a -DPASTA_ABLATE=... build must never carry the default stamp
+    h.update(repr([str(f) for f in extra_flags]).encode())
     extra = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith('.h')]
     extra.append(os.path.join(_INCLUDE, 'pasta_hip.h'))
     for path in list(sources) + extra:
@@ -66,7 +68,7 @@ def build(force=False, verbose=False, extra_flags=()):
     sources = _sources()
     lib_path = os.path.join(_LIBDIR, LIB_NAME)
     stamp = lib_path + '.md5'
-    digest = _digest(sources)
+    digest = _digest(sources, extra_flags)
     if not force and _stamp_matches(lib_path, stamp, digest):
         return lib_path
     hipcc = _hipcc()

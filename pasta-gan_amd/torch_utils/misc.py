@@ -3,15 +3,18 @@
 API-compatible subset of the reference's torch_utils/misc.py: ``assert_shape`` (:80-95),
 ``profiled_function`` (:104-109), ``suppress_tracer_warnings`` (:67-71), ``nan_to_num`` (:45),
 ``params_and_buffers`` / ``named_params_and_buffers`` / ``copy_params_and_buffers`` (:151-166),
-``ddp_sync`` (:172-179) and ``check_ddp_consistency`` (:184-196).  The dataset sampler (``InfiniteSampler``, :115-146)
-belongs to the data pipeline, which is outside this path; the synthetic batch is sharded by seed.
+``ddp_sync`` (:172-179), ``check_ddp_consistency`` (:184-196) and the dataset sampler ``InfiniteSampler`` (:115-146), which
+is how the reference's loop shards a dataset over the ranks (training_loop_wo_flow_fullbody.py:262-263); the synthetic batch
+of the benchmark is sharded by seed instead.
 """
 
 import contextlib
 import functools
+import itertools
 import re
 import warnings
 
+import numpy as np
 import torch
 
 nan_to_num = torch.nan_to_num
@@ -108,3 +111,38 @@ def check_ddp_consistency(module, ignore_regex=None):
         assert torch.equal(mine, theirs), prefix + name
 
 #----------------------------------------------------------------------------
+
+
+class InfiniteSampler(torch.utils.data.Sampler):
+    """Endless index stream over ``dataset`` for ``torch.utils.data.DataLoader(sampler=...)``: position ``t`` of ONE global
+    stream (identical on every rank: same seed, same draws) belongs to rank ``t % num_replicas``, so the ranks read disjoint
+    items; after each position the item just passed is swapped with one at most ``window_size * len(dataset)`` places behind
+    it, which keeps the order drifting without ever reshuffling the whole set.  Same constructor, same index stream for a
+    given seed as the reference's class (misc.py:115-146; pinned by tests/golden/sampler.npz)."""
+
+    def __init__(self, dataset, rank=0, num_replicas=1, shuffle=True, seed=0, window_size=0.5):
+        if len(dataset) <= 0:
+            raise AssertionError('InfiniteSampler: empty dataset')
+        if not (num_replicas > 0 and 0 <= rank < num_replicas):
+            raise AssertionError(f'InfiniteSampler: rank {rank} is not in [0, {num_replicas})')
+        if not 0 <= window_size <= 1:
+            raise AssertionError('InfiniteSampler: window_size must lie in [0, 1]')
+        super().__init__()
+        self.dataset, self.rank, self.num_replicas = dataset, rank, num_replicas
+        self.shuffle, self.seed, self.window_size = shuffle, seed, window_size
+
+    def __iter__(self):
+        n = len(self.dataset)
+        perm = np.arange(n)
+        draw, reach = None, 0
+        if self.shuffle:
+            draw = np.random.RandomState(self.seed)
+            draw.shuffle(perm)
+            reach = int(np.rint(n * self.window_size))
+        for t in itertools.count():
+            here = t % n
+            if t % self.num_replicas == self.rank:
+                yield perm[here]
+            if reach >= 2:      # every rank makes every draw, its own positions or not: the stream stays global
+                back = (here - draw.randint(reach)) % n
+                perm[[here, back]] = perm[[back, here]]

@@ -180,7 +180,9 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, 
     if launch_hook is None:
         launch()
     else:
-        launch_hook('conv' if iscale is None else 'conv_isc', desc, launch)      # 'conv_isc': the launch passes an input scale (another kernel instance)
+        # 'conv_isc': the launch passes an input scale (another kernel instance); flags = PASTA_PLAN_* of include/pasta_hip.h
+        flags = (1 if iscale is not None else 0) | (2 if oscale is not None else 0) | (4 if ep is not None else 0)
+        launch_hook('conv' if iscale is None else 'conv_isc', desc, launch, flags)
     return y.to(out_dtype)
 
 def _launch_wgrad(x, dy, cfg, w_shape, out_dtype=None):
@@ -214,7 +216,7 @@ def _launch_wgrad(x, dy, cfg, w_shape, out_dtype=None):
     if launch_hook is None:
         launch()
     else:
-        launch_hook('wgrad', desc, launch)
+        launch_hook('wgrad', desc, launch, 0)
     return dw.to(out_dtype)
 
 #----------------------------------------------------------------------------

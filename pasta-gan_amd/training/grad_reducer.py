@@ -26,17 +26,21 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ('flat', 'params', 'pending', 'work', 'touched')
+    __slots__ = ('flat', 'params', 'pending', 'work', 'touched', 'launched')
 
     def __init__(self, flat, params):
         self.flat, self.params = flat, params
-        self.pending, self.work, self.touched = 0, None, False
+        self.pending, self.work, self.touched, self.launched = 0, None, False, False
 
 
 class FlatGradReducer:
-    def __init__(self, module, world_size, bucket_mb=64, process_group=None):
+    def __init__(self, module, world_size, bucket_mb=64, process_group=None, force_collective=False):
         self.world = int(world_size)
         self.group = process_group
+        # force_collective: issue the asynchronous all-reduce even at world size 1 (a one-rank sum is the identity), so a
+        # single-GPU box can put RCCL's stream, the pre-scale and work.wait() under test
+        self.collective = self.world > 1 or bool(force_collective)
+        self.collectives_issued = 0
         params = [p for p in module.parameters()]
         assert params, 'FlatGradReducer: module has no parameters'
         assert all(p.dtype == torch.float32 for p in params), 'FlatGradReducer: fp32 master parameters expected'
@@ -82,7 +86,7 @@ class FlatGradReducer:
         self._touched.clear()
         for b in self.buckets:
             b.flat.zero_()
-            b.work, b.touched = None, False
+            b.work, b.touched, b.launched = None, False, False
             for p, view in b.params:
                 p.grad = view
 
@@ -98,6 +102,12 @@ class FlatGradReducer:
     def _on_grad(self, p):
         self._touched.add(p)
         b = self._where[p]
+        if b.launched:
+            # the bucket left (pre-scaled by 1/world) when its expected count was reached: a gradient arriving now would be
+            # added during or after the exchange and the replicas would diverge silently.  The count comes from
+            # StyleGAN2Loss.backward_passes - a loss variant that calls backward() once more must say so there.
+            raise RuntimeError('FlatGradReducer: a gradient arrived after its bucket was sent: arm(expected_backward_passes) '
+                               'was told fewer backward passes than reach this module in the last accumulation round')
         b.touched = True
         view = self._view[p]
         if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
@@ -111,9 +121,14 @@ class FlatGradReducer:
                 self.launched_early += 1
 
     def _launch(self, b):
-        if self.world > 1 and b.work is None:
-            b.flat.mul_(1.0 / self.world)
+        if b.launched:
+            return
+        b.launched = True
+        if self.collective:
+            if self.world > 1:
+                b.flat.mul_(1.0 / self.world)
             b.work = dist.all_reduce(b.flat, group=self.group, async_op=True)
+            self.collectives_issued += 1
 
     def finish(self):
         """End of a phase: exchange the buckets not yet sent, wait for all of them, and drop the gradients of

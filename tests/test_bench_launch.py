@@ -47,6 +47,21 @@ def test_two_ranks_on_one_gpu_over_gloo(ddp_mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(1200)
+def test_four_ranks_on_one_gpu_over_gloo():
+    """Four ranks on the one card (the box admits six processes on it; eight cannot be rehearsed here -- the world-size-8 logic
+    runs over gloo on the CPU, tests/test_ddp_cpu.py): 1/4 of the host cores per rank, four-way max-over-ranks timing, the
+    flat reducer's buckets at world size 4 through the real generator / discriminator."""
+    res = _run({'PASTA_DIST_BACKEND': 'gloo'}, '--gpus', '4', '--steps', '1', '--warmup', '1', '--batch-gpu', '2', '--no-cpu-baseline')
+    assert res.returncode == 0, res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 4 and out['config']['global_batch'] == 8 and out['value'] > 0 and out['scaling'] == 'weak'
+    assert 'world_size 4' in out['config']['parallelism'] and 'REHEARSAL' in out['config']['parallelism']
+
+
+@pytest.mark.gpu
 def test_rccl_refuses_more_ranks_than_gpus():
     if torch.cuda.device_count() >= 2:
         pytest.skip('needs a single-GPU box')

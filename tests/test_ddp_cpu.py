@@ -90,6 +90,28 @@ def _worker(rank, world, port, out, ddp_mode):
         dist.destroy_process_group()
 
 
+def _spawn(world, ddp_mode, salt):
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = 29500 + (os.getpid() + salt) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out, ddp_mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=400) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == 'ok', f'rank {rank}: {msg}'
+
+
+@pytest.mark.timeout(600)
+def test_data_parallel_step_world_size_8():
+    """The world size of BASELINE config 3 (one node, 8 ranks), rehearsed over gloo on the CPU -- the GPU box admits at most six
+    processes on its one card, so eight ranks cannot share it: bucket filling / arming, the 1/8 pre-scale, unused parameters and
+    replica consistency over five iterations with lazy regularisation, at the real rank count."""
+    _spawn(8, 'flat', 13)
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize('ddp_mode', ['flat', 'torch'])
 def test_data_parallel_step_world_size_2(ddp_mode):
@@ -104,3 +126,28 @@ def test_data_parallel_step_world_size_2(ddp_mode):
         p.join(timeout=60)
     for rank, msg in results:
         assert msg == 'ok', f'rank {rank}: {msg}'
+
+
+def test_flat_reducer_refuses_a_gradient_after_its_bucket_left():
+    """arm() told one backward pass, the loss makes two -> the second pass's gradients would be added to a
+    bucket that is already on the wire (pre-scaled).  The reducer must raise, not diverge silently."""
+    for p in (PKG, ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from training.grad_reducer import FlatGradReducer
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 4))
+    red = FlatGradReducer(net, world_size=1)
+    x = torch.randn(3, 8)
+    red.begin()
+    red.arm(2)
+    net(x).sum().backward()
+    net(x).sum().backward()           # two passes announced, two made: fine
+    red.finish()
+    assert red.launched_early == len(red.buckets)
+    red.begin()
+    red.arm(1)
+    net(x).sum().backward()
+    with pytest.raises(RuntimeError, match='after its bucket was sent'):
+        net(x).sum().backward()
+    red.remove()

@@ -93,14 +93,27 @@ def _rccl_worker(port, out):
         plain = [p.grad.clone() for p in D.parameters()]
         for p in D.parameters():
             p.grad = None
-        red = FlatGradReducer(D, world_size=1, bucket_mb=8)
+        # force_collective: the reducer's own all_reduce(bucket, async_op=True) + work.wait() run on RCCL's stream (a one-rank
+        # sum is the identity, so the plain gradients must come back bit for bit)
+        red = FlatGradReducer(D, world_size=1, bucket_mb=8, force_collective=True)
+        assert len(red.buckets) > 1
+        red.begin()
+        red.arm(1)
+        D(img, c).sum().backward()
+        assert red.launched_early == len(red.buckets) and all(b.work is not None for b in red.buckets)
+        red.finish()
+        assert red.collectives_issued == len(red.buckets)
+        torch.cuda.synchronize()
+        for p, g in zip(D.parameters(), plain):
+            assert p.grad is not None and torch.equal(p.grad, g)
+        # a second phase on the same buckets (zeroed, re-armed) while the first phase's collectives have completed
         red.begin()
         red.arm(1)
         D(img, c).sum().backward()
         red.finish()
         torch.cuda.synchronize()
         for p, g in zip(D.parameters(), plain):
-            assert p.grad is not None and torch.equal(p.grad, g)
+            assert torch.equal(p.grad, g)
         t = torch.ones([1 << 20], device=dev)
         dist.all_reduce(t)
         assert float(t.sum()) == float(1 << 20)

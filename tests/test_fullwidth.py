@@ -18,8 +18,8 @@ from oracle import make_golden_fullwidth as FW
 TOL_FWD, TOL_GRAD, TOL_FP16 = 1e-4, 1e-3, 2e-2
 
 
-def _summary_ok(g, key, tensor, tol):
-    s = PF.summarize(tensor, samples=FW.SAMPLES)
+def _summary_ok(g, key, tensor, tol, samples=FW.SAMPLES):
+    s = PF.summarize(tensor, samples=samples)
     e = rel_err(s['sample'], g[key + '.sample'])
     m, mg = s['moments'], g[key + '.moments']
     assert e < tol, (key, e)
@@ -103,6 +103,38 @@ def test_oracle_discriminator_at_full_width():
     _gradnorms_ok(g, 'D.gradnorms', grads, 3 * TOL_GRAD)
 
 
+def _r1_check(g, logits, gx, pen, grads, tol_fwd, tol_grad):
+    """Dreg phase against models_fullwidth_r1.npz: every parameter gradient here is a SECOND derivative (the loss is the R1
+    term alone), |d logit / d img| ~ 1e-4 and the penalty ~ 7e-5: nothing degenerate."""
+    from oracle import make_golden_fullwidth_r1 as R1
+    assert float(np.abs(g['Dr1.r1_grads.sample']).max()) > 1e-5 and float(g['Dr1.r1_penalty'].min()) > 1e-6      # the fixture itself
+    assert rel_err(logits, g['Dr1.logits']) < tol_fwd
+    _summary_ok(g, 'Dr1.r1_grads', gx, tol_fwd, R1.SAMPLES)
+    assert rel_err(pen, g['Dr1.r1_penalty']) < tol_fwd
+    checked = 0
+    for k in FW.GRAD_KEYS_D:
+        if 'Dr1.grad.' + k + '.sample' in g:
+            _summary_ok(g, 'Dr1.grad.' + k, grads[k], tol_grad, R1.SAMPLES)
+            checked += 1
+    assert checked >= 14
+    _gradnorms_ok(g, 'Dr1.gradnorms', grads, tol_grad, floor=1e-6)
+
+
+@pytest.mark.timeout(600)
+def test_oracle_discriminator_r1_phase_at_full_width():
+    from oracle import ref_networks as RN
+    from oracle import make_golden_fullwidth_r1 as R1
+    from training import networks
+    g = load_golden('models_fullwidth_r1.npz')
+    m = PF.fill_module(networks.Discriminator(**FW.D_KWARGS), kind='normal')
+    params = dict(m.named_parameters())
+    sd = {k: v.detach().clone().requires_grad_(k in params) for k, v in list(m.named_parameters()) + list(m.named_buffers())}
+    names = sorted(params)
+    x, c = R1.d_inputs()
+    logits, gx, pen, grads = R1.dreg_phase(lambda img: RN.discriminator(sd, img, c), x, [sd[k] for k in names])
+    _r1_check(g, logits, gx, pen, dict(zip(names, grads)), TOL_FWD, TOL_GRAD)
+
+
 # ---- the HIP path -------------------------------------------------------------------------------------------------------
 
 def _generator_gradients(math):
@@ -169,6 +201,27 @@ def test_hip_discriminator_with_r1_at_full_width():
     for k in FW.GRAD_KEYS_D:
         _summary_ok(g, 'D.grad.' + k, grads[k], TOL_GRAD)
     _gradnorms_ok(g, 'D.gradnorms', grads, TOL_GRAD)
+
+
+@pytest.mark.gpu
+def test_hip_discriminator_r1_phase_at_full_width():
+    """The Dreg phase exactly as the loss runs it (loss_wo_flow_fullbody.py:236-254: r1_grads under no_weight_gradients,
+    then backward through them): weight gradients of the input-gradient convolutions at 512 / 256 / 128 / 64 channels."""
+    from oracle import make_golden_fullwidth_r1 as R1
+    from training import networks
+    from torch_utils.ops import conv2d_gradfix
+    g = load_golden('models_fullwidth_r1.npz')
+    D = PF.fill_module(networks.Discriminator(**FW.D_KWARGS), kind='normal').cuda().train().requires_grad_(True)
+    names = sorted(dict(D.named_parameters()))
+    sd = dict(D.named_parameters())
+    x, c = (t.cuda() for t in R1.d_inputs())
+    x = x.detach().requires_grad_(True)
+    logits = D(x, c)
+    with conv2d_gradfix.no_weight_gradients():
+        gx, = torch.autograd.grad(outputs=[logits.sum()], inputs=[x], create_graph=True, only_inputs=True)
+    pen = gx.square().sum([1, 2, 3])
+    ((logits * 0 + pen * (R1.R1_GAMMA / 2)).mean() * R1.GAIN).backward()
+    _r1_check(g, logits, gx, pen, {k: sd[k].grad for k in names}, TOL_FWD, TOL_GRAD)
 
 
 @pytest.mark.gpu

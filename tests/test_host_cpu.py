@@ -147,3 +147,34 @@ def test_loss_rejects_terms_outside_the_path():
     with pytest.raises(FileNotFoundError):
         StyleGAN2Loss(vgg_weight=40, contextual_weight=0, **kw)      # no checkpoint and random weights not asked for
     StyleGAN2Loss(vgg_weight=0, contextual_weight=0, **kw)
+
+
+def test_infinite_sampler_reproduces_the_reference_index_streams():
+    """misc.InfiniteSampler (reference misc.py:115-146) against streams the reference's own class produced
+    (oracle/make_golden_sampler.py): same seed -> same indices, rank by rank; the ranks' streams interleave to one global one."""
+    import itertools
+    import json
+    from conftest import load_golden
+    from torch_utils import misc
+    g = load_golden('sampler.npz')
+    cases = json.loads(str(g['manifest']))
+    assert len(cases) >= 7
+    for k, c in enumerate(cases):
+        per_rank = []
+        for rank in range(c['world']):
+            s = misc.InfiniteSampler(list(range(c['n'])), rank=rank, num_replicas=c['world'], shuffle=c['shuffle'], seed=c['seed'],
+                                     window_size=c['window'])
+            got = np.asarray(list(itertools.islice(iter(s), c['count'])), dtype=np.int64)
+            assert np.array_equal(got, g[f'case{k}.rank{rank}']), (k, rank)
+            per_rank.append(got)
+        if not c['shuffle']:      # unshuffled: the global stream is 0, 1, 2, ... mod n dealt round-robin
+            merged = np.stack(per_rank, 1).reshape(-1)
+            assert np.array_equal(merged, np.arange(merged.size) % c['n'])
+    with pytest.raises(AssertionError):
+        misc.InfiniteSampler([], rank=0)
+    with pytest.raises(AssertionError):
+        misc.InfiniteSampler([1], rank=2, num_replicas=2)
+    # usable as a DataLoader sampler
+    import torch.utils.data as tud
+    it = iter(tud.DataLoader(list(range(10)), sampler=misc.InfiniteSampler(list(range(10)), seed=5), batch_size=4))
+    assert next(it).shape == (4,)

@@ -91,6 +91,52 @@ def test_upfirdn2d_live_shapes(idx, dtype):
     assert rel_err(dx.float(), dxr) < tol
 
 
+NONSQUARE_UPFIRDN = [   # planes whose one dimension is k*tile + 1 and whose other ends inside a tile
+    dict(shape=[2, 3, 19, 32], kw=dict(padding=[2, 2, 2, 2])),          # 20 x 33 on 32 x 32 tiles: remainder column
+    dict(shape=[2, 3, 32, 19], kw=dict(padding=[2, 2, 2, 2])),          # 33 x 20: remainder row
+    dict(shape=[2, 3, 45, 64], kw=dict(padding=[2, 2, 2, 2])),          # 46 x 65
+    dict(shape=[1, 2, 130, 256], kw=dict(padding=[2, 2, 2, 2])),        # 131 x 257 on 64 x 16 tiles
+    dict(shape=[1, 2, 256, 130], kw=dict(padding=[2, 2, 2, 2])),        # 257 x 131
+    dict(shape=[2, 3, 33, 50], kw=dict(padding=[1, 1, 1, 1], gain=4)),
+    dict(shape=[2, 3, 40, 24], kw=dict(up=2, padding=[2, 1, 2, 1], gain=4)),
+    dict(shape=[2, 3, 40, 66], kw=dict(down=2, padding=[1, 1, 1, 1])),
+]
+
+
+@pytest.mark.parametrize('idx', range(len(NONSQUARE_UPFIRDN)))
+def test_upfirdn2d_nonsquare_planes_stay_inside_their_plane(idx):
+    """The output is a view into a larger NaN-filled buffer: a store outside the plane (or past the tensor) shows."""
+    from torch_utils.ops import _native
+    from torch_utils.ops import upfirdn2d
+    c = NONSQUARE_UPFIRDN[idx]
+    gen = torch.Generator().manual_seed(100 + idx)
+    xc = torch.randn(c['shape'], generator=gen)
+    f = R.setup_filter([1, 3, 3, 1])
+    yr = R.upfirdn2d(xc, f, **c['kw'])
+    y = upfirdn2d.upfirdn2d(xc.cuda(), f.cuda(), **c['kw'])
+    assert y.shape == yr.shape and rel_err(y, yr) < TOL
+    # same launch through the C ABI into the middle of a canary buffer
+    lib = _native.lib()
+    n = yr.numel()
+    buf = torch.full([3 * n], float('nan'), device='cuda')
+    out = buf[n:2 * n].view(yr.shape)
+    kw = c['kw']
+    up, down = kw.get('up', 1), kw.get('down', 1)
+    px0, px1, py0, py1 = kw['padding']
+    x = xc.cuda()
+    fc = f.cuda()
+    import ctypes
+    i32x4, i64x4, i32x2 = ctypes.c_int32 * 4, ctypes.c_int64 * 4, ctypes.c_int32 * 2
+    rc = lib.pasta_upfirdn2d(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(fc.data_ptr()), ctypes.c_void_p(out.data_ptr()), 0,
+                             i32x4(*x.shape), i64x4(*x.stride()), i32x2(*fc.shape), i32x4(*out.shape), i64x4(*out.stride()),
+                             up, up, down, down, px0, px1, py0, py1, 0, ctypes.c_float(kw.get('gain', 1)),
+                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, lib.pasta_last_error()
+    torch.cuda.synchronize()
+    assert rel_err(out, yr) < TOL
+    assert bool(torch.isnan(buf[:n]).all()) and bool(torch.isnan(buf[2 * n:]).all()), 'stores outside the output tensor'
+
+
 def test_upfirdn2d_channels_last_and_fp64():
     from torch_utils.ops import upfirdn2d
     gen = torch.Generator().manual_seed(7)
