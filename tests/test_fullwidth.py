@@ -109,7 +109,14 @@ def _r1_check(g, logits, gx, pen, grads, tol_fwd, tol_grad):
     from oracle import make_golden_fullwidth_r1 as R1
     assert float(np.abs(g['Dr1.r1_grads.sample']).max()) > 1e-5 and float(g['Dr1.r1_penalty'].min()) > 1e-6      # the fixture itself
     assert rel_err(logits, g['Dr1.logits']) < tol_fwd
-    _summary_ok(g, 'Dr1.r1_grads', gx, tol_fwd, R1.SAMPLES)
+    # d logit / d img is a GRADIENT through 15 leaky-ReLU layers on unit-variance weights: a pre-activation within rounding
+    # of zero takes the other slope under another fp32 evaluation order and changes the gradient at the pixels it feeds, so
+    # single samples are held to the gradient tolerance (measured on MI355X, tools/diag_r1.py: split-bf16 2.8e-4, exact-fp32
+    # MFMA 5.3e-4 from the reference; the two differ by 4e-3 at isolated pixels of the full tensor) while its L1 / L2 moments
+    # and the penalty -- where isolated pixels average out -- meet the forward tolerance (measured 4e-6, 1.2e-5)
+    _summary_ok(g, 'Dr1.r1_grads', gx, tol_grad, R1.SAMPLES)
+    m, mg = PF.summarize(gx, samples=R1.SAMPLES)['moments'], g['Dr1.r1_grads.moments']
+    assert abs(m[1] - mg[1]) <= tol_fwd * abs(mg[1]) and abs(m[2] - mg[2]) <= tol_fwd * abs(mg[2])
     assert rel_err(pen, g['Dr1.r1_penalty']) < tol_fwd
     checked = 0
     for k in FW.GRAD_KEYS_D:
