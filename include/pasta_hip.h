@@ -116,6 +116,11 @@ typedef struct pasta_conv_desc {
                                      (>= 16 input channels per group, > 32 output channels; 3x3 / 1x1 weight gradients on
                                      rows of a multiple of 16 / 32 pixels): pasta_conv2d_plan / pasta_conv2d_wgrad_plan
                                      return an error otherwise and the caller converts that launch to fp32.            */
+    const float* x_amax;          /* PASTA_MATH_F16X3 only, optional: PASTA_AMAX_PARTS partial |max| of the tensor passed as x
+                                     (pasta_tensor_amax wrote them).  NULL: the launch computes them itself into its workspace
+                                     (one extra pass over x).  A caller that uses a tensor in several launches (forward and
+                                     weight gradient; input gradient and weight gradient) computes them once.            */
+    const float* dy_amax;         /* the same for dy (pasta_conv2d_wgrad only)                                         */
 } pasta_conv_desc;
 
 /* Arithmetic of the convolution products.  Accumulation is fp32 in every mode.
@@ -130,9 +135,26 @@ typedef struct pasta_conv_desc {
  *                     (training_loop_wo_flow_fullbody.py:247-249; TF32 keeps 2^-11).  Opt-in, never the default.
  *   PASTA_MATH_BF16   operands rounded to bf16, one product, fp32 accumulate and fp32 tensors in HBM: the arithmetic of
  *                     mixed-precision training (BASELINE config 5).  Opt-in.
- *   The three split modes share kernels (template argument NP = pieces) and the same coverage.
- *   PASTA_MATH_DEFAULT = PASTA_MATH_BF16X6. */
-enum { PASTA_MATH_DEFAULT = 0, PASTA_MATH_F32 = 1, PASTA_MATH_BF16X6 = 2, PASTA_MATH_BF16X3 = 3, PASTA_MATH_BF16 = 4 };
+ *   PASTA_MATH_F16X3  fp32-equivalent products from THREE fp16 products (v_mfma_f32_32x32x16_f16): each operand is scaled
+ *                     by a power of two taken from its tensor's largest magnitude and split into fp16 pieces h + 2^-11 l'
+ *                     (22 + 1 significand bits: representation error <= 2^-23, fp32's own rounding is 2^-24); h h, h l'
+ *                     and l' h are exact in fp32 and accumulate in fp32; the result is scaled back exactly.  Half the
+ *                     matrix work of BF16X6 at the same accuracy class (rms error against fp64 within 10 % of an fp32 FMA
+ *                     chain's: the fp32 accumulation dominates both).  Range: activations keep full precision down to 2^-28
+ *                     of their tensor's largest element, weights (and both operands of a weight gradient) down to 2^-16 of
+ *                     theirs; smaller elements contribute with an absolute error <= 2^-28 amax each.  Non-finite elements
+ *                     are skipped by the scale and stay local.  fp32 storage only; same kernels and coverage as BF16X6
+ *                     except per-sample modulated weights (pasta_conv2d_modulated), which run BF16X6.
+ *   The split modes share kernels (template argument NP = pieces) and the same coverage.
+ *   PASTA_MATH_DEFAULT = PASTA_MATH_BF16X6 (the library's default; the Python front end selects the mode). */
+enum { PASTA_MATH_DEFAULT = 0, PASTA_MATH_F32 = 1, PASTA_MATH_BF16X6 = 2, PASTA_MATH_BF16X3 = 3, PASTA_MATH_BF16 = 4, PASTA_MATH_F16X3 = 5 };
+
+/* Largest finite magnitude of a contiguous fp32 tensor as PASTA_AMAX_PARTS partial maxima (parts[i] >= 0; the maximum over
+ * i is the tensor's): the operand scales of PASTA_MATH_F16X3.  One pass at HBM rate, no atomics, no host round trip;
+ * non-finite elements are skipped.  parts 16-byte aligned.  No reference counterpart (the reference hands fp32
+ * tensors to cuDNN, conv2d_gradfix.py:38); it exists so that a tensor used by several launches is scanned once. */
+#define PASTA_AMAX_PARTS 256
+int pasta_tensor_amax(const void* x, int64_t numel, int dtype, float* parts, void* stream);
 
 /* Bytes of scratch the forward / weight-gradient launches need (caller allocs). */
 int64_t pasta_conv2d_workspace(const pasta_conv_desc* d);

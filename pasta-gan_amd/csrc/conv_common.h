@@ -8,6 +8,11 @@ namespace pasta {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// An empty asm that makes a VGPR value opaque to the SLP vectoriser (no instruction is emitted).
+#define PASTA_KEEP_SCALAR(x) asm("" : "+v"(x))
+// every component of a 16-byte vector counts as used: a partly used LDS read stays one ds_read_b128
+#define PASTA_KEEP_WHOLE(q) asm("" : "+v"((q).x), "+v"((q).y), "+v"((q).z), "+v"((q).w))
+
 constexpr int MAX_TAPS = 49;   // up to 7x7
 
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
@@ -85,6 +90,87 @@ template <int IO> __device__ __forceinline__ f32x16 io_mfma(bf16x8_t a, bf16x8_t
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
 }
 
+//------------------------------------------------------------------------------------
+// PASTA_MATH_F16X3: fp32-equivalent products from THREE fp16 matrix-core products (v_mfma_f32_32x32x16_f16).
+//
+// An fp32 operand v is scaled by a power of two S chosen from the largest magnitude of its tensor (amax * S in [2^13, 2^14):
+// exact, no overflow) and written as   v S = h + r,  h = fp16(v S)  (round to nearest, 11 significand bits),  r exact in fp32,
+// |r| <= 2^-11 |v S|.  The residual is kept as  l' = fp16(2^11 r)  ("pre-scaled low piece": the same magnitude as h, so it is a
+// NORMAL fp16 number wherever h is, and |r - 2^-11 l'| <= 2^-23 |v S| thanks to its own sign).  h h, h l' and l' h are
+// exact in fp32 (11 x 11 bits), so with a third piece  h'' = h 2^-11  (an exponent shift) on the OTHER operand
+//     a b S_a S_b = h_a h_b + h''_a l'_b + l_a h_b          (+ l_a l_b, dropped: <= 2^-22 |a b|)
+// is three MFMAs into ONE fp32 accumulator set; the epilogue multiplies by 1 / (S_a S_b) (exact).  Representation error
+// per operand <= 2^-23 relative (rms 4e-8; fp32's own rounding is 2^-24), i.e. the products are fp32-class, and the fp32
+// accumulation error (measured rms 3 - 8e-7 at K = 2304) dominates as it does for an fp32 FMA chain.
+// Pieces by index: 0 = h, 1 = low piece, 2 = h''.
+//   forward-type kernels: A = weights (packed once per launch: h, l = fp16(r) unscaled, h''), B = activations staged as
+//       (h, l'): TWO pieces, two thirds of the split-bf16 staging and LDS traffic.  Products (A,B): (0,0) (2,1) (1,0).
+//       Activations keep full precision down to 2^-28 of their tensor's largest element, weights down to 2^-16 of theirs
+//       (below that the unscaled l leaves fp16's normal range and an element keeps 11..22 bits: absolute error
+//       <= 2^-28 amax per term).
+//   weight-gradient kernels: both operands are activations: (h, l', h'') each, products (S,L): (0,0) (2,1) (1,2).
+// Scales: the tensor's |max| arrives as 256 partial maxima (pasta_tensor_amax: one pass at HBM rate, non-finite elements
+// skipped so that an inf / NaN stays local); every wave reduces them itself (one 16-byte load per lane) -- no finalising
+// launch, no atomics, no host round trip.
+constexpr int NP_F16X3 = 4;             // pseudo piece count of the template parameter NP: fp16 pieces, three products
+constexpr int AMAX_PARTS = 256;         // partial maxima per tensor
+
+template <int NP> struct Arith {
+    static constexpr bool f16x3 = NP == NP_F16X3;
+    static constexpr int npa = f16x3 ? 3 : NP;          // A pieces in LDS
+    static constexpr int npb = f16x3 ? 2 : NP;          // B pieces in LDS (forward-type kernels)
+    static constexpr int npw = f16x3 ? 3 : NP;          // pieces of either operand in the weight-gradient kernels
+};
+// is the product (A piece pa) x (B piece pb) part of the arithmetic?  forward-type kernels
+template <int NP> __host__ __device__ constexpr bool mm_on(int pa, int pb) {
+    return NP == NP_F16X3 ? ((pa == 0 && pb == 0) || (pa == 2 && pb == 1) || (pa == 1 && pb == 0)) : (pa + pb < NP);
+}
+// ... weight-gradient kernels (S piece pa, L piece pb)
+template <int NP> __host__ __device__ constexpr bool mmw_on(int pa, int pb) {
+    return NP == NP_F16X3 ? ((pa == 0 && pb == 0) || (pa == 2 && pb == 1) || (pa == 1 && pb == 2)) : (pa + pb < NP);
+}
+// the matrix-core instruction of an arithmetic / storage type
+template <int IO, int NP> __device__ __forceinline__ f32x16 mfma16(bf16x8_t a, bf16x8_t b, f32x16 acc) {
+    if constexpr (IO == IO_F16 || NP == NP_F16X3) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+
+// S (power of two) and 1 / S for a tensor whose largest finite magnitude is amax: amax S in [2^13, 2^14); amax == 0 or
+// subnormal: S = 2^120.  Exponent fields stay in [7, 247], so S, 1 / S and every v S are normal or exactly zero.
+__host__ __device__ __forceinline__ void scale_from_amax(float amax, float& S, float& invS) {
+    const uint32_t eb = __builtin_bit_cast(uint32_t, amax) >> 23;          // amax >= 0
+    int field = 267 - (int)eb;                                             // 127 + 14 - (eb - 126)
+    field = field < 7 ? 7 : field > 247 ? 247 : field;
+    S = __builtin_bit_cast(float, (uint32_t)field << 23);
+    invS = __builtin_bit_cast(float, (uint32_t)(254 - field) << 23);
+}
+// the largest of the AMAX_PARTS partial maxima at `parts`, computed redundantly by every wave (wave-uniform result)
+__device__ __forceinline__ float amax_of_parts(const float* __restrict__ parts) {
+    const float4 v = ((const float4*)parts)[threadIdx.x & 63];
+    float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
+}
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// two scaled fp32 values -> h (packed fp16 pair) and the pre-scaled low piece l' = fp16(2^11 (v - h))
+__device__ __forceinline__ void f16_split2(float v0, float v1, uint32_t& h, uint32_t& lp) {
+    const f16x2_t hh = __builtin_convertvector(f32x2_t{v0, v1}, f16x2_t);
+    h = __builtin_bit_cast(uint32_t, hh);
+    float r0 = v0 - (float)hh[0], r1 = v1 - (float)hh[1];
+    PASTA_KEEP_SCALAR(r0);
+    lp = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{r0 * 2048.f, r1 * 2048.f}, f16x2_t));
+}
+// h'' = h 2^-11 on a packed fp16 pair (exact while the result is a normal fp16 number)
+__device__ __forceinline__ uint32_t f16_shift11(uint32_t h) {
+    const f16x2_t k = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2_t, h) * k);
+}
+
+// AMAX_PARTS partial |max| of a contiguous tensor (amax.hip)
+int tensor_amax(const void* x, int64_t numel, int dtype, float* parts, hipStream_t s);
+
 // accumulator -> output value: demodulation scale and noise as mod_bias_act_kernel rounds them (fma(acc, d, noise * strength)),
 // residual, then bias / activation / gain / clamp.  d = 1 and nz = 0 leave the accumulator bit-identical.
 __device__ __forceinline__ float conv_scale_noise(float v, const float* osb, int o, float nz) {
@@ -95,6 +181,8 @@ __device__ __forceinline__ float conv_scale_noise(float v, const float* osb, int
 struct ConvFwdParams {
     const float* x; const float* wp; float* y;         // x, y (and res): elements of type `io` behind these pointers
     const float* iscale; const float* oscale;
+    const float* x_amax; const float* w_amax;           // PASTA_MATH_F16X3: AMAX_PARTS partial |max| of x and of w (w: before wscale)
+    float w_gain;                                       // |wscale|: the packed weights are w * wscale
     int io;                                             // IO_F32 / IO_F16 / IO_BF16
     int N, Cin, H, W;
     int Cout, OH, OW;
@@ -135,14 +223,10 @@ static int fwd_tile_bm(FwdTile t) { return t == T128x128 ? 128 : t == T32x256 ? 
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// An empty asm that makes a VGPR value opaque to the SLP vectoriser (no instruction is emitted).
-#define PASTA_KEEP_SCALAR(x) asm("" : "+v"(x))
-// every component of a 16-byte vector counts as used: a partly used LDS read stays one ds_read_b128
-#define PASTA_KEEP_WHOLE(q) asm("" : "+v"((q).x), "+v"((q).y), "+v"((q).z), "+v"((q).w))
-
 // Parameters of the weight-gradient kernels: dW[tap][a][b] = sum_pix S[a][pix] * L[b][pix * st + tap offset].
 struct WgradParams {
     const float* S; const float* L; float* slab;        // S, L: elements of type `io`; slab: fp32
+    const float* s_amax; const float* l_amax;           // PASTA_MATH_F16X3: AMAX_PARTS partial |max| of S and of L
     int io;                 // IO_F32 / IO_F16 / IO_BF16
     int N, SC, P, Q;        // S: [N, SC, P, Q]
     int LC, LH, LW;         // L: [N, LC, LH, LW]

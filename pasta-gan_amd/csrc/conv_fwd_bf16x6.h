@@ -30,7 +30,10 @@ __device__ __forceinline__ void split3(float v, __bf16& a, __bf16& b, __bf16& c)
 __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int G, int Ig,
                                                                 int Og, int Ig_pad, int Og_pad, int kh, int kw, int transposed,
                                                                 int flip, float wscale, int f16, const float* __restrict__ mod_s,
-                                                                const float* __restrict__ mod_d) {
+                                                                const float* __restrict__ mod_d, const float* __restrict__ w_amax) {
+    // f16: 0 = three bf16 pieces, 1 = fp16 storage (leading piece = the fp16 operand), 2 = PASTA_MATH_F16X3 (h, l, h'' of w S)
+    float w_S = 1.f;
+    if (f16 == 2) { float inv; scale_from_amax(amax_of_parts(w_amax) * fabsf(wscale), w_S, inv); }
     const int64_t total = (int64_t)G * kh * kw * Ig_pad * Og_pad;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int j = (int)(idx & 7);
@@ -55,7 +58,14 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __r
         }
         __bf16 p1, p2, p3;
         split3(v, p1, p2, p3);
-        if (f16) p1 = __builtin_bit_cast(__bf16, (_Float16)v);      // fp16 storage: the leading piece is the fp16 operand (the others are unused)
+        if (f16 == 1) p1 = __builtin_bit_cast(__bf16, (_Float16)v);      // fp16 storage: the leading piece is the fp16 operand (the others are unused)
+        if (f16 == 2) {              // conv_common.h, PASTA_MATH_F16X3: the weight side keeps its low piece unscaled and carries h'' = h 2^-11
+            const float vs = v * w_S;
+            const _Float16 h = (_Float16)vs;
+            const _Float16 l = (_Float16)(vs - (float)h);
+            const _Float16 h2 = h * (_Float16)0.00048828125f;
+            p1 = __builtin_bit_cast(__bf16, h); p2 = __builtin_bit_cast(__bf16, l); p3 = __builtin_bit_cast(__bf16, h2);
+        }
         const int64_t chunk = (((int64_t)g * kh * kw + t) * (Ig_pad / 16) + cc) * 6 * Og_pad * 8;
         const int64_t within = ((int64_t)half * Og_pad + o) * 8 + j;
         wp[chunk + within] = p1;
@@ -75,16 +85,18 @@ template <int BM, int BN, int OCC, int NP, int IO = IO_F32, bool ISC = false>   
 __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams p) {
     static_assert(IO == IO_F32 || NP == 1, "16-bit storage: the element is the operand, one product");
     constexpr unsigned ES = io_size<IO>::value;
+    constexpr bool HX = Arith<NP>::f16x3;               // PASTA_MATH_F16X3 (conv_common.h)
+    constexpr int NPA = Arith<NP>::npa, NPB = Arith<NP>::npb;
     constexpr int WMT = 2, WNT = 2, KC = 16;
     constexpr int WAVES_N = BN / 64;
     static_assert((BM / 64) * WAVES_N == 4, "four waves per workgroup");
     constexpr int ASEG = BM * 8, BSEG = BN * 8;         // bf16 elements of one (piece, half) segment
-    constexpr int AUNITS = 2 * NP * BM;                 // sixteen-byte units of the A chunk
+    constexpr int AUNITS = 2 * NPA * BM;                // sixteen-byte units of the A chunk
     constexpr int APT = (AUNITS + 255) / 256;           // per thread: 3 (BM 128) or 2 (BM 64, second one guarded)
     constexpr int BPT = BN * 2 / 256;                   // (pixel, k-half) pairs per thread: 1 or 2
     // A buffers are rounded up to APT * 256 units: every thread copies APT units without a guard (see load_chunk)
     __shared__ __attribute__((aligned(16))) __bf16 As[2][APT * 256 * 8];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][2 * NP * BSEG];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][2 * NPB * BSEG];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -135,6 +147,13 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     // The loop body is free of data-dependent control flow around its memory operations: every step issues the same
     // loads and stores (past the end of the K range they re-read valid addresses and the activations are zeroed), so
     // that the s_waitcnt counters the compiler derives let a fetch stay in flight for a whole step.
+    float x_scale = 1.f, out_scale = 1.f;          // PASTA_MATH_F16X3: operand scales from the tensors' partial maxima
+    if constexpr (HX) {
+        float sx, isx, sw, isw;
+        scale_from_amax(amax_of_parts(p.x_amax), sx, isx);
+        scale_from_amax(amax_of_parts(p.w_amax) * p.w_gain, sw, isw);
+        x_scale = sx; out_scale = isx * isw;
+    }
     struct Stage { float b[8 * BPT]; float sc[ISC ? 8 * BPT : 1]; int nvalid[BPT]; };
     Stage st0, st1;
     const float* const isb = ISC ? p.iscale + (int64_t)n_in * p.Cin + (int64_t)g * p.Ig : nullptr;
@@ -203,6 +222,10 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
             v0 = 2 * j < st.nvalid[i] ? v0 : 0.f;
             v1 = 2 * j + 1 < st.nvalid[i] ? v1 : 0.f;
         }
+        if constexpr (HX) {
+            f16_split2(v0 * x_scale, v1 * x_scale, q1[i][j], q2[i][j]);
+            return;
+        }
         f32x2 v = {v0, v1};
         uint32_t w = io_pack2<IO>(v0, v1);
         q1[i][j] = w;
@@ -229,8 +252,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
         for (int i = 0; i < BPT; i++) {
             __bf16* bd = &Bs[buf][((half0 + i) * BN + bcol) * 8];
             *(uint4*)(bd) = make_uint4(q1[i][0], q1[i][1], q1[i][2], q1[i][3]);
-            if constexpr (NP >= 2) *(uint4*)(bd + 2 * BSEG) = make_uint4(q2[i][0], q2[i][1], q2[i][2], q2[i][3]);
-            if constexpr (NP >= 3) *(uint4*)(bd + 4 * BSEG) = make_uint4(q3[i][0], q3[i][1], q3[i][2], q3[i][3]);
+            if constexpr (NPB >= 2) *(uint4*)(bd + 2 * BSEG) = make_uint4(q2[i][0], q2[i][1], q2[i][2], q2[i][3]);
+            if constexpr (NPB >= 3) *(uint4*)(bd + 4 * BSEG) = make_uint4(q3[i][0], q3[i][1], q3[i][2], q3[i][3]);
         }
     };
     auto store_a = [&](int buf) {
@@ -251,8 +274,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     // Fragments of one chunk: [tile][piece], read in the order the MFMA groups consume them.
     struct Frag { bf16x8 a[WMT][3], b[WNT][3]; };
     auto read_frag = [&](Frag& f, int buf) {
-#define PASTA_LDA(PC) if constexpr ((PC) < NP) { _Pragma("unroll") for (int a = 0; a < WMT; a++) f.a[a][PC] = *(const bf16x8*)&As[buf][(((PC) * 2 + hl) * BM + (wm * WMT + a) * 32 + jl) * 8]; }
-#define PASTA_LDB(PC) if constexpr ((PC) < NP) { _Pragma("unroll") for (int b = 0; b < WNT; b++) f.b[b][PC] = *(const bf16x8*)&Bs[buf][(((PC) * 2 + hl) * BN + (wn * WNT + b) * 32 + jl) * 8]; }
+#define PASTA_LDA(PC) if constexpr ((PC) < NPA) { _Pragma("unroll") for (int a = 0; a < WMT; a++) f.a[a][PC] = *(const bf16x8*)&As[buf][(((PC) * 2 + hl) * BM + (wm * WMT + a) * 32 + jl) * 8]; }
+#define PASTA_LDB(PC) if constexpr ((PC) < NPB) { _Pragma("unroll") for (int b = 0; b < WNT; b++) f.b[b][PC] = *(const bf16x8*)&Bs[buf][(((PC) * 2 + hl) * BN + (wn * WNT + b) * 32 + jl) * 8]; }
         PASTA_LDA(2) PASTA_LDB(0) PASTA_LDA(0) PASTA_LDB(2) PASTA_LDA(1) PASTA_LDB(1)
 #undef PASTA_LDA
 #undef PASTA_LDB
@@ -264,11 +287,19 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
         Frag f;
         read_frag(f, buf);
 #define PASTA_MM(PA, PB)                                                                                       \
-        if constexpr ((PA) + (PB) < NP) {                                                                        \
+        if constexpr (mm_on<NP>(PA, PB)) {                                                                       \
         _Pragma("unroll") for (int a = 0; a < WMT; a++) _Pragma("unroll") for (int b = 0; b < WNT; b++)          \
-            acc[a][b] = io_mfma<IO>(f.a[a][PA], f.b[b][PB], acc[a][b]); }
+            acc[a][b] = mfma16<IO, NP>(f.a[a][PA], f.b[b][PB], acc[a][b]); }
 #define PASTA_SPLIT(J) _Pragma("unroll") for (int i = 0; i < BPT; i++) split_pair(cur_next, i, J);
         // smallest terms first: a3b1, a1b3, a2b2, a2b1, a1b2, a1b1
+        if constexpr (HX) {
+            PASTA_MM(2, 1)
+            PASTA_SPLIT(0)
+            PASTA_SPLIT(1)
+            PASTA_MM(1, 0)
+            PASTA_SPLIT(2)
+            PASTA_SPLIT(3)
+        } else {
         PASTA_MM(2, 0)
         PASTA_SPLIT(0)
         PASTA_MM(0, 2)
@@ -278,6 +309,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
         PASTA_MM(1, 0)
         PASTA_SPLIT(3)
         PASTA_MM(0, 1)
+        }
         store_b(buf ^ 1); store_a(buf ^ 1);
         PASTA_MM(0, 0)
 #undef PASTA_MM
@@ -323,6 +355,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
                 const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
                 if (o < p.Og) {
                     float v = acc[a][b][r];
+                    if constexpr (HX) v *= out_scale;
                     v = conv_scale_noise(v, osb, o, nz);
                     if (has_res) v += io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES);
                     if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
@@ -374,14 +407,17 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     static_assert(!ISC || PIPE <= 1, "the input scale is staged by the default schedules only");
     static_assert(!PAIR || (PIPE == 2 && !ISC), "the parity-pair mode runs on the register-diet schedule");
     constexpr unsigned ES = io_size<IO>::value;
+    constexpr bool HX = Arith<NP>::f16x3;               // PASTA_MATH_F16X3 (conv_common.h): default schedules only
+    static_assert(!HX || (PIPE <= 1 && !PAIR), "the three-product fp16 arithmetic runs on the default schedules");
+    constexpr int NPA = Arith<NP>::npa, NPB = Arith<NP>::npb;
     constexpr int WMT = 2, WNT = 2, KC = 16;
     constexpr int WAVES_N = BN / 64;
     static_assert((BM / 64) * WAVES_N == 4, "four waves per workgroup");
-    constexpr int AUNITS = 2 * NP * BM;
+    constexpr int AUNITS = 2 * NPA * BM;
     constexpr int APT = (AUNITS + 255) / 256;
     constexpr int BPT = BN * 2 / 256;                   // (pixel, k-half) pairs per thread: 1 or 2
     constexpr int SLOTS = BN + 16;                      // up to 8 segments with two halo slots each
-    constexpr int ABUF = APT * 256 * 8, BSEG = SLOTS * 8, BBUF = 2 * NP * BSEG;      // bf16 elements
+    constexpr int ABUF = APT * 256 * 8, BSEG = SLOTS * 8, BBUF = 2 * NPB * BSEG;     // 16-bit elements
     extern __shared__ __attribute__((aligned(16))) __bf16 rows_smem[];
     __bf16* const As = rows_smem;                       // [2][ABUF]  (PIPE 3: the weights never enter LDS)
     __bf16* const Bs = rows_smem + (PIPE == 3 ? 0 : 2 * ABUF);            // [2][BBUF]
@@ -452,6 +488,13 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
         h_pix = h_ok ? hb_off + (unsigned)(hy * p.W + h_cx) * ES : hb_off;
     };
     set_row(b_dy);
+    float x_scale = 1.f, out_scale = 1.f;          // PASTA_MATH_F16X3: operand scales from the tensors' partial maxima
+    if constexpr (HX) {
+        float sx, isx, sw, isw;
+        scale_from_amax(amax_of_parts(p.x_amax), sx, isx);
+        scale_from_amax(amax_of_parts(p.w_amax) * p.w_gain, sw, isw);
+        x_scale = sx; out_scale = isx * isw;
+    }
     float mb[8 * BPT], hb[8 * BPT];
     float msc[ISC ? 8 * BPT : 1], hsc[ISC ? 8 * BPT : 1];           // ISC: the input scales of the channels in mb / hb
     const float* const m_isb = ISC ? p.iscale + (int64_t)n_in * p.Cin + (int64_t)g * p.Ig : nullptr;
@@ -545,6 +588,10 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
             v0 = 2 * j < nvalid[i] ? v0 : 0.f;
             v1 = 2 * j + 1 < nvalid[i] ? v1 : 0.f;
         }
+        if constexpr (HX) {
+            f16_split2(v0 * x_scale, v1 * x_scale, q1[i][j], q2[i][j]);
+            return;
+        }
         f32x2 v = {v0, v1};
         uint32_t w = io_pack2<IO>(v0, v1);
         q1[i][j] = w;
@@ -571,8 +618,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
         for (int i = 0; i < BPT; i++) {
             __bf16* bd = Bs + buf * BBUF + ((hbase + i) * SLOTS + slot) * 8;
             *(uint4*)(bd) = make_uint4(q1[i][0], q1[i][1], q1[i][2], q1[i][3]);
-            if constexpr (NP >= 2) *(uint4*)(bd + 2 * BSEG) = make_uint4(q2[i][0], q2[i][1], q2[i][2], q2[i][3]);
-            if constexpr (NP >= 3) *(uint4*)(bd + 4 * BSEG) = make_uint4(q3[i][0], q3[i][1], q3[i][2], q3[i][3]);
+            if constexpr (NPB >= 2) *(uint4*)(bd + 2 * BSEG) = make_uint4(q2[i][0], q2[i][1], q2[i][2], q2[i][3]);
+            if constexpr (NPB >= 3) *(uint4*)(bd + 4 * BSEG) = make_uint4(q3[i][0], q3[i][1], q3[i][2], q3[i][3]);
         }
     };
 
@@ -596,8 +643,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     auto read_frag = [&](Frag& f, int abuf, int bbuf, int off) {
         const __bf16* A_ = As + abuf * ABUF;
         const __bf16* B_ = Bs + bbuf * BBUF;
-#define PASTA_LDA(PC) if constexpr ((PC) < NP) { _Pragma("unroll") for (int a = 0; a < WMT; a++) f.a[a][PC] = *(const bf16x8*)&A_[(((PC) * 2 + hl) * BM + (wm * WMT + a) * 32 + jl) * 8]; }
-#define PASTA_LDB(PC) if constexpr ((PC) < NP) { _Pragma("unroll") for (int b = 0; b < WNT; b++) f.b[b][PC] = *(const bf16x8*)&B_[(((PC) * 2 + hl) * SLOTS + fslot[b] + off) * 8]; }
+#define PASTA_LDA(PC) if constexpr ((PC) < NPA) { _Pragma("unroll") for (int a = 0; a < WMT; a++) f.a[a][PC] = *(const bf16x8*)&A_[(((PC) * 2 + hl) * BM + (wm * WMT + a) * 32 + jl) * 8]; }
+#define PASTA_LDB(PC) if constexpr ((PC) < NPB) { _Pragma("unroll") for (int b = 0; b < WNT; b++) f.b[b][PC] = *(const bf16x8*)&B_[(((PC) * 2 + hl) * SLOTS + fslot[b] + off) * 8]; }
         PASTA_LDA(2) PASTA_LDB(0) PASTA_LDA(0) PASTA_LDB(2) PASTA_LDA(1) PASTA_LDB(1)
 #undef PASTA_LDA
 #undef PASTA_LDB
@@ -622,12 +669,20 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
         Frag f;
         read_frag(f, abuf, bbuf, p.rows_rev ? 2 - TAP : TAP);
 #define PASTA_MM(PA, PB)                                                                                       \
-        if constexpr ((PA) + (PB) < NP) {                                                                        \
+        if constexpr (mm_on<NP>(PA, PB)) {                                                                       \
         _Pragma("unroll") for (int a = 0; a < WMT; a++) _Pragma("unroll") for (int b = 0; b < WNT; b++)          \
-            acc[a][b] = io_mfma<IO>(f.a[a][PA], f.b[b][PB], acc[a][b]); }
+            acc[a][b] = mfma16<IO, NP>(f.a[a][PA], f.b[b][PB], acc[a][b]); }
 #define PASTA_SPLIT(J)                                                                                         \
         if (TAP == 1) { _Pragma("unroll") for (int i = 0; i < BPT; i++) split_pair(mb, m_nvalid, i, J, msc); }   \
         if (TAP == 2 && wave == h_owner) { _Pragma("unroll") for (int i = 0; i < BPT; i++) split_pair(hb, h_nvalid, i, J, hsc); }
+        if constexpr (HX) {
+            PASTA_MM(2, 1)
+            PASTA_SPLIT(0)
+            PASTA_SPLIT(1)
+            PASTA_MM(1, 0)
+            PASTA_SPLIT(2)
+            PASTA_SPLIT(3)
+        } else {
         PASTA_MM(2, 0)
         PASTA_SPLIT(0)
         PASTA_MM(0, 2)
@@ -637,6 +692,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
         PASTA_MM(1, 0)
         PASTA_SPLIT(3)
         PASTA_MM(0, 1)
+        }
         if (TAP == 1) store_q(bbuf ^ 1, m_slot, half0);
         if (TAP == 2 && wave == h_owner) store_q(bbuf ^ 1, h_slot, h_half);
         store_a(abuf ^ 1, PIPE == 1 ? abuf ^ 1 : 0);        // PIPE 1: the set fetched by the previous step
@@ -874,6 +930,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
                 const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
                 if (o < p.Og) {
                     float v = acc[a][b][r];
+                    if constexpr (HX) v *= out_scale;
                     v = conv_scale_noise(v, osb, o, nz);
                     if (has_res) v += io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES);
                     if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
@@ -894,12 +951,12 @@ template <int BM, int BN, int NP, int IO>
 static void launch_fwd_bf16_np(const ConvFwdParams& q, dim3 grid, hipStream_t s) {
     if (q.rows && q.ncls == 1 && rows_tile_ok(q.cls[0].P, q.cls[0].Q, BN)) {
         // row-reuse kernel: full tiles made of whole row segments inside one image
-        constexpr int APT = (2 * NP * BM + 255) / 256;
-        constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 2 * NP * (BN + 16) * 8) * sizeof(__bf16);
+        constexpr int APT = (2 * Arith<NP>::npa * BM + 255) / 256;
+        constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 2 * Arith<NP>::npb * (BN + 16) * 8) * sizeof(__bf16);
         static bool attr_set = false;
         static int pipe = 1;
         if (!attr_set) {
-            if constexpr (IO == IO_F32)
+            if constexpr (IO == IO_F32 && NP != NP_F16X3)
                 (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 0, NP, IO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if constexpr (IO == IO_F32 && NP == 3)
                 (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 3, 2, NP, IO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -921,7 +978,7 @@ static void launch_fwd_bf16_np(const ConvFwdParams& q, dim3 grid, hipStream_t s)
                 return;
             }
         }
-        if constexpr (IO == IO_F32) {
+        if constexpr (IO == IO_F32 && NP != NP_F16X3) {
             if (pipe == 0) { hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 0, NP, IO>), grid, dim3(256), lds, s, q); return; }
         }
         hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP, IO>), grid, dim3(256), lds, s, q);
@@ -932,20 +989,20 @@ static void launch_fwd_bf16_np(const ConvFwdParams& q, dim3 grid, hipStream_t s)
 
 // The same two kernels with the input scale in the staging (fp32 storage, six products: the no-grad forward of a modulated
 // convolution; other arithmetics keep the separate scaling pass).
-template <int BM, int BN>
+template <int BM, int BN, int NP = 3>
 static void launch_fwd_bf16_isc(const ConvFwdParams& q, dim3 grid, hipStream_t s) {
     if (q.rows && q.ncls == 1 && rows_tile_ok(q.cls[0].P, q.cls[0].Q, BN)) {
         constexpr int APT = (2 * 3 * BM + 255) / 256;
-        constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 2 * 3 * (BN + 16) * 8) * sizeof(__bf16);
+        constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 2 * Arith<NP>::npb * (BN + 16) * 8) * sizeof(__bf16);
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, 3, IO_F32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP, IO_F32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
-        hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, 3, IO_F32, true>), grid, dim3(256), lds, s, q);
+        hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP, IO_F32, true>), grid, dim3(256), lds, s, q);
         return;
     }
-    hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<BM, BN, 2, 3, IO_F32, true>), grid, dim3(256), 0, s, q);
+    hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<BM, BN, 2, NP, IO_F32, true>), grid, dim3(256), 0, s, q);
 }
 
 template <int BM, int BN>
@@ -960,11 +1017,13 @@ static void launch_fwd_bf16x6(const ConvFwdParams& p, hipStream_t s) {
     tiles *= p.ncls;
     dim3 grid((unsigned)tiles, q.o_tiles * q.ksplit, p.G);
     // p.bf16x6 = number of bf16 pieces per operand (3: six products, 2: three, 1: one)
-    if (p.iscale)           launch_fwd_bf16_isc<BM, BN>(q, grid, s);                  // fp32 storage, six products (the caller checked)
+    if (p.iscale && p.bf16x6 == NP_F16X3) launch_fwd_bf16_isc<BM, BN, NP_F16X3>(q, grid, s);
+    else if (p.iscale)      launch_fwd_bf16_isc<BM, BN>(q, grid, s);                  // fp32 storage, six products (the caller checked)
     else if (p.io == IO_BF16)    launch_fwd_bf16_np<BM, BN, 1, IO_BF16>(q, grid, s);       // 16-bit storage: always one product
     else if (p.io == IO_F16) launch_fwd_bf16_np<BM, BN, 1, IO_F16>(q, grid, s);
     else if (p.bf16x6 == 1) launch_fwd_bf16_np<BM, BN, 1, IO_F32>(q, grid, s);
     else if (p.bf16x6 == 2) launch_fwd_bf16_np<BM, BN, 2, IO_F32>(q, grid, s);
+    else if (p.bf16x6 == NP_F16X3) launch_fwd_bf16_np<BM, BN, NP_F16X3, IO_F32>(q, grid, s);
     else                    launch_fwd_bf16_np<BM, BN, 3, IO_F32>(q, grid, s);
 }
 

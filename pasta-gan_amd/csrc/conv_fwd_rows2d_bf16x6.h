@@ -28,7 +28,9 @@ namespace pasta {
 template <int BM, int BN, int R, int NP = 3, int IO = IO_F32, bool ISC = false, int NT = 256>
 __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_kernel(ConvFwdParams p) {
     static_assert(IO == IO_F32 || NP == 1, "16-bit storage: the element is the operand, one product");
-    static_assert(!ISC || (NP == 3 && IO == IO_F32), "the input scale rides in the six-product fp32 staging");
+    static_assert(!ISC || ((NP == 3 || NP == NP_F16X3) && IO == IO_F32), "the input scale rides in the fp32-equivalent staging");
+    constexpr bool HX = Arith<NP>::f16x3;               // PASTA_MATH_F16X3: fp16 pieces, three products (conv_common.h)
+    constexpr int NPA = Arith<NP>::npa, NPB = Arith<NP>::npb;
     constexpr unsigned ES = io_size<IO>::value;
     constexpr int WMT = 2, WNT = 2, KC = 16;
     constexpr int WAVES_N = BN / 64;
@@ -39,8 +41,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
     static_assert(UPT <= 4, "at most four staging units per thread and chunk");
     // unit k of the next chunk is fetched at step LSTEP(k) and split + stored at step TSTEP(k)
     constexpr int USTRIDE = UPT <= 3 ? 3 : 2;
-    constexpr int AUNITS = 2 * NP * BM, APT = (AUNITS + NT - 1) / NT;
-    constexpr int ABUF = APT * NT * 8, BSEG = SLOTS * 8, BBUF = 2 * NP * BSEG;      // bf16 elements
+    constexpr int AUNITS = 2 * NPA * BM, APT = (AUNITS + NT - 1) / NT;
+    constexpr int ABUF = APT * NT * 8, BSEG = SLOTS * 8, BBUF = 2 * NPB * BSEG;      // 16-bit elements
     extern __shared__ __attribute__((aligned(16))) __bf16 rows2d_smem[];
     __bf16* const As = rows2d_smem;                     // [2][ABUF]
     __bf16* const Bs = rows2d_smem + 2 * ABUF;          // [2][BBUF]
@@ -86,6 +88,14 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
         u_lds[k] = real ? (half * SLOTS + slot) * 8 : -1;           // element offset inside a piece of the B image; -1: no unit
     }
 
+    // PASTA_MATH_F16X3: power-of-two scales of the two operands (every wave reduces the partial maxima itself)
+    float x_scale = 1.f, out_scale = 1.f;
+    if constexpr (HX) {
+        float sx, isx, sw, isw;
+        scale_from_amax(amax_of_parts(p.x_amax), sx, isx);
+        scale_from_amax(amax_of_parts(p.w_amax) * p.w_gain, sw, isw);
+        x_scale = sx; out_scale = isx * isw;
+    }
     float sb0[8], sb1[8];                               // the two staging register sets
     float sc0[ISC ? 8 : 1], sc1[ISC ? 8 : 1];           // ISC: the input scales of their channels
     const float* const isb = ISC ? p.iscale + (int64_t)n_img * p.Cin + (int64_t)g * p.Ig : nullptr;
@@ -111,6 +121,10 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
             v0 = 2 * j < nv ? v0 : 0.f;
             v1 = 2 * j + 1 < nv ? v1 : 0.f;
         }
+        if constexpr (HX) {
+            f16_split2(v0 * x_scale, v1 * x_scale, q1[j], q2[j]);
+            return;
+        }
         f32x2 v = {v0, v1};
         uint32_t w = io_pack2<IO>(v0, v1);
         q1[j] = w;
@@ -134,8 +148,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
         if (u_lds[k] >= 0) {
             __bf16* bd = Bs + bbuf * BBUF + u_lds[k];
             *(uint4*)(bd) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
-            if constexpr (NP >= 2) *(uint4*)(bd + 2 * BSEG) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
-            if constexpr (NP >= 3) *(uint4*)(bd + 4 * BSEG) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+            if constexpr (NPB >= 2) *(uint4*)(bd + 2 * BSEG) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+            if constexpr (NPB >= 3) *(uint4*)(bd + 4 * BSEG) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
         }
     };
 
@@ -188,8 +202,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
     auto read_frag = [&](Frag& f, int abuf, int bbuf, int off) {
         const __bf16* A_ = As + abuf * ABUF;
         const __bf16* B_ = Bs + bbuf * BBUF;
-#define PASTA_LDA(PC) if constexpr ((PC) < NP) { _Pragma("unroll") for (int a = 0; a < WMT; a++) f.a[a][PC] = *(const bf16x8*)&A_[(((PC) * 2 + hl) * BM + (wm * WMT + a) * 32 + jl) * 8]; }
-#define PASTA_LDB(PC) if constexpr ((PC) < NP) { _Pragma("unroll") for (int b = 0; b < WNT; b++) f.b[b][PC] = *(const bf16x8*)&B_[(((PC) * 2 + hl) * SLOTS + fslot[b] + off) * 8]; }
+#define PASTA_LDA(PC) if constexpr ((PC) < NPA) { _Pragma("unroll") for (int a = 0; a < WMT; a++) f.a[a][PC] = *(const bf16x8*)&A_[(((PC) * 2 + hl) * BM + (wm * WMT + a) * 32 + jl) * 8]; }
+#define PASTA_LDB(PC) if constexpr ((PC) < NPB) { _Pragma("unroll") for (int b = 0; b < WNT; b++) f.b[b][PC] = *(const bf16x8*)&B_[(((PC) * 2 + hl) * SLOTS + fslot[b] + off) * 8]; }
         PASTA_LDA(2) PASTA_LDB(0) PASTA_LDA(0) PASTA_LDB(2) PASTA_LDA(1) PASTA_LDB(1)
 #undef PASTA_LDA
 #undef PASTA_LDB
@@ -221,10 +235,18 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
         Frag f;
         read_frag(f, gpar, PAR, toff[S]);
 #define PASTA_MM(PA, PB)                                                                                       \
-        if constexpr ((PA) + (PB) < NP) {                                                                        \
+        if constexpr (mm_on<NP>(PA, PB)) {                                                                       \
         _Pragma("unroll") for (int a = 0; a < WMT; a++) _Pragma("unroll") for (int b = 0; b < WNT; b++)          \
-            acc[a][b] = io_mfma<IO>(f.a[a][PA], f.b[b][PB], acc[a][b]); }
+            acc[a][b] = mfma16<IO, NP>(f.a[a][PA], f.b[b][PB], acc[a][b]); }
 #define PASTA_SPLIT(J) if (ku != NOUNIT) { if ((ku & 1) == 0) split_pair(sb0, sc0, nv0, J); else split_pair(sb1, sc1, nv1, J); }
+        if constexpr (HX) {                 // three product groups: h'' l', l h, h h -- smallest terms first
+            PASTA_MM(2, 1)
+            PASTA_SPLIT(0)
+            PASTA_SPLIT(1)
+            PASTA_MM(1, 0)
+            PASTA_SPLIT(2)
+            PASTA_SPLIT(3)
+        } else {
         PASTA_MM(2, 0)
         PASTA_SPLIT(0)
         PASTA_MM(0, 2)
@@ -234,6 +256,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
         PASTA_MM(1, 0)
         PASTA_SPLIT(3)
         PASTA_MM(0, 1)
+        }
         if (ku != NOUNIT) store_unit(ku, PAR ^ 1);
         store_a(gpar ^ 1, gpar ^ 1);
         PASTA_MM(0, 0)
@@ -280,6 +303,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
                 const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r16, lane);
                 if (o < p.Og) {
                     float v = acc[a][b][r16];
+                    if constexpr (HX) v *= out_scale;
                     v = conv_scale_noise(v, osb, o, nz);
                     if (has_res) v += io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES);
                     if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
@@ -300,8 +324,8 @@ static bool rows2d_tile_ok(int P, int Q) {
 template <int BM, int BN, int R, int NP, int IO, bool ISC = false, int NT = 256>
 static void launch_fwd_rows2d_np(const ConvFwdParams& q, dim3 grid, hipStream_t s) {
     constexpr int SEG = BN / R, SLOTS = (R + 2) * (SEG + 2);
-    constexpr int APT = (2 * NP * BM + NT - 1) / NT;
-    constexpr size_t lds = (size_t)(2 * APT * NT * 8 + 2 * 2 * NP * SLOTS * 8) * sizeof(__bf16);
+    constexpr int APT = (2 * Arith<NP>::npa * BM + NT - 1) / NT;
+    constexpr size_t lds = (size_t)(2 * APT * NT * 8 + 2 * 2 * Arith<NP>::npb * SLOTS * 8) * sizeof(__bf16);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_fwd_rows2d_bf16x6_kernel<BM, BN, R, NP, IO, ISC, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -317,11 +341,13 @@ static void launch_fwd_rows2d(const ConvFwdParams& p, hipStream_t s) {
     constexpr int SEG = BN / R;
     const int64_t tiles = (int64_t)p.N * (p.cls[0].P / R) * (p.cls[0].Q / SEG);
     dim3 grid((unsigned)tiles, q.o_tiles * q.ksplit, p.G);
-    if (p.iscale)            launch_fwd_rows2d_np<BM, BN, R, 3, IO_F32, true>(q, grid, s);   // fp32 storage, six products (the caller checked)
+    if (p.iscale && p.bf16x6 == NP_F16X3) launch_fwd_rows2d_np<BM, BN, R, NP_F16X3, IO_F32, true>(q, grid, s);
+    else if (p.iscale)       launch_fwd_rows2d_np<BM, BN, R, 3, IO_F32, true>(q, grid, s);   // fp32 storage, six products (the caller checked)
     else if (p.io == IO_BF16) launch_fwd_rows2d_np<BM, BN, R, 1, IO_BF16>(q, grid, s);     // 16-bit storage: one product
     else if (p.io == IO_F16) launch_fwd_rows2d_np<BM, BN, R, 1, IO_F16>(q, grid, s);
     else if (p.bf16x6 == 1)  launch_fwd_rows2d_np<BM, BN, R, 1, IO_F32>(q, grid, s);
     else if (p.bf16x6 == 2)  launch_fwd_rows2d_np<BM, BN, R, 2, IO_F32>(q, grid, s);
+    else if (p.bf16x6 == NP_F16X3) launch_fwd_rows2d_np<BM, BN, R, NP_F16X3, IO_F32>(q, grid, s);
     else                     launch_fwd_rows2d_np<BM, BN, R, 3, IO_F32>(q, grid, s);
 }
 
@@ -361,11 +387,13 @@ static bool try_fwd_rows2d(const ConvFwdParams& p, hipStream_t s) {
     ConvFwdParams q = p;
     q.rows_y0 = ymin;
     if constexpr (BN == 128) {
-        if (rows2d_wide(p.cls[0].P, p.cls[0].Q) && p.bf16x6 == 3 && p.io == IO_F32 && !p.iscale) {
+        if (rows2d_wide(p.cls[0].P, p.cls[0].Q) && (p.bf16x6 == 3 || p.bf16x6 == NP_F16X3) && p.io == IO_F32 && !p.iscale) {
             ConvFwdParams w8 = q;
             w8.o_tiles = (p.Og + BM - 1) / BM;
             const int64_t tiles = (int64_t)p.N * (p.cls[0].P / 8) * (p.cls[0].Q / 32);
-            launch_fwd_rows2d_np<128, 256, 8, 3, IO_F32, false, 512>(w8, dim3((unsigned)tiles, w8.o_tiles * w8.ksplit, p.G), s);
+            const dim3 grid8((unsigned)tiles, w8.o_tiles * w8.ksplit, p.G);
+            if (p.bf16x6 == NP_F16X3) launch_fwd_rows2d_np<128, 256, 8, NP_F16X3, IO_F32, false, 512>(w8, grid8, s);
+            else launch_fwd_rows2d_np<128, 256, 8, 3, IO_F32, false, 512>(w8, grid8, s);
             return true;
         }
         const int R = rows2d_rows(p.cls[0].P, p.cls[0].Q);

@@ -93,12 +93,30 @@ static int64_t fwd_lattice_pixels(const pasta_conv_desc* d) {
 // Which kernel a forward-type launch uses: the tile, the number of K slices, and whether the split-bf16 kernel may
 // run (it also needs iscale == nullptr, known only at launch).
 // bf16 pieces per operand of the split-bf16 kernels for a math mode
-static int math_pieces(int math) { return math == PASTA_MATH_BF16 ? 1 : math == PASTA_MATH_BF16X3 ? 2 : 3; }
+// (PASTA_MATH_F16X3: the pseudo count NP_F16X3 -- fp16 pieces, three products; conv_common.h)
+static int math_pieces(int math) { return math == PASTA_MATH_BF16 ? 1 : math == PASTA_MATH_BF16X3 ? 2 : math == PASTA_MATH_F16X3 ? NP_F16X3 : 3; }
+static bool fp32_equivalent(int pieces) { return pieces == 3 || pieces == NP_F16X3; }
+
+// Leading floats of every convolution workspace: the partial |max| of the two operands (PASTA_MATH_F16X3)
+constexpr int WS_AMAX_FLOATS = 2 * AMAX_PARTS;
+
+// parts[i] *= max |v|: the bound of |x * iscale| from the bound of |x| (one workgroup; iscale is [N, C_in])
+__global__ __launch_bounds__(256) void amax_times_kernel(const float* __restrict__ parts_in, const float* __restrict__ v, int n, float* __restrict__ parts_out) {
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { const float a = fabsf(v[i]); m = (a < __builtin_inff() && a > m) ? a : m; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    parts_out[threadIdx.x] = parts_in[threadIdx.x] * m;
+}
 
 struct FwdPlan { FwdTile tile; int ksplit; int bf16x6; };
 
 // Do the split-bf16 kernels of this launch take the input scale (modulation) in their staging code?
-static bool isc_in_staging(const pasta_conv_desc* d) { return d->io_dtype == PASTA_F32 && math_pieces(d->math) == 3; }
+static bool isc_in_staging(const pasta_conv_desc* d) { return d->io_dtype == PASTA_F32 && fp32_equivalent(math_pieces(d->math)); }
 
 static FwdPlan plan_fwd(const pasta_conv_desc* d) {
     const int Og = d->C_out / d->groups, Ig = d->C_in / d->groups;
@@ -192,7 +210,7 @@ static int check_desc(const pasta_conv_desc* d, const char* who) {
     PASTA_CHECK(d->kh >= 1 && d->kw >= 1 && d->kh * d->kw <= MAX_TAPS, "%s: kernel %dx%d unsupported (max %d taps)", who, d->kh, d->kw, MAX_TAPS);
     PASTA_CHECK(d->stride >= 1 && d->stride <= 4, "%s: stride %d unsupported", who, d->stride);
     PASTA_CHECK(d->pad_h >= 0 && d->pad_w >= 0, "%s: negative padding", who);
-    PASTA_CHECK(d->math >= PASTA_MATH_DEFAULT && d->math <= PASTA_MATH_BF16, "%s: unknown math mode %d", who, d->math);
+    PASTA_CHECK(d->math >= PASTA_MATH_DEFAULT && d->math <= PASTA_MATH_F16X3, "%s: unknown math mode %d", who, d->math);
     PASTA_CHECK(d->io_dtype == PASTA_F32 || d->io_dtype == PASTA_F16 || d->io_dtype == PASTA_BF16, "%s: io_dtype %d is not PASTA_F32 / PASTA_F16 / PASTA_BF16", who, d->io_dtype);
     PASTA_CHECK(d->groups >= 1 && d->C_in % d->groups == 0 && d->C_out % d->groups == 0, "%s: channels not divisible by groups=%d", who, d->groups);
     if (!d->transposed) {
@@ -224,7 +242,7 @@ extern "C" int64_t pasta_conv2d_workspace(const pasta_conv_desc* d) {
     // packed weights: fp32 (4 B) or three bf16 pieces (6 B) per element; sized for the larger, in floats
     const int64_t pack = ((int64_t)d->groups * d->kh * d->kw * round_up(Ig, fwd_ipad(Ig, t)) * round_up(Og, fwd_tile_bm(t)) * 3 + 1) / 2;
     const int64_t partial = ks > 1 ? (int64_t)ks * d->N * d->C_out * d->OH * d->OW : 0;
-    return (round_up((int)pack, 4) + partial) * (int64_t)sizeof(float);
+    return (WS_AMAX_FLOATS + round_up((int)pack, 4) + partial) * (int64_t)sizeof(float);
 }
 
 extern "C" int pasta_conv2d_tile(const pasta_conv_desc* d) {
@@ -252,7 +270,8 @@ extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int launch_flags, int
                                                       "output channels, or an input scale): convert the tensors to fp32 for this launch");
     if (tile) *tile = (int)f.tile;
     if (ksplit) *ksplit = f.ksplit;
-    if (math) *math = !sb ? PASTA_MATH_F32 : d->io_dtype != PASTA_F32 ? PASTA_MATH_BF16 : d->math == PASTA_MATH_BF16X3 ? PASTA_MATH_BF16X3 : d->math == PASTA_MATH_BF16 ? PASTA_MATH_BF16 : PASTA_MATH_BF16X6;
+    if (math) *math = !sb ? PASTA_MATH_F32 : d->io_dtype != PASTA_F32 ? PASTA_MATH_BF16 : d->math == PASTA_MATH_BF16X3 ? PASTA_MATH_BF16X3 : d->math == PASTA_MATH_BF16 ? PASTA_MATH_BF16 :
+                       d->math == PASTA_MATH_F16X3 ? PASTA_MATH_F16X3 : PASTA_MATH_BF16X6;
     const bool pair = sb && pair_launch_ok(d, math_pieces(d->math), f.ksplit, f.tile, pair_plain(launch_flags));
     if (launches) *launches = !d->transposed ? 1 : pair ? 1 + (d->OH > 2 * d->H || d->OW > 2 * d->W ? 1 : 0) : merged_classes(d, sb) ? 1 :
                               (d->stride < d->OH ? d->stride : d->OH) * (d->stride < d->OW ? d->stride : d->OW);
@@ -262,7 +281,7 @@ extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int launch_flags, int
         const bool plain6 = sb && d->stride == 1 && d->kw == 3 && d->kh == 3;
         const bool rows2d = plain6 && f.tile == T128x128 && rows2d_rows(d->OH, d->OW) > 0;
         const bool rows2d_256 = plain6 && f.tile == T64x256 && rows2d_rows256(d->OH, d->OW);
-        const bool wide = rows2d && !has_iscale && math_pieces(d->math) == 3 && d->io_dtype == PASTA_F32 && rows2d_wide(d->OH, d->OW);
+        const bool wide = rows2d && !has_iscale && fp32_equivalent(math_pieces(d->math)) && d->io_dtype == PASTA_F32 && rows2d_wide(d->OH, d->OW);
         *kernel = !sb ? 0 : pair ? 3 : wide ? 7 : rows2d ? (rows2d_rows(d->OH, d->OW) == 4 ? 4 : 5) : rows2d_256 ? 6 : rows ? 2 : 1;
     }
     return 0;
@@ -406,12 +425,16 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
     PASTA_CHECK(!ep || !ep->noise || ep->noise_strength, "conv2d: noise without noise_strength");
     PASTA_CHECK(x && w && y, "conv2d: null pointer");
     const int64_t need = pasta_conv2d_workspace(d);
+    PASTA_CHECK(!(d->math == PASTA_MATH_F16X3 && d->io_dtype != PASTA_F32) , "conv2d: PASTA_MATH_F16X3 is an arithmetic for fp32 tensors (16-bit tensors are their own operands)");
     PASTA_CHECK(workspace && workspace_bytes >= need, "conv2d: workspace of %lld bytes needed, %lld given", (long long)need, (long long)workspace_bytes);
     PASTA_CHECK(((uintptr_t)workspace & 15) == 0, "conv2d: workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
 
+    float* const ws_amax = (float*)workspace;                         // [2][AMAX_PARTS]: x, w
+    workspace = (float*)workspace + WS_AMAX_FLOATS;                  // packed weights and K-slice partial sums follow
     ConvFwdParams p;
     p.x = (const float*)x; p.y = (float*)y; p.wp = (const float*)workspace; p.iscale = iscale; p.oscale = oscale;
+    p.x_amax = nullptr; p.w_amax = nullptr; p.w_gain = 1.f;
     p.N = d->N; p.Cin = d->C_in; p.H = d->H; p.W = d->W;
     p.Cout = d->C_out; p.OH = d->OH; p.OW = d->OW;
     p.G = d->groups; p.Ig = d->C_in / d->groups; p.Og = d->C_out / d->groups;
@@ -427,6 +450,7 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
     p.partial = (float*)workspace + round_up((int)(((int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad * 3 + 1) / 2), 4);
     // bf16 pieces per operand; 0 = fp32 kernel.  An input scale rides in the staging of the six-product fp32-storage kernels only.
     p.bf16x6 = (plan.bf16x6 && (!iscale || isc_in_staging(d))) ? math_pieces(d->math) : 0;
+    if (p.bf16x6 == NP_F16X3 && wmod_s) p.bf16x6 = 3;               // per-sample modulated weights: their |max| is not w's; six products
     p.io = d->io_dtype;
     if (p.io != IO_F32) {
         PASTA_CHECK(p.bf16x6, "conv2d: no 16-bit-storage kernel for this shape (pasta_conv2d_plan tells beforehand)");
@@ -435,13 +459,29 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
     p.rows = 0; p.rows_d0 = 0; p.rows_rev = 0;
 
     const float wscale = d->wscale == 0.f ? 1.f : d->wscale;
+    if (p.bf16x6 == NP_F16X3 && p.io == IO_F32) {
+        // operand scales: partial |max| of x (the caller's, or one pass here), times max |iscale| when the styles ride in the
+        // staging, and of w (a few MB at most)
+        const float* xa = d->x_amax;
+        if (!xa) {
+            if (int e = tensor_amax(x, (int64_t)d->N * d->C_in * d->H * d->W, PASTA_F32, ws_amax, s)) return e;
+            xa = ws_amax;
+        }
+        if (iscale) {
+            hipLaunchKernelGGL(amax_times_kernel, dim3(1), dim3(256), 0, s, xa, iscale, d->N * d->C_in, ws_amax);
+            xa = ws_amax;
+        }
+        if (int e = tensor_amax(w, (int64_t)d->C_out * (d->C_in / d->groups) * d->kh * d->kw, PASTA_F32, ws_amax + AMAX_PARTS, s)) return e;
+        p.x_amax = xa; p.w_amax = ws_amax + AMAX_PARTS; p.w_gain = fabsf(wscale);
+    }
     {   // pack weights (times wscale)
         const int64_t total = (int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad;
         int64_t blocks = ceil_div64(total, 256);
         if (blocks > 4096) blocks = 4096;
         if (p.bf16x6)
             hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, (__bf16*)workspace, p.G, p.Ig, p.Og,
-                               p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip, wscale, p.io == IO_F16 ? 1 : 0, wmod_s, wmod_d);
+                               p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip, wscale, p.io == IO_F16 ? 1 : p.bf16x6 == NP_F16X3 ? 2 : 0, wmod_s, wmod_d,
+                               p.w_amax);
         else
             hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, (float*)workspace, p.G, p.Ig, p.Og,
                                p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip, wscale, wmod_s, wmod_d);
@@ -560,10 +600,10 @@ extern "C" int64_t pasta_conv2d_wgrad_workspace(const pasta_conv_desc* d) {
     if (check_desc(d, "conv2d_wgrad_workspace")) return -1;
     const int Ig = d->C_in / d->groups, Og = d->C_out / d->groups;
     const WgradSmallPlan ws = plan_wgrad_small(d);
-    if (ws.use) return ws.slab_floats * (int64_t)sizeof(float);
+    if (ws.use) return (WS_AMAX_FLOATS + ws.slab_floats) * (int64_t)sizeof(float);
     const WgradPlan w = d->transposed ? plan_wgrad(d->N, d->H, d->W, d->groups, Ig, Og, d->kh, d->kw, d->stride)
                                       : plan_wgrad(d->N, d->OH, d->OW, d->groups, Og, Ig, d->kh, d->kw, d->stride);
-    return w.slab_floats * (int64_t)sizeof(float);
+    return (WS_AMAX_FLOATS + w.slab_floats) * (int64_t)sizeof(float);
 }
 
 extern "C" int pasta_conv2d_wgrad(const void* xv, const void* dyv, float* dw, const pasta_conv_desc* d, void* workspace,
@@ -576,6 +616,10 @@ extern "C" int pasta_conv2d_wgrad(const void* xv, const void* dyv, float* dw, co
     PASTA_CHECK(workspace && workspace_bytes >= need, "conv2d_wgrad: workspace of %lld bytes needed, %lld given", (long long)need, (long long)workspace_bytes);
     hipStream_t s = (hipStream_t)stream;
     const int Ig = d->C_in / d->groups, Og = d->C_out / d->groups;
+    PASTA_CHECK(!(d->math == PASTA_MATH_F16X3 && d->io_dtype != PASTA_F32) , "conv2d_wgrad: PASTA_MATH_F16X3 is an arithmetic for fp32 tensors");
+    PASTA_CHECK(((uintptr_t)workspace & 15) == 0, "conv2d_wgrad: workspace must be 16-byte aligned");
+    float* const ws_amax = (float*)workspace;                         // [2][AMAX_PARTS]: x, dy
+    workspace = (float*)workspace + WS_AMAX_FLOATS;                  // the partial slabs follow
 
     const WgradSmallPlan ws = plan_wgrad_small(d);
     PASTA_CHECK(d->io_dtype == PASTA_F32 || !ws.use, "conv2d_wgrad: no 16-bit-storage kernel for this shape (pasta_conv2d_wgrad_plan tells beforehand)");
@@ -625,20 +669,29 @@ extern "C" int pasta_conv2d_wgrad(const void* xv, const void* dyv, float* dw, co
         if (w.kp == 16) { if (w.pipe) PASTA_WGRAD1(TR_, TS_, WA_, WB_, 1, 16); else PASTA_WGRAD1(TR_, TS_, WA_, WB_, 0, 16); } \
         else            { if (w.pipe) PASTA_WGRAD1(TR_, TS_, WA_, WB_, 1, 32); else PASTA_WGRAD1(TR_, TS_, WA_, WB_, 0, 32); } \
     } while (0)
-    const int np = p.io != IO_F32 ? 1 : math_pieces(d->math);          // bf16 pieces per operand of the split-bf16 kernels
+    const int np = p.io != IO_F32 ? 1 : math_pieces(d->math);          // bf16 pieces per operand of the split-bf16 kernels (NP_F16X3: fp16 pieces)
+    const int npw = np == NP_F16X3 ? 3 : np;                           // pieces per operand in LDS
+    p.s_amax = p.l_amax = nullptr;
+    if (np == NP_F16X3 && (wgrad_bf16x6(d, w) || wgrad_s2_bf16x6(d, w) || (wgrad_1x1_bf16x6(d, w) && !(w.TR == 3 && w.TS == 3) && w.TS != 7 && w.TS != 4))) {
+        const float* xa = d->x_amax; const float* ya = d->dy_amax;
+        if (!xa) { if (int e = tensor_amax(x, (int64_t)d->N * d->C_in * d->H * d->W, PASTA_F32, ws_amax, s)) return e; xa = ws_amax; }
+        if (!ya) { if (int e = tensor_amax(dy, (int64_t)d->N * d->C_out * d->OH * d->OW, PASTA_F32, ws_amax + AMAX_PARTS, s)) return e; ya = ws_amax + AMAX_PARTS; }
+        p.s_amax = d->transposed ? xa : ya;
+        p.l_amax = d->transposed ? ya : xa;
+    }
     PASTA_CHECK(p.io == IO_F32 || wgrad_bf16x6(d, w) || wgrad_s2_bf16x6(d, w) || (wgrad_1x1_bf16x6(d, w) && !(w.TR == 3 && w.TS == 3) && w.TS != 7 && w.TS != 4),
                 "conv2d_wgrad: no 16-bit-storage kernel for this shape (pasta_conv2d_wgrad_plan tells beforehand)");
 #define PASTA_NP(LAUNCH_)   /* LAUNCH_(NP, IO) for the runtime np and storage type */                                        \
     do { if (p.io == IO_BF16) { LAUNCH_(1, IO_BF16); } else if (p.io == IO_F16) { LAUNCH_(1, IO_F16); }                      \
-         else if (np == 1) { LAUNCH_(1, IO_F32); } else if (np == 2) { LAUNCH_(2, IO_F32); } else { LAUNCH_(3, IO_F32); } } while (0)
+         else if (np == 1) { LAUNCH_(1, IO_F32); } else if (np == 2) { LAUNCH_(2, IO_F32); } else if (np == NP_F16X3) { LAUNCH_(NP_F16X3, IO_F32); } else { LAUNCH_(3, IO_F32); } } while (0)
     if (wgrad_bf16x6(d, w)) {
-        const size_t lds = (size_t)(np * 64 * 40 + np * 64 * 3 * 40) * 2;
+        const size_t lds = (size_t)(npw * 64 * 40 + npw * 64 * 3 * 40) * 2;
 #define PASTA_L(NP_, IO_) hipLaunchKernelGGL((conv_wgrad3x3_bf16x6_kernel<NP_, IO_>), dim3((unsigned)blocks), dim3(256), lds, s, p)
         PASTA_NP(PASTA_L);
 #undef PASTA_L
     }
     else if (wgrad_s2_bf16x6(d, w)) {
-        const size_t lds = (size_t)(np * 64 * 16 + np * 64 * 3 * 40) * 2;
+        const size_t lds = (size_t)(npw * 64 * 16 + npw * 64 * 3 * 40) * 2;
 #define PASTA_L(NP_, IO_)                                                                                                     \
         if (d->pad_w == 1) hipLaunchKernelGGL((conv_wgrad3x3s2_bf16x6_kernel<1, NP_, IO_>), dim3((unsigned)blocks), dim3(256), lds, s, p); \
         else               hipLaunchKernelGGL((conv_wgrad3x3s2_bf16x6_kernel<0, NP_, IO_>), dim3((unsigned)blocks), dim3(256), lds, s, p)
@@ -649,7 +702,7 @@ extern "C" int pasta_conv2d_wgrad(const void* xv, const void* dyv, float* dw, co
     else if (w.TS == 7) PASTA_WGRAD(1, 7, 1, 1);
     else if (w.TS == 4) PASTA_WGRAD(1, 4, 1, 1);
     else if (wgrad_1x1_bf16x6(d, w)) {
-        const size_t lds = (size_t)(np * 64 * 40) * 2 * 2 * w.WA;         // S and L images of 64 WA (= 64 WB) channels
+        const size_t lds = (size_t)(npw * 64 * 40) * 2 * 2 * w.WA;        // S and L images of 64 WA (= 64 WB) channels
 #define PASTA_L(NP_, IO_)                                                                                                     \
         if (w.WA == 2) hipLaunchKernelGGL((conv_wgrad1x1_bf16x6_kernel<2, 2, NP_, IO_>), dim3((unsigned)blocks), dim3(256), lds, s, p); \
         else           hipLaunchKernelGGL((conv_wgrad1x1_bf16x6_kernel<1, 1, NP_, IO_>), dim3((unsigned)blocks), dim3(256), lds, s, p)

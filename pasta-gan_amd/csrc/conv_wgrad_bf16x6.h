@@ -17,17 +17,26 @@ namespace pasta {
 template <int NP, int IO = IO_F32>       // bf16 pieces per operand: 3 (six products), 2 (three), 1 (one); IO: storage type of S and L (conv_common.h)
 __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParams p) {
     static_assert(IO == IO_F32 || NP == 1, "16-bit storage: one product");
+    constexpr bool HX = Arith<NP>::f16x3;           // PASTA_MATH_F16X3: both operands as (h, l', h''), three products (conv_common.h)
+    constexpr int NPW = Arith<NP>::npw;             // pieces per operand in LDS
     constexpr int ES = io_size<IO>::value;
     constexpr int SP = 40, LP = 40;                 // row pitches in bf16 elements (80 B)
     constexpr int S_PIECE = 64 * SP;                // one piece of the S tile
     constexpr int L_PIECE = 64 * 3 * LP;            // one piece of the L halo tile
     extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
     __bf16* Ss = smem16;                            // [3][64][SP]
-    __bf16* Ls = smem16 + NP * S_PIECE;             // [NP][64][3][LP]
+    __bf16* Ls = smem16 + NPW * S_PIECE;            // [NPW][64][3][LP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wa = wave >> 1, wb = wave & 1;
     const int hl = lane >> 5, jl = lane & 31;
+    float s_scale = 1.f, l_scale = 1.f, out_scale = 1.f;       // PASTA_MATH_F16X3: operand scales from the tensors' partial maxima
+    if constexpr (HX) {
+        float is_, il_;
+        scale_from_amax(amax_of_parts(p.s_amax), s_scale, is_);
+        scale_from_amax(amax_of_parts(p.l_amax), l_scale, il_);
+        out_scale = is_ * il_;
+    }
 
     int bid = blockIdx.x;
     const int ks = bid % p.ksplit; bid /= p.ksplit;
@@ -93,12 +102,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     // split 8 floats (two float4 halves, each possibly invalid -> 0) into three packed bf16x8 pieces and store them
-    auto split_store = [&](float4 h0, float4 h1, bool ok0, bool ok1, __bf16* dst, int piece_stride) {
+    auto split_store = [&](float4 h0, float4 h1, bool ok0, bool ok1, __bf16* dst, int piece_stride, float scale) {
         const float vals[8] = {ok0 ? h0.x : 0.f, ok0 ? h0.y : 0.f, ok0 ? h0.z : 0.f, ok0 ? h0.w : 0.f,
                                ok1 ? h1.x : 0.f, ok1 ? h1.y : 0.f, ok1 ? h1.z : 0.f, ok1 ? h1.w : 0.f};
         uint32_t q1[4], q2[4], q3[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
+            if constexpr (HX) {
+                f16_split2(vals[2 * j] * scale, vals[2 * j + 1] * scale, q1[j], q2[j]);
+                q3[j] = f16_shift11(q1[j]);
+                continue;
+            }
             f32x2 v = {vals[2 * j], vals[2 * j + 1]};
             uint32_t w = io_pack2<IO>(vals[2 * j], vals[2 * j + 1]);
             q1[j] = w;
@@ -115,13 +129,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
             }
         }
         *(uint4*)(dst) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
-        if constexpr (NP >= 2) *(uint4*)(dst + piece_stride) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
-        if constexpr (NP >= 3) *(uint4*)(dst + 2 * piece_stride) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+        if constexpr (NPW >= 2) *(uint4*)(dst + piece_stride) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+        if constexpr (NPW >= 3) *(uint4*)(dst + 2 * piece_stride) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
     };
     // one L row from registers into ring slot `slot`
     auto stash_row = [&](const float4 (&r)[2][2], unsigned m, int slot) {
-        split_store(r[0][0], r[0][1], m & 1u, m & 2u, Ls + (l_b0 * 3 + slot) * LP + 8 * l_g0, L_PIECE);
-        if (tid < 64) split_store(r[1][0], r[1][1], m & 4u, m & 8u, Ls + (l_b1 * 3 + slot) * LP + 8 * l_g1, L_PIECE);
+        split_store(r[0][0], r[0][1], m & 1u, m & 2u, Ls + (l_b0 * 3 + slot) * LP + 8 * l_g0, L_PIECE, l_scale);
+        if (tid < 64) split_store(r[1][0], r[1][1], m & 4u, m & 8u, Ls + (l_b1 * 3 + slot) * LP + 8 * l_g1, L_PIECE, l_scale);
     };
     auto slot_of = [](int y) { return (y + 3) % 3; };       // y >= -1
 
@@ -145,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
             m = fetch_row(n_c, qb_c * 32, pp_c, t);
             stash_row(t, m, slot_of(pp_c));
         }
-        split_store(sreg[0], sreg[1], vmask & 1u, vmask & 2u, Ss + s_a * SP + 8 * s_grp, S_PIECE);
+        split_store(sreg[0], sreg[1], vmask & 1u, vmask & 2u, Ss + s_a * SP + 8 * s_grp, S_PIECE, s_scale);
         stash_row(lreg, vmask >> 2, slot_of(pp_c + 1));
         __syncthreads();
         if (ch + 1 < c_end) fetch(ch + 1);
@@ -154,9 +168,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
         for (int s = 0; s < 2; s++) {
             bf16x8 af[3];
 #pragma unroll
-            for (int pc = 0; pc < NP; pc++) af[pc] = *(const bf16x8*)&Ss[pc * S_PIECE + (wa * 32 + jl) * SP + 16 * s + 8 * hl];
+            for (int pc = 0; pc < NPW; pc++) af[pc] = *(const bf16x8*)&Ss[pc * S_PIECE + (wa * 32 + jl) * SP + 16 * s + 8 * hl];
 #pragma unroll
-            for (int pb = NP - 1; pb >= 0; pb--) {  // B pieces from the smallest to the largest
+            for (int pb = NPW - 1; pb >= 0; pb--) {  // B pieces from the smallest to the largest
 #pragma unroll
                 for (int row = 0; row < 3; row++) {
                     const int slot = slot0 + row >= 3 ? slot0 + row - 3 : slot0 + row;
@@ -179,10 +193,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
                     for (int ts = 0; ts < 3; ts++) {
                         const bf16x8 bw = __builtin_bit_cast(bf16x8, w[ts]);
                         const int tap = row * 3 + ts;
-                        // a_pa * b_pb with pa + pb <= 2, smallest A piece first
+                        // the products of the arithmetic (split-bf16: pa + pb < NP), smallest A piece first
 #pragma unroll
-                        for (int pa = NP - 1 - pb; pa >= 0; pa--)
-                            acc[tap] = io_mfma<IO>(af[pa], bw, acc[tap]);
+                        for (int pa = NPW - 1; pa >= 0; pa--)
+                            if (mmw_on<NP>(pa, pb)) acc[tap] = mfma16<IO, NP>(af[pa], bw, acc[tap]);
                     }
                 }
             }
@@ -198,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int a = a_blk + wa * 32 + acc_row(r, lane), b = b_blk + wb * 32 + jl;
-            ot[(int64_t)a * Bg_pad + b] = acc[t][r];
+            ot[(int64_t)a * Bg_pad + b] = HX ? acc[t][r] * out_scale : acc[t][r];
         }
     }
 }
@@ -215,17 +229,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
 template <int PW, int NP, int IO = IO_F32>
 __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradParams p) {
     static_assert(IO == IO_F32 || NP == 1, "16-bit storage: one product");
+    constexpr bool HX = Arith<NP>::f16x3;           // PASTA_MATH_F16X3: both operands as (h, l', h''), three products (conv_common.h)
+    constexpr int NPW = Arith<NP>::npw;             // pieces per operand in LDS
     constexpr int ES = io_size<IO>::value;
     constexpr int SP = 16, LP = 40;                 // row pitches in bf16 elements
     constexpr int S_PIECE = 64 * SP;
     constexpr int L_PIECE = 64 * 3 * LP;
     extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
     __bf16* Ss = smem16;                            // [3][64][SP]
-    __bf16* Ls = smem16 + NP * S_PIECE;             // [NP][64][3][LP]
+    __bf16* Ls = smem16 + NPW * S_PIECE;            // [NPW][64][3][LP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wa = wave >> 1, wb = wave & 1;
     const int hl = lane >> 5, jl = lane & 31;
+    float s_scale = 1.f, l_scale = 1.f, out_scale = 1.f;       // PASTA_MATH_F16X3: operand scales from the tensors' partial maxima
+    if constexpr (HX) {
+        float is_, il_;
+        scale_from_amax(amax_of_parts(p.s_amax), s_scale, is_);
+        scale_from_amax(amax_of_parts(p.l_amax), l_scale, il_);
+        out_scale = is_ * il_;
+    }
 
     int bid = blockIdx.x;
     const int ks = bid % p.ksplit; bid /= p.ksplit;
@@ -302,10 +325,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
     };
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    auto split_store = [&](const float* vals, __bf16* dst, int piece_stride) {
+    auto split_store = [&](const float* vals, __bf16* dst, int piece_stride, float scale) {
         uint32_t q1[4], q2[4], q3[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
+            if constexpr (HX) {
+                f16_split2(vals[2 * j] * scale, vals[2 * j + 1] * scale, q1[j], q2[j]);
+                q3[j] = f16_shift11(q1[j]);
+                continue;
+            }
             f32x2 v = {vals[2 * j], vals[2 * j + 1]};
             uint32_t w = io_pack2<IO>(vals[2 * j], vals[2 * j + 1]);
             q1[j] = w;
@@ -322,14 +350,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
             }
         }
         *(uint4*)(dst) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
-        if constexpr (NP >= 2) *(uint4*)(dst + piece_stride) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
-        if constexpr (NP >= 3) *(uint4*)(dst + 2 * piece_stride) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+        if constexpr (NPW >= 2) *(uint4*)(dst + piece_stride) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+        if constexpr (NPW >= 3) *(uint4*)(dst + 2 * piece_stride) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
     };
     auto stash = [&]() {
         if (tid < 128) {
             const float sv[8] = {s_ok ? sreg[0].x : 0.f, s_ok ? sreg[0].y : 0.f, s_ok ? sreg[0].z : 0.f, s_ok ? sreg[0].w : 0.f,
                                  s_ok ? sreg[1].x : 0.f, s_ok ? sreg[1].y : 0.f, s_ok ? sreg[1].z : 0.f, s_ok ? sreg[1].w : 0.f};
-            split_store(sv, Ss + s_a * SP + 8 * s_grp, S_PIECE);
+            split_store(sv, Ss + s_a * SP + 8 * s_grp, S_PIECE, s_scale);
         }
     };
     auto slot_of = [](int y) { return (y + 3) % 3; };       // y >= -1
@@ -338,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
         float lv[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) lv[e] = ((m >> e) & 1u) ? r[e] : 0.f;
-        split_store(lv, Ls + (b * 3 + slot) * LP + 8 * grp, L_PIECE);
+        split_store(lv, Ls + (b * 3 + slot) * LP + 8 * grp, L_PIECE, l_scale);
     };
 
     f32x16 acc[9];
@@ -373,9 +401,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
         const int slot0 = slot_of(y0);
         bf16x8 af[3];
 #pragma unroll
-        for (int pc = 0; pc < NP; pc++) af[pc] = *(const bf16x8*)&Ss[pc * S_PIECE + (wa * 32 + jl) * SP + 8 * hl];
+        for (int pc = 0; pc < NPW; pc++) af[pc] = *(const bf16x8*)&Ss[pc * S_PIECE + (wa * 32 + jl) * SP + 8 * hl];
 #pragma unroll
-        for (int pb = NP - 1; pb >= 0; pb--) {      // B pieces from the smallest to the largest
+        for (int pb = NPW - 1; pb >= 0; pb--) {      // B pieces from the smallest to the largest
 #pragma unroll
             for (int row = 0; row < 3; row++) {
                 const int slot = slot0 + row >= 3 ? slot0 + row - 3 : slot0 + row;
@@ -393,8 +421,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
                     const bf16x8 bw = __builtin_bit_cast(bf16x8, w);
                     const int tap = row * 3 + ts;
 #pragma unroll
-                    for (int pa = NP - 1 - pb; pa >= 0; pa--)
-                        acc[tap] = io_mfma<IO>(af[pa], bw, acc[tap]);
+                    for (int pa = NPW - 1; pa >= 0; pa--)
+                        if (mmw_on<NP>(pa, pb)) acc[tap] = mfma16<IO, NP>(af[pa], bw, acc[tap]);
                 }
             }
         }
@@ -408,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int a = a_blk + wa * 32 + acc_row(r, lane), b = b_blk + wb * 32 + jl;
-            ot[(int64_t)a * Bg_pad + b] = acc[t][r];
+            ot[(int64_t)a * Bg_pad + b] = HX ? acc[t][r] * out_scale : acc[t][r];
         }
     }
 }
@@ -422,6 +450,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
 template <int WA, int WB, int NP, int IO = IO_F32>
 __global__ __launch_bounds__(256, 2) void conv_wgrad1x1_bf16x6_kernel(WgradParams p) {
     static_assert(IO == IO_F32 || NP == 1, "16-bit storage: one product");
+    constexpr bool HX = Arith<NP>::f16x3;           // PASTA_MATH_F16X3: both operands as (h, l', h''), three products (conv_common.h)
+    constexpr int NPW = Arith<NP>::npw;             // pieces per operand in LDS
     constexpr int ES = io_size<IO>::value;
     constexpr int SP = 40;
     constexpr int TA = 64 * WA, TB = 64 * WB;
@@ -429,11 +459,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1x1_bf16x6_kernel(WgradParam
     constexpr int UA = TA * 4 / 256, UB = TB * 4 / 256;             // (channel, 8-pixel group) units per thread
     extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
     __bf16* Ss = smem16;                            // [3][TA][SP]
-    __bf16* Ls = smem16 + NP * A_PIECE;             // [NP][TB][SP]
+    __bf16* Ls = smem16 + NPW * A_PIECE;            // [NPW][TB][SP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wa = wave >> 1, wb = wave & 1;
     const int hl = lane >> 5, jl = lane & 31;
+    float s_scale = 1.f, l_scale = 1.f, out_scale = 1.f;       // PASTA_MATH_F16X3: operand scales from the tensors' partial maxima
+    if constexpr (HX) {
+        float is_, il_;
+        scale_from_amax(amax_of_parts(p.s_amax), s_scale, is_);
+        scale_from_amax(amax_of_parts(p.l_amax), l_scale, il_);
+        out_scale = is_ * il_;
+    }
 
     int bid = blockIdx.x;
     const int ks = bid % p.ksplit; bid /= p.ksplit;
@@ -468,12 +505,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1x1_bf16x6_kernel(WgradParam
     };
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    auto split_store = [&](float4 h0, float4 h1, bool ok, __bf16* dst, int piece_stride) {
+    auto split_store = [&](float4 h0, float4 h1, bool ok, __bf16* dst, int piece_stride, float scale) {
         const float vals[8] = {ok ? h0.x : 0.f, ok ? h0.y : 0.f, ok ? h0.z : 0.f, ok ? h0.w : 0.f,
                                ok ? h1.x : 0.f, ok ? h1.y : 0.f, ok ? h1.z : 0.f, ok ? h1.w : 0.f};
         uint32_t q1[4], q2[4], q3[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
+            if constexpr (HX) {
+                f16_split2(vals[2 * j] * scale, vals[2 * j + 1] * scale, q1[j], q2[j]);
+                q3[j] = f16_shift11(q1[j]);
+                continue;
+            }
             f32x2 v = {vals[2 * j], vals[2 * j + 1]};
             uint32_t w = io_pack2<IO>(vals[2 * j], vals[2 * j + 1]);
             q1[j] = w;
@@ -490,19 +532,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1x1_bf16x6_kernel(WgradParam
             }
         }
         *(uint4*)(dst) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
-        if constexpr (NP >= 2) *(uint4*)(dst + piece_stride) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
-        if constexpr (NP >= 3) *(uint4*)(dst + 2 * piece_stride) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+        if constexpr (NPW >= 2) *(uint4*)(dst + piece_stride) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+        if constexpr (NPW >= 3) *(uint4*)(dst + 2 * piece_stride) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
     };
     auto stash = [&]() {
 #pragma unroll
         for (int j = 0; j < UA; j++) {
             const int u = tid + 256 * j, c = u >> 2, grp = u & 3;
-            split_store(sreg[j][0], sreg[j][1], a_blk + c < p.Ag, Ss + c * SP + 8 * grp, A_PIECE);
+            split_store(sreg[j][0], sreg[j][1], a_blk + c < p.Ag, Ss + c * SP + 8 * grp, A_PIECE, s_scale);
         }
 #pragma unroll
         for (int j = 0; j < UB; j++) {
             const int u = tid + 256 * j, c = u >> 2, grp = u & 3;
-            split_store(lreg[j][0], lreg[j][1], b_blk + c < p.Bg, Ls + c * SP + 8 * grp, B_PIECE);
+            split_store(lreg[j][0], lreg[j][1], b_blk + c < p.Bg, Ls + c * SP + 8 * grp, B_PIECE, l_scale);
         }
     };
 
@@ -526,21 +568,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1x1_bf16x6_kernel(WgradParam
         for (int s = 0; s < 2; s++) {
             bf16x8 af[WA][3], bf[WB][3];
 #pragma unroll
-            for (int pc = 0; pc < NP; pc++) {
+            for (int pc = 0; pc < NPW; pc++) {
 #pragma unroll
                 for (int a = 0; a < WA; a++) af[a][pc] = *(const bf16x8*)&Ss[pc * A_PIECE + ((wa * WA + a) * 32 + jl) * SP + 16 * s + 8 * hl];
 #pragma unroll
                 for (int b = 0; b < WB; b++) bf[b][pc] = *(const bf16x8*)&Ls[pc * B_PIECE + ((wb * WB + b) * 32 + jl) * SP + 16 * s + 8 * hl];
             }
 #pragma unroll
-            for (int pb = NP - 1; pb >= 0; pb--)        // smallest terms first
+            for (int pb = NPW - 1; pb >= 0; pb--)        // smallest terms first
 #pragma unroll
-                for (int pa = NP - 1 - pb; pa >= 0; pa--)
+                for (int pa = NPW - 1; pa >= 0; pa--)
+                    if (mmw_on<NP>(pa, pb)) {
 #pragma unroll
                     for (int a = 0; a < WA; a++)
 #pragma unroll
                         for (int b = 0; b < WB; b++)
-                            acc[a][b] = io_mfma<IO>(af[a][pa], bf[b][pb], acc[a][b]);
+                            acc[a][b] = mfma16<IO, NP>(af[a][pa], bf[b][pb], acc[a][b]);
+                    }
         }
     }
 
@@ -553,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1x1_bf16x6_kernel(WgradParam
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int ai = a_blk + (wa * WA + a) * 32 + acc_row(r, lane), bi = b_blk + (wb * WB + b) * 32 + jl;
-                out[(int64_t)ai * Bg_pad + bi] = acc[a][b][r];
+                out[(int64_t)ai * Bg_pad + bi] = HX ? acc[a][b][r] * out_scale : acc[a][b][r];
             }
 }
 

@@ -120,7 +120,8 @@ class ConvDesc(ctypes.Structure):
     """Mirror of ``pasta_conv_desc`` (include/pasta_hip.h)."""
     _fields_ = [(name, _c_i32) for name in (
         'N', 'C_in', 'H', 'W', 'C_out', 'OH', 'OW', 'kh', 'kw', 'stride',
-        'pad_h', 'pad_w', 'groups', 'transposed', 'flip', 'math')] + [('wscale', _c_f32), ('io_dtype', _c_i32)]
+        'pad_h', 'pad_w', 'groups', 'transposed', 'flip', 'math')] + [('wscale', _c_f32), ('io_dtype', _c_i32),
+                                                                      ('x_amax', _c_ptr), ('dy_amax', _c_ptr)]
 
 class ConvEpilogue(ctypes.Structure):
     """Mirror of ``pasta_conv_epilogue`` (include/pasta_hip.h)."""
@@ -158,6 +159,7 @@ ABI = {
     'pasta_conv2d_ex':    (ctypes.c_int, [_c_ptr] * 5 + [ctypes.POINTER(ConvEpilogue), ctypes.POINTER(ConvDesc), _c_ptr, _c_i64, _c_ptr]),
     'pasta_conv2d_wgrad': (ctypes.c_int, [_c_ptr] * 3 + [ctypes.POINTER(ConvDesc), _c_ptr, _c_i64, _c_ptr]),
     'pasta_conv2d_modulated': (ctypes.c_int, [_c_ptr] * 5 + [ctypes.POINTER(ConvEpilogue), ctypes.POINTER(ConvDesc), _c_ptr, _c_i64, _c_ptr]),
+    'pasta_tensor_amax':  (ctypes.c_int, [_c_ptr, _c_i64, ctypes.c_int, _c_ptr, _c_ptr]),
     'pasta_demod_coefs':  (ctypes.c_int, [_c_ptr] * 3 + [ctypes.c_int] * 4 + [_c_f32, _c_ptr]),
     'pasta_scale_add':    (ctypes.c_int, [_c_ptr] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i64, ctypes.c_int, _c_ptr]),
     'pasta_plane_dot':    (ctypes.c_int, [_c_ptr] * 3 + [ctypes.c_int, _c_i64, _c_i64, _c_ptr]),

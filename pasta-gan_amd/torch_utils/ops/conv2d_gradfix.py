@@ -23,7 +23,7 @@ enabled = True                      # Kept for API compatibility; the HIP path i
 # Matrix-core arithmetic of the convolutions (include/pasta_hip.h PASTA_MATH_*): 'bf16x6' (default; split-bf16 with
 # fp32-equivalent products) or 'f32' (fp32 MFMA, bit-exact fp32 FMA chains). Overridable with PASTA_CONV_MATH.
 import os as _os
-MATH_CODES = {'default': 0, 'f32': 1, 'bf16x6': 2, 'bf16x3': 3, 'bf16': 4}
+MATH_CODES = {'default': 0, 'f32': 1, 'bf16x6': 2, 'bf16x3': 3, 'bf16': 4, 'f16x3': 5}
 conv_math = _os.environ.get('PASTA_CONV_MATH', 'default')
 assert conv_math in MATH_CODES, f'PASTA_CONV_MATH must be one of {sorted(MATH_CODES)}'
 weight_gradients_disabled = False   # Forcefully disable computation of gradients with respect to the weights.
@@ -86,6 +86,45 @@ def _native16(kind, desc, has_iscale=False):
         else:
             hit = lib.pasta_conv2d_wgrad_plan(ctypes.byref(desc), None) == 0
         _native16_cache[key] = hit
+    return hit
+
+# PASTA_MATH_F16X3 (include/pasta_hip.h): the power-of-two operand scales come from the tensors' largest magnitudes.  A tensor
+# is scanned ONCE (``pasta_tensor_amax``: 256 partial maxima, one pass at HBM rate) and the result travels with the Python
+# tensor object for as long as its version stands: the forward input serves the forward launch and, from the saved tensor,
+# the weight gradient; a gradient serves the input-gradient and the weight-gradient launch of the same backward.
+AMAX_PARTS = 256
+_f16x3_cache = {}
+
+def tensor_amax(t):
+    """[256] partial |max| of a contiguous fp32 GPU tensor (cached per tensor version)."""
+    hit = getattr(t, '_pasta_amax', None)
+    if hit is not None and hit[0] == t._version and hit[1] == t.data_ptr():
+        return hit[2]
+    parts = torch.empty([AMAX_PARTS], dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        _native.check(_native.lib().pasta_tensor_amax(_native.ptr(t), t.numel(), 0, _native.ptr(parts), _native.stream()))
+    try:
+        t._pasta_amax = (t._version, t.data_ptr(), parts)
+    except AttributeError:
+        pass
+    return parts
+
+def _runs_f16x3(kind, desc, flags=0):
+    """Does this launch run the three-product fp16 arithmetic (then it wants the operands' partial maxima)?"""
+    if desc.math != MATH_CODES['f16x3'] or desc.io_dtype != 0:
+        return False
+    key = (kind, flags & 1, desc.N, desc.C_in, desc.H, desc.W, desc.C_out, desc.OH, desc.OW, desc.kh, desc.kw, desc.stride, desc.pad_h,
+           desc.pad_w, desc.groups, desc.transposed)
+    hit = _f16x3_cache.get(key)
+    if hit is None:
+        lib = _native.lib()
+        if kind == 'conv':
+            math = ctypes.c_int()
+            hit = lib.pasta_conv2d_plan(ctypes.byref(desc), int(flags), None, None, ctypes.byref(math), None, None) == 0 and math.value == MATH_CODES['f16x3']
+        else:
+            kernel = ctypes.c_int()
+            hit = lib.pasta_conv2d_wgrad_plan(ctypes.byref(desc), ctypes.byref(kernel)) == 0 and kernel.value in (2, 3, 4)
+        _f16x3_cache[key] = hit
     return hit
 
 # Optional measurement hook (bench.py): when set, called as hook(kind, desc, launch) around every native
@@ -166,6 +205,10 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, 
         mod_s = _f32(wmod[0]).contiguous()
         mod_d = _f32(wmod[1]).contiguous() if wmod[1] is not None else None
         assert mod_s.numel() == x.shape[1] and (mod_d is None or mod_d.numel() == c_out)
+    x_amax = None
+    if wmod is None and _runs_f16x3('conv', desc, 1 if iscale is not None else 0):
+        x_amax = tensor_amax(x)
+        desc.x_amax = x_amax.data_ptr()
     def launch():
         with torch.cuda.device(x.device):
             if wmod is not None:
@@ -208,6 +251,9 @@ def _launch_wgrad(x, dy, cfg, w_shape, out_dtype=None):
     if nbytes < 0:
         _native.check(1)
     work = torch.empty([max(nbytes // 4, 4)], dtype=torch.float32, device=x.device)
+    if _runs_f16x3('wgrad', desc):
+        amax_x, amax_dy = tensor_amax(x), tensor_amax(dy)
+        desc.x_amax, desc.dy_amax = amax_x.data_ptr(), amax_dy.data_ptr()
     def launch():
         with torch.cuda.device(x.device):
             st = lib.pasta_conv2d_wgrad(_native.ptr(x), _native.ptr(dy), _native.ptr(dw), ctypes.byref(desc),
