@@ -36,7 +36,7 @@ PEAK_HBM_GBS = 8000.0
 STORAGE_IO = 0        # pasta_conv_desc.io_dtype of the run (0 f32, 1 f16, 3 bf16): part of the kernel names, sets the product count
 def _np():
     from torch_utils.ops import conv2d_gradfix
-    return 1 if STORAGE_IO else {'bf16x3': 2, 'bf16': 1}.get(conv2d_gradfix.conv_math, 3)
+    return 1 if STORAGE_IO else {'bf16x3': 2, 'bf16': 1, 'bf16x6': 3}.get(conv2d_gradfix.conv_math, 4)     # 4 = NP_F16X3: 'default' / 'f16x3'
 def bf16x6_names():         # template arguments as rocprofv3 prints them: <BM, BN, OCC, pieces, storage, input scale in the staging>
     return {0: f'conv_fwd_bf16x6_kernel<128,128,3,{_np()},{STORAGE_IO},false>', 1: f'conv_fwd_bf16x6_kernel<64,256,2,{_np()},{STORAGE_IO},false>'}
 def bf16x6_rows_names():    # <BM, BN, OCC, schedule, pieces, storage, input scale, parity pairs>
@@ -85,9 +85,9 @@ class ConvMeter:
             family = {0: TILE_NAMES, 1: bf16x6_names(), 2: bf16x6_rows_names(), 3: bf16x6_pair_names(),
                       4: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,128,4,{_np()},{STORAGE_IO},false,256>'}, 5: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,128,2,{_np()},{STORAGE_IO},false,256>'},
                       6: {1: f'conv_fwd_rows2d_bf16x6_kernel<64,256,8,{_np()},{STORAGE_IO},false,256>'},
-                      7: {0: 'conv_fwd_rows2d_bf16x6_kernel<128,256,8,3,0,false,512>'}}[kernel.value][tile.value]     # <BM, BN, rows per tile, pieces, storage, input scale, threads>
+                      7: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,256,8,{_np()},0,false,512>'}}[kernel.value][tile.value]     # <BM, BN, rows per tile, pieces, storage, input scale, threads>
             if isc and kernel.value != 0:       # the instance with the input scale: same family, another template argument (rocprofv3 names)
-                family = {1: family.replace(',3,3,0,false>', ',2,3,0,true>'), 2: family.replace(',false,false>', ',true,false>')}.get(
+                family = {1: family.replace(',3,3,0,false>', ',2,3,0,true>').replace(',3,4,0,false>', ',2,4,0,true>'), 2: family.replace(',false,false>', ',true,false>')}.get(
                     kernel.value, family.replace(',false,256>', ',true,256>'))
             kernels = launches.value
         else:
@@ -365,7 +365,7 @@ def main():
                     "headline; 'ada' = the shipped train.sh default, pipeline 'bgc', target 0.6)")
     ap.add_argument('--aug-p', type=float, default=0.5, help='initial (ada) or constant (fixed) augmentation probability; the reference starts '
                     'ADA at 0 and takes ~100 kimg to reach its working point, a benchmark has to start near it')
-    ap.add_argument('--conv-math', default=None, choices=['default', 'f32', 'bf16x6', 'bf16x3', 'bf16'],
+    ap.add_argument('--conv-math', default=None, choices=['default', 'f32', 'bf16x6', 'bf16x3', 'bf16', 'f16x3'],
                     help="matrix-core arithmetic of the convolutions (default: PASTA_CONV_MATH or 'default' = bf16x6, fp32-equivalent). "
                          "'bf16x3' = what TrainingStep selects for allow_tf32=True; 'bf16' = bf16 operands. Reduced modes are reported as such, never as the headline")
     ap.add_argument('--ddp-mode', default='flat', choices=['flat', 'torch'], help="gradient exchange at N > 1: 'flat' = one bucketed reducer per "
@@ -510,12 +510,14 @@ def main():
             traffic, src = pmc_traffic(name, expected)
             if 'bf16x6' in name:        # every split-bf16 kernel family (forward-type base / row / pair / 2-D, the three weight gradients)
                 # six (three, one) bf16 MFMA products per multiply-add: the matrix pipes execute that multiple of the algorithmic FLOPs
-                nprod = 1 if STORAGE_IO else {'bf16x3': 3, 'bf16': 1}.get(conv2d_gradfix.conv_math, 6)
+                nprod = 1 if STORAGE_IO else {'bf16x3': 3, 'bf16': 1, 'bf16x6': 6}.get(conv2d_gradfix.conv_math, 3)
                 peak = PEAK_BF16_MFMA_TFLOPS / nprod
-                note = ('split-bf16: %s products from %d x v_mfma_f32_32x32x16_bf16, fp32 accumulate; peak = 2500 TFLOP/s '
-                        'dense bf16 / %d; executed bf16 rate = %d x achieved = %.0f TFLOP/s = %.1f%% of 2.5 PFLOP/s' %
-                        ({6: 'fp32-equivalent', 3: '2^-16-accurate (opt-in allow_tf32 counterpart)', 1: 'bf16-operand (opt-in mixed precision)'}[nprod],
-                         nprod, nprod, nprod, nprod * achieved, 100 * nprod * achieved / PEAK_BF16_MFMA_TFLOPS))
+                f16x3 = not STORAGE_IO and conv2d_gradfix.conv_math in ('default', 'f16x3')
+                note = ('%s products from %d x v_mfma_f32_32x32x16_%s, fp32 accumulate; peak = 2500 TFLOP/s '
+                        'dense 16-bit MFMA / %d; executed 16-bit MFMA rate = %d x achieved = %.0f TFLOP/s = %.1f%% of 2.5 PFLOP/s' %
+                        ('fp32-equivalent (PASTA_MATH_F16X3: fp16 hi / lo pieces of power-of-two-scaled operands)' if f16x3 else
+                         {6: 'split-bf16: fp32-equivalent', 3: 'split-bf16: 2^-16-accurate (opt-in allow_tf32 counterpart)', 1: 'bf16-operand (opt-in mixed precision)'}[nprod],
+                         nprod, 'f16' if f16x3 else 'bf16', nprod, nprod, nprod * achieved, 100 * nprod * achieved / PEAK_BF16_MFMA_TFLOPS))
             else:
                 peak = PEAK_F32_MFMA_TFLOPS
                 note = 'dense fp32-input MFMA (v_mfma_f32_32x32x2_f32), exact-f32 products'
@@ -544,7 +546,9 @@ def main():
             del step
             torch.cuda.empty_cache()
             out['also_measured'] = {}
-            for tag, kw, vbatch, vres, note in [('d_fp16_res_3', dict(d_fp16_res=3), args.batch_gpu, 256, 'D blocks b256..b64 in fp16 storage + products: num_fp16_res = 3, conv_clamp = 256 as train_wo_flow_fullbody.py:195-196 sets them '
+            for tag, kw, vbatch, vres, note in [('conv_math_bf16x6', dict(), args.batch_gpu, 256, 'the same step with the six-product split-bf16 arithmetic (PASTA_MATH_BF16X6: the default until round 3; '
+                                                                        'fp32-equivalent as well, no operand scales, twice the matrix work)'),
+                                                ('d_fp16_res_3', dict(d_fp16_res=3), args.batch_gpu, 256, 'D blocks b256..b64 in fp16 storage + products: num_fp16_res = 3, conv_clamp = 256 as train_wo_flow_fullbody.py:195-196 sets them '
                                                                         '(GeneratorFull forces its blocks to fp32, networks.py:2307,2331): the reference script\'s default precision; '
                                                                         'parity: reference fixture with num_fp16_res = 4, tests/test_fullwidth.py (2e-2)'),
                                   ('storage_bf16', dict(act_dtype='bfloat16'), args.batch_gpu, 256, 'bf16 activation storage in G and D (BASELINE config 5 arithmetic at 256x256, batch 16); '
@@ -553,6 +557,7 @@ def main():
                                                                                'activation storage with fp32 demodulation / accumulation; the 512 model is the resolution-generalised GeneratorFull '
                                                                                '(parity UNPINNED: the reference ships no 512 class); parity vs the oracle in the same storage type: tests/test_config5_gpu.py')]:
                 vcfg = fashion_config(mbstd_group_size=min(vbatch, 4), **kw)
+                conv2d_gradfix.conv_math = 'bf16x6' if tag == 'conv_math_bf16x6' else 'default'
                 vstep = TrainingStep(device, cfg=vcfg, num_gpus=1, rank=0, batch_size=vbatch, batch_gpu=vbatch)
                 vdata = data if (vbatch, vres) == (args.batch_gpu, 256) else SyntheticFullBodyBatch(vbatch, device, seed=rank, res=vres)
                 for _ in range(2):
@@ -564,7 +569,9 @@ def main():
                 torch.cuda.synchronize()
                 tv = time.perf_counter() - tv
                 out['also_measured'][tag] = {'value': round(16 * vbatch / tv, 3), 'unit': 'images/sec', 'ms_per_step': round(1000 * tv / 16, 2),
-                                             'steps': 16, 'warmup': 2, 'batch': vbatch, 'resolution': vres, 'precision': 'REDUCED relative to the headline', 'note': note}
+                                             'steps': 16, 'warmup': 2, 'batch': vbatch, 'resolution': vres,
+                                             'precision': 'fp32-equivalent, as the headline' if tag == 'conv_math_bf16x6' else 'REDUCED relative to the headline', 'note': note}
+                conv2d_gradfix.conv_math = 'default'
                 del vstep, vdata
                 torch.cuda.empty_cache()
         if not args.no_cpu_baseline and world == 1:

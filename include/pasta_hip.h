@@ -146,7 +146,7 @@ typedef struct pasta_conv_desc {
  *                     are skipped by the scale and stay local.  fp32 storage only; same kernels and coverage as BF16X6
  *                     except per-sample modulated weights (pasta_conv2d_modulated), which run BF16X6.
  *   The split modes share kernels (template argument NP = pieces) and the same coverage.
- *   PASTA_MATH_DEFAULT = PASTA_MATH_BF16X6 (the library's default; the Python front end selects the mode). */
+ *   PASTA_MATH_DEFAULT = PASTA_MATH_F16X3 (round 3; BF16X6 before). */
 enum { PASTA_MATH_DEFAULT = 0, PASTA_MATH_F32 = 1, PASTA_MATH_BF16X6 = 2, PASTA_MATH_BF16X3 = 3, PASTA_MATH_BF16 = 4, PASTA_MATH_F16X3 = 5 };
 
 /* Largest finite magnitude of a contiguous fp32 tensor as PASTA_AMAX_PARTS partial maxima (parts[i] >= 0; the maximum over

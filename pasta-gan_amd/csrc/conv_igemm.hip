@@ -94,7 +94,7 @@ static int64_t fwd_lattice_pixels(const pasta_conv_desc* d) {
 // run (it also needs iscale == nullptr, known only at launch).
 // bf16 pieces per operand of the split-bf16 kernels for a math mode
 // (PASTA_MATH_F16X3: the pseudo count NP_F16X3 -- fp16 pieces, three products; conv_common.h)
-static int math_pieces(int math) { return math == PASTA_MATH_BF16 ? 1 : math == PASTA_MATH_BF16X3 ? 2 : math == PASTA_MATH_F16X3 ? NP_F16X3 : 3; }
+static int math_pieces(int math) { return math == PASTA_MATH_BF16 ? 1 : math == PASTA_MATH_BF16X3 ? 2 : math == PASTA_MATH_BF16X6 ? 3 : NP_F16X3; }    // PASTA_MATH_DEFAULT = PASTA_MATH_F16X3
 static bool fp32_equivalent(int pieces) { return pieces == 3 || pieces == NP_F16X3; }
 
 // Leading floats of every convolution workspace: the partial |max| of the two operands (PASTA_MATH_F16X3)
@@ -271,7 +271,7 @@ extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int launch_flags, int
     if (tile) *tile = (int)f.tile;
     if (ksplit) *ksplit = f.ksplit;
     if (math) *math = !sb ? PASTA_MATH_F32 : d->io_dtype != PASTA_F32 ? PASTA_MATH_BF16 : d->math == PASTA_MATH_BF16X3 ? PASTA_MATH_BF16X3 : d->math == PASTA_MATH_BF16 ? PASTA_MATH_BF16 :
-                       d->math == PASTA_MATH_F16X3 ? PASTA_MATH_F16X3 : PASTA_MATH_BF16X6;
+                       d->math == PASTA_MATH_BF16X6 ? PASTA_MATH_BF16X6 : PASTA_MATH_F16X3;
     const bool pair = sb && pair_launch_ok(d, math_pieces(d->math), f.ksplit, f.tile, pair_plain(launch_flags));
     if (launches) *launches = !d->transposed ? 1 : pair ? 1 + (d->OH > 2 * d->H || d->OW > 2 * d->W ? 1 : 0) : merged_classes(d, sb) ? 1 :
                               (d->stride < d->OH ? d->stride : d->OH) * (d->stride < d->OW ? d->stride : d->OW);
@@ -425,7 +425,6 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
     PASTA_CHECK(!ep || !ep->noise || ep->noise_strength, "conv2d: noise without noise_strength");
     PASTA_CHECK(x && w && y, "conv2d: null pointer");
     const int64_t need = pasta_conv2d_workspace(d);
-    PASTA_CHECK(!(d->math == PASTA_MATH_F16X3 && d->io_dtype != PASTA_F32) , "conv2d: PASTA_MATH_F16X3 is an arithmetic for fp32 tensors (16-bit tensors are their own operands)");
     PASTA_CHECK(workspace && workspace_bytes >= need, "conv2d: workspace of %lld bytes needed, %lld given", (long long)need, (long long)workspace_bytes);
     PASTA_CHECK(((uintptr_t)workspace & 15) == 0, "conv2d: workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
@@ -616,7 +615,6 @@ extern "C" int pasta_conv2d_wgrad(const void* xv, const void* dyv, float* dw, co
     PASTA_CHECK(workspace && workspace_bytes >= need, "conv2d_wgrad: workspace of %lld bytes needed, %lld given", (long long)need, (long long)workspace_bytes);
     hipStream_t s = (hipStream_t)stream;
     const int Ig = d->C_in / d->groups, Og = d->C_out / d->groups;
-    PASTA_CHECK(!(d->math == PASTA_MATH_F16X3 && d->io_dtype != PASTA_F32) , "conv2d_wgrad: PASTA_MATH_F16X3 is an arithmetic for fp32 tensors");
     PASTA_CHECK(((uintptr_t)workspace & 15) == 0, "conv2d_wgrad: workspace must be 16-byte aligned");
     float* const ws_amax = (float*)workspace;                         // [2][AMAX_PARTS]: x, dy
     workspace = (float*)workspace + WS_AMAX_FLOATS;                  // the partial slabs follow

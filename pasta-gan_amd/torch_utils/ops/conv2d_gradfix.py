@@ -20,8 +20,10 @@ from .. import custom_ops
 #----------------------------------------------------------------------------
 
 enabled = True                      # Kept for API compatibility; the HIP path is always used for GPU tensors.
-# Matrix-core arithmetic of the convolutions (include/pasta_hip.h PASTA_MATH_*): 'bf16x6' (default; split-bf16 with
-# fp32-equivalent products) or 'f32' (fp32 MFMA, bit-exact fp32 FMA chains). Overridable with PASTA_CONV_MATH.
+# Matrix-core arithmetic of the convolutions (include/pasta_hip.h PASTA_MATH_*): 'f16x3' (= 'default': fp32-equivalent
+# products from three fp16 MFMAs with power-of-two operand scales), 'bf16x6' (fp32-equivalent from six bf16 MFMAs; the default
+# until round 3) or 'f32' (fp32 MFMA, bit-exact fp32 FMA chains); 'bf16x3' / 'bf16' are opt-in reduced modes.  Overridable
+# with PASTA_CONV_MATH.
 import os as _os
 MATH_CODES = {'default': 0, 'f32': 1, 'bf16x6': 2, 'bf16x3': 3, 'bf16': 4, 'f16x3': 5}
 conv_math = _os.environ.get('PASTA_CONV_MATH', 'default')
@@ -111,7 +113,7 @@ def tensor_amax(t):
 
 def _runs_f16x3(kind, desc, flags=0):
     """Does this launch run the three-product fp16 arithmetic (then it wants the operands' partial maxima)?"""
-    if desc.math != MATH_CODES['f16x3'] or desc.io_dtype != 0:
+    if desc.math not in (0, MATH_CODES['f16x3']) or desc.io_dtype != 0:
         return False
     key = (kind, flags & 1, desc.N, desc.C_in, desc.H, desc.W, desc.C_out, desc.OH, desc.OW, desc.kh, desc.kw, desc.stride, desc.pad_h,
            desc.pad_w, desc.groups, desc.transposed)

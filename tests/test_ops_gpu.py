@@ -528,3 +528,31 @@ def test_spade_norm_with_gamma_beta_halves(hw, relu_gain):
     assert torch.equal(g1[0], g2[0]) and torch.equal(g1[1], g2[1])
     dx_only, = torch.autograd.grad(networks.spade_modulate(x, gb.detach(), None, **kw), [x], dy)
     assert torch.equal(dx_only, g2[0])
+
+
+# ----------------------------------------------------------------------------- tensor_amax (operand scales of PASTA_MATH_F16X3)
+
+@pytest.mark.parametrize('numel,offset', [(1, 0), (255, 0), (1 << 20, 0), ((1 << 22) + 3, 1), (16 * 64 * 129 * 129, 3)])
+def test_tensor_amax_partial_maxima(numel, offset):
+    """256 partial maxima whose maximum is the tensor's largest FINITE magnitude; any alignment (views into a larger tensor)."""
+    from torch_utils.ops import _native
+    lib = _native.lib()
+    g = torch.Generator().manual_seed(numel % 9973)
+    base = torch.randn([numel + offset], generator=g).cuda()
+    x = base[offset:]
+    x[numel // 2] = -77.5
+    if numel > 4:
+        x[1] = float('inf'); x[numel - 2] = float('nan'); x[3] = float('-inf')        # skipped by the scan
+    parts = torch.full([256], -1.0, device='cuda')
+    _native.check(lib.pasta_tensor_amax(_native.ptr(x), numel, 0, _native.ptr(parts), _native.stream()))
+    assert float(parts.min()) >= 0
+    finite = x[torch.isfinite(x)]
+    assert float(parts.max()) == float(finite.abs().max()) == 77.5
+    # cached front end
+    from torch_utils.ops import conv2d_gradfix as cg
+    t = torch.randn([4, 8, 16, 16], generator=g).cuda()
+    p1 = cg.tensor_amax(t)
+    assert cg.tensor_amax(t) is p1                      # same version: no second scan
+    t.mul_(2)
+    p2 = cg.tensor_amax(t)
+    assert p2 is not p1 and float(p2.max()) == float(t.abs().max())
