@@ -30,24 +30,33 @@ def _plan_kernel(cfg_desc):
     return kernel.value, launches.value
 
 
+@pytest.mark.parametrize('math', ['bf16x6', 'default'])
 @pytest.mark.parametrize('n,cin,cout,h,w,pad,opad', CASES)
-def test_transposed_stride2_pairs_match_fp64(n, cin, cout, h, w, pad, opad):
+def test_transposed_stride2_pairs_match_fp64(n, cin, cout, h, w, pad, opad, math):
+    """The pair kernel belongs to the six-product split-bf16 arithmetic ('bf16x6'); the default three-product fp16 arithmetic
+    runs these shapes on the class-merged base kernel -- both against fp64."""
     from torch_utils.ops import conv2d_gradfix as cg
     g = torch.Generator().manual_seed(h * 7 + cin)
     x = torch.randn([n, cin, h, w], generator=g)
     wt = torch.randn([cin, cout, 3, 3], generator=g) / (cin * 9) ** 0.5
     ref = torch.nn.functional.conv_transpose2d(x.double(), wt.double(), stride=2, padding=pad, output_padding=opad)
-    y = cg.conv_transpose2d(x.cuda(), wt.cuda(), stride=2, padding=pad, output_padding=opad)
+    old, cg.conv_math = cg.conv_math, math
+    try:
+        y = cg.conv_transpose2d(x.cuda(), wt.cuda(), stride=2, padding=pad, output_padding=opad)
+        cfg = cg._Cfg((True, 2, pad, pad, opad, opad, 1, 1.0))
+        kernel, launches = _plan_kernel(cg._desc(cfg, x.shape, cout, ref.shape[2], ref.shape[3], 3, 3))
+    finally:
+        cg.conv_math = old
     assert y.shape == ref.shape
     err = float((y.cpu().double() - ref).abs().max() / ref.abs().max())
     assert err < 2e-6, err
-    cfg = cg._Cfg((True, 2, pad, pad, opad, opad, 1, 1.0))
-    kernel, launches = _plan_kernel(cg._desc(cfg, x.shape, cout, ref.shape[2], ref.shape[3], 3, 3))
-    if cg.conv_math in ('default', 'bf16x6'):
+    if math == 'bf16x6':
         if opad == 1:                   # even output planes: always the pair kernel
             assert kernel == 3 and launches == 1
         elif h * w >= 128 * 128 or os.environ.get('PASTA_T2_PAIR') == '2':     # with a remainder row / column: planes of 128 x 128 and larger (csrc/conv_igemm.hip, pair_launch_ok)
             assert kernel == 3 and launches == 2
+    else:
+        assert kernel == 1 and launches == 1        # the four parity classes share one grid of conv_fwd_bf16x6_kernel
 
 
 def test_stride2_convolution_input_gradient_takes_the_pair_kernel():
