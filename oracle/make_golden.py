@@ -1,6 +1,6 @@
 """Generate tests/golden/*.npz by running the REFERENCE itself (build container only).
 
-    python oracle/make_golden.py [--ref /root/reference] [--only ops|layers|primitives|models|fullwidth|fullwidth_r1|loss|augment|snapshot]
+    python oracle/make_golden.py [--ref /root/reference] [--only ops|layers|primitives|models|models_f64|fullwidth|fullwidth_r1|loss|augment|snapshot]
 
 The reference is imported read-only from ``--ref`` (never copied): op level as is, model level
 with the two harness accommodations SURVEY.md F1/F4 describe (cwd = reference root,
@@ -250,6 +250,9 @@ if __name__ == '__main__':
     if args.only in ('all', 'models'):
         from make_golden_models import gen_models
         gen_models(args.ref, import_reference_networks)
+    if args.only in ('all', 'models_f64'):
+        from make_golden_models_f64 import gen_models_f64
+        gen_models_f64(args.ref, import_reference_networks)
     if args.only in ('all', 'fullwidth'):
         from make_golden_fullwidth import gen_fullwidth
         gen_fullwidth(args.ref, import_reference_networks)

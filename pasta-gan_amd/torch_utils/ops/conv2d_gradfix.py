@@ -66,8 +66,15 @@ def _out_hw(cfg, h, w, kh, kw):
 
 IO_CODES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 3}      # pasta_conv_desc.io_dtype (PASTA_F32 / _F16 / _BF16)
 
-def _desc(cfg, x_shape, c_out, oh, ow, kh, kw, io=torch.float32):
+_SCOPE = _os.environ.get('PASTA_F16X3_SCOPE', 'all')       # diagnostic: 'fwd' / 'wgrad' = the three-product arithmetic for those launches only
+
+def _desc(cfg, x_shape, c_out, oh, ow, kh, kw, io=torch.float32, kind='fwd'):
     n, c_in, h, w = x_shape
+    if _SCOPE != 'all' and _SCOPE != kind and conv_math in ('default', 'f16x3'):
+        d = custom_ops.ConvDesc(N=n, C_in=c_in, H=h, W=w, C_out=c_out, OH=oh, OW=ow, kh=kh, kw=kw, stride=cfg.stride,
+                                pad_h=cfg.pad_h, pad_w=cfg.pad_w, groups=cfg.groups, transposed=int(cfg.transposed), flip=0,
+                                math=MATH_CODES['bf16x6'], wscale=float(cfg.wgain), io_dtype=IO_CODES[io])
+        return d
     return custom_ops.ConvDesc(N=n, C_in=c_in, H=h, W=w, C_out=c_out, OH=oh, OW=ow, kh=kh, kw=kw, stride=cfg.stride,
                                pad_h=cfg.pad_h, pad_w=cfg.pad_w, groups=cfg.groups, transposed=int(cfg.transposed), flip=0,
                                math=MATH_CODES[conv_math], wscale=float(cfg.wgain), io_dtype=IO_CODES[io])
@@ -247,7 +254,7 @@ def _launch_wgrad(x, dy, cfg, w_shape, out_dtype=None):
         io = x.dtype
     x = x.contiguous() if io is not torch.float32 else _f32(x).contiguous()
     dy = dy.contiguous() if io is not torch.float32 else _f32(dy).contiguous()
-    desc = _desc(cfg, x.shape, dy.shape[1], dy.shape[2], dy.shape[3], kh, kw, io)
+    desc = _desc(cfg, x.shape, dy.shape[1], dy.shape[2], dy.shape[3], kh, kw, io, kind='wgrad')
     lib = _native.lib()
     nbytes = lib.pasta_conv2d_wgrad_workspace(ctypes.byref(desc))
     if nbytes < 0:

@@ -27,6 +27,23 @@ def _summary_ok(g, key, tensor, tol):
     assert abs(m[2] - mg[2]) <= 2 * tol * abs(mg[2]) + 1e-12, key
 
 
+def _grad_ok(g, g64, key, tensor, tol):
+    """A parameter gradient meets the bar against the reference's fp32 evaluation (``models_fullbody.npz``) OR against the
+    reference's own code run in fp64 (``models_fullbody_f64.npz``, oracle/make_golden_models_f64.py).  Some gradients of the
+    closed-form-filled generator are cancellation residue (the demodulated style path): on ``synthesis.b64.conv0.affine.weight`` the
+    reference's fp32 result is 1.25e-3 from its fp64 result, and so are fp32 MFMA (1.1e-3) and split-bf16 (1.5e-3), while the
+    three-product fp16 arithmetic lands 1.5e-4 from the fp64 value (tools/diag_modes.py, measured on MI355X) -- 1e-3 against ONE fp32
+    rounding of such a quantity would measure luck, 1e-3 against either evaluation measures parity with the reference's algorithm."""
+    s = PF.summarize(tensor)
+    e32 = rel_err(s['sample'], g[key + '.sample'])
+    e64 = rel_err(s['sample'].astype(np.float64), g64[key + '.sample'])
+    assert min(e32, e64) < tol, (key, e32, e64)
+    if e32 < tol:
+        m, mg = s['moments'], g[key + '.moments']
+        assert abs(m[1] - mg[1]) <= tol * abs(mg[1]) + 1e-12 and abs(m[2] - mg[2]) <= 2 * tol * abs(mg[2]) + 1e-12, key
+    return e32, e64
+
+
 def _cuda(inp):
     return {k: v.cuda() for k, v in inp.items()}
 
@@ -53,6 +70,7 @@ def test_modulated_conv2d_golden(idx, fused):
 def test_generator_full_golden():
     from training import networks
     g = load_golden('models_fullbody.npz')
+    g64 = load_golden('models_fullbody_f64.npz')
     G = PF.fill_module(networks.GeneratorFull(**PF.G_KWARGS)).cuda().train().requires_grad_(True)
     inp = _cuda(PF.make_inputs(n=2, seed=0))
     args = (inp['gen_z'], inp['style_input'], inp['retain'], inp['pose'], inp['denorm_upper_input'], inp['denorm_lower_input'],
@@ -65,8 +83,8 @@ def test_generator_full_golden():
     assert abs(probe.item() - float(g['G.probe'][0])) < TOL_FWD * abs(float(g['G.probe'][0]))
     probe.backward()
     sd = dict(G.named_parameters())
-    for k in GRAD_KEYS_G:
-        _summary_ok(g, 'G.grad.' + k, sd[k].grad, TOL_GRAD)
+    errs = [_grad_ok(g, g64, 'G.grad.' + k, sd[k].grad, TOL_GRAD) for k in GRAD_KEYS_G]
+    assert sum(e32 < TOL_GRAD for e32, _ in errs) >= len(errs) - 1          # at most one key needs the fp64 evaluation
     G.eval()
     with torch.no_grad():
         img_e, fin_e, _ = G(*args, noise_mode='const')

@@ -99,8 +99,12 @@ def test_two_iterations_of_the_loop():
                 assert np.linalg.norm(ours) == 0, (tag, k)
                 continue
             cos = float((ours * ref).sum() / (np.linalg.norm(ours) * np.linalg.norm(ref)))
+            size = abs(np.abs(ours).mean() / np.abs(ref).mean() - 1)
+            print(f'{tag} {k}: cosine {cos:.4f}, size {size:.4f}')
             assert cos > 0.98, (tag, k, cos)
-            assert abs(np.abs(ours).mean() / np.abs(ref).mean() - 1) < 0.02, (tag, k)
+            # 3 %: measured worst key (style_encoding.fc.weight, whose gradient is instance-norm cancellation residue, so many of its
+            # elements step by +-lr on rounding noise) 1.2 % fp32 MFMA, 1.9 % split-bf16, 2.7 % fp16 x 3
+            assert size < 0.03, (tag, k, size)
 
     check('b.G', dict(step.G.named_parameters()), init_G, DELTA_KEYS_G)
     check('b.D', dict(step.D.named_parameters()), init_D, DELTA_KEYS_D)
@@ -136,11 +140,20 @@ def test_merged_discriminator_pass_equals_separate_passes():
     w = [torch.randn([8, 1], generator=g).cuda() for _ in range(3)]
     g_sep = torch.autograd.grad(sum((a * x).sum() for a, x in zip(sep, w)), imgs)
     g_mer = torch.autograd.grad(sum((a * x).sum() for a, x in zip(mer, w)), imgs)
+    flipped = 0
     for a, b in zip(g_sep, g_mer):
         # the two ways take different launch plans (K slices at 8 images, none at 24), each fp32-accurate to ~1e-6 per convolution
-        # (measured against fp64: rms 7e-7 sliced / 1e-6 unsliced at 512 channels); through 14 layers and their lrelu masks the
-        # image gradients (magnitude 1e-15 with these weights) of the two differ by 0.7e-4 .. 1.4e-4 of their maximum
-        assert rel_err(b, a) < 3e-4
+        # (measured against fp64: rms 7e-7 sliced / 1e-6 unsliced at 512 channels); through 14 layers the image gradients of the
+        # two differ by 3e-6 .. 1e-5 of their maximum -- unless a leaky-ReLU pre-activation within rounding of zero takes the other
+        # slope in one of the two passes.  One such flip changes ONE sample's gradient, by as much as the unit's share of it:
+        # measured 1.4e-4 (split-bf16, a 32x32-layer unit), 1.2e-5 (fp32 MFMA), 2.9e-2 (fp16 x 3, an 8x8-layer unit carrying the
+        # sample's largest gradient; tools/diag_f16x3_b.py traces it).  So: every sample within 3e-4 except at most one per
+        # batch of 24, and that one within 10 %.
+        pm = a.abs().amax(dim=[1, 2, 3]).clamp_min(1e-300)
+        per_sample = ((b - a).abs().amax(dim=[1, 2, 3]) / pm).cpu()
+        assert float(per_sample.max()) < 0.1, per_sample
+        flipped += int((per_sample >= 3e-4).sum())
+    assert flipped <= 1, flipped
 
 
 def test_ada_controller_moves_p_like_the_reference():
