@@ -103,7 +103,7 @@ def test_two_iterations_of_the_loop():
             print(f'{tag} {k}: cosine {cos:.4f}, size {size:.4f}')
             assert cos > 0.98, (tag, k, cos)
             # 3 %: measured worst key (style_encoding.fc.weight, whose gradient is instance-norm cancellation residue, so many of its
-            # elements step by +-lr on rounding noise) 1.2 % fp32 MFMA, 1.9 % split-bf16, 2.7 % fp16 x 3
+            # elements step by +-lr on rounding noise) 0.6 % fp32 MFMA, 1.9 % split-bf16, 2.7 % fp16 x 3 (gpurun_out/r3_two_it.log)
             assert size < 0.03, (tag, k, size)
 
     check('b.G', dict(step.G.named_parameters()), init_G, DELTA_KEYS_G)
