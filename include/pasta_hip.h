@@ -121,6 +121,8 @@ typedef struct pasta_conv_desc {
                                      (one extra pass over x).  A caller that uses a tensor in several launches (forward and
                                      weight gradient; input gradient and weight gradient) computes them once.            */
     const float* dy_amax;         /* the same for dy (pasta_conv2d_wgrad only)                                         */
+    const float* w_amax;          /* the same for w (the UNSCALED weight tensor passed as w; pasta_conv2d / _ex): a layer's weight
+                                     changes once per optimiser step and is used by several launches in between            */
 } pasta_conv_desc;
 
 /* Arithmetic of the convolution products.  Accumulation is fp32 in every mode.

@@ -470,8 +470,12 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
             hipLaunchKernelGGL(amax_times_kernel, dim3(1), dim3(256), 0, s, xa, iscale, d->N * d->C_in, ws_amax);
             xa = ws_amax;
         }
-        if (int e = tensor_amax(w, (int64_t)d->C_out * (d->C_in / d->groups) * d->kh * d->kw, PASTA_F32, ws_amax + AMAX_PARTS, s)) return e;
-        p.x_amax = xa; p.w_amax = ws_amax + AMAX_PARTS; p.w_gain = fabsf(wscale);
+        const float* wa = d->w_amax;
+        if (!wa) {
+            if (int e = tensor_amax(w, (int64_t)d->C_out * (d->C_in / d->groups) * d->kh * d->kw, PASTA_F32, ws_amax + AMAX_PARTS, s)) return e;
+            wa = ws_amax + AMAX_PARTS;
+        }
+        p.x_amax = xa; p.w_amax = wa; p.w_gain = fabsf(wscale);
     }
     {   // pack weights (times wscale)
         const int64_t total = (int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad;

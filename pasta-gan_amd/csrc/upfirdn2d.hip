@@ -219,10 +219,20 @@ __global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p,
 // output planes leave as one contiguous write.
 constexpr int SMALL_LDS_FLOATS = 8192;      // 32 KB of input planes per workgroup
 
-template <class T>
-__global__ __launch_bounds__(256) void upfirdn2d_small_kernel(UpfirdnParams p, int planes, int PL) {
+// U, D, F > 0: compile-time factors and a square F x F filter (the live classes: 4-tap blur, x2 up, /2 down) -- the taps sit
+// in registers and the tap loops unroll; U = 0: any parameters (taps from a table in memory).  Output index -> (plane, row,
+// column) by multiplication with host-computed reciprocals (exact below 2^20 / divisor outputs per pass).
+template <class T, int U, int D, int F>
+__global__ __launch_bounds__(256) void upfirdn2d_small_kernel(UpfirdnParams p, int planes, int PL, unsigned magic_sz, unsigned magic_w) {
     __shared__ float sx[SMALL_LDS_FLOATS];
     const int in_sz = p.inH * p.inW, out_sz = p.outH * p.outW;
+    float g[U > 0 ? F : 1][U > 0 ? F : 1];
+    if constexpr (U > 0) {
+#pragma unroll
+        for (int a = 0; a < F; a++)
+#pragma unroll
+            for (int b = 0; b < F; b++) g[a][b] = p.f[(p.flip ? a : F - 1 - a) * F + (p.flip ? b : F - 1 - b)];
+    }
     for (int p0 = blockIdx.x * PL; p0 < planes; p0 += gridDim.x * PL) {
         const int np = planes - p0 < PL ? planes - p0 : PL;
         const T* xp = (const T*)p.x + (int64_t)p0 * in_sz;
@@ -231,41 +241,72 @@ __global__ __launch_bounds__(256) void upfirdn2d_small_kernel(UpfirdnParams p, i
         __syncthreads();
         T* yp = (T*)p.y + (int64_t)p0 * out_sz;
         for (int e = threadIdx.x; e < np * out_sz; e += 256) {
-            const int pl = e / out_sz, r = e - pl * out_sz;
-            const int oy = r / p.outW, ox = r - oy * p.outW;
-            const int ux0 = ox * p.downx - p.padx0, uy0 = oy * p.downy - p.pady0;
+            const int pl = (int)__umulhi((unsigned)e, magic_sz), r = e - pl * out_sz;
+            const int oy = (int)__umulhi((unsigned)r, magic_w), ox = r - oy * p.outW;
             const float* sp = sx + pl * in_sz;
             float v = 0.f;
-            for (int ty = posmod(-uy0, p.upy); ty < p.fh; ty += p.upy) {
-                const int uy = uy0 + ty;
-                if (uy < 0) continue;
-                const int iy = uy / p.upy;
-                if (iy >= p.inH) break;
-                const int gy = p.flip ? ty : p.fh - 1 - ty;
-                for (int tx = posmod(-ux0, p.upx); tx < p.fw; tx += p.upx) {
-                    const int ux = ux0 + tx;
-                    if (ux < 0) continue;
-                    const int ix = ux / p.upx;
-                    if (ix >= p.inW) break;
-                    const int gx = p.flip ? tx : p.fw - 1 - tx;
-                    v = fmaf(sp[iy * p.inW + ix], p.f[gy * p.fw + gx], v);
+            if constexpr (U > 0) {
+                const int ux0 = ox * D - p.padx0, uy0 = oy * D - p.pady0;
+#pragma unroll
+                for (int ty = 0; ty < F; ty++) {
+                    const int uy = uy0 + ty;
+                    const int iy = U == 1 ? uy : uy >> 1;
+                    const bool yok = (U == 1 || (uy & 1) == 0) && (unsigned)iy < (unsigned)p.inH;     // U in {1, 2}
+#pragma unroll
+                    for (int tx = 0; tx < F; tx++) {
+                        const int ux = ux0 + tx;
+                        const int ix = U == 1 ? ux : ux >> 1;
+                        const bool ok = yok && (U == 1 || (ux & 1) == 0) && (unsigned)ix < (unsigned)p.inW;
+                        v = fmaf(ok ? sp[iy * p.inW + ix] : 0.f, g[ty][tx], v);
+                    }
                 }
+                st<T>(yp + e, v * p.gain);
+            } else {
+                const int ux0 = ox * p.downx - p.padx0, uy0 = oy * p.downy - p.pady0;
+                for (int ty = posmod(-uy0, p.upy); ty < p.fh; ty += p.upy) {
+                    const int uy = uy0 + ty;
+                    if (uy < 0) continue;
+                    const int iy = uy / p.upy;
+                    if (iy >= p.inH) break;
+                    const int gy = p.flip ? ty : p.fh - 1 - ty;
+                    for (int tx = posmod(-ux0, p.upx); tx < p.fw; tx += p.upx) {
+                        const int ux = ux0 + tx;
+                        if (ux < 0) continue;
+                        const int ix = ux / p.upx;
+                        if (ix >= p.inW) break;
+                        const int gx = p.flip ? tx : p.fw - 1 - tx;
+                        v = fmaf(sp[iy * p.inW + ix], p.f[gy * p.fw + gx], v);
+                    }
+                }
+                st<T>(yp + e, v * p.gain);
             }
-            st<T>(yp + e, v * p.gain);
         }
     }
 }
 
+// ceil(2^32 / d): umulhi(e, magic) == e / d for e * d < 2^32
+static unsigned recip_magic(int d) { return d <= 1 ? 0xffffffffu : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
+
 template <class T>
 static bool try_small(const UpfirdnParams& p, hipStream_t s) {
     const int in_sz = p.inH * p.inW;
+    const int64_t out_sz = (int64_t)p.outH * p.outW;
     const int64_t planes = (int64_t)p.N * p.C;
-    if (in_sz > 1024 || (int64_t)p.outH * p.outW > 4096 || planes > INT32_MAX) return false;
+    if (in_sz > 1024 || out_sz > 4096 || planes > INT32_MAX) return false;
     int PL = SMALL_LDS_FLOATS / in_sz;
     // enough workgroups to fill the chip before planes are stacked deeper
     while (PL > 1 && planes / PL < 512) PL >>= 1;
+    if ((int64_t)PL * out_sz * out_sz >= (1ll << 32) || out_sz == 1 || p.outW == 1) return false;      // reciprocal range (d = 1 has no 32-bit reciprocal)
     const int64_t groups = (planes + PL - 1) / PL;
-    hipLaunchKernelGGL((upfirdn2d_small_kernel<T>), dim3((unsigned)(groups < 4096 ? groups : 4096)), dim3(256), 0, s, p, (int)planes, PL);
+    const dim3 grid((unsigned)(groups < 4096 ? groups : 4096));
+    const unsigned msz = recip_magic((int)out_sz), mw = recip_magic(p.outW);
+    const bool sq4 = p.fw == 4 && p.fh == 4 && p.upx == p.upy && p.downx == p.downy;
+#define PASTA_SMALL(U_, D_, F_) hipLaunchKernelGGL((upfirdn2d_small_kernel<T, U_, D_, F_>), grid, dim3(256), 0, s, p, (int)planes, PL, msz, mw)
+    if (sq4 && p.upx == 1 && p.downx == 1) PASTA_SMALL(1, 1, 4);
+    else if (sq4 && p.upx == 2 && p.downx == 1) PASTA_SMALL(2, 1, 4);
+    else if (sq4 && p.upx == 1 && p.downx == 2) PASTA_SMALL(1, 2, 4);
+    else PASTA_SMALL(0, 0, 0);
+#undef PASTA_SMALL
     return true;
 }
 

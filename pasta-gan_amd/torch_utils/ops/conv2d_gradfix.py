@@ -216,8 +216,8 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, 
         assert mod_s.numel() == x.shape[1] and (mod_d is None or mod_d.numel() == c_out)
     x_amax = None
     if wmod is None and _runs_f16x3('conv', desc, 1 if iscale is not None else 0):
-        x_amax = tensor_amax(x)
-        desc.x_amax = x_amax.data_ptr()
+        x_amax, w_amax = tensor_amax(x), tensor_amax(w)       # w: a parameter is scanned once per optimiser step
+        desc.x_amax, desc.w_amax = x_amax.data_ptr(), w_amax.data_ptr()
     def launch():
         with torch.cuda.device(x.device):
             if wmod is not None:
