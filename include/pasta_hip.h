@@ -49,7 +49,7 @@ int pasta_upfirdn2d(const void* x, const float* f, void* y, int dtype,
                     const int32_t out_size[4], const int64_t out_stride[4],
                     int upx, int upy, int downx, int downy,
                     int padx0, int padx1, int pady0, int pady1,
-                    int flip, float gain, void* stream);
+                    int flip, float gain, void* stream, float* y_amax);
 
 /* ------------------------------------------------------------------------- *
  * bias_act -- fused bias + activation + gain + clamp, and its 1st/2nd grads.
@@ -65,7 +65,7 @@ int pasta_upfirdn2d(const void* x, const float* f, void* y, int dtype,
 int pasta_bias_act(const void* x, const void* b, const void* xref,
                    const void* yref, const void* dy, void* y, int dtype,
                    int64_t n, int size_b, int64_t step_b, int grad, int act,
-                   float alpha, float gain, float clamp, void* stream);
+                   float alpha, float gain, float clamp, void* stream, float* y_amax);
 
 /* Column sums used for the bias gradient (bias_act.py:173 `dx.sum(...)`):
  * db[c] = sum over all i with (i / step_b) % size_b == c of dx[i].
@@ -83,7 +83,7 @@ int pasta_bias_grad(const void* dx, void* db, float* work, int dtype, int64_t n,
  * pasta_bias_act(grad=1) followed by pasta_bias_grad).  yref may be NULL only for act 1 without clamp. */
 int64_t pasta_bias_act_grad_db_workspace(int dtype, int64_t n, int size_b, int64_t step_b, int act);
 int pasta_bias_act_grad_db(const void* dy, const void* yref, void* dx, void* db, float* work, int dtype, int64_t n,
-                           int size_b, int64_t step_b, int act, float alpha, float gain, float clamp, void* stream);
+                           int size_b, int64_t step_b, int act, float alpha, float gain, float clamp, void* stream, float* dx_amax);
 
 /* ------------------------------------------------------------------------- *
  * Dense convolution family on fp32 matrix cores (v_mfma_f32_32x32x2_f32).
@@ -157,6 +157,11 @@ enum { PASTA_MATH_DEFAULT = 0, PASTA_MATH_F32 = 1, PASTA_MATH_BF16X6 = 2, PASTA_
  * tensors to cuDNN, conv2d_gradfix.py:38); it exists so that a tensor used by several launches is scanned once. */
 #define PASTA_AMAX_PARTS 256
 int pasta_tensor_amax(const void* x, int64_t numel, int dtype, float* parts, void* stream);
+/* Producer-side maxima: the operators that WRITE activation tensors (pasta_upfirdn2d, pasta_bias_act, pasta_bias_act_grad_db,
+ * pasta_scale_add, pasta_mod_bias_act(_bwd), pasta_spade_norm(_bwd) and the convolutions through pasta_conv_epilogue.y_amax) take
+ * a last argument `float* y_amax` (NULL = off): PASTA_AMAX_PARTS floats ZEROED by the caller, into which the kernel leaves
+ * partial maxima of the largest finite magnitude it stored (one agent-scope integer atomic per wavefront on the bit patterns:
+ * order-independent, hence deterministic).  What pasta_tensor_amax would find, without the extra pass over the tensor. */
 
 /* Bytes of scratch the forward / weight-gradient launches need (caller allocs). */
 int64_t pasta_conv2d_workspace(const pasta_conv_desc* d);
@@ -219,6 +224,9 @@ typedef struct pasta_conv_epilogue {
     const float* noise;           /* fp32 [OH*OW] (noise_per_sample 0) or [N][OH*OW] (1), or NULL */
     const float* noise_strength;  /* device scalar (SynthesisLayer.noise_strength); required with noise */
     int32_t noise_per_sample;
+    float* y_amax;                /* optional: PASTA_AMAX_PARTS floats, ZEROED by the caller, that receive partial maxima of the
+                                     largest finite |y| (fp32 storage): the launch that consumes y under PASTA_MATH_F16X3 then needs
+                                     no scan of y (see "producer-side maxima" below).  NULL = off. */
 } pasta_conv_epilogue;
 
 /* pasta_conv2d with the epilogue above (ep NULL = plain pasta_conv2d). */
@@ -257,7 +265,7 @@ int pasta_demod_coefs(const float* w, const float* styles, float* d, int N, int 
 /* (this and the following plane kernels: `dtype` = storage type of the activation tensors -- PASTA_F32, PASTA_F16 or
  * PASTA_BF16; per-channel scales, statistics, bias, noise strength and partial sums are always fp32, as is the arithmetic) */
 int pasta_scale_add(const void* x, const float* a, const void* b, void* y, int dtype,
-                    int N, int C, int64_t HW, int b_per_sample, void* stream);
+                    int N, int C, int64_t HW, int b_per_sample, void* stream, float* y_amax);
 
 /* Per-(n,c) plane reductions used by fma / modulation backward:
  * out[n,c] = sum_hw p[n,c,hw] * q[n,c,hw]   (q NULL => sum of p) */
@@ -273,11 +281,11 @@ int pasta_plane_dot(const void* p, const void* q, float* out, int dtype, int64_t
  * bytes), from which the caller forms dd[n,c], dstrength and db[c]. */
 int pasta_mod_bias_act(const void* u, const float* d, const float* noise, const float* strength, const float* b, void* y,
                        int dtype, int N, int C, int64_t HW, int noise_per_sample, int act, float alpha, float gain, float clamp,
-                       void* stream);
+                       void* stream, float* y_amax);
 int64_t pasta_mod_bias_act_bwd_workspace(int N, int C, int64_t HW);
 int pasta_mod_bias_act_bwd(const void* dy, const void* y, const void* u, const float* d, const float* noise, void* du,
                            float* partial, int dtype, int N, int C, int64_t HW, int noise_per_sample, int act, float alpha, float gain,
-                           float clamp, void* stream);
+                           float clamp, void* stream, float* du_amax);
 
 /* ------------------------------------------------------------------------- *
  * SPADE normalisation (training/networks.py:4371-4379):
@@ -292,12 +300,12 @@ int pasta_mod_bias_act_bwd(const void* dy, const void* y, const void* u, const f
  * ------------------------------------------------------------------------- */
 int pasta_spade_norm(const void* x, const void* gamma, const void* beta,
                      void* out, float* stats, int dtype, int64_t planes, int64_t HW,
-                     float eps, int act, float gain, float clamp, int C, int64_t gb_stride, void* stream);
+                     float eps, int act, float gain, float clamp, int C, int64_t gb_stride, void* stream, float* y_amax);
 int pasta_spade_norm_bwd(const void* dout, const void* x, const void* gamma,
                          const float* stats, void* dx, void* dgamma,
                          void* dbeta, int dtype, int64_t planes, int64_t HW,
                          const void* beta, int act, float gain, float clamp, int C, int64_t gb_stride, int64_t dgb_stride,
-                         void* stream);
+                         void* stream, float* dx_amax);
 
 /* ------------------------------------------------------------------------- *
  * ADA augmentation (training/augment.py:121-431).

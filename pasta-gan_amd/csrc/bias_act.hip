@@ -17,6 +17,7 @@ struct BiasActParams {
     const void* x; const void* b; const void* xref; const void* yref; const void* dy; void* y;
     int64_t n; int size_b; int64_t step_b;
     float alpha, gain, clamp;
+    float* y_amax;              // optional: PASTA_AMAX_PARTS zeroed floats that receive the largest finite |y| (common.h, amax_commit)
 };
 
 template <int A, int G, class S>
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(256) void bias_act_kernel(BiasActParams p) {
     const Pack<T, V>* yr = (const Pack<T, V>*)p.yref;
     const Pack<T, V>* dys = (const Pack<T, V>*)p.dy;
     Pack<T, V>* ys = (Pack<T, V>*)p.y;
+    uint32_t am = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
         Pack<T, V> vx = xs[i], vxr, vyr, vdy, out;
         if (xr) vxr = xr[i];
@@ -100,9 +102,11 @@ __global__ __launch_bounds__(256) void bias_act_kernel(BiasActParams p) {
             S r = bias_act_point<A, G, S>(ld<T>(&vx.v[k]), b, xr ? ld<T>(&vxr.v[k]) : (S)0, yr ? ld<T>(&vyr.v[k]) : (S)0,
                                           dys ? ld<T>(&vdy.v[k]) : (S)1, alpha, gain, clamp);
             st<T>(&out.v[k], r);
+            if (p.y_amax) amax_take(am, (float)ld<T>(&out.v[k]));
         }
         ys[i] = out;
     }
+    amax_commit(am, p.y_amax);
 }
 
 template <class T, int A, int G>
@@ -202,6 +206,7 @@ __global__ __launch_bounds__(256) void bias_act_grad_db_kernel(BiasActParams p, 
     Pack<T, V>* dxs = (Pack<T, V>*)p.y + (int64_t)plane * plane_packs;
     const int j1 = min(plane_packs, (chunk + 1) * DB_CHUNK_PACKS);
     float acc = 0.f;
+    uint32_t am = 0;
     for (int j = chunk * DB_CHUNK_PACKS + threadIdx.x; j < j1; j += 256) {
         Pack<T, V> vdy = dys[j], vyr, out;
         if (yr) vyr = yr[j];
@@ -210,9 +215,11 @@ __global__ __launch_bounds__(256) void bias_act_grad_db_kernel(BiasActParams p, 
             const S r = bias_act_point<A, 1, S>(ld<T>(&vdy.v[k]), (S)0, (S)0, yr ? ld<T>(&vyr.v[k]) : (S)0, (S)1, alpha, gain, clamp);
             st<T>(&out.v[k], r);
             acc += (float)ld<T>(&out.v[k]);          // the stored (rounded) value, as a sum over dx would see it
+            if (p.y_amax) amax_take(am, (float)ld<T>(&out.v[k]));
         }
         dxs[j] = out;
     }
+    amax_commit(am, p.y_amax);
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     __shared__ float part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
@@ -253,7 +260,7 @@ extern "C" int64_t pasta_bias_act_grad_db_workspace(int dtype, int64_t n, int si
 }
 
 extern "C" int pasta_bias_act_grad_db(const void* dy, const void* yref, void* dx, void* db, float* work, int dtype, int64_t n,
-                                      int size_b, int64_t step_b, int act, float alpha, float gain, float clamp, void* stream) {
+                                      int size_b, int64_t step_b, int act, float alpha, float gain, float clamp, void* stream, float* dx_amax) {
     using namespace pasta;
     const int chunks = grad_db_chunks(dtype, n, size_b, step_b, act);
     PASTA_CHECK(chunks > 0, "bias_act_grad_db: unsupported case (dtype %d, n %lld, size_b %d, step_b %lld, act %d)", dtype,
@@ -264,7 +271,7 @@ extern "C" int pasta_bias_act_grad_db(const void* dy, const void* yref, void* dx
     BiasActParams p;
     p.x = dy; p.b = nullptr; p.xref = nullptr; p.yref = yref; p.dy = nullptr; p.y = dx;
     p.n = n; p.size_b = size_b; p.step_b = step_b;
-    p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.y_amax = dx_amax;
     const int outer = (int)(n / ((int64_t)size_b * step_b));
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PASTA_F32) return launch_grad_db<float, 4>(p, work, db, act, outer, chunks, s);
@@ -274,7 +281,7 @@ extern "C" int pasta_bias_act_grad_db(const void* dy, const void* yref, void* dx
 
 extern "C" int pasta_bias_act(const void* x, const void* b, const void* xref, const void* yref, const void* dy, void* y,
                               int dtype, int64_t n, int size_b, int64_t step_b, int grad, int act, float alpha,
-                              float gain, float clamp, void* stream) {
+                              float gain, float clamp, void* stream, float* y_amax) {
     using namespace pasta;
     PASTA_CHECK(n >= 0, "bias_act: negative element count");
     if (n == 0) return 0;
@@ -285,7 +292,7 @@ extern "C" int pasta_bias_act(const void* x, const void* b, const void* xref, co
     BiasActParams p;
     p.x = x; p.b = b; p.xref = xref; p.yref = yref; p.dy = dy; p.y = y;
     p.n = n; p.size_b = b ? size_b : 1; p.step_b = b ? step_b : 1;
-    p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.y_amax = y_amax;
     hipStream_t s = (hipStream_t)stream;
     switch (dtype) {
         case PASTA_F32: return launch_act<float>(p, act, grad, s);

@@ -74,6 +74,22 @@ template <>        __device__ __forceinline__ void st4<__half>(__half* p, float4
 // V elements moved as one 16-byte (or narrower) access.
 template <class T, int V> struct alignas(sizeof(T) * V) Pack { T v[V]; };
 
+// Producer-side |max| (PASTA_MATH_F16X3, conv_common.h): a kernel that writes a tensor can leave the tensor's largest finite
+// magnitude behind in `parts` -- PASTA_AMAX_PARTS floats the CALLER has zeroed -- so that the convolution consuming the tensor
+// needs no scan of its own.  Non-negative floats order like their bit patterns, so the running maximum is an integer maximum
+// and the commit one agent-scope atomic per wave (order-independent: the result is deterministic).
+__device__ __forceinline__ void amax_take(uint32_t& m, float v) {
+    const uint32_t b = __builtin_bit_cast(uint32_t, v) & 0x7fffffffu;
+    m = (b < 0x7f800000u && b > m) ? b : m;
+}
+__device__ __forceinline__ void amax_commit(uint32_t m, float* parts) {
+    if (!parts) return;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m != 0)
+        atomicMax((unsigned int*)parts + ((blockIdx.x + 37u * blockIdx.y + (threadIdx.x >> 6)) & 255u), m);
+}
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // floor(a / b) for b > 0 and any sign of a.

@@ -183,6 +183,7 @@ struct ConvFwdParams {
     const float* iscale; const float* oscale;
     const float* x_amax; const float* w_amax;           // PASTA_MATH_F16X3: AMAX_PARTS partial |max| of x and of w (w: before wscale)
     float w_gain;                                       // |wscale|: the packed weights are w * wscale
+    float* y_amax;                                      // optional (fused epilogue): zeroed partial |max| slots of y (common.h, amax_commit)
     int io;                                             // IO_F32 / IO_F16 / IO_BF16
     int N, Cin, H, W;
     int Cout, OH, OW;

@@ -333,6 +333,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     }
 
     const int OHW = p.OH * p.OW;
+    uint32_t y_am = 0;
     const bool has_noise = p.noise && p.ksplit == 1;
     const float nstr = has_noise ? p.noise_strength[0] : 0.f;
 #pragma unroll
@@ -360,10 +361,11 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
                     if (has_res) v += io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES);
                     if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
                     if (pb) pb[(int64_t)o * OHW] = v;
-                    else io_st<IO>(p.y, yoff + (int64_t)o * OHW, v);
+                    else { io_st<IO>(p.y, yoff + (int64_t)o * OHW, v); if (p.y_amax) amax_take(y_am, v); }
                 }
             }
     }
+    if (p.ksplit == 1) amax_commit(y_am, p.y_amax);
 }
 
 
@@ -884,6 +886,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     }
 
     const int OHW = p.OH * p.OW;
+    uint32_t y_am = 0;
     if constexpr (PAIR) {
         // (p, q) of the input lattice -> output row 2p + a, columns 2q and 2q + 1: one 8-byte store per lane
         struct __attribute__((packed, aligned(4))) Pair { float even, odd; };
@@ -935,10 +938,11 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
                     if (has_res) v += io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES);
                     if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
                     if (pb) pb[(int64_t)o * OHW] = v;
-                    else io_st<IO>(p.y, yoff + (int64_t)o * OHW, v);
+                    else { io_st<IO>(p.y, yoff + (int64_t)o * OHW, v); if (p.y_amax) amax_take(y_am, v); }
                 }
             }
     }
+    if (p.ksplit == 1) amax_commit(y_am, p.y_amax);
 }
 
 // Pixel tiles of the row-reuse kernel: full tiles of BN pixels made of whole row segments inside one image.

@@ -284,6 +284,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
     }
 
     const int OHW = p.OH * p.OW;
+    uint32_t y_am = 0;
     const bool has_noise = p.noise && p.ksplit == 1;
     const float nstr = has_noise ? p.noise_strength[0] : 0.f;
 #pragma unroll
@@ -308,10 +309,11 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
                     if (has_res) v += io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES);
                     if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
                     if (pb) pb[(int64_t)o * OHW] = v;
-                    else io_st<IO>(p.y, yoff + (int64_t)o * OHW, v);
+                    else { io_st<IO>(p.y, yoff + (int64_t)o * OHW, v); if (p.y_amax) amax_take(y_am, v); }
                 }
             }
     }
+    if (p.ksplit == 1) amax_commit(y_am, p.y_amax);
 }
 
 // Is the 2-D tile applicable: 3x3 stride-1 lattice (9 taps in 3 rows of 3, any order), planes divisible into R x (BN / R) tiles.

@@ -64,8 +64,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             const float* __restrict__ oscale, int64_t numel, int ohw, int ksplit,
                                                             const float* __restrict__ bias, int cout, int act, float alpha, float gain,
                                                             float clamp, const void* __restrict__ res, const float* __restrict__ noise,
-                                                            const float* __restrict__ noise_strength, int noise_ps) {
+                                                            const float* __restrict__ noise_strength, int noise_ps, float* __restrict__ y_amax) {
     const float nstr = noise ? noise_strength[0] : 0.f;
+    uint32_t am = 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
         float v = 0.f;
         int k = 0;
@@ -81,7 +82,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         if (res) v += io_ld1<IO>((const char*)res + i * io_size<IO>::value);
         if (act) v = conv_epilogue(v, bias ? bias[nc % cout] : 0.f, act, alpha, gain, clamp);
         io_st<IO>(y, i, v);
+        if (y_amax) amax_take(am, v);
     }
+    amax_commit(am, y_amax);
 }
 
 // K slices for launches that would leave most CUs idle (the 4..17 pixel layers: K = 9*512 against <= 4624 pixels).
@@ -444,6 +447,7 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
     p.bias = ep ? ep->bias : nullptr; p.act = ep ? ep->act : 0; p.res = ep ? (const float*)ep->res : nullptr;
     p.alpha = ep ? ep->alpha : 0.f; p.gain = ep ? ep->gain : 1.f; p.clamp = ep ? ep->clamp : -1.f;
     p.noise = ep ? ep->noise : nullptr; p.noise_strength = ep ? ep->noise_strength : nullptr; p.noise_ps = ep ? ep->noise_per_sample : 0;
+    p.y_amax = ep ? ep->y_amax : nullptr;
     p.ksplit = plan.ksplit;
     p.o_tiles = 1;
     p.partial = (float*)workspace + round_up((int)(((int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad * 3 + 1) / 2), 4);
@@ -547,10 +551,13 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
         int64_t blocks = ceil_div64(numel, 256);
         if (blocks > 2048) blocks = 2048;
 #define PASTA_SK(IO_) hipLaunchKernelGGL(splitk_reduce_kernel<IO_>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)p.partial, (void*)y, oscale, numel, \
-                                         d->OH * d->OW, p.ksplit, p.bias, d->C_out, p.act, p.alpha, p.gain, p.clamp, (const void*)p.res, p.noise, p.noise_strength, p.noise_ps)
+                                         d->OH * d->OW, p.ksplit, p.bias, d->C_out, p.act, p.alpha, p.gain, p.clamp, (const void*)p.res, p.noise, p.noise_strength, p.noise_ps, p.y_amax)
         if (p.io == IO_BF16) PASTA_SK(IO_BF16); else if (p.io == IO_F16) PASTA_SK(IO_F16); else PASTA_SK(IO_F32);
 #undef PASTA_SK
     }
+    // y_amax with a launch whose kernel does not take it (fp32 MFMA tiles; the parity-pair mode returned above): one scan of y
+    if (p.y_amax && !p.bf16x6 && p.io == IO_F32)
+        if (int e = tensor_amax(y, (int64_t)d->N * d->C_out * d->OH * d->OW, PASTA_F32, p.y_amax, s)) return e;
     return launch_status("conv2d");
 }
 

@@ -36,8 +36,9 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 template <class T, int V>
 __global__ __launch_bounds__(256) void scale_add_kernel(const T* __restrict__ x, const float* __restrict__ a,
                                                         const T* __restrict__ b, T* __restrict__ y,
-                                                        int64_t planes, int C, int64_t HW, int b_per_sample) {
+                                                        int64_t planes, int C, int64_t HW, int b_per_sample, float* __restrict__ y_amax) {
     const int64_t hwv = HW / V;
+    uint32_t am = 0;
     for (int64_t plane = blockIdx.y; plane < planes; plane += gridDim.y) {
         const float s = a ? a[plane] : 1.f;
         const T* xp = x + plane * HW;
@@ -47,12 +48,17 @@ __global__ __launch_bounds__(256) void scale_add_kernel(const T* __restrict__ x,
             if constexpr (V == 4) {
                 float4 v = ld4<T>(xp + 4 * i);
                 const float4 w = bp ? ld4<T>(bp + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
-                st4<T>(yp + 4 * i, make_float4(fmaf(v.x, s, w.x), fmaf(v.y, s, w.y), fmaf(v.z, s, w.z), fmaf(v.w, s, w.w)));
+                const float4 o = make_float4(fmaf(v.x, s, w.x), fmaf(v.y, s, w.y), fmaf(v.z, s, w.z), fmaf(v.w, s, w.w));
+                st4<T>(yp + 4 * i, o);
+                if (y_amax) { amax_take(am, o.x); amax_take(am, o.y); amax_take(am, o.z); amax_take(am, o.w); }
             } else {
-                st<T>(yp + i, fmaf(ld<T>(xp + i), s, bp ? ld<T>(bp + i) : 0.f));
+                const float o = fmaf(ld<T>(xp + i), s, bp ? ld<T>(bp + i) : 0.f);
+                st<T>(yp + i, o);
+                if (y_amax) amax_take(am, o);
             }
         }
     }
+    amax_commit(am, y_amax);
 }
 
 //------------------------------------------------------------------------------------
@@ -89,8 +95,9 @@ template <class T, int EPT>   // EPT == 0: generic loops; T = storage type of x,
 __global__ __launch_bounds__(1024) void spade_norm_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
                                                           const T* __restrict__ beta, T* __restrict__ out,
                                                           float* __restrict__ stats, int64_t planes, int64_t HW, float eps,
-                                                          int act, float gain, float clamp, int C, int64_t gb_ns) {
+                                                          int act, float gain, float clamp, int C, int64_t gb_ns, float* __restrict__ y_amax) {
     __shared__ float red[16];
+    uint32_t am = 0;
     // optional relu * gain with clamp on the way out (the activation Spade_Conv2dLayer applies before its convolution)
     auto post = [&](float v) {
         if (act == 2) { v = v > 0.f ? v * gain : 0.f; if (clamp >= 0.f && v > clamp) v = clamp; }
@@ -127,6 +134,7 @@ __global__ __launch_bounds__(1024) void spade_norm_kernel(const T* __restrict__ 
                 o.z = post(fmaf((r[k].z - mean) * rstd, 1.f + g.z, b.z));
                 o.w = post(fmaf((r[k].w - mean) * rstd, 1.f + g.w, b.w));
                 st4<T>(out + plane * HW + 4 * i, o);
+                if (y_amax) { amax_take(am, o.x); amax_take(am, o.y); amax_take(am, o.z); amax_take(am, o.w); }
             }
         } else {
             float s = 0.f;
@@ -137,11 +145,14 @@ __global__ __launch_bounds__(1024) void spade_norm_kernel(const T* __restrict__ 
             rstd = rsqrtf(block_sum<1024>(q, red) * inv + eps);
             for (int64_t i = tid; i < HW; i += 1024) {
                 float g = gamma ? ld<T>(gamma + gb + i) : 0.f, b = beta ? ld<T>(beta + gb + i) : 0.f;
-                st<T>(out + plane * HW + i, post(fmaf((ld<T>(xp + i) - mean) * rstd, 1.f + g, b)));
+                const float o = post(fmaf((ld<T>(xp + i) - mean) * rstd, 1.f + g, b));
+                st<T>(out + plane * HW + i, o);
+                if (y_amax) amax_take(am, o);
             }
         }
         if (tid == 0 && stats) { stats[2 * plane] = mean; stats[2 * plane + 1] = rstd; }
     }
+    amax_commit(am, y_amax);
 }
 
 // Backward.  xhat = (x-mean)*rstd, t = dout*(1+gamma):
@@ -153,8 +164,9 @@ __global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const T* __restric
                                                               T* __restrict__ dx, T* __restrict__ dgamma,
                                                               T* __restrict__ dbeta, int64_t planes, int64_t HW,
                                                               const T* __restrict__ beta, int act, float gain, float clamp,
-                                                              int C, int64_t gb_ns, int64_t dgb_ns) {
+                                                              int C, int64_t gb_ns, int64_t dgb_ns, float* __restrict__ dx_amax) {
     __shared__ float red[16];
+    uint32_t am = 0;
     // gradient through the optional relu * gain / clamp of the forward: v = x_hat * (1 + gamma) + beta is recomputed
     auto pre = [&](float d, float h, float g, float b) {
         if (act == 2) {
@@ -205,6 +217,7 @@ __global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const T* __restric
                     o.z = rstd * (t[k * 4 + 2] - m1 - xh[k * 4 + 2] * m2);
                     o.w = rstd * (t[k * 4 + 3] - m1 - xh[k * 4 + 3] * m2);
                     st4<T>(dx + base + 4 * (k * 1024 + tid), o);
+                    if (dx_amax) { amax_take(am, o.x); amax_take(am, o.y); amax_take(am, o.z); amax_take(am, o.w); }
                 }
             }
         } else {
@@ -225,11 +238,14 @@ __global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const T* __restric
                     const float gi = gamma ? ld<T>(gamma + gb + i) : 0.f;
                     float d = pre(ld<T>(dout + base + i), h, gi, (act == 2 && beta) ? ld<T>(beta + gb + i) : 0.f);
                     float tt = d * (1.f + gi);
-                    st<T>(dx + base + i, rstd * (tt - m1 - h * m2));
+                    const float o = rstd * (tt - m1 - h * m2);
+                    st<T>(dx + base + i, o);
+                    if (dx_amax) amax_take(am, o);
                 }
             }
         }
     }
+    amax_commit(am, dx_amax);
 }
 
 
@@ -253,8 +269,9 @@ template <class T>      // storage type of u and y; d, noise, strength and b are
 __global__ __launch_bounds__(256) void mod_bias_act_kernel(const T* __restrict__ u, const float* __restrict__ d,
                                                            const float* __restrict__ noise, const float* __restrict__ strength,
                                                            const float* __restrict__ b, T* __restrict__ y, int C, int64_t HW,
-                                                           int noise_per_sample, int act, float alpha, float gain, float clamp) {
+                                                           int noise_per_sample, int act, float alpha, float gain, float clamp, float* __restrict__ y_amax) {
     const int64_t plane = blockIdx.x;
+    uint32_t am = 0;
     const int n = (int)(plane / C), c = (int)(plane - (int64_t)n * C);
     const float dv = d ? d[plane] : 1.f, bv = b ? b[c] : 0.f, ns = noise ? strength[0] : 0.f;
     const T* up = u + plane * HW;
@@ -271,11 +288,16 @@ __global__ __launch_bounds__(256) void mod_bias_act_kernel(const T* __restrict__
             o.z = mba_fwd(uv.z, dv, nv.z * ns, bv, act, alpha, gain, clamp);
             o.w = mba_fwd(uv.w, dv, nv.w * ns, bv, act, alpha, gain, clamp);
             st4<T>(yp + i, o);
+            if (y_amax) { amax_take(am, o.x); amax_take(am, o.y); amax_take(am, o.z); amax_take(am, o.w); }
         }
     } else {
-        for (int64_t i = i0 + threadIdx.x; i < i1; i += 256)
-            st<T>(yp + i, mba_fwd(ld<T>(up + i), dv, np_ ? np_[i] * ns : 0.f, bv, act, alpha, gain, clamp));
+        for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+            const float o = mba_fwd(ld<T>(up + i), dv, np_ ? np_[i] * ns : 0.f, bv, act, alpha, gain, clamp);
+            st<T>(yp + i, o);
+            if (y_amax) amax_take(am, o);
+        }
     }
+    amax_commit(am, y_amax);
 }
 
 __device__ __forceinline__ float mba_dz(float dy, float y, int act, float alpha, float gain, float clamp) {
@@ -290,8 +312,9 @@ __global__ __launch_bounds__(256) void mod_bias_act_bwd_kernel(const T* __restri
                                                                const T* __restrict__ u, const float* __restrict__ d,
                                                                const float* __restrict__ noise, T* __restrict__ du,
                                                                float* __restrict__ partial, int C, int64_t HW, int chunks,
-                                                               int noise_per_sample, int act, float alpha, float gain, float clamp) {
+                                                               int noise_per_sample, int act, float alpha, float gain, float clamp, float* __restrict__ du_amax) {
     __shared__ float red[4];
+    uint32_t am = 0;
     const int64_t plane = blockIdx.x;
     const int n = (int)(plane / C);
     const float dv = d ? d[plane] : 1.f;
@@ -309,15 +332,19 @@ __global__ __launch_bounds__(256) void mod_bias_act_bwd_kernel(const T* __restri
             s0 += z0 * uv.x + z1 * uv.y + z2 * uv.z + z3 * uv.w;
             s1 += z0 * nv.x + z1 * nv.y + z2 * nv.z + z3 * nv.w;
             s2 += z0 + z1 + z2 + z3;
-            st4<T>(dup + i, make_float4(z0 * dv, z1 * dv, z2 * dv, z3 * dv));
+            const float4 o = make_float4(z0 * dv, z1 * dv, z2 * dv, z3 * dv);
+            st4<T>(dup + i, o);
+            if (du_amax) { amax_take(am, o.x); amax_take(am, o.y); amax_take(am, o.z); amax_take(am, o.w); }
         }
     } else {
         for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
             const float z = mba_dz(ld<T>(dyp + i), ld<T>(yp + i), act, alpha, gain, clamp);
             s0 += z * ld<T>(up + i); s1 += np_ ? z * np_[i] : 0.f; s2 += z;
             st<T>(dup + i, z * dv);
+            if (du_amax) amax_take(am, z * dv);
         }
     }
+    amax_commit(am, du_amax);
     s0 = block_sum<256>(s0, red); s1 = block_sum<256>(s1, red); s2 = block_sum<256>(s2, red);
     if (threadIdx.x == 0) {
         float* o = partial + (plane * chunks + blockIdx.y) * 3;
@@ -367,7 +394,7 @@ __global__ __launch_bounds__(256) void demod_coefs_kernel(const float* __restric
     }
 
 extern "C" int pasta_scale_add(const void* x, const float* a, const void* b, void* y, int dtype, int N, int C, int64_t HW,
-                               int b_per_sample, void* stream) {
+                               int b_per_sample, void* stream, float* y_amax) {
     using namespace pasta;
     PASTA_CHECK(x && y, "scale_add: null pointer");
     PASTA_CHECK(N >= 1 && C >= 1 && HW >= 1, "scale_add: empty tensor");
@@ -378,8 +405,8 @@ extern "C" int pasta_scale_add(const void* x, const float* a, const void* b, voi
     int gy = (int)(planes < 65535 ? planes : 65535);
     hipStream_t s = (hipStream_t)stream;
 #define PASTA_L(T)                                                                                                                         \
-    if (vec) hipLaunchKernelGGL((scale_add_kernel<T, 4>), dim3(gx, gy), dim3(256), 0, s, (const T*)x, a, (const T*)b, (T*)y, planes, C, HW, b_per_sample); \
-    else     hipLaunchKernelGGL((scale_add_kernel<T, 1>), dim3(gx, gy), dim3(256), 0, s, (const T*)x, a, (const T*)b, (T*)y, planes, C, HW, b_per_sample)
+    if (vec) hipLaunchKernelGGL((scale_add_kernel<T, 4>), dim3(gx, gy), dim3(256), 0, s, (const T*)x, a, (const T*)b, (T*)y, planes, C, HW, b_per_sample, y_amax); \
+    else     hipLaunchKernelGGL((scale_add_kernel<T, 1>), dim3(gx, gy), dim3(256), 0, s, (const T*)x, a, (const T*)b, (T*)y, planes, C, HW, b_per_sample, y_amax)
     PASTA_BY_DTYPE(dtype, "scale_add", PASTA_L)
 #undef PASTA_L
     return launch_status("scale_add");
@@ -458,7 +485,7 @@ __global__ __launch_bounds__(256) void nan_to_num_multi_kernel(NanToNumTable tab
 
 extern "C" int pasta_spade_norm(const void* x, const void* gamma, const void* beta, void* out, float* stats, int dtype,
                                 int64_t planes, int64_t HW, float eps, int act, float gain, float clamp, int C, int64_t gb_stride,
-                                void* stream) {
+                                void* stream, float* y_amax) {
     using namespace pasta;
     PASTA_CHECK(x && out, "spade_norm: null pointer");
     PASTA_CHECK(act == 0 || act == 1 || act == 2, "spade_norm: fused activation code %d (0/1 = none, 2 = relu)", act);
@@ -469,7 +496,7 @@ extern "C" int pasta_spade_norm(const void* x, const void* gamma, const void* be
     int grid = (int)(planes < 65535 ? planes : 65535);
     hipStream_t s = (hipStream_t)stream;
     const bool al = (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out) & 15) == 0 && gb_ns % 4 == 0;
-#define PASTA_ARGS(T) (const T*)x, (const T*)gamma, (const T*)beta, (T*)out, stats, planes, HW, eps, act, gain, clamp, C, gb_ns
+#define PASTA_ARGS(T) (const T*)x, (const T*)gamma, (const T*)beta, (T*)out, stats, planes, HW, eps, act, gain, clamp, C, gb_ns, y_amax
 #define PASTA_L(T)                                                                                                        \
     if (HW == 16384 && al) hipLaunchKernelGGL((spade_norm_kernel<T, 16>), dim3(grid), dim3(1024), 0, s, PASTA_ARGS(T));  \
     else if (HW == 4096 && al) hipLaunchKernelGGL((spade_norm_kernel<T, 4>), dim3(grid), dim3(1024), 0, s, PASTA_ARGS(T)); \
@@ -482,7 +509,7 @@ extern "C" int pasta_spade_norm(const void* x, const void* gamma, const void* be
 
 extern "C" int pasta_spade_norm_bwd(const void* dout, const void* x, const void* gamma, const float* stats, void* dx,
                                     void* dgamma, void* dbeta, int dtype, int64_t planes, int64_t HW, const void* beta, int act, float gain,
-                                    float clamp, int C, int64_t gb_stride, int64_t dgb_stride, void* stream) {
+                                    float clamp, int C, int64_t gb_stride, int64_t dgb_stride, void* stream, float* dx_amax) {
     using namespace pasta;
     PASTA_CHECK(dout && x && stats, "spade_norm_bwd: null pointer");
     PASTA_CHECK(act == 0 || act == 1 || act == 2, "spade_norm_bwd: fused activation code %d (0/1 = none, 2 = relu)", act);
@@ -495,7 +522,7 @@ extern "C" int pasta_spade_norm_bwd(const void* dout, const void* x, const void*
     hipStream_t s = (hipStream_t)stream;
     const bool al = (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dout | (uintptr_t)dx | (uintptr_t)dgamma | (uintptr_t)dbeta | (uintptr_t)beta) & 15) == 0 &&
                     gb_ns % 4 == 0 && dgb_ns % 4 == 0;
-#define PASTA_ARGS(T) (const T*)dout, (const T*)x, (const T*)gamma, stats, (T*)dx, (T*)dgamma, (T*)dbeta, planes, HW, (const T*)beta, act, gain, clamp, C, gb_ns, dgb_ns
+#define PASTA_ARGS(T) (const T*)dout, (const T*)x, (const T*)gamma, stats, (T*)dx, (T*)dgamma, (T*)dbeta, planes, HW, (const T*)beta, act, gain, clamp, C, gb_ns, dgb_ns, dx_amax
 #define PASTA_L(T)                                                                                                            \
     if (HW == 16384 && al) hipLaunchKernelGGL((spade_norm_bwd_kernel<T, 16>), dim3(grid), dim3(1024), 0, s, PASTA_ARGS(T));  \
     else if (HW == 4096 && al) hipLaunchKernelGGL((spade_norm_bwd_kernel<T, 4>), dim3(grid), dim3(1024), 0, s, PASTA_ARGS(T)); \
@@ -508,7 +535,7 @@ extern "C" int pasta_spade_norm_bwd(const void* dout, const void* x, const void*
 
 extern "C" int pasta_mod_bias_act(const void* u, const float* d, const float* noise, const float* strength, const float* b, void* y,
                                   int dtype, int N, int C, int64_t HW, int noise_per_sample, int act, float alpha, float gain, float clamp,
-                                  void* stream) {
+                                  void* stream, float* y_amax) {
     using namespace pasta;
     PASTA_CHECK(u && y, "mod_bias_act: null pointer");
     PASTA_CHECK(N >= 1 && C >= 1 && HW >= 1, "mod_bias_act: empty tensor");
@@ -518,7 +545,7 @@ extern "C" int pasta_mod_bias_act(const void* u, const float* d, const float* no
     const int64_t chunks = (HW + MBA_CHUNK - 1) / MBA_CHUNK;
     PASTA_CHECK(chunks <= 65535 && (int64_t)N * C <= INT32_MAX, "mod_bias_act: tensor too large");
 #define PASTA_L(T) hipLaunchKernelGGL(mod_bias_act_kernel<T>, dim3((unsigned)(N * C), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, (const T*)u, d, noise, \
-                                      strength, b, (T*)y, C, HW, noise_per_sample, act, alpha, gain, clamp)
+                                      strength, b, (T*)y, C, HW, noise_per_sample, act, alpha, gain, clamp, y_amax)
     PASTA_BY_DTYPE(dtype, "mod_bias_act", PASTA_L)
 #undef PASTA_L
     return launch_status("mod_bias_act");
@@ -531,7 +558,7 @@ extern "C" int64_t pasta_mod_bias_act_bwd_workspace(int N, int C, int64_t HW) {
 
 extern "C" int pasta_mod_bias_act_bwd(const void* dy, const void* y, const void* u, const float* d, const float* noise, void* du,
                                       float* partial, int dtype, int N, int C, int64_t HW, int noise_per_sample, int act, float alpha, float gain,
-                                      float clamp, void* stream) {
+                                      float clamp, void* stream, float* du_amax) {
     using namespace pasta;
     PASTA_CHECK(dy && y && u && du && partial, "mod_bias_act_bwd: null pointer");
     PASTA_CHECK(N >= 1 && C >= 1 && HW >= 1, "mod_bias_act_bwd: empty tensor");
@@ -541,7 +568,7 @@ extern "C" int pasta_mod_bias_act_bwd(const void* dy, const void* y, const void*
     const int64_t chunks = (HW + MBA_CHUNK - 1) / MBA_CHUNK;
     PASTA_CHECK(chunks <= 65535 && (int64_t)N * C <= INT32_MAX, "mod_bias_act_bwd: tensor too large");
 #define PASTA_L(T) hipLaunchKernelGGL(mod_bias_act_bwd_kernel<T>, dim3((unsigned)(N * C), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (const T*)y, \
-                                      (const T*)u, d, noise, (T*)du, partial, C, HW, (int)chunks, noise_per_sample, act, alpha, gain, clamp)
+                                      (const T*)u, d, noise, (T*)du, partial, C, HW, (int)chunks, noise_per_sample, act, alpha, gain, clamp, du_amax)
     PASTA_BY_DTYPE(dtype, "mod_bias_act_bwd", PASTA_L)
 #undef PASTA_L
     return launch_status("mod_bias_act_bwd");

@@ -39,6 +39,7 @@ struct UpfirdnParams {
     int padx0, pady0;
     int flip;
     float gain;
+    float* y_amax;                // optional: PASTA_AMAX_PARTS zeroed floats that receive the largest finite |y| (common.h)
 };
 
 //------------------------------------------------------------------------------------
@@ -48,6 +49,7 @@ template <class T>
 __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(UpfirdnParams p) {
     typedef typename acc_of<T>::type A;
     const int64_t total = (int64_t)p.N * p.C * p.outH * p.outW;
+    uint32_t am = 0;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         int ox = (int)(idx % p.outW);
@@ -79,7 +81,9 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(UpfirdnParams p)
         }
         v *= (A)p.gain;
         st<T>((T*)p.y + n * p.osn + c * p.osc + oy * p.osy + ox * p.osx, v);
+        if (p.y_amax) amax_take(am, (float)v);
     }
+    amax_commit(am, p.y_amax);
 }
 
 //------------------------------------------------------------------------------------
@@ -147,6 +151,7 @@ __global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p,
         }
     };
 
+    uint32_t am = 0;
     int item = blockIdx.x;
     if (item < nitems) fetch(item);
     while (item < nitems) {
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p,
             if (oy + b >= p.outH) break;
 #pragma unroll
             for (int a = 0; a < MX; a++)
-                if (ox + a < p.outW) st<T>(yp + (int64_t)(oy + b) * p.outW + ox + a, acc[b][a]);
+                if (ox + a < p.outW) { st<T>(yp + (int64_t)(oy + b) * p.outW + ox + a, acc[b][a]); if (p.y_amax) amax_take(am, acc[b][a]); }
         }
         if constexpr (REM == 1) {
             // one extra output column / row / corner of the plane, by the last thread column / row of the last tile
@@ -197,6 +202,7 @@ __global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p,
 #pragma unroll
                     for (int jx = 0; jx < FW; jx++) v = fmaf(g[jy][jx], sx[(yy + jy) * LDW + xx + jx], v);
                 st<T>(yp + (int64_t)(tile_y * TOH + yy) * p.outW + tile_x * TOW + xx, v * p.gain);
+                if (p.y_amax) amax_take(am, v * p.gain);
             };
             if (ex) {
 #pragma unroll
@@ -210,6 +216,7 @@ __global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p,
         }
         item = next;
     }
+    amax_commit(am, p.y_amax);
 }
 
 //------------------------------------------------------------------------------------
@@ -233,6 +240,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_small_kernel(UpfirdnParams p, i
 #pragma unroll
             for (int b = 0; b < F; b++) g[a][b] = p.f[(p.flip ? a : F - 1 - a) * F + (p.flip ? b : F - 1 - b)];
     }
+    uint32_t am = 0;
     for (int p0 = blockIdx.x * PL; p0 < planes; p0 += gridDim.x * PL) {
         const int np = planes - p0 < PL ? planes - p0 : PL;
         const T* xp = (const T*)p.x + (int64_t)p0 * in_sz;
@@ -261,6 +269,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_small_kernel(UpfirdnParams p, i
                     }
                 }
                 st<T>(yp + e, v * p.gain);
+                if (p.y_amax) amax_take(am, v * p.gain);
             } else {
                 const int ux0 = ox * p.downx - p.padx0, uy0 = oy * p.downy - p.pady0;
                 for (int ty = posmod(-uy0, p.upy); ty < p.fh; ty += p.upy) {
@@ -279,9 +288,11 @@ __global__ __launch_bounds__(256) void upfirdn2d_small_kernel(UpfirdnParams p, i
                     }
                 }
                 st<T>(yp + e, v * p.gain);
+                if (p.y_amax) amax_take(am, v * p.gain);
             }
         }
     }
+    amax_commit(am, p.y_amax);
 }
 
 // ceil(2^32 / d): umulhi(e, magic) == e / d for e * d < 2^32
@@ -398,7 +409,7 @@ extern "C" int pasta_upfirdn2d(const void* x, const float* f, void* y, int dtype
                                const int32_t out_size[4], const int64_t out_stride[4],
                                int upx, int upy, int downx, int downy,
                                int padx0, int padx1, int pady0, int pady1,
-                               int flip, float gain, void* stream) {
+                               int flip, float gain, void* stream, float* y_amax) {
     using namespace pasta;
     PASTA_CHECK(x && f && y, "upfirdn2d: null pointer");
     PASTA_CHECK(upx >= 1 && upy >= 1, "upfirdn2d: upsampling factor must be at least 1");
@@ -422,7 +433,7 @@ extern "C" int pasta_upfirdn2d(const void* x, const float* f, void* y, int dtype
     p.isn = in_stride[0]; p.isc = in_stride[1]; p.isy = in_stride[2]; p.isx = in_stride[3];
     p.osn = out_stride[0]; p.osc = out_stride[1]; p.osy = out_stride[2]; p.osx = out_stride[3];
     p.upx = upx; p.upy = upy; p.downx = downx; p.downy = downy;
-    p.padx0 = padx0; p.pady0 = pady0; p.flip = flip ? 1 : 0; p.gain = gain;
+    p.padx0 = padx0; p.pady0 = pady0; p.flip = flip ? 1 : 0; p.gain = gain; p.y_amax = y_amax;
 
     const bool dense_nchw =
         p.isx == 1 && p.isy == p.inW && p.isc == (int64_t)p.inH * p.inW && (p.N == 1 || p.isn == p.isc * p.C) &&

@@ -126,7 +126,7 @@ class ConvDesc(ctypes.Structure):
 class ConvEpilogue(ctypes.Structure):
     """Mirror of ``pasta_conv_epilogue`` (include/pasta_hip.h)."""
     _fields_ = [('bias', _c_ptr), ('act', _c_i32), ('alpha', _c_f32), ('gain', _c_f32), ('clamp', _c_f32), ('res', _c_ptr),
-                ('noise', _c_ptr), ('noise_strength', _c_ptr), ('noise_per_sample', _c_i32)]
+                ('noise', _c_ptr), ('noise_strength', _c_ptr), ('noise_per_sample', _c_i32), ('y_amax', _c_ptr)]
 
 class AdaConfig(ctypes.Structure):
     """Mirror of ``pasta_ada_config`` (include/pasta_hip.h)."""
@@ -142,14 +142,14 @@ ABI = {
     'pasta_build_info':   (ctypes.c_char_p, []),
     'pasta_upfirdn2d':    (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, ctypes.c_int,
                                           ctypes.POINTER(_c_i32), ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i32),
-                                          ctypes.POINTER(_c_i32), ctypes.POINTER(_c_i64)] + [ctypes.c_int] * 9 + [_c_f32, _c_ptr]),
+                                          ctypes.POINTER(_c_i32), ctypes.POINTER(_c_i64)] + [ctypes.c_int] * 9 + [_c_f32, _c_ptr, _c_ptr]),
     'pasta_bias_act':     (ctypes.c_int, [_c_ptr] * 6 + [ctypes.c_int, _c_i64, ctypes.c_int, _c_i64, ctypes.c_int, ctypes.c_int,
-                                                           _c_f32, _c_f32, _c_f32, _c_ptr]),
+                                                           _c_f32, _c_f32, _c_f32, _c_ptr, _c_ptr]),
     'pasta_bias_grad_workspace': (_c_i64, [_c_i64, ctypes.c_int, _c_i64]),
     'pasta_bias_grad':    (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, ctypes.c_int, _c_i64, ctypes.c_int, _c_i64, _c_ptr]),
     'pasta_bias_act_grad_db_workspace': (_c_i64, [ctypes.c_int, _c_i64, ctypes.c_int, _c_i64, ctypes.c_int]),
     'pasta_bias_act_grad_db': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, ctypes.c_int, _c_i64, ctypes.c_int, _c_i64, ctypes.c_int,
-                                              ctypes.c_float, ctypes.c_float, ctypes.c_float, _c_ptr]),
+                                              ctypes.c_float, ctypes.c_float, ctypes.c_float, _c_ptr, _c_ptr]),
     'pasta_conv2d_workspace':       (_c_i64, [ctypes.POINTER(ConvDesc)]),
     'pasta_conv2d_wgrad_workspace': (_c_i64, [ctypes.POINTER(ConvDesc)]),
     'pasta_conv2d_tile':  (ctypes.c_int, [ctypes.POINTER(ConvDesc)]),
@@ -161,15 +161,15 @@ ABI = {
     'pasta_conv2d_modulated': (ctypes.c_int, [_c_ptr] * 5 + [ctypes.POINTER(ConvEpilogue), ctypes.POINTER(ConvDesc), _c_ptr, _c_i64, _c_ptr]),
     'pasta_tensor_amax':  (ctypes.c_int, [_c_ptr, _c_i64, ctypes.c_int, _c_ptr, _c_ptr]),
     'pasta_demod_coefs':  (ctypes.c_int, [_c_ptr] * 3 + [ctypes.c_int] * 4 + [_c_f32, _c_ptr]),
-    'pasta_scale_add':    (ctypes.c_int, [_c_ptr] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i64, ctypes.c_int, _c_ptr]),
+    'pasta_scale_add':    (ctypes.c_int, [_c_ptr] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i64, ctypes.c_int, _c_ptr, _c_ptr]),
     'pasta_plane_dot':    (ctypes.c_int, [_c_ptr] * 3 + [ctypes.c_int, _c_i64, _c_i64, _c_ptr]),
     'pasta_mod_bias_act': (ctypes.c_int, [_c_ptr] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_float,
-                                          ctypes.c_float, ctypes.c_float, _c_ptr]),
+                                          ctypes.c_float, ctypes.c_float, _c_ptr, _c_ptr]),
     'pasta_mod_bias_act_bwd_workspace': (_c_i64, [ctypes.c_int, ctypes.c_int, _c_i64]),
     'pasta_mod_bias_act_bwd': (ctypes.c_int, [_c_ptr] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_float,
-                                              ctypes.c_float, ctypes.c_float, _c_ptr]),
-    'pasta_spade_norm':   (ctypes.c_int, [_c_ptr] * 5 + [ctypes.c_int, _c_i64, _c_i64, _c_f32, ctypes.c_int, _c_f32, _c_f32, ctypes.c_int, _c_i64, _c_ptr]),
-    'pasta_spade_norm_bwd': (ctypes.c_int, [_c_ptr] * 7 + [ctypes.c_int, _c_i64, _c_i64, _c_ptr, ctypes.c_int, _c_f32, _c_f32, ctypes.c_int, _c_i64, _c_i64, _c_ptr]),
+                                              ctypes.c_float, ctypes.c_float, _c_ptr, _c_ptr]),
+    'pasta_spade_norm':   (ctypes.c_int, [_c_ptr] * 5 + [ctypes.c_int, _c_i64, _c_i64, _c_f32, ctypes.c_int, _c_f32, _c_f32, ctypes.c_int, _c_i64, _c_ptr, _c_ptr]),
+    'pasta_spade_norm_bwd': (ctypes.c_int, [_c_ptr] * 7 + [ctypes.c_int, _c_i64, _c_i64, _c_ptr, ctypes.c_int, _c_f32, _c_f32, ctypes.c_int, _c_i64, _c_i64, _c_ptr, _c_ptr]),
     'pasta_ada_matrices': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, ctypes.c_int, ctypes.c_int, _c_ptr, ctypes.POINTER(AdaConfig)] +
                                          [ctypes.c_int] * 4 + [_c_f32, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     'pasta_ada_theta':    (ctypes.c_int, [_c_ptr, _c_i64, ctypes.POINTER(_c_f32), ctypes.POINTER(_c_f32), _c_ptr, _c_ptr]),

@@ -42,3 +42,31 @@ def i32x(*vals):
 
 def i64x(*vals):
     return (ctypes.c_int64 * len(vals))(*[int(v) for v in vals])
+
+# ---- producer-side maxima (include/pasta_hip.h, "producer-side maxima"): a kernel that writes an fp32 activation tensor leaves the
+# tensor's largest magnitude in a zeroed 256-float row, and the row travels with the Python tensor object (conv2d_gradfix.tensor_amax
+# finds it there), so the convolution that consumes the tensor under PASTA_MATH_F16X3 scans nothing.
+_amax_pools = {}
+_AMAX_ROWS = 1024
+
+def amax_slot(like):
+    """A zeroed [256] fp32 row on ``like``'s device, or None when the running arithmetic has no use for it."""
+    from . import conv2d_gradfix
+    if conv2d_gradfix.conv_math not in ('default', 'f16x3') or like.dtype != torch.float32 or like.device.type != 'cuda':
+        return None
+    pool = _amax_pools.get(like.device)
+    if pool is None or pool[1] >= _AMAX_ROWS:
+        pool = [torch.zeros([_AMAX_ROWS, 256], dtype=torch.float32, device=like.device), 0]      # one fill per 1024 tensors
+        _amax_pools[like.device] = pool
+    row = pool[0][pool[1]]
+    pool[1] += 1
+    return row
+
+def amax_attach(t, row):
+    """Hang the producer's row on the tensor it describes (valid for the tensor's current version)."""
+    if row is not None:
+        try:
+            t._pasta_amax = (t._version, t.data_ptr(), row)
+        except AttributeError:
+            pass
+    return t

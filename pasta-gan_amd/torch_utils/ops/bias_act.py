@@ -60,13 +60,14 @@ def _launch(x, b, xref, yref, dy, grad, dim, act_idx, alpha, gain, clamp):
     y = torch.empty_like(x)
     if x.numel() == 0:
         return y
+    row = _native.amax_slot(y) if x.numel() >= 1 << 16 else None      # feature maps: the convolution after this one wants |max|
     with torch.cuda.device(x.device):
         st = _native.lib().pasta_bias_act(
             _native.ptr(x), _native.ptr(b), _native.ptr(xref), _native.ptr(yref), _native.ptr(dy), _native.ptr(y),
             _native.dtype_code(x, 'bias_act'), x.numel(), size_b, step_b, grad, act_idx,
-            float(alpha), float(gain), float(clamp), _native.stream())
+            float(alpha), float(gain), float(clamp), _native.stream(), _native.ptr(row))
     _native.check(st)
-    return y
+    return _native.amax_attach(y, row)
 
 def _bias_grad(dx, dim):
     """Sum ``dx`` over every dimension but ``dim`` with the native two-stage reduction."""
@@ -96,12 +97,13 @@ def _launch_grad_db(dy, y, dim, act_idx, alpha, gain, clamp, nbytes):
     dx = torch.empty_like(dy)
     db = torch.empty([dy.shape[dim]], dtype=dy.dtype, device=dy.device)
     work = torch.empty([nbytes // 4], dtype=torch.float32, device=dy.device)
+    row = _native.amax_slot(dx)
     with torch.cuda.device(dy.device):
         st = _native.lib().pasta_bias_act_grad_db(
             _native.ptr(dy), _native.ptr(y), _native.ptr(dx), _native.ptr(db), _native.ptr(work), _native.dtype_code(dy, 'bias_act'),
-            dy.numel(), dy.shape[dim], dy.stride(dim), act_idx, float(alpha), float(gain), float(clamp), _native.stream())
+            dy.numel(), dy.shape[dim], dy.stride(dim), act_idx, float(alpha), float(gain), float(clamp), _native.stream(), _native.ptr(row))
     _native.check(st)
-    return dx, db
+    return _native.amax_attach(dx, row), db
 
 def grad_with_bias_grad(dy, y, cfg):
     """(dx, db) of ``bias_act`` for the piecewise-linear activations whose derivative is expressed in y

@@ -189,7 +189,7 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, 
     if oscale is not None:
         oscale = _f32(oscale).contiguous()
         assert oscale.shape == (x.shape[0], c_out)
-    ep = None
+    ep = y_row = None
     if epilogue is not None:
         bias, act_code, alpha, gain, clamp = epilogue[:5]
         res = epilogue[5] if len(epilogue) > 5 else None
@@ -207,6 +207,9 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, 
                                      gain=float(gain), clamp=float(clamp), res=res.data_ptr() if res is not None else None,
                                      noise=nz.data_ptr() if nz is not None else None, noise_strength=nstr.data_ptr() if nz is not None else None,
                                      noise_per_sample=int(nz is not None and nz.numel() != oh * ow))
+        y_row = _native.amax_slot(y)            # the layer's output usually feeds the next convolution
+        if y_row is not None:
+            ep.y_amax = y_row.data_ptr()
     elif noise is not None:
         raise RuntimeError('conv2d: the noise operand is part of the fused epilogue')
     if wmod is not None:
@@ -235,6 +238,8 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, 
         # 'conv_isc': the launch passes an input scale (another kernel instance); flags = PASTA_PLAN_* of include/pasta_hip.h
         flags = (1 if iscale is not None else 0) | (2 if oscale is not None else 0) | (4 if ep is not None else 0)
         launch_hook('conv' if iscale is None else 'conv_isc', desc, launch, flags)
+    if y_row is not None and y.dtype == out_dtype:
+        _native.amax_attach(y, y_row)
     return y.to(out_dtype)
 
 def _launch_wgrad(x, dy, cfg, w_shape, out_dtype=None):

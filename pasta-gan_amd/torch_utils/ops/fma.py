@@ -41,11 +41,12 @@ def scale_planes(x, s, noise=None):
         per_sample = int(noise.ndim == 4 and noise.shape[0] == n and n > 1)
         noise = noise.to(x.dtype).contiguous()
     y = torch.empty_like(x)
+    row = _native.amax_slot(y)
     with torch.cuda.device(x.device):
         st = _native.lib().pasta_scale_add(_native.ptr(x), _native.ptr(s), _native.ptr(noise), _native.ptr(y), _native.dtype_code(x, 'scale_add'),
-                                           n, ch, h * w, per_sample, _native.stream())
+                                           n, ch, h * w, per_sample, _native.stream(), _native.ptr(row))
     _native.check(st)
-    return y
+    return _native.amax_attach(y, row)
 
 def plane_dot(p, q=None):
     """out[n,c] = sum_hw p*q (or sum_hw p) as fp32; NCHW fp32 / fp16 / bf16 on the GPU, fixed summation order."""

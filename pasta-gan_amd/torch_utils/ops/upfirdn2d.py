@@ -100,19 +100,20 @@ def _launch(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, ga
     if y.numel() == 0:
         return y
     f2d = f2d.contiguous()
+    row = _native.amax_slot(y) if y.numel() >= 1 << 16 else None
     def launch():
         with torch.cuda.device(x.device):
             st = _native.lib().pasta_upfirdn2d(
                 _native.ptr(x), _native.ptr(f2d), _native.ptr(y), _native.dtype_code(x, 'upfirdn2d'),
                 _native.i32x(*x.shape), _native.i64x(*x.stride()), _native.i32x(fh, fw),
                 _native.i32x(*y.shape), _native.i64x(*y.stride()),
-                upx, upy, downx, downy, padx0, padx1, pady0, pady1, int(bool(flip)), float(gain), _native.stream())
+                upx, upy, downx, downy, padx0, padx1, pady0, pady1, int(bool(flip)), float(gain), _native.stream(), _native.ptr(row))
         _native.check(st)
     if launch_hook is None:
         launch()
     else:       # algorithmic bytes of the launch: (numel_in + numel_out) * sizeof(T)
         launch_hook((x.numel() + y.numel()) * x.element_size(), (tuple(x.shape), upx, downx, fw), launch)
-    return y
+    return _native.amax_attach(y, row)
 
 class _Upfirdn2dHip(torch.autograd.Function):
     """y = upfirdn2d(x, f); the gradient is the same operator with up/down exchanged and the

@@ -73,11 +73,13 @@ class _SpadeModulate(torch.autograd.Function):
         out = torch.empty_like(x)
         stats = torch.empty([n * c, 2], dtype=torch.float32, device=x.device)
         act, gain, clamp = post                     # (2, gain, clamp): relu * gain with clamp on the way out; (0, 1, -1): none
+        row = _native.amax_slot(out)
         with torch.cuda.device(x.device):
             st = _native.lib().pasta_spade_norm(_native.ptr(x), _native.ptr(gamma), beta_ptr, _native.ptr(out),
                                                 _native.ptr(stats), _native.dtype_code(x, 'spade_norm'), n * c, h * w, float(eps), act, float(gain), float(clamp),
-                                                c, gstride, _native.stream())
+                                                c, gstride, _native.stream(), _native.ptr(row))
         _native.check(st)
+        _native.amax_attach(out, row)
         ctx.save_for_backward(x, gamma, stats, beta if (act == 2 and not fused) else None)
         ctx.post, ctx.fused = post, fused
         return out
@@ -90,6 +92,7 @@ class _SpadeModulate(torch.autograd.Function):
         n, c, h, w = x.shape
         dout = dout.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        row = _native.amax_slot(dx) if dx is not None else None
         lib = _native.lib()
         if ctx.fused:       # gamma | beta and their gradients as channel halves of one tensor each
             half = x.element_size() * c * h * w
@@ -100,8 +103,10 @@ class _SpadeModulate(torch.autograd.Function):
                                                   _native.ptr(dgb), dgb.data_ptr() + half if dgb is not None else None,
                                                   _native.dtype_code(x, 'spade_norm_bwd'), n * c, h * w,
                                                   gamma.data_ptr() + half, act, float(gain), float(clamp), c, 2 * c * h * w, 2 * c * h * w,
-                                                  _native.stream())
+                                                  _native.stream(), _native.ptr(row))
                 _native.check(st)
+                if dx is not None:
+                    _native.amax_attach(dx, row)
             return dx, dgb, None, None, None
         dgamma = torch.empty_like(x) if ctx.needs_input_grad[1] else None
         # without a fused activation d/dbeta is dout itself; with one it is dout through the activation, written by the kernel
@@ -114,8 +119,11 @@ class _SpadeModulate(torch.autograd.Function):
             with torch.cuda.device(x.device):
                 st = lib.pasta_spade_norm_bwd(_native.ptr(dout), _native.ptr(x), _native.ptr(gamma), _native.ptr(stats),
                                               _native.ptr(dx), _native.ptr(dgamma), _native.ptr(dbeta if act == 2 else None),
-                                              _native.dtype_code(x, 'spade_norm_bwd'), n * c, h * w, _native.ptr(beta), act, float(gain), float(clamp), c, 0, 0, _native.stream())
+                                              _native.dtype_code(x, 'spade_norm_bwd'), n * c, h * w, _native.ptr(beta), act, float(gain), float(clamp), c, 0, 0, _native.stream(),
+                                              _native.ptr(row))
             _native.check(st)
+            if dx is not None:
+                _native.amax_attach(dx, row)
         return dx, dgamma, (dbeta if ctx.needs_input_grad[2] else None), None, None
 
 def spade_modulate(x, gamma, beta, eps=1e-5, relu_gain=None, clamp=None):
@@ -146,11 +154,13 @@ class _ModBiasAct(torch.autograd.Function):
             assert noise.numel() in (h * w, n * h * w)
             noise = noise.contiguous()
         y = torch.empty_like(u)
+        row = _native.amax_slot(y)
         with torch.cuda.device(u.device):
             st = _native.lib().pasta_mod_bias_act(_native.ptr(u), _native.ptr(d), _native.ptr(noise), _native.ptr(strength), _native.ptr(b),
                                                   _native.ptr(y), _native.dtype_code(u, 'mod_bias_act'), n, c, h * w, per_sample, act_idx, float(alpha), float(gain), float(clamp),
-                                                  _native.stream())
+                                                  _native.stream(), _native.ptr(row))
         _native.check(st)
+        _native.amax_attach(y, row)
         ctx.save_for_backward(u, d, noise, y)
         ctx.cfg, ctx.per_sample = cfg, per_sample
         return y
@@ -164,12 +174,14 @@ class _ModBiasAct(torch.autograd.Function):
         dy = dy.contiguous()
         lib = _native.lib()
         du = torch.empty_like(u)
+        row = _native.amax_slot(du)
         part = torch.empty([lib.pasta_mod_bias_act_bwd_workspace(n, c, h * w) // 4], dtype=torch.float32, device=u.device)
         with torch.cuda.device(u.device):
             st = lib.pasta_mod_bias_act_bwd(_native.ptr(dy), _native.ptr(y), _native.ptr(u), _native.ptr(d), _native.ptr(noise), _native.ptr(du),
                                             _native.ptr(part), _native.dtype_code(u, 'mod_bias_act_bwd'), n, c, h * w, ctx.per_sample, act_idx, float(alpha), float(gain), float(clamp),
-                                            _native.stream())
+                                            _native.stream(), _native.ptr(row))
         _native.check(st)
+        _native.amax_attach(du, row)
         sums = part.reshape(n, c, -1, 3).sum(dim=2)                    # [N, C, 3]: sum dz*u, sum dz*noise, sum dz
         dd = sums[:, :, 0] if d is not None and ctx.needs_input_grad[1] else None
         dstrength = sums[:, :, 1].sum() if noise is not None and ctx.needs_input_grad[3] else None

@@ -120,6 +120,7 @@ def test_upfirdn2d_nonsquare_planes_stay_inside_their_plane(idx):
     n = yr.numel()
     buf = torch.full([3 * n], float('nan'), device='cuda')
     out = buf[n:2 * n].view(yr.shape)
+    parts = torch.zeros([256], device='cuda')
     kw = c['kw']
     up, down = kw.get('up', 1), kw.get('down', 1)
     px0, px1, py0, py1 = kw['padding']
@@ -130,10 +131,11 @@ def test_upfirdn2d_nonsquare_planes_stay_inside_their_plane(idx):
     rc = lib.pasta_upfirdn2d(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(fc.data_ptr()), ctypes.c_void_p(out.data_ptr()), 0,
                              i32x4(*x.shape), i64x4(*x.stride()), i32x2(*fc.shape), i32x4(*out.shape), i64x4(*out.stride()),
                              up, up, down, down, px0, px1, py0, py1, 0, ctypes.c_float(kw.get('gain', 1)),
-                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.c_void_p(parts.data_ptr()))
     assert rc == 0, lib.pasta_last_error()
     torch.cuda.synchronize()
     assert rel_err(out, yr) < TOL
+    assert float(parts.max()) == float(out.abs().max()) and float(parts.min()) >= 0      # producer-side |max| of the output
     assert bool(torch.isnan(buf[:n]).all()) and bool(torch.isnan(buf[2 * n:]).all()), 'stores outside the output tensor'
 
 
@@ -556,3 +558,49 @@ def test_tensor_amax_partial_maxima(numel, offset):
     t.mul_(2)
     p2 = cg.tensor_amax(t)
     assert p2 is not p1 and float(p2.max()) == float(t.abs().max())
+
+
+def test_producer_side_maxima_match_a_scan():
+    """Every operator that writes activations leaves its output's largest magnitude behind (include/pasta_hip.h, "producer-side
+    maxima"); conv2d_gradfix.tensor_amax then finds it on the tensor instead of scanning.  Here: each producer's row against
+    the tensor's true |max|, and a convolution fed by each against fp64."""
+    from torch_utils.ops import bias_act, upfirdn2d, fma, conv2d_gradfix as cg
+    from training import networks
+    g = torch.Generator().manual_seed(21)
+    x = (torch.randn([2, 32, 64, 64], generator=g) * 3).cuda()
+    b = torch.randn([32], generator=g).cuda()
+    f = R.setup_filter([1, 3, 3, 1]).cuda()
+    s = torch.randn([2, 32], generator=g).cuda()
+    outs = {
+        'bias_act': bias_act.bias_act(x, b, act='lrelu', gain=2 ** 0.5, clamp=256),
+        'upfirdn2d': upfirdn2d.upfirdn2d(x, f, padding=[2, 2, 2, 2]),
+        'upfirdn2d_up': upfirdn2d.upsample2d(x, f),
+        'scale_planes': fma.scale_planes(x, s),
+        'spade': networks.spade_modulate(x, x * 0.1, x * 0.2),
+        'mod_bias_act': networks.mod_bias_act(x, s.abs(), None, None, b, act='lrelu', clamp=256),
+        'conv_epilogue': cg.conv2d_bias_act(x, torch.randn([48, 32, 3, 3], generator=g).cuda() / 17, b.new_zeros(48), padding=1, act='lrelu'),
+    }
+    w = (torch.randn([64, 32, 3, 3], generator=g) / 17).cuda()
+    for name, t in outs.items():
+        hit = getattr(t, '_pasta_amax', None)
+        assert hit is not None and hit[0] == t._version and hit[1] == t.data_ptr(), name
+        assert float(hit[2].max()) == float(t.abs().max()), name
+        assert cg.tensor_amax(t) is hit[2], name                       # the convolution takes the producer's row
+        if t.shape[1] == 32:
+            y = cg.conv2d(t, w, padding=1)
+            ref = torch.nn.functional.conv2d(t.double(), w.double(), padding=1)
+            assert float((y.double() - ref).abs().max() / ref.abs().max()) < 2e-6, name
+    # backward producers: the fused bias_act gradient, the SPADE and mod_bias_act backward kernels
+    xg = x.clone().requires_grad_(True)
+    y = cg.conv2d_bias_act(xg, w, b.new_zeros(64), padding=1, act='lrelu')
+    seen = []
+    orig = cg.tensor_amax
+    def spy(t):
+        seen.append(getattr(t, '_pasta_amax', None) is not None and t._pasta_amax[0] == t._version)
+        return orig(t)
+    cg.tensor_amax = spy
+    try:
+        y.square().mean().backward()
+    finally:
+        cg.tensor_amax = orig
+    assert seen and all(seen[i] for i in range(len(seen)) if i != 1), seen      # dz (and the saved x) arrive with their maxima; the weight is scanned once
