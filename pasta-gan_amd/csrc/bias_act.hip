@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void bias_act_kernel(BiasActParams p) {
     const Pack<T, V>* dys = (const Pack<T, V>*)p.dy;
     Pack<T, V>* ys = (Pack<T, V>*)p.y;
     uint32_t am = 0;
+    const AmaxSlot aslot = amax_begin(p.y_amax);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
         Pack<T, V> vx = xs[i], vxr, vyr, vdy, out;
         if (xr) vxr = xr[i];
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void bias_act_kernel(BiasActParams p) {
         }
         ys[i] = out;
     }
-    amax_commit(am, p.y_amax);
+    amax_commit(am, aslot);
 }
 
 template <class T, int A, int G>
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(256) void bias_act_grad_db_kernel(BiasActParams p, 
     const int j1 = min(plane_packs, (chunk + 1) * DB_CHUNK_PACKS);
     float acc = 0.f;
     uint32_t am = 0;
+    const AmaxSlot aslot = amax_begin(p.y_amax);
     for (int j = chunk * DB_CHUNK_PACKS + threadIdx.x; j < j1; j += 256) {
         Pack<T, V> vdy = dys[j], vyr, out;
         if (yr) vyr = yr[j];
@@ -219,7 +221,8 @@ __global__ __launch_bounds__(256) void bias_act_grad_db_kernel(BiasActParams p, 
         }
         dxs[j] = out;
     }
-    amax_commit(am, p.y_amax);
+    __shared__ uint32_t amred[4];
+    amax_commit_block<256>(am, aslot, amred);
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     __shared__ float part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;

@@ -82,12 +82,41 @@ __device__ __forceinline__ void amax_take(uint32_t& m, float v) {
     const uint32_t b = __builtin_bit_cast(uint32_t, v) & 0x7fffffffu;
     m = (b < 0x7f800000u && b > m) ? b : m;
 }
-__device__ __forceinline__ void amax_commit(uint32_t m, float* parts) {
-    if (!parts) return;
+// Where this wave will leave its maximum, and what the slot holds NOW -- read at the start of the kernel, so that the round trip
+// hides behind the kernel's own work.  A slot only grows: a stale value can cause a redundant atomic, never a missed one.
+struct AmaxSlot { unsigned int* slot; uint32_t seen; };
+__device__ __forceinline__ AmaxSlot amax_begin(float* parts) {
+    AmaxSlot a = {nullptr, 0u};
+    if (parts) {
+        a.slot = (unsigned int*)parts + ((blockIdx.x + 37u * blockIdx.y + (threadIdx.x >> 6)) & 255u);
+        if ((threadIdx.x & 63) == 0) a.seen = __hip_atomic_load(a.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return a;
+}
+// One no-return atomic per wave, and only when it would raise what the wave saw (measured: sixteen thousand unconditional atomics
+// on these eight cache lines cost a kernel as much as the scan they replace; a look at commit time holds every wave for an L2
+// round trip at the end of its life).  After the first round of workgroups most waves see a slot at or above their own maximum.
+__device__ __forceinline__ void amax_commit(uint32_t m, const AmaxSlot& a) {
+    if (!a.slot) return;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
-    if ((threadIdx.x & 63) == 0 && m != 0)
-        atomicMax((unsigned int*)parts + ((blockIdx.x + 37u * blockIdx.y + (threadIdx.x >> 6)) & 255u), m);
+    if ((threadIdx.x & 63) == 0 && m > a.seen) atomicMax(a.slot, m);
+}
+
+// The same for a whole workgroup of NT threads that owns a few words of LDS anyway (kernels of many small workgroups: one
+// commit per workgroup instead of one per wave).  `red`: NT / 64 words of shared memory; contains a barrier.
+template <int NT>
+__device__ __forceinline__ void amax_commit_block(uint32_t m, const AmaxSlot& a, uint32_t* red) {
+    if (!a.slot) return;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 1; i < NT / 64; i++) m = red[i] > m ? red[i] : m;
+        if (m > a.seen) atomicMax(a.slot, m);
+    }
 }
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

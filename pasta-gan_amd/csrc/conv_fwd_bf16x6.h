@@ -271,6 +271,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
     const int hl = lane >> 5, jl = lane & 31;
+    uint32_t y_am = 0;
+    const AmaxSlot y_slot = amax_begin(p.y_amax);      // the slot's present value arrives behind the K loop
     // Fragments of one chunk: [tile][piece], read in the order the MFMA groups consume them.
     struct Frag { bf16x8 a[WMT][3], b[WNT][3]; };
     auto read_frag = [&](Frag& f, int buf) {
@@ -333,7 +335,6 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     }
 
     const int OHW = p.OH * p.OW;
-    uint32_t y_am = 0;
     const bool has_noise = p.noise && p.ksplit == 1;
     const float nstr = has_noise ? p.noise_strength[0] : 0.f;
 #pragma unroll
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
                 }
             }
     }
-    if (p.ksplit == 1) amax_commit(y_am, p.y_amax);
+    if (p.ksplit == 1) amax_commit(y_am, y_slot);
 }
 
 
@@ -635,6 +636,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
             for (int r = 0; r < 16; r++) { acc[a][b][r] = 0.f; if constexpr (PAIR) acc2[a][b][r] = 0.f; }
 
     const int hl = lane >> 5, jl = lane & 31;
+    uint32_t y_am = 0;
+    const AmaxSlot y_slot = amax_begin(p.y_amax);      // the slot's present value arrives behind the K loop
     int fslot[WNT];                                  // slot of this lane's pixel of B fragment b, for tap offset 0
 #pragma unroll
     for (int b = 0; b < WNT; b++) {
@@ -886,7 +889,6 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     }
 
     const int OHW = p.OH * p.OW;
-    uint32_t y_am = 0;
     if constexpr (PAIR) {
         // (p, q) of the input lattice -> output row 2p + a, columns 2q and 2q + 1: one 8-byte store per lane
         struct __attribute__((packed, aligned(4))) Pair { float even, odd; };
@@ -942,7 +944,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
                 }
             }
     }
-    if (p.ksplit == 1) amax_commit(y_am, p.y_amax);
+    if (p.ksplit == 1) amax_commit(y_am, y_slot);
 }
 
 // Pixel tiles of the row-reuse kernel: full tiles of BN pixels made of whole row segments inside one image.

@@ -186,6 +186,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
     const int hl = lane >> 5, jl = lane & 31;
+    uint32_t y_am = 0;
+    const AmaxSlot y_slot = amax_begin(p.y_amax);      // the slot's present value arrives behind the K loop
     int fslot[WNT];                                  // slot of this lane's pixel of B fragment b for the tap (ymin, d0)
 #pragma unroll
     for (int b = 0; b < WNT; b++) {
@@ -284,7 +286,6 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
     }
 
     const int OHW = p.OH * p.OW;
-    uint32_t y_am = 0;
     const bool has_noise = p.noise && p.ksplit == 1;
     const float nstr = has_noise ? p.noise_strength[0] : 0.f;
 #pragma unroll
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
                 }
             }
     }
-    if (p.ksplit == 1) amax_commit(y_am, p.y_amax);
+    if (p.ksplit == 1) amax_commit(y_am, y_slot);
 }
 
 // Is the 2-D tile applicable: 3x3 stride-1 lattice (9 taps in 3 rows of 3, any order), planes divisible into R x (BN / R) tiles.

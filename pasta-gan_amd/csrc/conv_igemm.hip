@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             const float* __restrict__ noise_strength, int noise_ps, float* __restrict__ y_amax) {
     const float nstr = noise ? noise_strength[0] : 0.f;
     uint32_t am = 0;
+    const AmaxSlot aslot = amax_begin(y_amax);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
         float v = 0.f;
         int k = 0;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         io_st<IO>(y, i, v);
         if (y_amax) amax_take(am, v);
     }
-    amax_commit(am, y_amax);
+    amax_commit(am, aslot);
 }
 
 // K slices for launches that would leave most CUs idle (the 4..17 pixel layers: K = 9*512 against <= 4624 pixels).
@@ -551,12 +552,13 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
         int64_t blocks = ceil_div64(numel, 256);
         if (blocks > 2048) blocks = 2048;
 #define PASTA_SK(IO_) hipLaunchKernelGGL(splitk_reduce_kernel<IO_>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)p.partial, (void*)y, oscale, numel, \
-                                         d->OH * d->OW, p.ksplit, p.bias, d->C_out, p.act, p.alpha, p.gain, p.clamp, (const void*)p.res, p.noise, p.noise_strength, p.noise_ps, p.y_amax)
+                                         d->OH * d->OW, p.ksplit, p.bias, d->C_out, p.act, p.alpha, p.gain, p.clamp, (const void*)p.res, p.noise, p.noise_strength, p.noise_ps, (float*)nullptr)
         if (p.io == IO_BF16) PASTA_SK(IO_BF16); else if (p.io == IO_F16) PASTA_SK(IO_F16); else PASTA_SK(IO_F32);
 #undef PASTA_SK
     }
-    // y_amax with a launch whose kernel does not take it (fp32 MFMA tiles; the parity-pair mode returned above): one scan of y
-    if (p.y_amax && !p.bf16x6 && p.io == IO_F32)
+    // y_amax with a launch whose kernel does not take it (fp32 MFMA tiles; K slices: few pixels, thousands of small workgroups in
+    // the reduction): one scan of y
+    if (p.y_amax && (!p.bf16x6 || p.ksplit > 1) && p.io == IO_F32)
         if (int e = tensor_amax(y, (int64_t)d->N * d->C_out * d->OH * d->OW, PASTA_F32, p.y_amax, s)) return e;
     return launch_status("conv2d");
 }

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void scale_add_kernel(const T* __restrict__ x,
                                                         int64_t planes, int C, int64_t HW, int b_per_sample, float* __restrict__ y_amax) {
     const int64_t hwv = HW / V;
     uint32_t am = 0;
+    const AmaxSlot aslot = amax_begin(y_amax);
     for (int64_t plane = blockIdx.y; plane < planes; plane += gridDim.y) {
         const float s = a ? a[plane] : 1.f;
         const T* xp = x + plane * HW;
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void scale_add_kernel(const T* __restrict__ x,
             }
         }
     }
-    amax_commit(am, y_amax);
+    amax_commit(am, aslot);
 }
 
 //------------------------------------------------------------------------------------
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(1024) void spade_norm_kernel(const T* __restrict__ 
                                                           int act, float gain, float clamp, int C, int64_t gb_ns, float* __restrict__ y_amax) {
     __shared__ float red[16];
     uint32_t am = 0;
+    const AmaxSlot aslot = amax_begin(y_amax);
     // optional relu * gain with clamp on the way out (the activation Spade_Conv2dLayer applies before its convolution)
     auto post = [&](float v) {
         if (act == 2) { v = v > 0.f ? v * gain : 0.f; if (clamp >= 0.f && v > clamp) v = clamp; }
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(1024) void spade_norm_kernel(const T* __restrict__ 
         }
         if (tid == 0 && stats) { stats[2 * plane] = mean; stats[2 * plane + 1] = rstd; }
     }
-    amax_commit(am, y_amax);
+    amax_commit(am, aslot);
 }
 
 // Backward.  xhat = (x-mean)*rstd, t = dout*(1+gamma):
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const T* __restric
                                                               int C, int64_t gb_ns, int64_t dgb_ns, float* __restrict__ dx_amax) {
     __shared__ float red[16];
     uint32_t am = 0;
+    const AmaxSlot aslot = amax_begin(dx_amax);
     // gradient through the optional relu * gain / clamp of the forward: v = x_hat * (1 + gamma) + beta is recomputed
     auto pre = [&](float d, float h, float g, float b) {
         if (act == 2) {
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const T* __restric
             }
         }
     }
-    amax_commit(am, dx_amax);
+    amax_commit(am, aslot);
 }
 
 
@@ -272,6 +275,7 @@ __global__ __launch_bounds__(256) void mod_bias_act_kernel(const T* __restrict__
                                                            int noise_per_sample, int act, float alpha, float gain, float clamp, float* __restrict__ y_amax) {
     const int64_t plane = blockIdx.x;
     uint32_t am = 0;
+    const AmaxSlot aslot = amax_begin(y_amax);
     const int n = (int)(plane / C), c = (int)(plane - (int64_t)n * C);
     const float dv = d ? d[plane] : 1.f, bv = b ? b[c] : 0.f, ns = noise ? strength[0] : 0.f;
     const T* up = u + plane * HW;
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(256) void mod_bias_act_kernel(const T* __restrict__
             if (y_amax) amax_take(am, o);
         }
     }
-    amax_commit(am, y_amax);
+    amax_commit(am, aslot);
 }
 
 __device__ __forceinline__ float mba_dz(float dy, float y, int act, float alpha, float gain, float clamp) {
@@ -315,6 +319,7 @@ __global__ __launch_bounds__(256) void mod_bias_act_bwd_kernel(const T* __restri
                                                                int noise_per_sample, int act, float alpha, float gain, float clamp, float* __restrict__ du_amax) {
     __shared__ float red[4];
     uint32_t am = 0;
+    const AmaxSlot aslot = amax_begin(du_amax);
     const int64_t plane = blockIdx.x;
     const int n = (int)(plane / C);
     const float dv = d ? d[plane] : 1.f;
@@ -344,7 +349,8 @@ __global__ __launch_bounds__(256) void mod_bias_act_bwd_kernel(const T* __restri
             if (du_amax) amax_take(am, z * dv);
         }
     }
-    amax_commit(am, du_amax);
+    __shared__ uint32_t amred[4];
+    amax_commit_block<256>(am, aslot, amred);
     s0 = block_sum<256>(s0, red); s1 = block_sum<256>(s1, red); s2 = block_sum<256>(s2, red);
     if (threadIdx.x == 0) {
         float* o = partial + (plane * chunks + blockIdx.y) * 3;

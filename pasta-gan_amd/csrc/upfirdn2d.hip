@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(UpfirdnParams p)
     typedef typename acc_of<T>::type A;
     const int64_t total = (int64_t)p.N * p.C * p.outH * p.outW;
     uint32_t am = 0;
+    const AmaxSlot aslot = amax_begin(p.y_amax);
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         int ox = (int)(idx % p.outW);
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(UpfirdnParams p)
         st<T>((T*)p.y + n * p.osn + c * p.osc + oy * p.osy + ox * p.osx, v);
         if (p.y_amax) amax_take(am, (float)v);
     }
-    amax_commit(am, p.y_amax);
+    amax_commit(am, aslot);
 }
 
 //------------------------------------------------------------------------------------
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p,
     };
 
     uint32_t am = 0;
+    const AmaxSlot aslot = amax_begin(p.y_amax);
     int item = blockIdx.x;
     if (item < nitems) fetch(item);
     while (item < nitems) {
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p,
         }
         item = next;
     }
-    amax_commit(am, p.y_amax);
+    amax_commit(am, aslot);
 }
 
 //------------------------------------------------------------------------------------
@@ -241,6 +243,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_small_kernel(UpfirdnParams p, i
             for (int b = 0; b < F; b++) g[a][b] = p.f[(p.flip ? a : F - 1 - a) * F + (p.flip ? b : F - 1 - b)];
     }
     uint32_t am = 0;
+    const AmaxSlot aslot = amax_begin(p.y_amax);
     for (int p0 = blockIdx.x * PL; p0 < planes; p0 += gridDim.x * PL) {
         const int np = planes - p0 < PL ? planes - p0 : PL;
         const T* xp = (const T*)p.x + (int64_t)p0 * in_sz;
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_small_kernel(UpfirdnParams p, i
             }
         }
     }
-    amax_commit(am, p.y_amax);
+    amax_commit(am, aslot);
 }
 
 // ceil(2^32 / d): umulhi(e, magic) == e / d for e * d < 2^32

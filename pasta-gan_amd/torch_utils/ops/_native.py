@@ -47,11 +47,15 @@ def i64x(*vals):
 # tensor's largest magnitude in a zeroed 256-float row, and the row travels with the Python tensor object (conv2d_gradfix.tensor_amax
 # finds it there), so the convolution that consumes the tensor under PASTA_MATH_F16X3 scans nothing.
 _amax_pools = {}
+import os as _os
+_AMAX_PRODUCERS = _os.environ.get('PASTA_AMAX_PRODUCERS', '1') != '0'       # A/B switch: 0 = every consumer scans its operand
 _AMAX_ROWS = 1024
 
 def amax_slot(like):
     """A zeroed [256] fp32 row on ``like``'s device, or None when the running arithmetic has no use for it."""
     from . import conv2d_gradfix
+    if not _AMAX_PRODUCERS:
+        return None
     if conv2d_gradfix.conv_math not in ('default', 'f16x3') or like.dtype != torch.float32 or like.device.type != 'cuda':
         return None
     pool = _amax_pools.get(like.device)

@@ -567,10 +567,10 @@ def test_producer_side_maxima_match_a_scan():
     from torch_utils.ops import bias_act, upfirdn2d, fma, conv2d_gradfix as cg
     from training import networks
     g = torch.Generator().manual_seed(21)
-    x = (torch.randn([2, 32, 64, 64], generator=g) * 3).cuda()
+    x = (torch.randn([4, 32, 64, 64], generator=g) * 3).cuda()          # 16384 pixels: the matrix-core tiles (and the three-product arithmetic) run
     b = torch.randn([32], generator=g).cuda()
     f = R.setup_filter([1, 3, 3, 1]).cuda()
-    s = torch.randn([2, 32], generator=g).cuda()
+    s = torch.randn([4, 32], generator=g).cuda()
     outs = {
         'bias_act': bias_act.bias_act(x, b, act='lrelu', gain=2 ** 0.5, clamp=256),
         'upfirdn2d': upfirdn2d.upfirdn2d(x, f, padding=[2, 2, 2, 2]),
@@ -583,6 +583,9 @@ def test_producer_side_maxima_match_a_scan():
     w = (torch.randn([64, 32, 3, 3], generator=g) / 17).cuda()
     for name, t in outs.items():
         hit = getattr(t, '_pasta_amax', None)
+        if name in ('scale_planes', 'mod_bias_act'):       # thousands of four-instruction waves: a commit per wave costs what the scan costs; the consumer scans
+            assert hit is None, name
+            hit = (t._version, t.data_ptr(), cg.tensor_amax(t))
         assert hit is not None and hit[0] == t._version and hit[1] == t.data_ptr(), name
         assert float(hit[2].max()) == float(t.abs().max()), name
         assert cg.tensor_amax(t) is hit[2], name                       # the convolution takes the producer's row
