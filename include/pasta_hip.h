@@ -143,7 +143,7 @@ typedef struct pasta_conv_desc {
  *                     and l' h are exact in fp32 and accumulate in fp32; the result is scaled back exactly.  Half the
  *                     matrix work of BF16X6 at the same accuracy class (rms error against fp64 within 10 % of an fp32 FMA
  *                     chain's: the fp32 accumulation dominates both).  Range: activations keep full precision down to 2^-28
- *                     of their tensor's largest element, weights (and both operands of a weight gradient) down to 2^-16 of
+ *                     of their tensor's largest element, weights (and both operands of a weight gradient) down to 2^-16 .. 2^-17 of
  *                     theirs; smaller elements contribute with an absolute error <= 2^-28 amax each.  Non-finite elements
  *                     are skipped by the scale and stay local.  fp32 storage only; same kernels and coverage as BF16X6
  *                     except per-sample modulated weights (pasta_conv2d_modulated), which run BF16X6.

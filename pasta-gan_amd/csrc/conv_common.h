@@ -108,7 +108,10 @@ template <int IO> __device__ __forceinline__ f32x16 io_mfma(bf16x8_t a, bf16x8_t
 //       Activations keep full precision down to 2^-28 of their tensor's largest element, weights down to 2^-16 of theirs
 //       (below that the unscaled l leaves fp16's normal range and an element keeps 11..22 bits: absolute error
 //       <= 2^-28 amax per term).
-//   weight-gradient kernels: both operands are activations: (h, l', h'') each, products (S,L): (0,0) (2,1) (1,2).
+//   weight-gradient kernels: both operands are activations and symmetric, so the exponent-shift trick buys nothing there (h'' of
+//       EITHER operand leaves fp16's normal range below 2^-16 of its tensor's largest element, whichever way the low pieces are
+//       scaled): each operand is (h, l = fp16(r)), TWO pieces, products (S,L): (0,0) (0,1) (1,0) -- full precision for elements
+//       within 2^-17 of their tensor's largest, absolute error <= 2^-39 amax per element below that.
 // Scales: the tensor's |max| arrives as 256 partial maxima (pasta_tensor_amax: one pass at HBM rate, non-finite elements
 // skipped so that an inf / NaN stays local); every wave reduces them itself (one 16-byte load per lane) -- no finalising
 // launch, no atomics, no host round trip.
@@ -119,7 +122,7 @@ template <int NP> struct Arith {
     static constexpr bool f16x3 = NP == NP_F16X3;
     static constexpr int npa = f16x3 ? 3 : NP;          // A pieces in LDS
     static constexpr int npb = f16x3 ? 2 : NP;          // B pieces in LDS (forward-type kernels)
-    static constexpr int npw = f16x3 ? 3 : NP;          // pieces of either operand in the weight-gradient kernels
+    static constexpr int npw = f16x3 ? 2 : NP;          // pieces of either operand in the weight-gradient kernels
 };
 // is the product (A piece pa) x (B piece pb) part of the arithmetic?  forward-type kernels
 template <int NP> __host__ __device__ constexpr bool mm_on(int pa, int pb) {
@@ -127,7 +130,7 @@ template <int NP> __host__ __device__ constexpr bool mm_on(int pa, int pb) {
 }
 // ... weight-gradient kernels (S piece pa, L piece pb)
 template <int NP> __host__ __device__ constexpr bool mmw_on(int pa, int pb) {
-    return NP == NP_F16X3 ? ((pa == 0 && pb == 0) || (pa == 2 && pb == 1) || (pa == 1 && pb == 2)) : (pa + pb < NP);
+    return NP == NP_F16X3 ? (pa + pb < 2) : (pa + pb < NP);
 }
 // the matrix-core instruction of an arithmetic / storage type
 template <int IO, int NP> __device__ __forceinline__ f32x16 mfma16(bf16x8_t a, bf16x8_t b, f32x16 acc) {
@@ -161,6 +164,14 @@ __device__ __forceinline__ void f16_split2(float v0, float v1, uint32_t& h, uint
     float r0 = v0 - (float)hh[0], r1 = v1 - (float)hh[1];
     PASTA_KEEP_SCALAR(r0);
     lp = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{r0 * 2048.f, r1 * 2048.f}, f16x2_t));
+}
+// ... and with the low piece left unscaled: l = fp16(v - h) (weight-gradient kernels)
+__device__ __forceinline__ void f16_split2_direct(float v0, float v1, uint32_t& h, uint32_t& l) {
+    const f16x2_t hh = __builtin_convertvector(f32x2_t{v0, v1}, f16x2_t);
+    h = __builtin_bit_cast(uint32_t, hh);
+    float r0 = v0 - (float)hh[0], r1 = v1 - (float)hh[1];
+    PASTA_KEEP_SCALAR(r0);
+    l = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{r0, r1}, f16x2_t));
 }
 // h'' = h 2^-11 on a packed fp16 pair (exact while the result is a normal fp16 number)
 __device__ __forceinline__ uint32_t f16_shift11(uint32_t h) {

@@ -681,7 +681,7 @@ extern "C" int pasta_conv2d_wgrad(const void* xv, const void* dyv, float* dw, co
         else            { if (w.pipe) PASTA_WGRAD1(TR_, TS_, WA_, WB_, 1, 32); else PASTA_WGRAD1(TR_, TS_, WA_, WB_, 0, 32); } \
     } while (0)
     const int np = p.io != IO_F32 ? 1 : math_pieces(d->math);          // bf16 pieces per operand of the split-bf16 kernels (NP_F16X3: fp16 pieces)
-    const int npw = np == NP_F16X3 ? 3 : np;                           // pieces per operand in LDS
+    const int npw = np == NP_F16X3 ? 2 : np;                           // pieces per operand in LDS
     p.s_amax = p.l_amax = nullptr;
     if (np == NP_F16X3 && (wgrad_bf16x6(d, w) || wgrad_s2_bf16x6(d, w) || (wgrad_1x1_bf16x6(d, w) && !(w.TR == 3 && w.TS == 3) && w.TS != 7 && w.TS != 4))) {
         const float* xa = d->x_amax; const float* ya = d->dy_amax;

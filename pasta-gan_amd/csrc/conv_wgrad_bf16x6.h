@@ -17,7 +17,7 @@ namespace pasta {
 template <int NP, int IO = IO_F32>       // bf16 pieces per operand: 3 (six products), 2 (three), 1 (one); IO: storage type of S and L (conv_common.h)
 __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParams p) {
     static_assert(IO == IO_F32 || NP == 1, "16-bit storage: one product");
-    constexpr bool HX = Arith<NP>::f16x3;           // PASTA_MATH_F16X3: both operands as (h, l', h''), three products (conv_common.h)
+    constexpr bool HX = Arith<NP>::f16x3;           // PASTA_MATH_F16X3: both operands as (h, l), three products (conv_common.h)
     constexpr int NPW = Arith<NP>::npw;             // pieces per operand in LDS
     constexpr int ES = io_size<IO>::value;
     constexpr int SP = 40, LP = 40;                 // row pitches in bf16 elements (80 B)
@@ -109,8 +109,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if constexpr (HX) {
-                f16_split2(vals[2 * j] * scale, vals[2 * j + 1] * scale, q1[j], q2[j]);
-                q3[j] = f16_shift11(q1[j]);
+                f16_split2_direct(vals[2 * j] * scale, vals[2 * j + 1] * scale, q1[j], q2[j]);
                 continue;
             }
             f32x2 v = {vals[2 * j], vals[2 * j + 1]};
@@ -181,6 +180,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
                     // (250 of 256 registers) it spilled and ran 12 % slower, round 2 (with the row ring's smaller staging state it
                     // fits: 252 registers, no scratch) it runs 1 - 3 % slower than the narrowed reads
                     // (profiles/r2_wgrad_ring.txt) -- the conflicts are not what limits this kernel.
+                    // (whole ds_read_b128 under the three-product arithmetic, where the conflicts could weigh more: measured, no change --
+                    // gpurun_out/r3_ab_wgrad_whole.txt)
                     const uint4 b0 = *(const uint4*)lb, b1 = *(const uint4*)(lb + 8);
                     const uint32_t d[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
                     uint4 w[3];
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
 template <int PW, int NP, int IO = IO_F32>
 __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradParams p) {
     static_assert(IO == IO_F32 || NP == 1, "16-bit storage: one product");
-    constexpr bool HX = Arith<NP>::f16x3;           // PASTA_MATH_F16X3: both operands as (h, l', h''), three products (conv_common.h)
+    constexpr bool HX = Arith<NP>::f16x3;           // PASTA_MATH_F16X3: both operands as (h, l), three products (conv_common.h)
     constexpr int NPW = Arith<NP>::npw;             // pieces per operand in LDS
     constexpr int ES = io_size<IO>::value;
     constexpr int SP = 16, LP = 40;                 // row pitches in bf16 elements
@@ -330,8 +331,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if constexpr (HX) {
-                f16_split2(vals[2 * j] * scale, vals[2 * j + 1] * scale, q1[j], q2[j]);
-                q3[j] = f16_shift11(q1[j]);
+                f16_split2_direct(vals[2 * j] * scale, vals[2 * j + 1] * scale, q1[j], q2[j]);
                 continue;
             }
             f32x2 v = {vals[2 * j], vals[2 * j + 1]};
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
 template <int WA, int WB, int NP, int IO = IO_F32>
 __global__ __launch_bounds__(256, 2) void conv_wgrad1x1_bf16x6_kernel(WgradParams p) {
     static_assert(IO == IO_F32 || NP == 1, "16-bit storage: one product");
-    constexpr bool HX = Arith<NP>::f16x3;           // PASTA_MATH_F16X3: both operands as (h, l', h''), three products (conv_common.h)
+    constexpr bool HX = Arith<NP>::f16x3;           // PASTA_MATH_F16X3: both operands as (h, l), three products (conv_common.h)
     constexpr int NPW = Arith<NP>::npw;             // pieces per operand in LDS
     constexpr int ES = io_size<IO>::value;
     constexpr int SP = 40;
@@ -512,8 +512,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1x1_bf16x6_kernel(WgradParam
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if constexpr (HX) {
-                f16_split2(vals[2 * j] * scale, vals[2 * j + 1] * scale, q1[j], q2[j]);
-                q3[j] = f16_shift11(q1[j]);
+                f16_split2_direct(vals[2 * j] * scale, vals[2 * j + 1] * scale, q1[j], q2[j]);
                 continue;
             }
             f32x2 v = {vals[2 * j], vals[2 * j + 1]};

@@ -347,3 +347,30 @@ def test_non_finite_operand_stays_local(bad, mode):
     assert torch.equal(y[~hit], clean[~hit])
     ref = torch.nn.functional.conv2d(xp.cpu(), w.cpu(), padding=1)
     assert not torch.isfinite(ref[hit.cpu()]).any()          # the fp32 reference is non-finite at the same outputs
+
+
+@pytest.mark.parametrize('ratio,bound', [(1e-4, 1e-6), (1e-7, 2e-3)])
+def test_f16x3_weight_gradient_dynamic_range(ratio, bound):
+    """Both operands of a weight gradient carry ONE scale per tensor and keep fp32-class accuracy for elements within 2^-17
+    (7.6e-6) of their tensor's largest.  Here dy lives only where x is `ratio` times smaller than elsewhere in the same tensor, so
+    every product of the sum has a small x: at 1e-4 the gradient is as accurate as with uniform magnitudes (rms <= 1e-6 against
+    fp64); at 1e-7, outside the range, the low pieces fall below fp16's normal numbers and accuracy degrades gracefully (an
+    absolute error of 2^-39 of the tensor's maximum per element: ~1e-4 relative here), it does not collapse."""
+    from torch_utils.ops import conv2d_gradfix as cg
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn([4, 64, 64, 64], generator=g)
+    x[:, :, :, 32:] *= ratio
+    w = torch.randn([128, 64, 3, 3], generator=g) / 24
+    dy = torch.randn([4, 128, 64, 64], generator=g)
+    dy[:, :, :, :34] = 0                               # only the small half of x meets a gradient
+    w64 = w.double().requires_grad_(True)
+    rw, = torch.autograd.grad(torch.nn.functional.conv2d(x.double(), w64, padding=1), w64, dy.double())
+    cg.conv_math = 'f16x3'
+    try:
+        wg = w.cuda().requires_grad_(True)
+        gw, = torch.autograd.grad(cg.conv2d(x.cuda(), wg, padding=1), wg, dy.cuda())
+    finally:
+        cg.conv_math = 'default'
+    rms = float((gw.double().cpu() - rw).pow(2).mean().sqrt() / rw.pow(2).mean().sqrt())
+    print(f'ratio {ratio}: rms {rms:.2e}')
+    assert rms < bound, rms
