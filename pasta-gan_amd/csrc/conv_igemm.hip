@@ -26,7 +26,6 @@
 //     second kernel that also writes PyTorch's [.., .., kh, kw] layout (bitwise reproducible).
 //
 // C/D fragment map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
-#include <mutex>
 #include "conv_common.h"
 #include "conv_fwd_f32.h"
 #include "conv_fwd_bf16x6.h"
@@ -313,34 +312,13 @@ static bool pair_launch_ok(const pasta_conv_desc* d, int pieces, int ksplit, Fwd
     return rows_tile_ok(d->H, d->W, tile == T128x128 ? 128 : 256);
 }
 
-// A second stream per device for work that is independent of the caller's stream for the length of one call (fork and
-// join with events inside the call: the caller sees one stream-ordered operation).
-struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool tried = false; };
-static std::mutex side_mutex;          // held from the fork to the join of one call: the stream and its events are shared by the host threads
-static SideStream* side_stream() {
-    static SideStream table[32];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
-    SideStream& t = table[dev];
-    if (!t.tried) {
-        t.tried = true;
-        const char* e = getenv("PASTA_SIDE_STREAM");
-        if (!(e && e[0] == '0') && hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking) == hipSuccess) {
-            if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&t.join, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(t.stream); t.stream = nullptr; }
-        } else t.stream = nullptr;
-    }
-    return t.stream ? &t : nullptr;
-}
-
 static void launch_transposed_pairs(const pasta_conv_desc* d, const ConvFwdParams& base, FwdTile tile, hipStream_t s) {
     const int pad = d->pad_h, H = d->H, W = d->W;
     // remainder: output row 2H and / or column 2W, as lattices of conv_fwd_bf16x6_kernel.  A few dozen workgroups whose K
-    // loops are as long as anyone's (0.1 - 0.2 ms of latency for 1 % of the work): they run on the side stream, under the
-    // main launch.
+    // loops are as long as anyone's (0.1 - 0.2 ms of latency for 1 % of the work).  Round 2 ran them on a library-owned side
+    // stream under the main launch; round 3 keeps everything on the caller's stream (the library owns nothing persistent, and
+    // the default three-product arithmetic does not take this path at all).
     const bool xrow = d->OH == 2 * H + 1, xcol = d->OW == 2 * W + 1;
-    SideStream* side = nullptr;
-    std::unique_lock<std::mutex> lock(side_mutex, std::defer_lock);
     if (xrow || xcol) {
         ConvFwdParams q = base;
         q.rows = 0; q.ncls = 0;
@@ -369,11 +347,7 @@ static void launch_transposed_pairs(const pasta_conv_desc* d, const ConvFwdParam
             add_class(0, 0, H, 1, 0, 2 * W, 0, W);
             add_class(1, 0, H, 1, 1, 2 * W, 0, W);
         }
-        lock.lock();
-        side = side_stream();
-        if (side && (hipEventRecord(side->fork, s) != hipSuccess || hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess)) side = nullptr;
-        dispatch_fwd(tile, q, side ? side->stream : s);
-        if (side && hipEventRecord(side->join, side->stream) != hipSuccess) { (void)hipStreamSynchronize(side->stream); side = nullptr; }
+        dispatch_fwd(tile, q, s);
     }
     ConvFwdParams p = base;
     // main lattice: (p, q) of the input plane -> outputs (2p + a, 2q + b), a, b in {0, 1}
@@ -398,8 +372,6 @@ static void launch_transposed_pairs(const pasta_conv_desc* d, const ConvFwdParam
         p.cls[k] = {H, W, a, 0, nt, 6 * k};
     }
     if (tile == T128x128) launch_fwd_pair<128, 128>(p, s); else launch_fwd_pair<64, 256>(p, s);
-
-    if (side) (void)hipStreamWaitEvent(s, side->join, 0);
 }
 
 static int conv2d_run(const void* x, const float* w, void* y, const float* iscale, const float* oscale,
