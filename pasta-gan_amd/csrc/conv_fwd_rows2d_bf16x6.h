@@ -25,6 +25,10 @@ namespace pasta {
 // ISC: p.iscale[n, channel] (the styles of a modulated convolution) multiplied onto the activations between fetch and split.
 // NT = threads per workgroup: 256 (four waves; two workgroups per CU) or 512 (eight waves on a 128 x 256 tile, one workgroup per
 // CU: the weights of a step are fetched and stored once for 256 pixels instead of once for 128).
+// Measured and dropped (round 3, three-product arithmetic, profiles/r3_ab_tap_pairs.txt): TWO taps per barrier on the eight-wave
+// tile (four weight buffers; the weights of the next pair fetched when a pair begins, stored when it ends; 246 VGPRs): 2 % SLOWER
+// on every live shape (248 / 304 / 318 / 324 against 255 / 310 / 325 / 328 TFLOP/s) although 34 % of the wave cycles are parked
+// at s_waitcnt / s_barrier -- the barrier count is not what parks them.
 template <int BM, int BN, int R, int NP = 3, int IO = IO_F32, bool ISC = false, int NT = 256>
 __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_kernel(ConvFwdParams p) {
     static_assert(IO == IO_F32 || NP == 1, "16-bit storage: the element is the operand, one product");

@@ -11,7 +11,7 @@ for V in on off on off; do
     if [ $V = on ]; then python3 -c "import sys; sys.path.insert(0, 'pasta-gan_amd'); from torch_utils import custom_ops; custom_ops.build(extra_flags=['-D$FLAG'])";
     else python3 -c "import sys; sys.path.insert(0, 'pasta-gan_amd'); from torch_utils import custom_ops; custom_ops.build()"; fi
     echo "== $FLAG $V"
-    python3 - "$V" "$FLAG" $@ <<'PY'
+    python3 - "$V" "$FLAG" "$@" <<'PY'
 import sys, os
 sys.path.insert(0, 'pasta-gan_amd')
 from torch_utils import custom_ops
