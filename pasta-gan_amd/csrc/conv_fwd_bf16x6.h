@@ -278,7 +278,10 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     auto read_frag = [&](Frag& f, int buf) {
 #define PASTA_LDA(PC) if constexpr ((PC) < NPA) { _Pragma("unroll") for (int a = 0; a < WMT; a++) f.a[a][PC] = *(const bf16x8*)&As[buf][(((PC) * 2 + hl) * BM + (wm * WMT + a) * 32 + jl) * 8]; }
 #define PASTA_LDB(PC) if constexpr ((PC) < NPB) { _Pragma("unroll") for (int b = 0; b < WNT; b++) f.b[b][PC] = *(const bf16x8*)&Bs[buf][(((PC) * 2 + hl) * BN + (wn * WNT + b) * 32 + jl) * 8]; }
-        PASTA_LDA(2) PASTA_LDB(0) PASTA_LDA(0) PASTA_LDB(2) PASTA_LDA(1) PASTA_LDB(1)
+        // in the order the product groups consume them, so that the first group starts when ITS operands have landed (the LDS
+        // returns reads in order: counted lgkmcnt waits): three-product arithmetic (h'' l'), (l h), (h h)
+        if constexpr (HX) { PASTA_LDA(2) PASTA_LDB(1) PASTA_LDA(1) PASTA_LDB(0) PASTA_LDA(0) }
+        else { PASTA_LDA(2) PASTA_LDB(0) PASTA_LDA(0) PASTA_LDB(2) PASTA_LDA(1) PASTA_LDB(1) }
 #undef PASTA_LDA
 #undef PASTA_LDB
     };
@@ -650,7 +653,10 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
         const __bf16* B_ = Bs + bbuf * BBUF;
 #define PASTA_LDA(PC) if constexpr ((PC) < NPA) { _Pragma("unroll") for (int a = 0; a < WMT; a++) f.a[a][PC] = *(const bf16x8*)&A_[(((PC) * 2 + hl) * BM + (wm * WMT + a) * 32 + jl) * 8]; }
 #define PASTA_LDB(PC) if constexpr ((PC) < NPB) { _Pragma("unroll") for (int b = 0; b < WNT; b++) f.b[b][PC] = *(const bf16x8*)&B_[(((PC) * 2 + hl) * SLOTS + fslot[b] + off) * 8]; }
-        PASTA_LDA(2) PASTA_LDB(0) PASTA_LDA(0) PASTA_LDB(2) PASTA_LDA(1) PASTA_LDB(1)
+        // in the order the product groups consume them, so that the first group starts when ITS operands have landed (the LDS
+        // returns reads in order: counted lgkmcnt waits): three-product arithmetic (h'' l'), (l h), (h h)
+        if constexpr (HX) { PASTA_LDA(2) PASTA_LDB(1) PASTA_LDA(1) PASTA_LDB(0) PASTA_LDA(0) }
+        else { PASTA_LDA(2) PASTA_LDB(0) PASTA_LDA(0) PASTA_LDB(2) PASTA_LDA(1) PASTA_LDB(1) }
 #undef PASTA_LDA
 #undef PASTA_LDB
     };

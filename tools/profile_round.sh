@@ -4,7 +4,7 @@
 # --pmc gpurun_out --pmc-prefix r2pmc_ --steps 16` condenses them into profiles/.  Counters are collected in passes of
 # their own (never together with a trace), the program itself follows `--` (no env / bash -c hop).
 set -e -o pipefail
-TAG=${1:-r2}
+TAG=${1:-r3}
 export TMPDIR=/tmp
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"
