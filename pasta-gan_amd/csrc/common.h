@@ -100,7 +100,9 @@ __device__ __forceinline__ void amax_commit(uint32_t m, const AmaxSlot& a) {
     if (!a.slot) return;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
-    if ((threadIdx.x & 63) == 0 && m > a.seen) atomicMax(a.slot, m);
+    // waves of the first round all saw an empty slot: those look once more now (they finish at different times, so most find the
+    // slot already raised) before spending an atomic
+    if ((threadIdx.x & 63) == 0 && m > a.seen && m > __hip_atomic_load(a.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.slot, m);
 }
 
 // The same for a whole workgroup of NT threads that owns a few words of LDS anyway (kernels of many small workgroups: one
@@ -115,7 +117,7 @@ __device__ __forceinline__ void amax_commit_block(uint32_t m, const AmaxSlot& a,
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int i = 1; i < NT / 64; i++) m = red[i] > m ? red[i] : m;
-        if (m > a.seen) atomicMax(a.slot, m);
+        if (m > a.seen && m > __hip_atomic_load(a.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.slot, m);
     }
 }
 
