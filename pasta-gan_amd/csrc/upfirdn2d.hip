@@ -22,6 +22,11 @@
 // strip kernel whose wave stores are 256-byte aligned in the output address (235 us: sixteen LDS reads per output and no
 // load / compute overlap cost more than the aligned stores return).  What the odd plane width costs is in the stores:
 // the same filter into 256-column rows takes 136 us, an odd number of rows costs nothing.
+// Round 3, measured and dropped again: full-width strips of 16 rows whose loads AND stores are 16-byte packs aligned to the address
+// (a strip of whole rows is one contiguous block on both sides, whatever the row length), (row, column) of a pack's elements by
+// reciprocal multiplication, four outputs of a row sharing a 4 x 7 LDS window: 199 us (257 -> 256) and 234 us (256 -> 257) against
+// 148 / 209 for the tile kernel on the same box -- the address arithmetic per element and two barriers per 4112 outputs cost more than
+// the partial cache lines.
 #include "common.h"
 
 namespace pasta {

@@ -48,7 +48,14 @@ def main():
         rows[key][0] += len(kernels)
         rows[key][1] += us
         total += us
-    print(f'framework kernels: {total / 1000 / args.steps:.2f} ms of GPU time per step')
+    print(f'framework kernels: {total / 1000 / args.steps:.2f} ms of GPU time per step, {sum(v[0] for v in rows.values()) / args.steps:.0f} launches per step')
+    bysite = collections.defaultdict(lambda: [0, 0.0])
+    for (name, shapes, where), (count, us) in rows.items():
+        bysite[where][0] += count; bysite[where][1] += us
+    print('--- by Python site (launches per step)')
+    for where, (count, us) in sorted(bysite.items(), key=lambda kv: -kv[1][0])[:30]:
+        print(f'{count / args.steps:7.1f} launches {us / 1000 / args.steps:8.3f} ms/step  {where}')
+    print('--- by operator and shape (time)')
     for key, (count, us) in sorted(rows.items(), key=lambda kv: -kv[1][1])[:args.top]:
         print(f'{us / 1000 / args.steps:8.3f} ms/step {count / args.steps:7.1f} calls  {key[0]:<28} {key[1]:<92} {key[2]}')
 
