@@ -43,7 +43,7 @@ def bf16x6_rows_names():    # <BM, BN, OCC, schedule, pieces, storage, input sca
     return {0: f'conv_fwd_rows_bf16x6_kernel<128,128,2,1,{_np()},{STORAGE_IO},false,false>',
             1: f'conv_fwd_rows_bf16x6_kernel<64,256,2,1,{_np()},{STORAGE_IO},false,false>'}
 def bf16x6_pair_names():    # stride-2 conv_transpose2d on the row-reuse kernel's parity-pair mode (+ its remainder launch)
-    return {0: 'conv_fwd_rows_bf16x6_kernel<128,128,2,2,3,0,false,true>', 1: 'conv_fwd_rows_bf16x6_kernel<64,256,2,2,3,0,false,true>'}
+    return {0: f'conv_fwd_rows_bf16x6_kernel<128,128,2,2,{_np()},0,false,true>', 1: f'conv_fwd_rows_bf16x6_kernel<64,256,2,2,{_np()},0,false,true>'}
 
 TILE_NAMES = {0: 'conv_fwd_kernel<128,128,2,2,8,4>', 1: 'conv_fwd_kernel<64,256,2,2,8,4>',
               2: 'conv_fwd_kernel<32,256,1,2,8>', 3: 'conv_fwd_kernel<64,64,1,1,8>'}

@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     static_assert(!PAIR || (PIPE == 2 && !ISC), "the parity-pair mode runs on the register-diet schedule");
     constexpr unsigned ES = io_size<IO>::value;
     constexpr bool HX = Arith<NP>::f16x3;               // PASTA_MATH_F16X3 (conv_common.h): default schedules only
-    static_assert(!HX || (PIPE <= 1 && !PAIR), "the three-product fp16 arithmetic runs on the default schedules");
+    static_assert(!HX || PIPE <= 1 || (PIPE == 2 && PAIR), "the three-product fp16 arithmetic runs on the default schedules and in the parity-pair mode");
     constexpr int NPA = Arith<NP>::npa, NPB = Arith<NP>::npb;
     constexpr int WMT = 2, WNT = 2, KC = 16;
     constexpr int WAVES_N = BN / 64;
@@ -766,8 +766,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
             for (int a = 0; a < WMT; a++)
 #pragma unroll
                 for (int b = 0; b < WNT; b++) {
-                    if (PAIR && TAP == 1) acc2[a][b] = io_mfma<IO>(fa[a], fb[b], acc2[a][b]);
-                    else acc[a][b] = io_mfma<IO>(fa[a], fb[b], acc[a][b]);
+                    if (PAIR && TAP == 1) acc2[a][b] = mfma16<IO, NP>(fa[a], fb[b], acc2[a][b]);
+                    else acc[a][b] = mfma16<IO, NP>(fa[a], fb[b], acc[a][b]);
                 }
         };
         const bool mine = TAP == 1 || (TAP == 2 && wave == h_owner);
@@ -786,6 +786,27 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
             if (mine) { split_piece(sb, sv, q, false); store_piece(bbuf ^ 1, sslot, shalf, 2, q); }
             store_a(abuf ^ 1, 0);
             ldb(0); mm();                                           // a1 b1
+        }
+        if constexpr (HX) {
+            // three products, five operand reads: (h'' l') (l h) (h h); the split yields both pieces at once (no residual chain)
+            const float* const ssc = TAP == 1 ? msc : hsc;
+            lda(2); ldb(1); mm();
+            if (mine) {
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int i = 0; i < BPT; i++) split_pair(sb, sv, i, j, ssc);
+            }
+            lda(1); ldb(0); mm();
+            if (mine) {
+#pragma unroll
+                for (int j = 2; j < 4; j++)
+#pragma unroll
+                    for (int i = 0; i < BPT; i++) split_pair(sb, sv, i, j, ssc);
+                store_q(bbuf ^ 1, sslot, shalf);
+            }
+            store_a(abuf ^ 1, 0);
+            lda(0); mm();
         }
         __syncthreads();
     };
@@ -881,7 +902,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
             step_areg(0, 1, ar1, ar0); step_areg(1, 1, ar0, ar1); step_areg(2, 1, ar1, ar0);
         }
     } else if constexpr (PIPE == 2) {
-        static_assert(NP == 3, "the register-diet schedule exists for the six-product arithmetic");
+        static_assert(NP == 3 || HX, "the register-diet schedule exists for the six- and the three-product arithmetic");
         for (int s = 0; s < nstages; s += 2) {
             step_diet(0, 0, 0); step_diet(1, 1, 0); step_diet(2, 0, 0);
             step_diet(0, 1, 1); step_diet(1, 0, 1); step_diet(2, 1, 1);
@@ -914,6 +935,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
                         Pair v;
                         v.even = p.pair_bx ? acc2[a][b][r] : acc[a][b][r];
                         v.odd = p.pair_bx ? acc[a][b][r] : acc2[a][b][r];
+                        if constexpr (HX) { v.even *= out_scale; v.odd *= out_scale; }
                         *(Pair*)(p.y + yoff + (int64_t)o * OHW) = v;
                     }
                 }
@@ -1041,20 +1063,20 @@ static void launch_fwd_bf16x6(const ConvFwdParams& p, hipStream_t s) {
 
 // Parity-pair launch of the row-reuse kernel (see its PAIR note): p.cls[0..1] are the two vertical parities over the input
 // lattice, tap tables per class, p.pair_off / p.pair_bx / p.rows_d0 set by the caller.
-template <int BM, int BN>
+template <int BM, int BN, int NP = 3>
 static void launch_fwd_pair(const ConvFwdParams& p, hipStream_t s) {
     ConvFwdParams q = p;
     q.o_tiles = (p.Og + BM - 1) / BM;
     const int64_t tiles = (int64_t)p.N * p.cls[0].P * p.cls[0].Q / BN;
     dim3 grid((unsigned)(2 * tiles), q.o_tiles, p.G);
-    constexpr int APT = (2 * 3 * BM + 255) / 256;
-    constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 2 * 3 * (BN + 16) * 8) * sizeof(__bf16);
+    constexpr int APT = (2 * Arith<NP>::npa * BM + 255) / 256;
+    constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 2 * Arith<NP>::npb * (BN + 16) * 8) * sizeof(__bf16);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 2, 3, IO_F32, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 2, NP, IO_F32, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 2, 3, IO_F32, false, true>), grid, dim3(256), lds, s, q);
+    hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 2, NP, IO_F32, false, true>), grid, dim3(256), lds, s, q);
 }
 
 // Do the T taps at table positions [0, T) form rows of three horizontally adjacent offsets (ascending or descending)?

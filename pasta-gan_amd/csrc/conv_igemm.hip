@@ -301,7 +301,7 @@ namespace pasta {
 static bool pair_launch_ok(const pasta_conv_desc* d, int pieces, int ksplit, FwdTile tile, bool plain) {
     static const bool enabled = !(getenv("PASTA_T2_PAIR") && getenv("PASTA_T2_PAIR")[0] == '0');
     if (!enabled || !d->transposed || d->stride != 2 || d->kh != 3 || d->kw != 3 || d->pad_h != d->pad_w || d->pad_h > 1) return false;
-    if (pieces != 3 || d->io_dtype != PASTA_F32 || !plain || ksplit != 1) return false;
+    if ((pieces != 3 && pieces != NP_F16X3) || d->io_dtype != PASTA_F32 || !plain || ksplit != 1) return false;
     if (d->OH < 2 * d->H || d->OH > 2 * d->H + 1 || d->OW < 2 * d->W || d->OW > 2 * d->W + 1) return false;
     if (tile != T128x128 && tile != T64x256) return false;
     // Measured (profiles/r2_conv_pairs.txt): onto 2H x 2W outputs (no remainder) the pair kernel is 1.4x the per-class launch at
@@ -312,16 +312,95 @@ static bool pair_launch_ok(const pasta_conv_desc* d, int pieces, int ksplit, Fwd
     return rows_tile_ok(d->H, d->W, tile == T128x128 ? 128 : 256);
 }
 
-static void launch_transposed_pairs(const pasta_conv_desc* d, const ConvFwdParams& base, FwdTile tile, hipStream_t s) {
+// The remainder of the parity-pair launch: output row 2H and / or column 2W of a stride-2 conv_transpose2d onto an odd plane --
+// 1 % of the outputs, each a dot product over ONE input row or column (one or two taps).  As lattices of the MFMA kernels these
+// were a few dozen workgroups whose K loops are as long as anyone's: 0.17 ms of latency behind a 0.2 ms main launch (measured,
+// profiles/r3_ab_pair_f16x3.txt).  Here: plain fp32 FMAs on the raw weights, one thread per (pixel, 16 output channels), the
+// lanes of a wave along the lattice -- thousands of short independent chains instead of thirty long ones.
+struct EdgeWeights { const float* w; const float* mod_s; const float* mod_d; float wscale; int flip; };
+
+template <bool MOD>          // MOD: one shared weight modulated per group on the way (pasta_conv2d_modulated), as the packing kernel does
+__global__ __launch_bounds__(256) void conv_t2_edge_kernel(ConvFwdParams p, EdgeWeights ew) {
+    constexpr int OC = 16, KC = 64;                      // a workgroup: 64 lattice pixels x 64 output channels, K in chunks of 64 channels
+    __shared__ float xs[KC][64];                         // [channel][pixel]
+    __shared__ __attribute__((aligned(16))) float wsm[KC][64];     // [channel][output channel]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.z;
+    int c = 0, tile = blockIdx.x;
+    for (; c < p.ncls - 1; c++) {                        // classes share the grid's x axis
+        const int t = (p.N * p.cls[c].P * p.cls[c].Q + 63) >> 6;
+        if (tile < t) break;
+        tile -= t;
+    }
+    const int P = p.cls[c].P, Q = p.cls[c].Q, T = p.cls[c].T, tap0 = p.cls[c].tap0;
+    const int pix = tile * 64 + lane;                    // the same pixel in all four waves: lanes along the lattice
+    const bool live = pix < p.N * P * Q;
+    const int n = live ? pix / (P * Q) : 0;
+    const int rem = live ? pix - n * P * Q : 0;
+    const int pp = rem / Q, qq = rem - pp * Q;
+    const int ob = blockIdx.y * 64;                      // this workgroup's output channels; this wave's: ob + 16 wave ...
+    const int HW = p.H * p.W;
+    float acc[OC];
+#pragma unroll
+    for (int j = 0; j < OC; j++) acc[j] = 0.f;
+    const float* const xb = p.x + ((int64_t)n * p.Cin + (int64_t)g * p.Ig) * HW;
+    const int gs = MOD ? 0 : g;
+    const int wo = ob + lane < p.Og ? ob + lane : p.Og - 1;           // staging role of this thread: weight column `lane`
+    const float wlive = ob + lane < p.Og ? ew.wscale : 0.f;
+    float md = 1.f;
+    if constexpr (MOD) md = ew.mod_d ? ew.mod_d[(int64_t)g * p.Og + wo] : 1.f;
+    for (int t = 0; t < T; t++) {
+        const int iy = pp + p.tap_dy[tap0 + t], ix = qq + p.tap_dx[tap0 + t];
+        const bool ok = live && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const float* const xp = xb + (ok ? iy * p.W + ix : 0);
+        const int slab = ew.flip ? 8 - p.tap_slab[tap0 + t] : p.tap_slab[tap0 + t];
+        const float* const wt = ew.w + ((int64_t)gs * p.Ig * p.Og + wo) * 9 + slab;      // [C_in][C_out / G][3][3]
+        for (int i0 = 0; i0 < p.Ig; i0 += KC) {
+            // every load of the chunk in flight at once: one round trip for the column gather, one for the weights
+            float xr[KC / 4], wr[KC / 4];
+#pragma unroll
+            for (int k = 0; k < KC / 4; k++) {
+                const int ii = i0 + wave + 4 * k;
+                const int ic = ii < p.Ig ? ii : p.Ig - 1;
+                xr[k] = (ok && ii < p.Ig) ? xp[(int64_t)ic * HW] : 0.f;
+                float wv = wt[(int64_t)ic * p.Og * 9] * (ii < p.Ig ? wlive : 0.f);
+                if constexpr (MOD) { wv *= ew.mod_s[(int64_t)g * p.Ig + ic]; wv *= md; }
+                wr[k] = wv;
+            }
+            __syncthreads();                             // the previous chunk has been consumed
+#pragma unroll
+            for (int k = 0; k < KC / 4; k++) { xs[wave + 4 * k][lane] = xr[k]; wsm[wave + 4 * k][lane] = wr[k]; }
+            __syncthreads();
+#pragma unroll 8
+            for (int ii = 0; ii < KC; ii++) {
+                const float xv = xs[ii][lane];
+#pragma unroll
+                for (int q4 = 0; q4 < OC / 4; q4++) {
+                    const float4 w4 = *(const float4*)&wsm[ii][wave * OC + 4 * q4];      // wave-uniform address: a broadcast read
+                    acc[4 * q4 + 0] = fmaf(xv, w4.x, acc[4 * q4 + 0]);
+                    acc[4 * q4 + 1] = fmaf(xv, w4.y, acc[4 * q4 + 1]);
+                    acc[4 * q4 + 2] = fmaf(xv, w4.z, acc[4 * q4 + 2]);
+                    acc[4 * q4 + 3] = fmaf(xv, w4.w, acc[4 * q4 + 3]);
+                }
+            }
+        }
+    }
+    if (!live) return;
+    const int o0 = ob + wave * OC;
+    float* const yb = p.y + (((int64_t)n * p.Cout + (int64_t)g * p.Og + o0) * p.OH + p.cls[c].oy0 + pp * p.osy) * p.OW + p.cls[c].ox0 + qq * p.osx;
+#pragma unroll
+    for (int j = 0; j < OC; j++)
+        if (o0 + j < p.Og) yb[(int64_t)j * p.OH * p.OW] = acc[j];
+}
+
+static void launch_transposed_pairs(const pasta_conv_desc* d, const ConvFwdParams& base, FwdTile tile, hipStream_t s, const EdgeWeights& ew) {
     const int pad = d->pad_h, H = d->H, W = d->W;
-    // remainder: output row 2H and / or column 2W, as lattices of conv_fwd_bf16x6_kernel.  A few dozen workgroups whose K
-    // loops are as long as anyone's (0.1 - 0.2 ms of latency for 1 % of the work).  Round 2 ran them on a library-owned side
-    // stream under the main launch; round 3 keeps everything on the caller's stream (the library owns nothing persistent, and
-    // the default three-product arithmetic does not take this path at all).
+    // remainder: output row 2H and / or column 2W, by conv_t2_edge_kernel over the class tables below (everything stays on the
+    // caller's stream: the library owns nothing persistent)
     const bool xrow = d->OH == 2 * H + 1, xcol = d->OW == 2 * W + 1;
+    ConvFwdParams q = base;
+    q.rows = 0; q.ncls = 0;
     if (xrow || xcol) {
-        ConvFwdParams q = base;
-        q.rows = 0; q.ncls = 0;
         int ntap = 0;
         auto add_class = [&](int a, int b, int P, int Q, int oy0, int ox0, int py_shift, int px_shift) {
             const int tap0 = ntap;
@@ -347,8 +426,18 @@ static void launch_transposed_pairs(const pasta_conv_desc* d, const ConvFwdParam
             add_class(0, 0, H, 1, 0, 2 * W, 0, W);
             add_class(1, 0, H, 1, 1, 2 * W, 0, W);
         }
-        dispatch_fwd(tile, q, s);
     }
+    static const int edge_mode = getenv("PASTA_T2_EDGE") ? getenv("PASTA_T2_EDGE")[0] - '0' : 1;      // A/B: 0 = the remainder as MFMA lattices, 2 = after the main launch
+    auto launch_edge = [&]() {
+        if (!q.ncls) return;
+        if (edge_mode == 0) { dispatch_fwd(tile, q, s); return; }
+        int tiles = 0;
+        for (int c = 0; c < q.ncls; c++) tiles += (q.N * q.cls[c].P * q.cls[c].Q + 63) >> 6;
+        const dim3 grid((unsigned)tiles, (unsigned)((q.Og + 63) / 64), (unsigned)q.G);
+        if (ew.mod_s) hipLaunchKernelGGL(conv_t2_edge_kernel<true>, grid, dim3(256), 0, s, q, ew);
+        else hipLaunchKernelGGL(conv_t2_edge_kernel<false>, grid, dim3(256), 0, s, q, ew);
+    };
+    if (edge_mode != 2) launch_edge();
     ConvFwdParams p = base;
     // main lattice: (p, q) of the input plane -> outputs (2p + a, 2q + b), a, b in {0, 1}
     p.ncls = 2; p.rows = 1; p.rows_rev = 0;
@@ -371,7 +460,9 @@ static void launch_transposed_pairs(const pasta_conv_desc* d, const ConvFwdParam
         }
         p.cls[k] = {H, W, a, 0, nt, 6 * k};
     }
-    if (tile == T128x128) launch_fwd_pair<128, 128>(p, s); else launch_fwd_pair<64, 256>(p, s);
+    if (p.bf16x6 == NP_F16X3) { if (tile == T128x128) launch_fwd_pair<128, 128, NP_F16X3>(p, s); else launch_fwd_pair<64, 256, NP_F16X3>(p, s); }
+    else if (tile == T128x128) launch_fwd_pair<128, 128>(p, s); else launch_fwd_pair<64, 256>(p, s);
+    if (edge_mode == 2) launch_edge();
 }
 
 static int conv2d_run(const void* x, const float* w, void* y, const float* iscale, const float* oscale,
@@ -484,7 +575,7 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
         const int u = d->stride;
         p.osy = u; p.osx = u; p.isy = 1; p.isx = 1;
         if (pair_launch_ok(d, p.bf16x6, p.ksplit, tile, pair_plain(launch_flags_of(iscale, oscale, ep)))) {
-            launch_transposed_pairs(d, p, tile, s);
+            launch_transposed_pairs(d, p, tile, s, EdgeWeights{w, wmod_s, wmod_d, wscale, d->flip});
             return launch_status("conv2d");
         }
         const bool merged = merged_classes(d, p.bf16x6 != 0);

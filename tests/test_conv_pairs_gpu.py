@@ -33,8 +33,8 @@ def _plan_kernel(cfg_desc):
 @pytest.mark.parametrize('math', ['bf16x6', 'default'])
 @pytest.mark.parametrize('n,cin,cout,h,w,pad,opad', CASES)
 def test_transposed_stride2_pairs_match_fp64(n, cin, cout, h, w, pad, opad, math):
-    """The pair kernel belongs to the six-product split-bf16 arithmetic ('bf16x6'); the default three-product fp16 arithmetic
-    runs these shapes on the class-merged base kernel -- both against fp64."""
+    """Both fp32-class arithmetics (six-product split-bf16, and the default three products of scaled fp16 pieces) run these
+    shapes on the pair kernel -- against fp64."""
     from torch_utils.ops import conv2d_gradfix as cg
     g = torch.Generator().manual_seed(h * 7 + cin)
     x = torch.randn([n, cin, h, w], generator=g)
@@ -50,11 +50,10 @@ def test_transposed_stride2_pairs_match_fp64(n, cin, cout, h, w, pad, opad, math
     assert y.shape == ref.shape
     err = float((y.cpu().double() - ref).abs().max() / ref.abs().max())
     assert err < 2e-6, err
-    if math == 'bf16x6':
-        if opad == 1:                   # even output planes: always the pair kernel
-            assert kernel == 3 and launches == 1
-        elif h * w >= 128 * 128 or os.environ.get('PASTA_T2_PAIR') == '2':     # with a remainder row / column: planes of 128 x 128 and larger (csrc/conv_igemm.hip, pair_launch_ok)
-            assert kernel == 3 and launches == 2
+    if opad == 1:                   # even output planes: always the pair kernel
+        assert kernel == 3 and launches == 1
+    elif h * w >= 128 * 128 or os.environ.get('PASTA_T2_PAIR') == '2':     # with a remainder row / column: planes of 128 x 128 and larger (csrc/conv_igemm.hip, pair_launch_ok)
+        assert kernel == 3 and launches == 2
     else:
         assert kernel == 1 and launches == 1        # the four parity classes share one grid of conv_fwd_bf16x6_kernel
 
