@@ -113,10 +113,19 @@ __global__ __launch_bounds__(1024) void spade_norm_kernel(const T* __restrict__ 
         const int64_t gb = (plane / C) * gb_ns + (plane % C) * HW;
         float mean, rstd;
         if constexpr (EPT > 0) {
-            float4 r[EPT / 4];
+            float4 r[EPT / 4], gq[EPT / 4], bq[EPT / 4];
             float s = 0.f;
+            // gamma and beta are fetched WITH the plane, ahead of the two workgroup reductions: three operands in flight instead of one
 #pragma unroll
-            for (int k = 0; k < EPT / 4; k++) { r[k] = ld4<T>(xp + 4 * (k * 1024 + tid)); s += r[k].x + r[k].y + r[k].z + r[k].w; }
+            for (int k = 0; k < EPT / 4; k++) r[k] = ld4<T>(xp + 4 * (k * 1024 + tid));
+#pragma unroll
+            for (int k = 0; k < EPT / 4; k++) {
+                const int64_t i = k * 1024 + tid;
+                gq[k] = gamma ? ld4<T>(gamma + gb + 4 * i) : make_float4(0, 0, 0, 0);
+                bq[k] = beta ? ld4<T>(beta + gb + 4 * i) : make_float4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < EPT / 4; k++) s += r[k].x + r[k].y + r[k].z + r[k].w;
             mean = block_sum<1024>(s, red) * inv;
             float q = 0.f;
 #pragma unroll
@@ -128,8 +137,7 @@ __global__ __launch_bounds__(1024) void spade_norm_kernel(const T* __restrict__ 
 #pragma unroll
             for (int k = 0; k < EPT / 4; k++) {
                 const int64_t i = k * 1024 + tid;
-                float4 g = gamma ? ld4<T>(gamma + gb + 4 * i) : make_float4(0, 0, 0, 0);
-                float4 b = beta ? ld4<T>(beta + gb + 4 * i) : make_float4(0, 0, 0, 0);
+                const float4 g = gq[k], b = bq[k];
                 float4 o;
                 o.x = post(fmaf((r[k].x - mean) * rstd, 1.f + g.x, b.x));
                 o.y = post(fmaf((r[k].y - mean) * rstd, 1.f + g.y, b.y));
@@ -154,7 +162,8 @@ __global__ __launch_bounds__(1024) void spade_norm_kernel(const T* __restrict__ 
         }
         if (tid == 0 && stats) { stats[2 * plane] = mean; stats[2 * plane + 1] = rstd; }
     }
-    amax_commit(am, aslot);
+    __shared__ uint32_t amred[16];
+    amax_commit_block<1024>(am, aslot, amred);        // one commit per workgroup (sixteen waves)
 }
 
 // Backward.  xhat = (x-mean)*rstd, t = dout*(1+gamma):
@@ -248,7 +257,8 @@ __global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const T* __restric
             }
         }
     }
-    amax_commit(am, aslot);
+    __shared__ uint32_t amred[16];
+    amax_commit_block<1024>(am, aslot, amred);        // one commit per workgroup (sixteen waves)
 }
 
 
@@ -283,14 +293,24 @@ __global__ __launch_bounds__(256) void mod_bias_act_kernel(const T* __restrict__
     T* yp = y + plane * HW;
     const int64_t i0 = (int64_t)blockIdx.y * MBA_CHUNK, i1 = i0 + MBA_CHUNK < HW ? i0 + MBA_CHUNK : HW;
     if ((HW & 3) == 0) {
-        for (int64_t i = i0 + 4 * threadIdx.x; i < i1; i += 1024) {
-            const float4 uv = ld4<T>(up + i);
-            const float4 nv = np_ ? *(const float4*)(np_ + i) : make_float4(0, 0, 0, 0);
+        // the chunk's four fetches per operand first, then the arithmetic and the stores: 64 - 128 bytes in flight per thread
+        constexpr int U = MBA_CHUNK / 1024;
+        float4 uv[U], nv[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const int64_t i = i0 + 4 * threadIdx.x + 1024 * k, ic = i < i1 ? i : i1 - 4;
+            uv[k] = ld4<T>(up + ic);
+            nv[k] = np_ ? *(const float4*)(np_ + ic) : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const int64_t i = i0 + 4 * threadIdx.x + 1024 * k;
+            if (i >= i1) continue;
             float4 o;
-            o.x = mba_fwd(uv.x, dv, nv.x * ns, bv, act, alpha, gain, clamp);
-            o.y = mba_fwd(uv.y, dv, nv.y * ns, bv, act, alpha, gain, clamp);
-            o.z = mba_fwd(uv.z, dv, nv.z * ns, bv, act, alpha, gain, clamp);
-            o.w = mba_fwd(uv.w, dv, nv.w * ns, bv, act, alpha, gain, clamp);
+            o.x = mba_fwd(uv[k].x, dv, nv[k].x * ns, bv, act, alpha, gain, clamp);
+            o.y = mba_fwd(uv[k].y, dv, nv[k].y * ns, bv, act, alpha, gain, clamp);
+            o.z = mba_fwd(uv[k].z, dv, nv[k].z * ns, bv, act, alpha, gain, clamp);
+            o.w = mba_fwd(uv[k].w, dv, nv[k].w * ns, bv, act, alpha, gain, clamp);
             st4<T>(yp + i, o);
             if (y_amax) { amax_take(am, o.x); amax_take(am, o.y); amax_take(am, o.z); amax_take(am, o.w); }
         }
@@ -329,9 +349,19 @@ __global__ __launch_bounds__(256) void mod_bias_act_bwd_kernel(const T* __restri
     const int64_t i0 = (int64_t)blockIdx.y * MBA_CHUNK, i1 = i0 + MBA_CHUNK < HW ? i0 + MBA_CHUNK : HW;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     if ((HW & 3) == 0) {
-        for (int64_t i = i0 + 4 * threadIdx.x; i < i1; i += 1024) {
-            const float4 gv = ld4<T>(dyp + i), yv = ld4<T>(yp + i), uv = ld4<T>(up + i);
-            const float4 nv = np_ ? *(const float4*)(np_ + i) : make_float4(0, 0, 0, 0);
+        constexpr int U = MBA_CHUNK / 1024;             // fetches first, as in the forward kernel
+        float4 gvs[U], yvs[U], uvs[U], nvs[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const int64_t i = i0 + 4 * threadIdx.x + 1024 * k, ic = i < i1 ? i : i1 - 4;
+            gvs[k] = ld4<T>(dyp + ic); yvs[k] = ld4<T>(yp + ic); uvs[k] = ld4<T>(up + ic);
+            nvs[k] = np_ ? *(const float4*)(np_ + ic) : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const int64_t i = i0 + 4 * threadIdx.x + 1024 * k;
+            if (i >= i1) continue;
+            const float4 gv = gvs[k], yv = yvs[k], uv = uvs[k], nv = nvs[k];
             const float z0 = mba_dz(gv.x, yv.x, act, alpha, gain, clamp), z1 = mba_dz(gv.y, yv.y, act, alpha, gain, clamp);
             const float z2 = mba_dz(gv.z, yv.z, act, alpha, gain, clamp), z3 = mba_dz(gv.w, yv.w, act, alpha, gain, clamp);
             s0 += z0 * uv.x + z1 * uv.y + z2 * uv.z + z3 * uv.w;

@@ -223,7 +223,8 @@ __global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p,
         }
         item = next;
     }
-    amax_commit(am, aslot);
+    __shared__ uint32_t amred[NT / 64];
+    amax_commit_block<NT>(am, aslot, amred);          // one commit per workgroup
 }
 
 //------------------------------------------------------------------------------------

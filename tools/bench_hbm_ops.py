@@ -87,6 +87,12 @@ def main():
         rows.append(('torch add (reference point)', list(x.shape), 3 * x.numel() * 4, ms))
         ms = timeit(lambda: x.clone())
         rows.append(('torch copy (reference point)', list(x.shape), 2 * x.numel() * 4, ms))
+        # the same at twice the size (537 MB: beyond what the 256 MB Infinity Cache keeps between repetitions)
+        xb = torch.randn([16, 64, 256, 256], device=dev); gb_ = torch.randn_like(xb)
+        ms = timeit(lambda: xb + gb_)
+        rows.append(('torch add (reference point)', list(xb.shape), 3 * xb.numel() * 4, ms))
+        ms = timeit(lambda: xb.clone())
+        rows.append(('torch copy (reference point)', list(xb.shape), 2 * xb.numel() * 4, ms))
     print(f"{'kernel':34s} {'shape':24s} {'MB':>8s} {'us':>8s} {'GB/s':>8s} {'of 8 TB/s':>9s}")
     for name, shape, nbytes, ms in rows:
         gbs = nbytes / ms / 1e6
