@@ -103,12 +103,27 @@ def _native16(kind, desc, has_iscale=False):
 # the weight gradient; a gradient serves the input-gradient and the weight-gradient launch of the same backward.
 AMAX_PARTS = 256
 _f16x3_cache = {}
+_SCAN_TRACE = {} if _os.environ.get('PASTA_AMAX_TRACE') else None
+if _SCAN_TRACE is not None:
+    import atexit as _atexit
+    def _dump_scans():
+        import sys
+        rows = sorted(_SCAN_TRACE.items(), key=lambda kv: -kv[1] * max(1, int(torch.Size(kv[0][0]).numel())))
+        for (shape, src), n in rows[:60]:
+            print(f'amax scan x{n:5d}  {str(shape):28s} {src}', file=sys.stderr)
+    _atexit.register(_dump_scans)
 
 def tensor_amax(t):
     """[256] partial |max| of a contiguous fp32 GPU tensor (cached per tensor version)."""
     hit = getattr(t, '_pasta_amax', None)
     if hit is not None and hit[0] == t._version and hit[1] == t.data_ptr():
         return hit[2]
+    if _SCAN_TRACE is not None:                        # diagnostic (PASTA_AMAX_TRACE=1): which tensors still cost a scan
+        import sys as _sys
+        fr = _sys._getframe(1)
+        key = (tuple(t.shape), (type(t.grad_fn).__name__ if t.grad_fn is not None else ('param' if t.requires_grad else 'plain'))
+               + f' <- {fr.f_code.co_name}:{fr.f_lineno}' + (' [stale attr]' if hit is not None else ''))
+        _SCAN_TRACE[key] = _SCAN_TRACE.get(key, 0) + 1
     parts = torch.empty([AMAX_PARTS], dtype=torch.float32, device=t.device)
     with torch.cuda.device(t.device):
         _native.check(_native.lib().pasta_tensor_amax(_native.ptr(t), t.numel(), 0, _native.ptr(parts), _native.stream()))

@@ -51,7 +51,8 @@ def _layer(cls, **kw):
     return layer
 
 
-@pytest.mark.parametrize('cin,cout,res,up', [(64, 64, 64, 1), (128, 64, 64, 2), (512, 512, 16, 1), (512, 256, 32, 2), (48, 40, 32, 1)])
+@pytest.mark.parametrize('cin,cout,res,up', [(64, 64, 64, 1), (128, 64, 64, 2), (512, 512, 16, 1), (512, 256, 32, 2), (48, 40, 32, 1),
+                                             (128, 128, 256, 2)])      # 128^2 -> 257^2 with per-sample weights: parity-pair kernel + the fp32 remainder kernel on modulated weights
 @pytest.mark.parametrize('fused', [False, True])
 @pytest.mark.parametrize('noise_mode', ['const', 'none'])
 def test_synthesis_layer_forward_only_equals_the_differentiable_path(cin, cout, res, up, fused, noise_mode):
