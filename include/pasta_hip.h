@@ -305,7 +305,8 @@ int pasta_spade_norm_bwd(const void* dout, const void* x, const void* gamma,
                          const float* stats, void* dx, void* dgamma,
                          void* dbeta, int dtype, int64_t planes, int64_t HW,
                          const void* beta, int act, float gain, float clamp, int C, int64_t gb_stride, int64_t dgb_stride,
-                         void* stream, float* dx_amax);
+                         void* stream, float* dx_amax, float* dgb_amax);     /* dgb_amax: |max| over what is written to dgamma AND dbeta (they
+                                                                               feed one convolution when they are halves of one tensor) */
 
 /* ------------------------------------------------------------------------- *
  * ADA augmentation (training/augment.py:121-431).

@@ -97,16 +97,19 @@ class _SpadeModulate(torch.autograd.Function):
         if ctx.fused:       # gamma | beta and their gradients as channel halves of one tensor each
             half = x.element_size() * c * h * w
             dgb = torch.empty_like(gamma) if ctx.needs_input_grad[1] else None
+            grow = _native.amax_slot(dgb) if dgb is not None else None         # dgamma | dbeta is the dy of ONE convolution's backward
             if dx is not None or dgb is not None:
                 with torch.cuda.device(x.device):
                     st = lib.pasta_spade_norm_bwd(_native.ptr(dout), _native.ptr(x), _native.ptr(gamma), _native.ptr(stats), _native.ptr(dx),
                                                   _native.ptr(dgb), dgb.data_ptr() + half if dgb is not None else None,
                                                   _native.dtype_code(x, 'spade_norm_bwd'), n * c, h * w,
                                                   gamma.data_ptr() + half, act, float(gain), float(clamp), c, 2 * c * h * w, 2 * c * h * w,
-                                                  _native.stream(), _native.ptr(row))
+                                                  _native.stream(), _native.ptr(row), _native.ptr(grow))
                 _native.check(st)
                 if dx is not None:
                     _native.amax_attach(dx, row)
+                if dgb is not None:
+                    _native.amax_attach(dgb, grow)
             return dx, dgb, None, None, None
         dgamma = torch.empty_like(x) if ctx.needs_input_grad[1] else None
         # without a fused activation d/dbeta is dout itself; with one it is dout through the activation, written by the kernel
@@ -120,7 +123,7 @@ class _SpadeModulate(torch.autograd.Function):
                 st = lib.pasta_spade_norm_bwd(_native.ptr(dout), _native.ptr(x), _native.ptr(gamma), _native.ptr(stats),
                                               _native.ptr(dx), _native.ptr(dgamma), _native.ptr(dbeta if act == 2 else None),
                                               _native.dtype_code(x, 'spade_norm_bwd'), n * c, h * w, _native.ptr(beta), act, float(gain), float(clamp), c, 0, 0, _native.stream(),
-                                              _native.ptr(row))
+                                              _native.ptr(row), None)
             _native.check(st)
             if dx is not None:
                 _native.amax_attach(dx, row)

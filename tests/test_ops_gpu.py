@@ -607,3 +607,12 @@ def test_producer_side_maxima_match_a_scan():
     finally:
         cg.tensor_amax = orig
     assert seen and all(seen[i] for i in range(len(seen)) if i != 1), seen      # dz (and the saved x) arrive with their maxima; the weight is scanned once
+    # the SPADE backward with gamma | beta as halves of one tensor: dgamma | dbeta (the dy of ONE convolution's backward) carries its own row
+    xs = x.clone().requires_grad_(True)
+    gb = torch.cat([x * 0.1, x * 0.2], dim=1).requires_grad_(True)
+    out = networks.spade_modulate(xs, gb, None, relu_gain=2 ** 0.5, clamp=256)
+    dxs, dgb = torch.autograd.grad(out, [xs, gb], torch.randn(out.shape, generator=g).cuda())
+    for name, t in (('spade dx', dxs), ('spade dgamma|dbeta', dgb)):
+        hit = getattr(t, '_pasta_amax', None)
+        assert hit is not None and hit[0] == t._version and hit[1] == t.data_ptr(), name
+        assert float(hit[2].max()) == float(t.abs().max()), name
