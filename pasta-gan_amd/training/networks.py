@@ -450,10 +450,14 @@ class Spade_Conv2dLayer(_FilteredConv):
             return _scaled_act(self.activation, gain, self.conv_clamp)
         return None
 
-    def forward(self, x, gain=1, no_act=False):
+    def forward(self, x, gain=1, no_act=False, residual=None):
+        """``residual`` (shape of the output): added in the convolution's epilogue -- the block's ``shortcut.add_(x)`` without its
+        pass over HBM (two reads and a write of the activation)."""
         if not no_act:
             act_gain, act_clamp = _scaled_act(self.activation, gain, self.conv_clamp)
             x = bias_act.bias_act(x, (None if self.bias is None else self.bias.to(x.dtype)), act=self.activation, gain=act_gain, clamp=act_clamp)
+        if residual is not None:
+            return conv2d_resample.conv2d_resample_bias_act(x=x, b=None, act='linear', gain=1, residual=residual, **self._resample_args(x))
         return conv2d_resample.conv2d_resample(x=x, **self._resample_args(x))
 
 #----------------------------------------------------------------------------
@@ -722,19 +726,24 @@ class Spade_ResBlockV2(torch.nn.Module):
         self.spade1 = Spade_Norm_Block(feat_channels, out_channels)
 
     @staticmethod
-    def _norm_then_conv(norm, conv, x, feat, gain):
-        """conv(norm(x, feat), gain); the activation in front of the convolution is applied by the SPADE kernel when the
-        layer allows it (bias-free relu)."""
+    def _norm_then_conv(norm, conv, x, feat, gain, residual=None):
+        """conv(norm(x, feat), gain) [+ residual]; the activation in front of the convolution is applied by the SPADE kernel when
+        the layer allows it (bias-free relu)."""
         post = conv.fusable_activation(gain)
         if post is None:
-            return conv(norm(x, feat), gain=gain)
-        return conv(norm(x, feat, post_act=post), no_act=True)
+            return conv(norm(x, feat), gain=gain, residual=residual)
+        return conv(norm(x, feat, post_act=post), no_act=True, residual=residual)
 
     def forward(self, x, denorm_feat):
         half = np.sqrt(0.5)
         x = self.conv(x, no_act=True)
         shortcut = self._norm_then_conv(self.spade_skip, self.skip, x, denorm_feat, half)
         x = self._norm_then_conv(self.spade0, self.conv0, x, denorm_feat, 1)
+        if x.dtype == torch.float32 and x.device.type == 'cuda' and self.conv1.up == 1 and self.conv1.down == 1:
+            # shortcut + conv1(.): the sum is formed in conv1's epilogue (the layers are activation-FIRST: the convolution is the last step).
+            # fp32 storage only: in 16-bit storage the reference rounds conv1's output to the storage type BEFORE the addition, and the
+            # config-5 fixtures (tests/test_config5_gpu.py) hold this path to that sequence of roundings
+            return self._norm_then_conv(self.spade1, self.conv1, x, denorm_feat, half, residual=shortcut)
         x = self._norm_then_conv(self.spade1, self.conv1, x, denorm_feat, half)
         return shortcut.add_(x)
 
