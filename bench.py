@@ -38,7 +38,9 @@ def _np():
     from torch_utils.ops import conv2d_gradfix
     return 1 if STORAGE_IO else {'bf16x3': 2, 'bf16': 1, 'bf16x6': 3}.get(conv2d_gradfix.conv_math, 4)     # 4 = NP_F16X3: 'default' / 'f16x3'
 def bf16x6_names():         # template arguments as rocprofv3 prints them: <BM, BN, OCC, pieces, storage, input scale in the staging>
-    return {0: f'conv_fwd_bf16x6_kernel<128,128,3,{_np()},{STORAGE_IO},false>', 1: f'conv_fwd_bf16x6_kernel<64,256,2,{_np()},{STORAGE_IO},false>'}
+    return {0: f'conv_fwd_bf16x6_kernel<128,128,3,{_np()},{STORAGE_IO},false,false>', 1: f'conv_fwd_bf16x6_kernel<64,256,2,{_np()},{STORAGE_IO},false,false>'}
+def bf16x6_packed_names():  # the few-input-channel (packed-K) mode: last template argument
+    return {0: f'conv_fwd_bf16x6_kernel<128,128,3,{_np()},0,false,true>', 1: f'conv_fwd_bf16x6_kernel<64,256,2,{_np()},0,false,true>'}
 def bf16x6_rows_names():    # <BM, BN, OCC, schedule, pieces, storage, input scale, parity pairs>
     return {0: f'conv_fwd_rows_bf16x6_kernel<128,128,2,1,{_np()},{STORAGE_IO},false,false>',
             1: f'conv_fwd_rows_bf16x6_kernel<64,256,2,1,{_np()},{STORAGE_IO},false,false>'}
@@ -82,12 +84,12 @@ class ConvMeter:
             tile, ksplit, math, launches, kernel = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
             self.lib.pasta_conv2d_plan(ctypes.byref(desc), int(flags) | int(isc), ctypes.byref(tile), ctypes.byref(ksplit), ctypes.byref(math), ctypes.byref(launches),
                                        ctypes.byref(kernel))
-            family = {0: TILE_NAMES, 1: bf16x6_names(), 2: bf16x6_rows_names(), 3: bf16x6_pair_names(),
+            family = {0: TILE_NAMES, 1: bf16x6_names(), 2: bf16x6_rows_names(), 3: bf16x6_pair_names(), 8: bf16x6_packed_names(),
                       4: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,128,4,{_np()},{STORAGE_IO},false,256>'}, 5: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,128,2,{_np()},{STORAGE_IO},false,256>'},
                       6: {1: f'conv_fwd_rows2d_bf16x6_kernel<64,256,8,{_np()},{STORAGE_IO},false,256>'},
                       7: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,256,8,{_np()},0,false,512>'}}[kernel.value][tile.value]     # <BM, BN, rows per tile, pieces, storage, input scale, threads>
             if isc and kernel.value != 0:       # the instance with the input scale: same family, another template argument (rocprofv3 names)
-                family = {1: family.replace(',3,3,0,false>', ',2,3,0,true>').replace(',3,4,0,false>', ',2,4,0,true>'), 2: family.replace(',false,false>', ',true,false>')}.get(
+                family = {1: family.replace(',3,3,0,false,false>', ',2,3,0,true,false>').replace(',3,4,0,false,false>', ',2,4,0,true,false>'), 2: family.replace(',false,false>', ',true,false>')}.get(
                     kernel.value, family.replace(',false,256>', ',true,256>'))
             kernels = launches.value
         else:

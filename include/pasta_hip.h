@@ -186,6 +186,7 @@ int pasta_conv2d_tile(const pasta_conv_desc* d);
 #define PASTA_PLAN_ISCALE   1
 #define PASTA_PLAN_OSCALE   2
 #define PASTA_PLAN_EPILOGUE 4
+#define PASTA_PLAN_MODULATED 8   /* pasta_conv2d_modulated (per-group modulated weights) */
 int pasta_conv2d_plan(const pasta_conv_desc* d, int launch_flags, int* tile, int* ksplit, int* math, int* launches, int* kernel);
 
 /* Same for pasta_conv2d_wgrad: *kernel = 0 conv_wgrad_kernel (fp32 MFMA, taps x 64 x 64 tiles), 1

@@ -226,6 +226,9 @@ struct ConvFwdParams {
     // parity-pair mode of the row-reuse kernel (stride-2 conv_transpose2d): B-image offset of tap c, and whether the
     // two-tap column (taps 0 and 2) is the odd output column
     int pair_off[3], pair_bx;
+    // packed-K mode of conv_fwd_bf16x6_kernel (few input channels): "channel" k of the K loop is (input channel, tap) and lives
+    // koff[k] bytes behind the pixel's base address in a zero-padded copy of the input; null = off
+    const unsigned* koff;
 };
 
 // Tile choice.  O_pad multiple returned so that the caller can pack weights accordingly.

@@ -81,9 +81,14 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __r
 // ISC: the activations are multiplied by p.iscale[n, channel] (the styles of a modulated convolution, networks.py:74) on
 // their way from the fetch registers to the split -- x * s rounded to fp32 exactly as a separate scaling pass would, so
 // the modulated activation tensor never exists in HBM.
-template <int BM, int BN, int OCC, int NP, int IO = IO_F32, bool ISC = false>      // (128, 128): waves 2 x 2;  (64, 256): waves 1 x 4; each wave 64 rows x 64 pixels
+// KT (round 3, few input channels -- the RGB stems: 3 -> 64 at 7x7, 3x3, 1x1): the K loop runs over (input channel, tap) PAIRS
+// instead of taps x 16-channel chunks, of which an RGB tensor fills three lanes in sixteen: one pseudo-tap, Ig = C_in kh kw "channels",
+// channel k at byte offset p.koff[k] (scalar loads) from the pixel's base in a zero-padded copy of the input, so no bound is checked
+// per element.  The weights are the tensor as it lies ([O][C_in kh kw] is a 1x1 weight over those channels).
+template <int BM, int BN, int OCC, int NP, int IO = IO_F32, bool ISC = false, bool KT = false>      // (128, 128): waves 2 x 2;  (64, 256): waves 1 x 4; each wave 64 rows x 64 pixels
 __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams p) {
     static_assert(IO == IO_F32 || NP == 1, "16-bit storage: the element is the operand, one product");
+    static_assert(!KT || (IO == IO_F32 && !ISC), "the packed-K mode serves fp32 tensors without an input scale");
     constexpr unsigned ES = io_size<IO>::value;
     constexpr bool HX = Arith<NP>::f16x3;               // PASTA_MATH_F16X3 (conv_common.h)
     constexpr int NPA = Arith<NP>::npa, NPB = Arith<NP>::npb;
@@ -181,7 +186,9 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
             const int c0 = cc * KC + (half0 + i) * 8;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const unsigned coff = (unsigned)(c0 + j < last ? c0 + j : last) * (unsigned)HW * ES;    // scalar
+                unsigned coff;                                                                           // scalar
+                if constexpr (KT) coff = p.koff[c0 + j < last ? c0 + j : last];
+                else coff = (unsigned)(c0 + j < last ? c0 + j : last) * (unsigned)HW * ES;
                 st.b[8 * i + j] = io_ld<IO>(xbytes, ld_pix + coff);
                 if constexpr (ISC) st.sc[8 * i + j] = isb[c0 + j < last ? c0 + j : last];
             }
@@ -1017,6 +1024,9 @@ static void launch_fwd_bf16_np(const ConvFwdParams& q, dim3 grid, hipStream_t s)
         }
         hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP, IO>), grid, dim3(256), lds, s, q);
         return;
+    }
+    if constexpr (IO == IO_F32 && (NP == 3 || NP == NP_F16X3)) {
+        if (q.koff) { hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<BM, BN, (BN == 256 ? 2 : 3), NP, IO, false, true>), grid, dim3(256), 0, s, q); return; }
     }
     hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<BM, BN, (BN == 256 ? 2 : 3), NP, IO>), grid, dim3(256), 0, s, q);     // <= 64 KB of LDS: two or three workgroups per CU
 }

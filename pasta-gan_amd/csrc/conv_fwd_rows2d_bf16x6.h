@@ -30,22 +30,22 @@ namespace pasta {
 // on every live shape (248 / 304 / 318 / 324 against 255 / 310 / 325 / 328 TFLOP/s) although 34 % of the wave cycles are parked
 // at s_waitcnt / s_barrier -- the barrier count is not what parks them.
 // Also measured and dropped (round 3, profiles/r3_ab_wave128.txt, r3_ab_rows2d_pipe*.txt, r3_pipe_ablation.txt; the kernel is kept, out of
-// the build, as tools/experiments/conv_fwd_rows2d_pipe.h): FOUR waves of 64 x 128 outputs on the same tile (WNT_ = 4: 14 fragment reads per
+// the build, as tools/experiments/conv_fwd_rows2d_pipe.h): FOUR waves of 64 x 128 outputs on the same tile (14 fragment reads per
 // 24 MFMAs instead of 10 per 12), one wave per SIMD -- equal to the eight waves within 2 % on every shape, with or without the fragments of
 // step g + 1 read behind the MFMAs of step g (two fragment sets, 253 + 128 registers, the order within a step pinned by
 // sched_group_barrier).  Its timing-only instances on the 512 -> 512 layer at 32 x 32: MFMAs + barriers alone 509 TFLOP/s, + fragment
 // reads 421, + staging (everything) 339: the chip is at its power cap (1.9 GHz), and every LDS byte and fetch next to the MFMAs costs
 // clock, however well it is hidden in the schedule.
-template <int BM, int BN, int R, int NP = 3, int IO = IO_F32, bool ISC = false, int NT = 256, int WNT_ = 2>
-__global__ __launch_bounds__(NT, (NT == 256 && WNT_ == 2) ? 2 : 1) void conv_fwd_rows2d_bf16x6_kernel(ConvFwdParams p) {
+template <int BM, int BN, int R, int NP = 3, int IO = IO_F32, bool ISC = false, int NT = 256>
+__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_kernel(ConvFwdParams p) {
     static_assert(IO == IO_F32 || NP == 1, "16-bit storage: the element is the operand, one product");
     static_assert(!ISC || ((NP == 3 || NP == NP_F16X3) && IO == IO_F32), "the input scale rides in the fp32-equivalent staging");
     constexpr bool HX = Arith<NP>::f16x3;               // PASTA_MATH_F16X3: fp16 pieces, three products (conv_common.h)
     constexpr int NPA = Arith<NP>::npa, NPB = Arith<NP>::npb;
     constexpr unsigned ES = io_size<IO>::value;
-    constexpr int WMT = 2, WNT = WNT_, KC = 16;          // a wave: 64 output channels x 32 WNT pixels
-    constexpr int WAVES_N = BN / (32 * WNT);
-    static_assert((BM / 64) * WAVES_N == NT / 64, "one wave per 64 x (32 WNT) sub-tile");
+    constexpr int WMT = 2, WNT = 2, KC = 16;
+    constexpr int WAVES_N = BN / 64;
+    static_assert((BM / 64) * WAVES_N == NT / 64, "one wave per 64 x 64 sub-tile");
     constexpr int SEG = BN / R, SW = SEG + 2, SLOTS = (R + 2) * SW;
     static_assert(SEG % 32 == 0, "a fragment's 32 pixels lie in one tile row");
     constexpr int UNITS = 2 * SLOTS, UPT = (UNITS + NT - 1) / NT;          // (slot, k-half) staging units; per thread
@@ -338,17 +338,17 @@ static bool rows2d_tile_ok(int P, int Q) {
     return P % R == 0 && Q % SEG == 0;
 }
 
-template <int BM, int BN, int R, int NP, int IO, bool ISC = false, int NT = 256, int WNT = 2>
+template <int BM, int BN, int R, int NP, int IO, bool ISC = false, int NT = 256>
 static void launch_fwd_rows2d_np(const ConvFwdParams& q, dim3 grid, hipStream_t s) {
     constexpr int SEG = BN / R, SLOTS = (R + 2) * (SEG + 2);
     constexpr int APT = (2 * Arith<NP>::npa * BM + NT - 1) / NT;
     constexpr size_t lds = (size_t)(2 * APT * NT * 8 + 2 * 2 * Arith<NP>::npb * SLOTS * 8) * sizeof(__bf16);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_fwd_rows2d_bf16x6_kernel<BM, BN, R, NP, IO, ISC, NT, WNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv_fwd_rows2d_bf16x6_kernel<BM, BN, R, NP, IO, ISC, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_fwd_rows2d_bf16x6_kernel<BM, BN, R, NP, IO, ISC, NT, WNT>), grid, dim3(NT), lds, s, q);
+    hipLaunchKernelGGL((conv_fwd_rows2d_bf16x6_kernel<BM, BN, R, NP, IO, ISC, NT>), grid, dim3(NT), lds, s, q);
 }
 
 template <int BM, int BN, int R>

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void amax_times_kernel(const float* __restrict
     parts_out[threadIdx.x] = parts_in[threadIdx.x] * m;
 }
 
-struct FwdPlan { FwdTile tile; int ksplit; int bf16x6; };
+struct FwdPlan { FwdTile tile; int ksplit; int bf16x6; int packed; };     // packed: the few-input-channel mode (conv_fwd_bf16x6_kernel, KT)
 
 // Do the split-bf16 kernels of this launch take the input scale (modulation) in their staging code?
 static bool isc_in_staging(const pasta_conv_desc* d) { return d->io_dtype == PASTA_F32 && fp32_equivalent(math_pieces(d->math)); }
@@ -125,7 +125,15 @@ static FwdPlan plan_fwd(const pasta_conv_desc* d) {
     const int Og = d->C_out / d->groups, Ig = d->C_in / d->groups;
     const int64_t npix = fwd_lattice_pixels(d);
     const bool sb = (d->math != PASTA_MATH_F32 || d->io_dtype != PASTA_F32) && Ig >= 16 && (int64_t)d->N * d->C_in * d->H * d->W < (1ll << 30);
+    // fewer than 16 input channels into more than 32 output channels over a large plane with at least 64 (channel, tap) pairs -- the 7x7
+    // RGB stems: 0.394 -> 0.234 ms.  Below (3x3: 27 pairs, 1x1: 3) the output store is what the launch costs and the fp32 kernel's
+    // epilogue is the faster one: 0.113 -> 0.141 ms and 0.205 -> 0.366 ms when forced (profiles/r3_ab_packed_k.txt)
+    static const bool packed_on = !(getenv("PASTA_PACKED_K") && getenv("PASTA_PACKED_K")[0] == '0');
+    const bool few = packed_on && !d->transposed && d->groups == 1 && Ig < 16 && Og > 32 && npix > 8192 && d->io_dtype == PASTA_F32 &&
+                     d->math != PASTA_MATH_F32 && fp32_equivalent(math_pieces(d->math)) && Ig * d->kh * d->kw >= 64 && Ig * d->kh * d->kw <= 1024 &&
+                     (int64_t)d->N * d->C_in * (d->H + 2 * d->pad_h) * (d->W + 2 * d->pad_w) < (1ll << 28);
     FwdPlan f;
+    f.packed = few;
     // ToRGB / parsing heads (<= 16 output channels): HBM-bound, few rows, fp32 MFMA.  17..32 output channels (the 512^2 block of the
     // 512 generator) take the 64-row split-bf16 tile half empty: 80 (fp32 storage) / 175 (16-bit) TFLOP/s effective against 55 on the
     // fp32 tile, and 16-bit tensors are not converted for the launch.
@@ -133,7 +141,8 @@ static FwdPlan plan_fwd(const pasta_conv_desc* d) {
     else if (npix <= 8192) f.tile = (sb && Og > 64) ? T128x128 : T64x64;     // 4..16 pixel layers: K is sliced to fill the chip
     else if (Og <= 64) f.tile = T64x256;
     else f.tile = T128x128;
-    f.bf16x6 = sb && (f.tile == T128x128 || f.tile == T64x256);
+    f.bf16x6 = (sb || few) && (f.tile == T128x128 || f.tile == T64x256);
+    f.packed = f.packed && f.bf16x6;
     f.ksplit = 1;
     if (npix <= 8192 && f.tile != T32x256) {
         const int bm = fwd_tile_bm(f.tile), bn = f.tile == T64x64 ? 64 : 128;
@@ -235,6 +244,14 @@ static int check_desc(const pasta_conv_desc* d, const char* who) {
 //------------------------------------------------------------------------------------
 // C ABI.
 
+namespace pasta {
+// floats of the zero-padded input copy of the packed-K mode (0: the convolution has no padding, the input itself serves)
+static int64_t packed_input_floats(const pasta_conv_desc* d) {
+    if (d->pad_h == 0 && d->pad_w == 0) return 0;
+    return (int64_t)d->N * d->C_in * (d->H + 2 * d->pad_h) * (d->W + 2 * d->pad_w);
+}
+}
+
 extern "C" int64_t pasta_conv2d_workspace(const pasta_conv_desc* d) {
     using namespace pasta;
     if (check_desc(d, "conv2d_workspace")) return -1;
@@ -243,9 +260,16 @@ extern "C" int64_t pasta_conv2d_workspace(const pasta_conv_desc* d) {
     const FwdTile t = f.tile;
     const int ks = f.ksplit;
     // packed weights: fp32 (4 B) or three bf16 pieces (6 B) per element; sized for the larger, in floats
-    const int64_t pack = ((int64_t)d->groups * d->kh * d->kw * round_up(Ig, fwd_ipad(Ig, t)) * round_up(Og, fwd_tile_bm(t)) * 3 + 1) / 2;
+    int64_t pack = ((int64_t)d->groups * d->kh * d->kw * round_up(Ig, fwd_ipad(Ig, t)) * round_up(Og, fwd_tile_bm(t)) * 3 + 1) / 2;
     const int64_t partial = ks > 1 ? (int64_t)ks * d->N * d->C_out * d->OH * d->OW : 0;
-    return (WS_AMAX_FLOATS + round_up((int)pack, 4) + partial) * (int64_t)sizeof(float);
+    int64_t extra = 0;
+    if (f.packed) {         // [O][C_in kh kw] packed as a 1x1 weight, the offset table, the zero-padded copy of the input
+        const int64_t kp = round_up(Ig * d->kh * d->kw, 16);
+        const int64_t pk = (kp * round_up(Og, fwd_tile_bm(t)) * 3 + 1) / 2;
+        pack = pack > pk ? pack : pk;
+        extra = kp + packed_input_floats(d);
+    }
+    return (WS_AMAX_FLOATS + round_up((int)pack, 4) + partial + round_up((int)extra, 4)) * (int64_t)sizeof(float);
 }
 
 extern "C" int pasta_conv2d_tile(const pasta_conv_desc* d) {
@@ -268,7 +292,8 @@ extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int launch_flags, int
     if (int e = check_desc(d, "conv2d_plan")) return e;
     const bool has_iscale = (launch_flags & PASTA_PLAN_ISCALE) != 0;
     const FwdPlan f = plan_fwd(d);
-    const bool sb = f.bf16x6 && (!has_iscale || isc_in_staging(d));
+    const bool packed = f.packed && !has_iscale && !(launch_flags & PASTA_PLAN_MODULATED);
+    const bool sb = f.bf16x6 && (!has_iscale || isc_in_staging(d)) && (!f.packed || packed);
     if (d->io_dtype != PASTA_F32 && !sb) return fail("conv2d: no 16-bit-storage kernel for this shape (fewer than 16 input channels per group, at most 32 "
                                                       "output channels, or an input scale): convert the tensors to fp32 for this launch");
     if (tile) *tile = (int)f.tile;
@@ -285,7 +310,7 @@ extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int launch_flags, int
         const bool rows2d = plain6 && f.tile == T128x128 && rows2d_rows(d->OH, d->OW) > 0;
         const bool rows2d_256 = plain6 && f.tile == T64x256 && rows2d_rows256(d->OH, d->OW);
         const bool wide = rows2d && !has_iscale && fp32_equivalent(math_pieces(d->math)) && d->io_dtype == PASTA_F32 && rows2d_wide(d->OH, d->OW);
-        *kernel = !sb ? 0 : pair ? 3 : wide ? 7 : rows2d ? (rows2d_rows(d->OH, d->OW) == 4 ? 4 : 5) : rows2d_256 ? 6 : rows ? 2 : 1;
+        *kernel = !sb ? 0 : packed ? 8 : pair ? 3 : wide ? 7 : rows2d ? (rows2d_rows(d->OH, d->OW) == 4 ? 4 : 5) : rows2d_256 ? 6 : rows ? 2 : 1;
     }
     return 0;
 }
@@ -391,6 +416,29 @@ __global__ __launch_bounds__(256) void conv_t2_edge_kernel(ConvFwdParams p, Edge
 #pragma unroll
     for (int j = 0; j < OC; j++)
         if (o0 + j < p.Og) yb[(int64_t)j * p.OH * p.OW] = acc[j];
+}
+
+// Packed-K mode (conv_fwd_bf16x6_kernel, KT): byte offset of "channel" k = (input channel c, tap (ty, tx)) from a pixel's base
+// address in the padded input -- the tap the weight element [o][c][ty][tx] multiplies (mirrored when the launch flips the weight).
+__global__ __launch_bounds__(256) void packed_koff_kernel(unsigned* __restrict__ koff, int K, int kh, int kw, int flip, int HWp, int Wp) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const int c = k / (kh * kw), t = k - c * kh * kw;
+    int ty = t / kw, tx = t - ty * kw;
+    if (flip) { ty = kh - 1 - ty; tx = kw - 1 - tx; }
+    koff[k] = (unsigned)(c * HWp + ty * Wp + tx) * 4u;
+}
+
+__global__ __launch_bounds__(256) void pad_planes_kernel(const float* __restrict__ x, float* __restrict__ xp, int64_t planes, int H, int W,
+                                                         int ph, int pw) {
+    const int Hp = H + 2 * ph, Wp = W + 2 * pw;
+    const int64_t total = planes * Hp * Wp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t plane = i / (Hp * Wp);
+        const int r = (int)(i - plane * Hp * Wp);
+        const int y = r / Wp - ph, xx = r - (r / Wp) * Wp - pw;
+        xp[i] = ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) ? x[(plane * H + y) * W + xx] : 0.f;
+    }
 }
 
 static void launch_transposed_pairs(const pasta_conv_desc* d, const ConvFwdParams& base, FwdTile tile, hipStream_t s, const EdgeWeights& ew) {
@@ -516,7 +564,7 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
     p.o_tiles = 1;
     p.partial = (float*)workspace + round_up((int)(((int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad * 3 + 1) / 2), 4);
     // bf16 pieces per operand; 0 = fp32 kernel.  An input scale rides in the staging of the six-product fp32-storage kernels only.
-    p.bf16x6 = (plan.bf16x6 && (!iscale || isc_in_staging(d))) ? math_pieces(d->math) : 0;
+    p.bf16x6 = (plan.bf16x6 && (!iscale || isc_in_staging(d)) && !(plan.packed && (iscale || wmod_s))) ? math_pieces(d->math) : 0;
     if (p.bf16x6 == NP_F16X3 && wmod_s) p.bf16x6 = 3;               // per-sample modulated weights: their |max| is not w's; six products
     p.io = d->io_dtype;
     if (p.io != IO_F32) {
@@ -545,20 +593,49 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
         }
         p.x_amax = xa; p.w_amax = wa; p.w_gain = fabsf(wscale);
     }
+    p.koff = nullptr;
+    const bool packed = plan.packed && p.bf16x6 && !iscale && !wmod_s;
+    int pk_kh = d->kh, pk_kw = d->kw, pk_tr = d->transposed, pk_flip = d->flip;
+    if (packed) {
+        // K = (input channel, tap) pairs: one pseudo-tap over C_in kh kw "channels" of a zero-padded input (workspace: ... | offsets | copy)
+        const int K = p.Ig * d->kh * d->kw, Kpad = round_up(K, 16);
+        const int Hp = d->H + 2 * d->pad_h, Wp = d->W + 2 * d->pad_w;
+        int64_t pk = ((int64_t)p.G * d->kh * d->kw * p.Ig_pad * p.Og_pad * 3 + 1) / 2;
+        const int64_t pk2 = ((int64_t)Kpad * p.Og_pad * 3 + 1) / 2;
+        pk = pk > pk2 ? pk : pk2;
+        unsigned* const koff = (unsigned*)((float*)workspace + round_up((int)pk, 4));      // ksplit == 1: no partial sums in between
+        hipLaunchKernelGGL(packed_koff_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s, koff, K, d->kh, d->kw, d->flip, Hp * Wp, Wp);
+        if (d->pad_h || d->pad_w) {
+            float* const xp = (float*)koff + Kpad;
+            const int64_t total = (int64_t)d->N * d->C_in * Hp * Wp;
+            hipLaunchKernelGGL(pad_planes_kernel, dim3((unsigned)(ceil_div64(total, 256) < 4096 ? ceil_div64(total, 256) : 4096)), dim3(256), 0, s,
+                               (const float*)x, xp, (int64_t)d->N * d->C_in, d->H, d->W, d->pad_h, d->pad_w);
+            p.x = xp;
+        }
+        p.koff = koff;
+        p.H = Hp; p.W = Wp;
+        p.Ig = K; p.Ig_pad = Kpad; p.KK = 1;
+        pk_kh = pk_kw = 1; pk_tr = 0; pk_flip = 0;           // [O][C_in kh kw] as it lies: a 1x1 weight over the K "channels"
+    }
     {   // pack weights (times wscale)
         const int64_t total = (int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad;
         int64_t blocks = ceil_div64(total, 256);
         if (blocks > 4096) blocks = 4096;
         if (p.bf16x6)
             hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, (__bf16*)workspace, p.G, p.Ig, p.Og,
-                               p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip, wscale, p.io == IO_F16 ? 1 : p.bf16x6 == NP_F16X3 ? 2 : 0, wmod_s, wmod_d,
+                               p.Ig_pad, p.Og_pad, pk_kh, pk_kw, pk_tr, pk_flip, wscale, p.io == IO_F16 ? 1 : p.bf16x6 == NP_F16X3 ? 2 : 0, wmod_s, wmod_d,
                                p.w_amax);
         else
             hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, (float*)workspace, p.G, p.Ig, p.Og,
                                p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip, wscale, wmod_s, wmod_d);
     }
 
-    if (!d->transposed) {
+    if (packed) {
+        p.P = d->OH; p.Q = d->OW; p.oy0 = 0; p.ox0 = 0; p.osy = 1; p.osx = 1; p.isy = d->stride; p.isx = d->stride;
+        p.T = 1; p.tap_dy[0] = 0; p.tap_dx[0] = 0; p.tap_slab[0] = 0;      // the window's corner in the padded plane; the taps are in koff
+        p.ncls = 1; p.cls[0] = {p.P, p.Q, 0, 0, 1, 0};
+        if (tile == T128x128) launch_fwd_bf16x6<128, 128>(p, s); else launch_fwd_bf16x6<64, 256>(p, s);
+    } else if (!d->transposed) {
         p.P = d->OH; p.Q = d->OW; p.oy0 = 0; p.ox0 = 0; p.osy = 1; p.osx = 1; p.isy = d->stride; p.isx = d->stride;
         p.T = p.KK;
         for (int r = 0; r < d->kh; r++)
