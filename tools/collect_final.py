@@ -38,3 +38,17 @@ for f, what in runs.items():
     lines.append(json.dumps(dd))
     print(f, dd['value'], dd['ms_per_step'], (dd.get('roofline') or {}).get('frac'), (dd.get('roofline') or {}).get('traffic_source'))
 open(path, 'w').write('\n'.join(lines) + '\n')
+
+# one line per kernel: where the waves' cycles go (SQ pass) next to the matrix-pipe utilisation (MFMA-busy pass)
+import csv
+sq = list(csv.DictReader(open(os.path.join(P, f'{tag}_sq_stalls.csv'))))
+pmc = json.load(open(os.path.join(P, f'{tag}_pmc.json')))
+def _f(v):
+    return float(v) if v not in ('', None) else 0.0
+with open(os.path.join(P, f'{tag}_pmc_summary.txt'), 'w') as fh:
+    for r in sq[:16]:
+        k = r['kernel']
+        busy = (pmc.get(k) or {}).get('mfma_util_percent') or 0.0
+        fh.write('%-96s wave-cycles %.3e issue %.3f wait %.3f issue-stall %.3f lds-stall %.3f bank-conflict/lds %.3f mfma-busy %.3f\n' % (
+            k[:95], _f(r['wave_cycles_per_launch']) * _f(r['launches']), _f(r['SQ_ACTIVE_INST_ANY/SQ_WAVE_CYCLES']), _f(r['SQ_WAIT_ANY/SQ_WAVE_CYCLES']),
+            _f(r['SQ_WAIT_INST_ANY/SQ_WAVE_CYCLES']), _f(r['SQ_WAIT_INST_LDS/SQ_WAVE_CYCLES']), _f(r['SQ_LDS_BANK_CONFLICT/SQ_LDS_IDX_ACTIVE']), busy / 100.0))
