@@ -182,7 +182,11 @@ int pasta_conv2d_tile(const pasta_conv_desc* d);
  * launch of kernel 1 for the last row / column), 4 / 5 / 6 conv_fwd_rows2d_bf16x6_kernel<128,128,4>, <128,128,2>, <64,256,8>: R output rows per
  * pixel tile (3x3 stride-1 lattices on the 128 x 128 tile whose planes divide into R x 128/R tiles: the R + 2 input rows of a
  * tile are staged once per 16-channel chunk), 7 the same kernel on eight waves and a 128 x 256 tile (<128,256,8,3,0,false,512>: plain
- * six-product fp32 launches on planes of a multiple of 8 rows).  Any out pointer may be NULL. */
+ * six-product fp32 launches on planes of a multiple of 8 rows; round 3: the launch of kernel 3's last row / column is
+ * conv_t2_edge_kernel, and kernels 1 - 7 also run PASTA_MATH_F16X3), 8 conv_fwd_bf16x6_kernel in its packed-K mode (round 3: fewer than
+ * 16 input channels, more than 32 output channels, at least 64 (channel, tap) pairs, planes above 8192 pixels -- the 7x7 RGB stems:
+ * K runs over the pairs; the workspace then also holds the offset table and a zero-padded copy of the input, and two small
+ * kernels fill them).  Any out pointer may be NULL. */
 #define PASTA_PLAN_ISCALE   1
 #define PASTA_PLAN_OSCALE   2
 #define PASTA_PLAN_EPILOGUE 4

@@ -251,7 +251,7 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, 
         launch()
     else:
         # 'conv_isc': the launch passes an input scale (another kernel instance); flags = PASTA_PLAN_* of include/pasta_hip.h
-        flags = (1 if iscale is not None else 0) | (2 if oscale is not None else 0) | (4 if ep is not None else 0)
+        flags = (1 if iscale is not None else 0) | (2 if oscale is not None else 0) | (4 if ep is not None else 0) | (8 if wmod is not None else 0)
         launch_hook('conv' if iscale is None else 'conv_isc', desc, launch, flags)
     if y_row is not None and y.dtype == out_dtype:
         _native.amax_attach(y, y_row)
