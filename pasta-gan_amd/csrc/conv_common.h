@@ -229,6 +229,7 @@ struct ConvFwdParams {
     // packed-K mode of conv_fwd_bf16x6_kernel (few input channels): "channel" k of the K loop is (input channel, tap) and lives
     // koff[k] bytes behind the pixel's base address in a zero-padded copy of the input; null = off
     const unsigned* koff;
+    int xcd_order;                        // conv_fwd_rows2d_bf16x6_kernel, eight-wave tile: consecutive pixel tiles on ONE XCD (PASTA_XCD_ORDER=0: off)
 };
 
 // Tile choice.  O_pad multiple returned so that the caller can pack weights accordingly.

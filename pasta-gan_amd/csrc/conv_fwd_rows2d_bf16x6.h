@@ -70,8 +70,14 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
     const int nchunks = (int)((int64_t)NC * (ks + 1) / p.ksplit) - c_first;
     // tile -> (image, row block, column block)
     const int cblocks = Q / SEG, tpi = (P / R) * cblocks;
-    const int n_img = blockIdx.x / tpi;
-    const int t_in = blockIdx.x - n_img * tpi;
+    // Workgroups go round-robin to the eight XCDs (one L2 each).  On the eight-wave tile an XCD receives CONSECUTIVE pixel tiles -- the
+    // neighbours that share halo rows -- instead of every eighth: +2 - 3.5 % on every 128-channel shape, dominant kernel 326 -> 336
+    // TFLOP/s, step 155.3 -> 154.4 ms (same box, twice; profiles/r3_ab_xcd_order.txt).  The same order on the four-wave 64 x 256 tile:
+    // -2.4 %; on the base kernel: nothing (r3_ab_xcd_order2.txt) -- not applied there.  PASTA_XCD_ORDER=0 switches it off.
+    unsigned bx = blockIdx.x;
+    if (NT == 512 && p.xcd_order && (gridDim.x & 7u) == 0) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
+    const int n_img = bx / tpi;
+    const int t_in = bx - n_img * tpi;
     const int p0 = (t_in / cblocks) * R, q0 = (t_in % cblocks) * SEG;
     const int ymin = p.rows_y0, d0 = p.rows_d0;
 

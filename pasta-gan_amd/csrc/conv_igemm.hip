@@ -594,6 +594,8 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
         p.x_amax = xa; p.w_amax = wa; p.w_gain = fabsf(wscale);
     }
     p.koff = nullptr;
+    static const int xcd_order = getenv("PASTA_XCD_ORDER") ? atoi(getenv("PASTA_XCD_ORDER")) : 1;
+    p.xcd_order = xcd_order;
     const bool packed = plan.packed && p.bf16x6 && !iscale && !wmod_s;
     int pk_kh = d->kh, pk_kw = d->kw, pk_tr = d->transposed, pk_flip = d->flip;
     if (packed) {
