@@ -254,6 +254,7 @@ struct WgradParams {
     int chunks_total;       // ceil(rows_total / CHH) * qblocks
     int ksplit;             // K slices
     int a_tiles, b_tiles, tap_groups_r, tap_groups_s;
+    int xcd_order;          // split weight-gradient kernels: workgroup order (0: K slice fastest; 1: see wgrad_decode)
 };
 
 }  // namespace pasta

@@ -806,6 +806,10 @@ extern "C" int pasta_conv2d_wgrad(const void* xv, const void* dyv, float* dw, co
     const WgradPlan w = plan_wgrad(p.N, p.P, p.Q, p.G, p.Ag, p.Bg, p.kh, p.kw, p.st);
     p.cw_log2 = w.cw_log2; p.rows_total = w.rows_total; p.qblocks = w.qblocks; p.chunks_total = w.chunks_total;
     p.ksplit = w.ksplit; p.a_tiles = w.a_tiles; p.b_tiles = w.b_tiles; p.tap_groups_r = w.tgr; p.tap_groups_s = w.tgs;
+    // measured (profiles/r3_ab_wgrad_xcd.txt): 256 -> 128 at 128^2 298.6 -> 303.4 TFLOP/s, stride 2 at 256^2 143 -> 154, at 257^2 140.7 -> 143.4,
+    // every other shape within 0.5 %
+    static const int wgrad_xcd = getenv("PASTA_WGRAD_XCD") ? atoi(getenv("PASTA_WGRAD_XCD")) : 1;
+    p.xcd_order = wgrad_xcd;
     PASTA_CHECK(w.lds_bytes <= 160 * 1024, "conv2d_wgrad: LDS footprint %zu too large", w.lds_bytes);
     PASTA_CHECK(w.npos <= 256, "conv2d_wgrad: halo of %d positions per chunk is not supported", w.npos);
 

@@ -4,6 +4,27 @@
 
 namespace pasta {
 
+// Workgroup -> (K slice, b tile, a tile, group).  The workgroups that read the same pixels are the tiles (a, b) of one K slice.
+// Order 0 (the original): K slice fastest -- those workgroups are ksplit apart in the grid (on one XCD when ksplit is a multiple
+// of 8, but dispatched far from each other).  Order 1: the slice index modulo 8 fastest, then the tile, then the rest of the slice
+// index: the tiles of a slice are 8 apart -- the same XCD (workgroups go round-robin to the eight XCDs), dispatched together.
+__device__ __forceinline__ void wgrad_decode(const WgradParams& p, int& ks, int& bt, int& at, int& g) {
+    int bid = blockIdx.x;
+    if (p.xcd_order && (p.ksplit & 7) == 0) {
+        const int lo = bid & 7; bid >>= 3;
+        const int tiles = p.a_tiles * p.b_tiles;
+        const int tile = bid % tiles; bid /= tiles;
+        const int hi = bid % (p.ksplit >> 3); bid /= (p.ksplit >> 3);
+        ks = hi * 8 + lo; bt = tile % p.b_tiles; at = tile / p.b_tiles; g = bid;
+        return;
+    }
+    ks = bid % p.ksplit; bid /= p.ksplit;
+    bt = bid % p.b_tiles; bid /= p.b_tiles;
+    at = bid % p.a_tiles; bid /= p.a_tiles;
+    g = bid;
+}
+
+
 //------------------------------------------------------------------------------------
 // Weight gradient of 3x3 / stride-1 / pad-1 convolutions on the bf16 matrix cores with split-bf16 products
 // (same arithmetic as conv_fwd_bf16x6_kernel: three bf16 pieces per fp32 operand, six exact products, fp32
@@ -38,11 +59,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
         out_scale = is_ * il_;
     }
 
-    int bid = blockIdx.x;
-    const int ks = bid % p.ksplit; bid /= p.ksplit;
-    const int bt = bid % p.b_tiles; bid /= p.b_tiles;
-    const int at = bid % p.a_tiles; bid /= p.a_tiles;
-    const int g = bid;
+    int ks, bt, at, g;
+    wgrad_decode(p, ks, bt, at, g);
     const int a_blk = at * 64, b_blk = bt * 64;
     const int PQ = p.P * p.Q;
     const char* const Sg = (const char*)p.S + ((int64_t)g * p.Ag + a_blk) * PQ * ES;
@@ -251,11 +269,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
         out_scale = is_ * il_;
     }
 
-    int bid = blockIdx.x;
-    const int ks = bid % p.ksplit; bid /= p.ksplit;
-    const int bt = bid % p.b_tiles; bid /= p.b_tiles;
-    const int at = bid % p.a_tiles; bid /= p.a_tiles;
-    const int g = bid;
+    int ks, bt, at, g;
+    wgrad_decode(p, ks, bt, at, g);
     const int a_blk = at * 64, b_blk = bt * 64;
     const int PQ = p.P * p.Q, LHW = p.LH * p.LW;
     const char* const Sg = (const char*)p.S + ((int64_t)g * p.Ag + a_blk) * PQ * ES;
@@ -472,11 +487,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1x1_bf16x6_kernel(WgradParam
         out_scale = is_ * il_;
     }
 
-    int bid = blockIdx.x;
-    const int ks = bid % p.ksplit; bid /= p.ksplit;
-    const int bt = bid % p.b_tiles; bid /= p.b_tiles;
-    const int at = bid % p.a_tiles; bid /= p.a_tiles;
-    const int g = bid;
+    int ks, bt, at, g;
+    wgrad_decode(p, ks, bt, at, g);
     const int a_blk = at * TA, b_blk = bt * TB;
     const int PQ = p.P * p.Q;
     const char* const Sg = (const char*)p.S + ((int64_t)g * p.Ag + a_blk) * PQ * ES;
