@@ -73,7 +73,9 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
     // Workgroups go round-robin to the eight XCDs (one L2 each).  On the eight-wave tile an XCD receives CONSECUTIVE pixel tiles -- the
     // neighbours that share halo rows -- instead of every eighth: +2 - 3.5 % on every 128-channel shape, dominant kernel 326 -> 336
     // TFLOP/s, step 155.3 -> 154.4 ms (same box, twice; profiles/r3_ab_xcd_order.txt).  The same order on the four-wave 64 x 256 tile:
-    // -2.4 %; on the base kernel: nothing (r3_ab_xcd_order2.txt) -- not applied there.  PASTA_XCD_ORDER=0 switches it off.
+    // -2.4 %; on the base kernel: nothing (r3_ab_xcd_order2.txt) -- not applied there.  Also measured: the output-channel tiles of a pixel
+    // tile back to back on one XCD (layers with more than 128 output channels): 315 -> 303 TFLOP/s on 128 -> 256, nothing on 256 -> 256 and
+    // 512 -> 512 (r3_ab_xcd_otiles.txt).  PASTA_XCD_ORDER=0 switches it off.
     unsigned bx = blockIdx.x;
     if (NT == 512 && p.xcd_order && (gridDim.x & 7u) == 0) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
     const int n_img = bx / tpi;
