@@ -314,6 +314,17 @@ int pasta_spade_norm_bwd(const void* dout, const void* x, const void* gamma,
                                                                                feed one convolution when they are halves of one tensor) */
 
 /* ------------------------------------------------------------------------- *
+ * Garment features of the SPADE stage (training/networks.py:5777-5800, get_spade_feat): fp32, NCHW.
+ *   backward = 0:  out[n,c,i] = a[n,c,i] * (1 - hole[n,i]) + hole[n,i]  * inv_count[n] * sum_j a[n,c,j] * valid[n,j]
+ *   backward = 1:  out[n,c,i] = a[n,c,i] * (1 - hole[n,i]) + valid[n,i] * inv_count[n] * sum_j a[n,c,j] * hole[n,j]   (a = d out)
+ * valid, hole: [N, HW]; inv_count: [N]; a / out: sample strides in elements (0 = C * HW), so that the two garments' results
+ * are written into (their gradients read from) the channel halves of ONE [N, 2C, H, W] tensor -- no torch.cat.
+ * ------------------------------------------------------------------------- */
+int pasta_masked_mean_fill(const float* a, const float* valid, const float* hole, const float* inv_count, float* out,
+                           int N, int C, int64_t HW, int64_t a_sample_stride, int64_t out_sample_stride, int backward,
+                           void* stream, float* y_amax);
+
+/* ------------------------------------------------------------------------- *
  * ADA augmentation (training/augment.py:121-431).
  * pasta_ada_matrices: sample s turns its draws u[s, :] ~ U(0,1), z[s, :] ~ N(0,1) into the inverse geometric
  *   transform g_inv[s] (3x3 row-major, augment.py:186-263) and the colour transform c[s] (4x4, :306-350); margins[4]

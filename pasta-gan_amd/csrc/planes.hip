@@ -274,6 +274,70 @@ __global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const T* __restric
 
 
 //------------------------------------------------------------------------------------
+// Garment features of the SPADE stage (training/networks.py:5777-5800): where the predicted region is not covered by a patch
+// (hole) the feature is replaced by the mean feature of the covered part (valid):
+//   out[n,c,i] = x[n,c,i] * (1 - hole[n,i]) + hole[n,i] * inv_count[n] * sum_j x[n,c,j] * valid[n,j]
+// The reference forms this with six element-wise / reduction passes over the 134 MB feature map and a torch.cat of the two
+// garments' results; here one workgroup per (n, c) plane holds the plane in registers between the sum and the fill, and writes
+// straight into its half of the concatenated tensor (out: sample stride out_ns).  Backward:
+//   dx[n,c,i] = dout[n,c,i] * (1 - hole[n,i]) + valid[n,i] * inv_count[n] * sum_j dout[n,c,j] * hole[n,j].
+// BWD = false: a = x, m1 = valid (weights of the sum), m2 = hole (where the mean goes); BWD = true: a = dout, m1 = hole, m2 = valid.
+// The factor (1 - hole) multiplies a in both.
+template <int EPT, bool BWD>       // EPT == 0: generic loops
+__global__ __launch_bounds__(1024) void masked_mean_fill_kernel(const float* __restrict__ a, const float* __restrict__ valid,
+                                                                const float* __restrict__ hole, const float* __restrict__ inv_count,
+                                                                float* __restrict__ out, int64_t planes, int C, int64_t HW, int64_t a_ns,
+                                                                int64_t out_ns, float* __restrict__ y_amax) {
+    __shared__ float red[16];
+    uint32_t am = 0;
+    const AmaxSlot aslot = amax_begin(y_amax);
+    const int tid = threadIdx.x;
+    for (int64_t plane = blockIdx.x; plane < planes; plane += gridDim.x) {
+        const int64_t n = plane / C, c = plane - n * C;
+        const float* ap = a + n * a_ns + c * HW;
+        const float* vp = valid + n * HW;
+        const float* hp = hole + n * HW;
+        float* op = out + n * out_ns + c * HW;
+        const float ic = inv_count[n];
+        if constexpr (EPT > 0) {
+            float4 r[EPT / 4], v[EPT / 4], h[EPT / 4];
+#pragma unroll
+            for (int k = 0; k < EPT / 4; k++) {
+                const int64_t i = 4 * (k * 1024 + tid);
+                r[k] = *(const float4*)(ap + i); v[k] = *(const float4*)(vp + i); h[k] = *(const float4*)(hp + i);
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < EPT / 4; k++) {
+                const float4 w = BWD ? h[k] : v[k];
+                s += r[k].x * w.x + r[k].y * w.y + r[k].z * w.z + r[k].w * w.w;
+            }
+            const float t = block_sum<1024>(s, red) * ic;
+#pragma unroll
+            for (int k = 0; k < EPT / 4; k++) {
+                const float4 w = BWD ? v[k] : h[k];
+                float4 o;
+                o.x = fmaf(r[k].x, 1.f - h[k].x, t * w.x); o.y = fmaf(r[k].y, 1.f - h[k].y, t * w.y);
+                o.z = fmaf(r[k].z, 1.f - h[k].z, t * w.z); o.w = fmaf(r[k].w, 1.f - h[k].w, t * w.w);
+                *(float4*)(op + 4 * (k * 1024 + tid)) = o;
+                if (y_amax) { amax_take(am, o.x); amax_take(am, o.y); amax_take(am, o.z); amax_take(am, o.w); }
+            }
+        } else {
+            float s = 0.f;
+            for (int64_t i = tid; i < HW; i += 1024) s += ap[i] * (BWD ? hp[i] : vp[i]);
+            const float t = block_sum<1024>(s, red) * ic;
+            for (int64_t i = tid; i < HW; i += 1024) {
+                const float o = fmaf(ap[i], 1.f - hp[i], t * (BWD ? vp[i] : hp[i]));
+                op[i] = o;
+                if (y_amax) amax_take(am, o);
+            }
+        }
+    }
+    __shared__ uint32_t amred[16];
+    amax_commit_block<1024>(am, aslot, amred);
+}
+
+//------------------------------------------------------------------------------------
 // Tail of a modulated convolution layer in one pass (SynthesisLayer, training/networks.py:72-82 + 313-314):
 //   y = clamp(act(u * d[n,c] + noise[n|.,hw] * strength + b[c]) * gain),   act = linear (1) or leaky relu (3)
 // and its backward: with dz = dy * act'(y) * gain (zero where |y| >= clamp)
@@ -578,6 +642,26 @@ extern "C" int pasta_spade_norm_bwd(const void* dout, const void* x, const void*
 #undef PASTA_L
 #undef PASTA_ARGS
     return launch_status("spade_norm_bwd");
+}
+
+extern "C" int pasta_masked_mean_fill(const float* a, const float* valid, const float* hole, const float* inv_count, float* out,
+                                      int N, int C, int64_t HW, int64_t a_sample_stride, int64_t out_sample_stride, int backward,
+                                      void* stream, float* y_amax) {
+    using namespace pasta;
+    PASTA_CHECK(a && valid && hole && inv_count && out, "masked_mean_fill: null pointer");
+    PASTA_CHECK(N >= 1 && C >= 1 && HW >= 1, "masked_mean_fill: empty tensor");
+    const int64_t a_ns = a_sample_stride > 0 ? a_sample_stride : (int64_t)C * HW, out_ns = out_sample_stride > 0 ? out_sample_stride : (int64_t)C * HW;
+    PASTA_CHECK(a_ns >= (int64_t)C * HW && out_ns >= (int64_t)C * HW, "masked_mean_fill: sample stride below C * HW");
+    const int64_t planes = (int64_t)N * C;
+    const int grid = (int)(planes < 65535 ? planes : 65535);
+    hipStream_t s = (hipStream_t)stream;
+    const bool al = (((uintptr_t)a | (uintptr_t)valid | (uintptr_t)hole | (uintptr_t)out) & 15) == 0 && a_ns % 4 == 0 && out_ns % 4 == 0;
+#define PASTA_MMF(E, B) hipLaunchKernelGGL((masked_mean_fill_kernel<E, B>), dim3(grid), dim3(1024), 0, s, a, valid, hole, inv_count, out, planes, C, HW, a_ns, out_ns, y_amax)
+    if (HW == 16384 && al) { if (backward) PASTA_MMF(16, true); else PASTA_MMF(16, false); }
+    else if (HW == 4096 && al) { if (backward) PASTA_MMF(4, true); else PASTA_MMF(4, false); }
+    else { if (backward) PASTA_MMF(0, true); else PASTA_MMF(0, false); }
+#undef PASTA_MMF
+    return launch_status("masked_mean_fill");
 }
 
 extern "C" int pasta_mod_bias_act(const void* u, const float* d, const float* noise, const float* strength, const float* b, void* y,

@@ -11,6 +11,8 @@ coefficients, minibatch statistics) stays on PyTorch-ROCm's BLAS.
 Reference line numbers are cited per class as ``networks.py:<lines>``.
 """
 
+import ctypes
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -140,6 +142,59 @@ def spade_modulate(x, gamma, beta, eps=1e-5, relu_gain=None, clamp=None):
     return _SpadeModulate.apply(x, gamma, beta, eps, post)
 
 #----------------------------------------------------------------------------
+
+import os as _os
+_GARMENT_FUSED = _os.environ.get('PASTA_GARMENT_FUSED', '1') != '0'         # A/B switch: 0 = the reference's element-wise passes + torch.cat
+
+class _GarmentFeat(torch.autograd.Function):
+    """``cat([fill(feat_u), fill(feat_l)], dim=1)`` with ``fill(x) = x * (1 - hole) + (sum_hw(x * valid) / count) * hole`` -- the tail of
+    ``get_spade_feat`` for the upper and the lower garment (networks.py:5777-5800, 5836) -- by ``pasta_masked_mean_fill``: one workgroup
+    per (n, c) plane holds the plane in registers between the sum and the fill and writes into its half of the result."""
+    @staticmethod
+    def forward(ctx, feat_u, valid_u, hole_u, count_u, feat_l, valid_l, hole_l, count_l):
+        n, c, h, w = feat_u.shape
+        out = torch.empty([n, 2 * c, h, w], dtype=torch.float32, device=feat_u.device)
+        row = _native.amax_slot(out)
+        keep = []
+        lib = _native.lib()
+        with torch.cuda.device(out.device):
+            for k, (f, v, ho, cnt) in enumerate(((feat_u, valid_u, hole_u, count_u), (feat_l, valid_l, hole_l, count_l))):
+                f, v, ho = f.contiguous(), v.reshape(n, h * w).contiguous(), ho.reshape(n, h * w).contiguous()
+                inv = (1.0 / cnt.reshape(n).float()).contiguous()
+                _native.check(lib.pasta_masked_mean_fill(_native.ptr(f), _native.ptr(v), _native.ptr(ho), _native.ptr(inv),
+                                                         ctypes.c_void_p(out.data_ptr() + 4 * k * c * h * w), n, c, h * w, 0, 2 * c * h * w, 0,
+                                                         _native.stream(), _native.ptr(row)))
+                keep += [v, ho, inv]
+        _native.amax_attach(out, row)
+        ctx.save_for_backward(*keep)
+        ctx.dims = (n, c, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n, c, h, w = ctx.dims
+        saved = ctx.saved_tensors
+        grads = []
+        if torch.is_grad_enabled() and dout.requires_grad:          # a gradient of this gradient is wanted: differentiable torch operations
+            for k in range(2):
+                v, ho, inv = (t.reshape(n, 1, h, w) if t.ndim == 2 else t.reshape(n, 1, 1, 1) for t in saved[3 * k:3 * k + 3])
+                d = dout[:, k * c:(k + 1) * c]
+                grads.append(d * (1 - ho) + v * inv * (d * ho).sum(dim=(2, 3), keepdim=True))
+        else:
+            dout = dout.contiguous()
+            lib = _native.lib()
+            with torch.cuda.device(dout.device):
+                for k in range(2):
+                    v, ho, inv = saved[3 * k:3 * k + 3]
+                    dx = torch.empty([n, c, h, w], dtype=torch.float32, device=dout.device)
+                    row = _native.amax_slot(dx) if ctx.needs_input_grad[4 * k] else None
+                    if ctx.needs_input_grad[4 * k]:
+                        _native.check(lib.pasta_masked_mean_fill(ctypes.c_void_p(dout.data_ptr() + 4 * k * c * h * w), _native.ptr(v), _native.ptr(ho),
+                                                                 _native.ptr(inv), _native.ptr(dx), n, c, h * w, 2 * c * h * w, 0, 1, _native.stream(),
+                                                                 _native.ptr(row)))
+                        _native.amax_attach(dx, row)
+                    grads.append(dx if ctx.needs_input_grad[4 * k] else None)
+        return grads[0], None, None, None, grads[1], None, None, None
 
 class _ModBiasAct(torch.autograd.Function):
     """Tail of a modulated-convolution layer in one pass: ``clamp(act(u * d[n,c] + noise * strength + b[c]) * gain)``
@@ -889,11 +944,8 @@ class _PatchRoutedSynthesis(torch.nn.Module):
                                            ResBlock(ngf, ngf, kernel_size=4, activation='relu'),
                                            ResBlock(ngf, 2 * ngf, kernel_size=4, activation='relu', down=2))
 
-    def get_spade_feat(self, mask_256, denorm_mask, denorm_input):
-        """Garment features at the SPADE resolution (networks.py:5777-5800).  ``mask_256``: the region the pyramid predicts
-        for this garment, at image resolution; ``denorm_mask`` / ``denorm_input``: the warped patches and their coverage.
-        Where the predicted region is not covered by a patch the feature is replaced by the mean feature of the covered
-        part (of the whole map when fewer than 11 pixels are covered: the mean over ``spade_resolution^2`` positions)."""
+    def _spade_feat_parts(self, mask_256, denorm_mask, denorm_input):
+        """-> (encoder features, valid mask, hole mask, divisor of the mean) of ``get_spade_feat``."""
         dt = mask_256.dtype
         halve = lambda m: torch.nn.functional.interpolate(m, scale_factor=0.5)
         region = (mask_256 > 0.9).to(dt)
@@ -903,13 +955,24 @@ class _PatchRoutedSynthesis(torch.nn.Module):
         hole = region_s - valid
         act = getattr(self, 'act_dtype', None) or dt
         feat = self.spade_encoder((denorm_input * region - (1 - region)).to(act))
-        total = (feat.float() * valid).sum(dim=(2, 3), keepdim=True)
         count = valid.sum(dim=(2, 3), keepdim=True)
         enough = (count > 10).to(dt)
         count = count * enough + float(self.spade_resolution ** 2) * (1 - enough)
-        if feat.dtype == dt:
+        return feat, valid, hole, count
+
+    def get_spade_feat(self, mask_256, denorm_mask, denorm_input):
+        """Garment features at the SPADE resolution (networks.py:5777-5800).  ``mask_256``: the region the pyramid predicts
+        for this garment, at image resolution; ``denorm_mask`` / ``denorm_input``: the warped patches and their coverage.
+        Where the predicted region is not covered by a patch the feature is replaced by the mean feature of the covered
+        part (of the whole map when fewer than 11 pixels are covered: the mean over ``spade_resolution^2`` positions)."""
+        return self._spade_fill(*self._spade_feat_parts(mask_256, denorm_mask, denorm_input))
+
+    @staticmethod
+    def _spade_fill(feat, valid, hole, count):
+        total = (feat.float() * valid).sum(dim=(2, 3), keepdim=True)
+        if feat.dtype == valid.dtype:
             return feat * (1 - hole) + (total / count) * hole
-        return (feat * (1 - hole).to(act) + ((total / count) * hole).to(act))
+        return (feat * (1 - hole).to(feat.dtype) + ((total / count) * hole).to(feat.dtype))
 
     def _regions(self, heads):
         """(upper, lower) garment regions at image resolution from the last block's extra ToRGB outputs."""
@@ -932,7 +995,14 @@ class _PatchRoutedSynthesis(torch.nn.Module):
     def _finetune(self, keep, top_rows, heads, pose_feat, cat_feat, denorm, block_kwargs):
         du_in, dl_in, du_mask, dl_mask = denorm
         upper, lower = self._regions(heads)
-        feat = torch.cat([self.get_spade_feat(upper.detach(), du_mask, du_in), self.get_spade_feat(lower.detach(), dl_mask, dl_in)], dim=1)
+        pu = self._spade_feat_parts(upper.detach(), du_mask, du_in)
+        pl = self._spade_feat_parts(lower.detach(), dl_mask, dl_in)
+        if _GARMENT_FUSED and pu[0].dtype == torch.float32 and pu[0].device.type == 'cuda' and pu[1].dtype == torch.float32 and pu[0].shape == pl[0].shape:
+            # both garments' masked-mean fills written straight into the halves of the concatenated map: two launches instead of
+            # twelve element-wise / reduction passes and a torch.cat (fp32 storage; 16-bit storage keeps the reference's roundings)
+            feat = _GarmentFeat.apply(*pu, *pl)
+        else:
+            feat = torch.cat([self._spade_fill(*pu), self._spade_fill(*pl)], dim=1)
         x, img_below = keep
         for i in (1, 2, 3):
             x = getattr(self, f'spade_b{self.spade_resolution}_{i}')(x, feat)

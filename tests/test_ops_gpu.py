@@ -616,3 +616,50 @@ def test_producer_side_maxima_match_a_scan():
         hit = getattr(t, '_pasta_amax', None)
         assert hit is not None and hit[0] == t._version and hit[1] == t.data_ptr(), name
         assert float(hit[2].max()) == float(t.abs().max()), name
+
+
+# ----------------------------------------------------------------------------- garment features of the SPADE stage
+
+@pytest.mark.parametrize('hw', [(128, 128), (64, 64), (24, 40)])
+def test_garment_feature_fill_matches_the_reference_expression(hw):
+    """``cat([fill(feat_u), fill(feat_l)], 1)``, ``fill(x) = x (1 - hole) + (sum_hw(x valid) / count) hole`` (networks.py:5777-5800, 5836)
+    by ``pasta_masked_mean_fill`` against the same expression in float64 torch operations: values, both feature gradients, the row of maxima."""
+    from training import networks
+    h, w = hw
+    g = torch.Generator().manual_seed(h + w)
+    n, c = 3, 8
+    def garment():
+        feat = torch.randn([n, c, h, w], generator=g)
+        valid = (torch.rand([n, 1, h, w], generator=g) > 0.6).float()
+        hole = ((torch.rand([n, 1, h, w], generator=g) > 0.7).float() * (1 - valid))
+        valid[1] = 0                                        # a sample without a covered pixel: the divisor is the plane size
+        count = valid.sum(dim=(2, 3), keepdim=True)
+        enough = (count > 10).float()
+        count = count * enough + float(h * w) * (1 - enough)
+        return feat, valid, hole, count
+    pu, pl = garment(), garment()
+    def ref(parts):
+        feat, valid, hole, count = (t.double() for t in parts)
+        feat.requires_grad_(True)
+        total = (feat * valid).sum(dim=(2, 3), keepdim=True)
+        return feat, feat * (1 - hole) + (total / count) * hole
+    fu, ou = ref(pu); fl, ol = ref(pl)
+    want = torch.cat([ou, ol], dim=1)
+    dy = torch.randn(want.shape, generator=g, dtype=torch.float64)
+    gu, gl = torch.autograd.grad(want, [fu, fl], dy)
+    cu = [t.cuda() for t in pu]; cl = [t.cuda() for t in pl]
+    cu[0].requires_grad_(True); cl[0].requires_grad_(True)
+    out = networks._GarmentFeat.apply(*cu, *cl)
+    assert out.shape == want.shape and rel_err(out, want) < TOL
+    hit = getattr(out, '_pasta_amax', None)
+    if hit is not None:
+        assert float(hit[2].max()) == float(out.abs().max())
+    du, dl = torch.autograd.grad(out, [cu[0], cl[0]], dy.float().cuda())
+    assert rel_err(du, gu) < TOL and rel_err(dl, gl) < TOL
+    # a gradient of the gradient (create_graph): the differentiable fallback of the backward
+    cu[0].grad = None
+    out2 = networks._GarmentFeat.apply(*cu, *cl)
+    v = dy.float().cuda().requires_grad_(True)
+    d1, = torch.autograd.grad(out2, [cu[0]], v, create_graph=True)
+    dd, = torch.autograd.grad(d1.square().sum(), [v])
+    assert rel_err(d1, gu) < TOL and torch.isfinite(dd).all()
