@@ -368,7 +368,8 @@ def main():
     ap.add_argument('--aug-p', type=float, default=0.5, help='initial (ada) or constant (fixed) augmentation probability; the reference starts '
                     'ADA at 0 and takes ~100 kimg to reach its working point, a benchmark has to start near it')
     ap.add_argument('--conv-math', default=None, choices=['default', 'f32', 'bf16x6', 'bf16x3', 'bf16', 'f16x3'],
-                    help="matrix-core arithmetic of the convolutions (default: PASTA_CONV_MATH or 'default' = bf16x6, fp32-equivalent). "
+                    help="matrix-core arithmetic of the convolutions (default: PASTA_CONV_MATH or 'default' = f16x3: fp32-equivalent products from three fp16 MFMAs; "
+                         "'bf16x6' = the six-product fp32-equivalent arithmetic, the default until round 3; 'f32' = fp32 MFMA). "
                          "'bf16x3' = what TrainingStep selects for allow_tf32=True; 'bf16' = bf16 operands. Reduced modes are reported as such, never as the headline")
     ap.add_argument('--ddp-mode', default='flat', choices=['flat', 'torch'], help="gradient exchange at N > 1: 'flat' = one bucketed reducer per "
                     "optimised module (training/grad_reducer.py); 'torch' = the reference's five DistributedDataParallel wrappers")
@@ -548,6 +549,7 @@ def main():
             del step
             torch.cuda.empty_cache()
             out['also_measured'] = {}
+            math_before = conv2d_gradfix.conv_math          # the side lines set their own arithmetic; the caller's comes back afterwards
             for tag, kw, vbatch, vres, note in [('conv_math_bf16x6', dict(), args.batch_gpu, 256, 'the same step with the six-product split-bf16 arithmetic (PASTA_MATH_BF16X6: the default until round 3; '
                                                                         'fp32-equivalent as well, no operand scales, twice the matrix work)'),
                                                 ('d_fp16_res_3', dict(d_fp16_res=3), args.batch_gpu, 256, 'D blocks b256..b64 in fp16 storage + products: num_fp16_res = 3, conv_clamp = 256 as train_wo_flow_fullbody.py:195-196 sets them '
@@ -559,7 +561,7 @@ def main():
                                                                                'activation storage with fp32 demodulation / accumulation; the 512 model is the resolution-generalised GeneratorFull '
                                                                                '(parity UNPINNED: the reference ships no 512 class); parity vs the oracle in the same storage type: tests/test_config5_gpu.py')]:
                 vcfg = fashion_config(mbstd_group_size=min(vbatch, 4), **kw)
-                conv2d_gradfix.conv_math = 'bf16x6' if tag == 'conv_math_bf16x6' else 'default'
+                conv2d_gradfix.conv_math = 'bf16x6' if tag == 'conv_math_bf16x6' else math_before
                 vstep = TrainingStep(device, cfg=vcfg, num_gpus=1, rank=0, batch_size=vbatch, batch_gpu=vbatch)
                 vdata = data if (vbatch, vres) == (args.batch_gpu, 256) else SyntheticFullBodyBatch(vbatch, device, seed=rank, res=vres)
                 for _ in range(2):
@@ -573,7 +575,7 @@ def main():
                 out['also_measured'][tag] = {'value': round(16 * vbatch / tv, 3), 'unit': 'images/sec', 'ms_per_step': round(1000 * tv / 16, 2),
                                              'steps': 16, 'warmup': 2, 'batch': vbatch, 'resolution': vres,
                                              'precision': 'fp32-equivalent, as the headline' if tag == 'conv_math_bf16x6' else 'REDUCED relative to the headline', 'note': note}
-                conv2d_gradfix.conv_math = 'default'
+                conv2d_gradfix.conv_math = math_before
                 del vstep, vdata
                 torch.cuda.empty_cache()
         if not args.no_cpu_baseline and world == 1:

@@ -120,9 +120,9 @@ typedef struct pasta_conv_desc {
                                      (pasta_tensor_amax wrote them).  NULL: the launch computes them itself into its workspace
                                      (one extra pass over x).  A caller that uses a tensor in several launches (forward and
                                      weight gradient; input gradient and weight gradient) computes them once.            */
-    const float* dy_amax;         /* the same for dy (pasta_conv2d_wgrad only)                                         */
-    const float* w_amax;          /* the same for w (the UNSCALED weight tensor passed as w; pasta_conv2d / _ex): a layer's weight
-                                     changes once per optimiser step and is used by several launches in between            */
+    const float* dy_amax;         /* the same for dy (pasta_conv2d_wgrad only).  The WEIGHTS need nothing of the kind (ABI 17): their
+                                     packing kernel finds one scale per output row itself at every launch, so no |max| of w is
+                                     passed, cached or trusted across launches                                            */
 } pasta_conv_desc;
 
 /* Arithmetic of the convolution products.  Accumulation is fp32 in every mode.
@@ -143,10 +143,11 @@ typedef struct pasta_conv_desc {
  *                     and l' h are exact in fp32 and accumulate in fp32; the result is scaled back exactly.  Half the
  *                     matrix work of BF16X6 at the same accuracy class (rms error against fp64 within 10 % of an fp32 FMA
  *                     chain's: the fp32 accumulation dominates both).  Range: activations keep full precision down to 2^-28
- *                     of their tensor's largest element, weights (and both operands of a weight gradient) down to 2^-16 .. 2^-17 of
- *                     theirs; smaller elements contribute with an absolute error <= 2^-28 amax each.  Non-finite elements
- *                     are skipped by the scale and stay local.  fp32 storage only; same kernels and coverage as BF16X6
- *                     except per-sample modulated weights (pasta_conv2d_modulated), which run BF16X6.
+ *                     of their tensor's largest element; weights are scaled PER OUTPUT ROW (output channel of the launch) and keep
+ *                     full precision down to 2^-16 of their row's largest element; both operands of a weight gradient down to
+ *                     2^-17 of their tensor's; smaller elements contribute with an absolute error <= 2^-28 amax each.  Non-finite
+ *                     elements are skipped by the scale and stay local.  fp32 storage only; same kernels and coverage as BF16X6,
+ *                     per-sample modulated weights (pasta_conv2d_modulated) included since ABI 17.
  *   The split modes share kernels (template argument NP = pieces) and the same coverage.
  *   PASTA_MATH_DEFAULT = PASTA_MATH_F16X3 (round 3; BF16X6 before). */
 enum { PASTA_MATH_DEFAULT = 0, PASTA_MATH_F32 = 1, PASTA_MATH_BF16X6 = 2, PASTA_MATH_BF16X3 = 3, PASTA_MATH_BF16 = 4, PASTA_MATH_F16X3 = 5 };

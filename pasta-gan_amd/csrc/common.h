@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 
 #include "../../include/pasta_hip.h"
 
@@ -25,6 +26,19 @@ int   fail(const char* fmt, ...);
         if (e__ != hipSuccess)                                                     \
             return ::pasta::fail("%s failed: %s", #expr, hipGetErrorString(e__)); \
     } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE).  Each call site remembers on which devices it has
+// applied it as one bit per device in an atomic word: no `static bool` that a second device of the same process would find already
+// set, and two threads racing here at worst both set the same value.
+static inline void set_max_lds(std::atomic<uint64_t>& done, const void* fn, int bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.fetch_or(bit, std::memory_order_release);
+}
+#define PASTA_SET_LDS(FN, BYTES) do { static std::atomic<uint64_t> done_{0}; ::pasta::set_max_lds(done_, (const void*)(FN), (int)(BYTES)); } while (0)
 
 static inline int launch_status(const char* what) {
     hipError_t e = hipGetLastError();

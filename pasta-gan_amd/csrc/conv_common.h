@@ -103,11 +103,20 @@ template <int IO> __device__ __forceinline__ f32x16 io_mfma(bf16x8_t a, bf16x8_t
 // per operand <= 2^-23 relative (rms 4e-8; fp32's own rounding is 2^-24), i.e. the products are fp32-class, and the fp32
 // accumulation error (measured rms 3 - 8e-7 at K = 2304) dominates as it does for an fp32 FMA chain.
 // Pieces by index: 0 = h, 1 = low piece, 2 = h''.
-//   forward-type kernels: A = weights (packed once per launch: h, l = fp16(r) unscaled, h''), B = activations staged as
+//   forward-type kernels: A = weights (packed once per launch: h, l = fp16(r) unscaled, h'' = h 2^-11), B = activations staged as
 //       (h, l'): TWO pieces, two thirds of the split-bf16 staging and LDS traffic.  Products (A,B): (0,0) (2,1) (1,0).
-//       Activations keep full precision down to 2^-28 of their tensor's largest element, weights down to 2^-16 of theirs
-//       (below that the unscaled l leaves fp16's normal range and an element keeps 11..22 bits: absolute error
-//       <= 2^-28 amax per term).
+//       Round 4, measured and dropped (profiles/r4_ab_hpp_in_registers.txt, same-box A/B of two source trees under rocprofv3):
+//       forming h'' in registers from the h fragment (four v_pk_mul_f16 per fragment) instead of packing, staging and reading it
+//       -- a third of the weight stream, of its LDS stores and of its fragment reads gone: the eight-wave 2-D tile 290.9 -> 290.1 us
+//       per launch (nothing), the four-wave 64 x 256 tile 294 -> 329 us (11 % SLOWER), the base kernel 121 -> 125 us: eight more
+//       VALU instructions per step and wave next to the MFMAs cost what the LDS bytes saved, and more where a wave also stages
+//       three units per chunk.
+//       The weight scale is PER OUTPUT ROW of the GEMM (round 4): the packing kernel takes the largest magnitude of each
+//       output channel's weights (after wscale and, for per-sample weights, after the modulation) itself, so no |max| of w is
+//       passed in or cached anywhere, and a row's elements keep full precision down to 2^-16 of THEIR ROW's largest (below
+//       that the unscaled l leaves fp16's normal range and an element keeps 11..22 bits: absolute error <= 2^-28 of the row's
+//       amax per term).  The epilogue multiplies row o by 1 / (S_x S_w[o]) (p.w_rowinv).  Activations keep full precision
+//       down to 2^-28 of their tensor's largest element.
 //   weight-gradient kernels: both operands are activations and symmetric, so the exponent-shift trick buys nothing there (h'' of
 //       EITHER operand leaves fp16's normal range below 2^-16 of its tensor's largest element, whichever way the low pieces are
 //       scaled): each operand is (h, l = fp16(r)), TWO pieces, products (S,L): (0,0) (0,1) (1,0) -- full precision for elements
@@ -173,12 +182,6 @@ __device__ __forceinline__ void f16_split2_direct(float v0, float v1, uint32_t& 
     PASTA_KEEP_SCALAR(r0);
     l = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{r0, r1}, f16x2_t));
 }
-// h'' = h 2^-11 on a packed fp16 pair (exact while the result is a normal fp16 number)
-__device__ __forceinline__ uint32_t f16_shift11(uint32_t h) {
-    const f16x2_t k = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
-    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2_t, h) * k);
-}
-
 // AMAX_PARTS partial |max| of a contiguous tensor (amax.hip)
 int tensor_amax(const void* x, int64_t numel, int dtype, float* parts, hipStream_t s);
 
@@ -192,8 +195,8 @@ __device__ __forceinline__ float conv_scale_noise(float v, const float* osb, int
 struct ConvFwdParams {
     const float* x; const float* wp; float* y;         // x, y (and res): elements of type `io` behind these pointers
     const float* iscale; const float* oscale;
-    const float* x_amax; const float* w_amax;           // PASTA_MATH_F16X3: AMAX_PARTS partial |max| of x and of w (w: before wscale)
-    float w_gain;                                       // |wscale|: the packed weights are w * wscale
+    const float* x_amax;                                // PASTA_MATH_F16X3: AMAX_PARTS partial |max| of x
+    const float* w_rowinv;                              // PASTA_MATH_F16X3: [G][Og_pad] 1 / S_w of every packed weight row (pack_weights_f16x3_kernel)
     float* y_amax;                                      // optional (fused epilogue): zeroed partial |max| slots of y (common.h, amax_commit)
     int io;                                             // IO_F32 / IO_F16 / IO_BF16
     int N, Cin, H, W;

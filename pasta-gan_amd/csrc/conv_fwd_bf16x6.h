@@ -30,10 +30,8 @@ __device__ __forceinline__ void split3(float v, __bf16& a, __bf16& b, __bf16& c)
 __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int G, int Ig,
                                                                 int Og, int Ig_pad, int Og_pad, int kh, int kw, int transposed,
                                                                 int flip, float wscale, int f16, const float* __restrict__ mod_s,
-                                                                const float* __restrict__ mod_d, const float* __restrict__ w_amax) {
-    // f16: 0 = three bf16 pieces, 1 = fp16 storage (leading piece = the fp16 operand), 2 = PASTA_MATH_F16X3 (h, l, h'' of w S)
-    float w_S = 1.f;
-    if (f16 == 2) { float inv; scale_from_amax(amax_of_parts(w_amax) * fabsf(wscale), w_S, inv); }
+                                                                const float* __restrict__ mod_d) {
+    // f16: 0 = three bf16 pieces, 1 = fp16 storage (leading piece = the fp16 operand).  PASTA_MATH_F16X3: pack_weights_f16x3_kernel
     const int64_t total = (int64_t)G * kh * kw * Ig_pad * Og_pad;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int j = (int)(idx & 7);
@@ -59,18 +57,115 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __r
         __bf16 p1, p2, p3;
         split3(v, p1, p2, p3);
         if (f16 == 1) p1 = __builtin_bit_cast(__bf16, (_Float16)v);      // fp16 storage: the leading piece is the fp16 operand (the others are unused)
-        if (f16 == 2) {              // conv_common.h, PASTA_MATH_F16X3: the weight side keeps its low piece unscaled and carries h'' = h 2^-11
-            const float vs = v * w_S;
-            const _Float16 h = (_Float16)vs;
-            const _Float16 l = (_Float16)(vs - (float)h);
-            const _Float16 h2 = h * (_Float16)0.00048828125f;
-            p1 = __builtin_bit_cast(__bf16, h); p2 = __builtin_bit_cast(__bf16, l); p3 = __builtin_bit_cast(__bf16, h2);
-        }
         const int64_t chunk = (((int64_t)g * kh * kw + t) * (Ig_pad / 16) + cc) * 6 * Og_pad * 8;
         const int64_t within = ((int64_t)half * Og_pad + o) * 8 + j;
         wp[chunk + within] = p1;
         wp[chunk + 2 * Og_pad * 8 + within] = p2;
         wp[chunk + 4 * Og_pad * 8 + within] = p3;
+    }
+}
+
+// PASTA_MATH_F16X3 (conv_common.h): the same layout with the fp16 pieces h = fp16(v S), l = fp16(v S - h), h'' = h 2^-11 and the power-of-two scale S taken
+// PER OUTPUT ROW from the row's own largest magnitude, found here: one workgroup owns one row o of one group over the whole K
+// range (C_in kh kw values: at most a few thousand), first pass = fetch the row (every load of a thread in flight at once), form
+// v = w wscale (s[g,i] d[g,o]), keep it in LDS and reduce |v| over the workgroup (non-finite values skipped, as the tensor scan
+// does); second pass = split and store sixteen-byte units out of LDS, plus rowinv[g][o] = 1 / S for the convolution's epilogue.
+// Hundreds of short workgroups: 5 - 8 us per layer like the element-parallel kernel it replaces (a first version with eight rows
+// per workgroup and serial loads took 50 - 100 us: 341 launches per training step).  Nothing about w is cached between launches: a
+// weight written behind autograd's back (`p.data.mul_()`, an optimiser that works on `.data`) cannot meet a stale scale, and
+// per-sample modulated weights (pasta_conv2d_modulated) get their own scale per (sample, output channel).
+constexpr int PACK_ROW_LDS = 8192;          // floats of a row kept in LDS; longer rows are re-read from global memory (L2)
+__global__ __launch_bounds__(256) void pack_weights_f16x3_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, float* __restrict__ rowinv,
+                                                                 int Ig, int Og, int Ig_pad, int Og_pad, int kh, int kw, int transposed, int flip,
+                                                                 float wscale, const float* __restrict__ mod_s, const float* __restrict__ mod_d) {
+    const int g = blockIdx.y, o = blockIdx.x;               // one packed row
+    const int taps = kh * kw, NC = Ig_pad / 16, K = Ig * taps;
+    const int tid = threadIdx.x;
+    const int gs = mod_s ? 0 : g;
+    __shared__ float row[PACK_ROW_LDS];                     // v[i * taps + t], t = the tap index of the WEIGHT tensor (before the flip)
+    __shared__ float wmax[4];
+    const bool real = o < Og;
+    const float md = (real && mod_d) ? mod_d[(int64_t)g * Og + o] : 1.f;
+    // element k = i * taps + t of the row, as it lies in the weight tensor: the taps of one input channel are contiguous in both layouts
+    auto tap_run = [&](int i) -> const float* {
+        return w + (transposed ? ((int64_t)(gs * Ig + i) * Og + o) * taps : ((int64_t)(gs * Og + o) * Ig + i) * taps);
+    };
+    auto fetch = [&](int k) -> float {                       // rows longer than PACK_ROW_LDS: the second pass re-reads the tail
+        const int i = k / taps, t = k - i * taps;
+        float v = tap_run(i)[t] * wscale;
+        if (mod_s) { v *= mod_s[(int64_t)g * Ig + i]; v *= md; }
+        return v;
+    };
+    float m = 0.f;
+    if (real) {
+        if (taps <= 9) {
+            // a thread owns input channels tid, tid + 256, ...: up to nine contiguous loads in flight, no division
+            for (int i = tid; i < Ig; i += 256) {
+                const float* const src = tap_run(i);
+                const float ms = mod_s ? mod_s[(int64_t)g * Ig + i] : 1.f;
+                float v[9];
+#pragma unroll
+                for (int t = 0; t < 9; t++) v[t] = t < taps ? src[t] : 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; t++) {
+                    if (t < taps) {
+                        float x = v[t] * wscale;
+                        if (mod_s) { x *= ms; x *= md; }
+                        const int k = i * taps + t;
+                        if (k < PACK_ROW_LDS) row[k] = x;
+                        const float a = fabsf(x);
+                        m = (a < __builtin_inff() && a > m) ? a : m;
+                    }
+                }
+            }
+        } else {
+            for (int k0 = tid; k0 < K; k0 += 256 * 8) {          // eight loads in flight per thread and trip
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { const int k = k0 + 256 * j; v[j] = k < K ? fetch(k) : 0.f; }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int k = k0 + 256 * j;
+                    if (k < K && k < PACK_ROW_LDS) row[k] = v[j];
+                    const float a = fabsf(v[j]);
+                    m = (a < __builtin_inff() && a > m) ? a : m;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((tid & 63) == 0) wmax[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    float S, inv;
+    scale_from_amax(m, S, inv);
+    if (tid == 0) rowinv[(int64_t)g * Og_pad + o] = inv;
+    // second pass: unit u = (t_packed NC + cc) 2 + half -> sixteen bytes of h and of l: channels cc 16 + half 8 + 0..7 of packed tap t_packed
+    const int units = taps * NC * 2;
+    for (int u = tid; u < units; u += 256) {
+        const int half = u & 1, k2 = u >> 1;
+        const int cc = k2 % NC, tp = k2 / NC;
+        int ty = tp / kw, tx = tp - ty * kw;
+        if (flip) { ty = kh - 1 - ty; tx = kw - 1 - tx; }
+        const int t = ty * kw + tx;
+        uint32_t hq[4], lq[4], sq[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = cc * 16 + half * 8 + 2 * j;
+            float v0 = 0.f, v1 = 0.f;
+            if (real) {
+                const int k = i * taps + t;
+                if (i < Ig) v0 = k < PACK_ROW_LDS ? row[k] : fetch(k);
+                if (i + 1 < Ig) v1 = k + taps < PACK_ROW_LDS ? row[k + taps] : fetch(k + taps);
+            }
+            f16_split2_direct(v0 * S, v1 * S, hq[j], lq[j]);
+            sq[j] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2_t, hq[j]) * f16x2_t{(_Float16)0.00048828125f, (_Float16)0.00048828125f});
+        }
+        __bf16* const d = wp + (((int64_t)g * taps + tp) * NC + cc) * 6 * Og_pad * 8 + ((int64_t)half * Og_pad + o) * 8;
+        *(uint4*)d = make_uint4(hq[0], hq[1], hq[2], hq[3]);
+        *(uint4*)(d + 2 * Og_pad * 8) = make_uint4(lq[0], lq[1], lq[2], lq[3]);
+        *(uint4*)(d + 4 * Og_pad * 8) = make_uint4(sq[0], sq[1], sq[2], sq[3]);
     }
 }
 
@@ -154,10 +249,9 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     // that the s_waitcnt counters the compiler derives let a fetch stay in flight for a whole step.
     float x_scale = 1.f, out_scale = 1.f;          // PASTA_MATH_F16X3: operand scales from the tensors' partial maxima
     if constexpr (HX) {
-        float sx, isx, sw, isw;
+        float sx, isx;
         scale_from_amax(amax_of_parts(p.x_amax), sx, isx);
-        scale_from_amax(amax_of_parts(p.w_amax) * p.w_gain, sw, isw);
-        x_scale = sx; out_scale = isx * isw;
+        x_scale = sx; out_scale = isx;                 // the weight rows carry their own scales: p.w_rowinv, applied per output row in the epilogue
     }
     struct Stage { float b[8 * BPT]; float sc[ISC ? 8 * BPT : 1]; int nvalid[BPT]; };
     Stage st0, st1;
@@ -345,6 +439,25 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     }
 
     const int OHW = p.OH * p.OW;
+    if constexpr (HX) {
+        // back to the operands' units: 1 / S_x for the tile, 1 / S_w per weight row (p.w_rowinv, written by the packing kernel).  The 32 row
+        // scales of this lane are fetched in one go in front of the stores (a load in front of every store cost 9 % of the kernel).
+        const float* const wri = p.w_rowinv + (int64_t)g * p.Og_pad + o_blk;
+        float ws[WMT][16];
+#pragma unroll
+        for (int a = 0; a < WMT; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) ws[a][r] = wri[(wm * WMT + a) * 32 + acc_row(r, lane)];
+#pragma unroll
+        for (int a = 0; a < WMT; a++)
+#pragma unroll
+            for (int b = 0; b < WNT; b++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    acc[a][b][r] = (acc[a][b][r] * out_scale) * ws[a][r];
+                    
+                }
+    }
     const bool has_noise = p.noise && p.ksplit == 1;
     const float nstr = has_noise ? p.noise_strength[0] : 0.f;
 #pragma unroll
@@ -367,7 +480,6 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
                 const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
                 if (o < p.Og) {
                     float v = acc[a][b][r];
-                    if constexpr (HX) v *= out_scale;
                     v = conv_scale_noise(v, osb, o, nz);
                     if (has_res) v += io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES);
                     if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
@@ -503,10 +615,9 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     set_row(b_dy);
     float x_scale = 1.f, out_scale = 1.f;          // PASTA_MATH_F16X3: operand scales from the tensors' partial maxima
     if constexpr (HX) {
-        float sx, isx, sw, isw;
+        float sx, isx;
         scale_from_amax(amax_of_parts(p.x_amax), sx, isx);
-        scale_from_amax(amax_of_parts(p.w_amax) * p.w_gain, sw, isw);
-        x_scale = sx; out_scale = isx * isw;
+        x_scale = sx; out_scale = isx;                 // the weight rows carry their own scales: p.w_rowinv, applied per output row in the epilogue
     }
     float mb[8 * BPT], hb[8 * BPT];
     float msc[ISC ? 8 * BPT : 1], hsc[ISC ? 8 * BPT : 1];           // ISC: the input scales of the channels in mb / hb
@@ -923,6 +1034,25 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     }
 
     const int OHW = p.OH * p.OW;
+    if constexpr (HX) {
+        // back to the operands' units: 1 / S_x for the tile, 1 / S_w per weight row (p.w_rowinv, written by the packing kernel).  The 32 row
+        // scales of this lane are fetched in one go in front of the stores (a load in front of every store cost 9 % of the kernel).
+        const float* const wri = p.w_rowinv + (int64_t)g * p.Og_pad + o_blk;
+        float ws[WMT][16];
+#pragma unroll
+        for (int a = 0; a < WMT; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) ws[a][r] = wri[(wm * WMT + a) * 32 + acc_row(r, lane)];
+#pragma unroll
+        for (int a = 0; a < WMT; a++)
+#pragma unroll
+            for (int b = 0; b < WNT; b++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    acc[a][b][r] = (acc[a][b][r] * out_scale) * ws[a][r];
+                    if constexpr (PAIR) acc2[a][b][r] = (acc2[a][b][r] * out_scale) * ws[a][r];
+                }
+    }
     if constexpr (PAIR) {
         // (p, q) of the input lattice -> output row 2p + a, columns 2q and 2q + 1: one 8-byte store per lane
         struct __attribute__((packed, aligned(4))) Pair { float even, odd; };
@@ -942,7 +1072,6 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
                         Pair v;
                         v.even = p.pair_bx ? acc2[a][b][r] : acc[a][b][r];
                         v.odd = p.pair_bx ? acc[a][b][r] : acc2[a][b][r];
-                        if constexpr (HX) { v.even *= out_scale; v.odd *= out_scale; }
                         *(Pair*)(p.y + yoff + (int64_t)o * OHW) = v;
                     }
                 }
@@ -970,7 +1099,6 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
                 const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
                 if (o < p.Og) {
                     float v = acc[a][b][r];
-                    if constexpr (HX) v *= out_scale;
                     v = conv_scale_noise(v, osb, o, nz);
                     if (has_res) v += io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES);
                     if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
@@ -994,27 +1122,17 @@ static void launch_fwd_bf16_np(const ConvFwdParams& q, dim3 grid, hipStream_t s)
         // row-reuse kernel: full tiles made of whole row segments inside one image
         constexpr int APT = (2 * Arith<NP>::npa * BM + 255) / 256;
         constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 2 * Arith<NP>::npb * (BN + 16) * 8) * sizeof(__bf16);
-        static bool attr_set = false;
-        static int pipe = 1;
-        if (!attr_set) {
-            if constexpr (IO == IO_F32 && NP != NP_F16X3)
-                (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 0, NP, IO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if constexpr (IO == IO_F32 && NP == 3)
-                (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 3, 2, NP, IO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP, IO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            const char* e = getenv("PASTA_ROWS_PIPE");
-            if (e) pipe = e[0] - '0';
-            attr_set = true;
-        }
+        static const int pipe = getenv("PASTA_ROWS_PIPE") ? getenv("PASTA_ROWS_PIPE")[0] - '0' : 1;        // read once (thread-safe initialisation), never written again
+        if constexpr (IO == IO_F32 && NP != NP_F16X3)
+            PASTA_SET_LDS((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 0, NP, IO>), lds);
+        if constexpr (IO == IO_F32 && NP == 3)
+            PASTA_SET_LDS((conv_fwd_rows_bf16x6_kernel<BM, BN, 3, 2, NP, IO>), lds);
+        PASTA_SET_LDS((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP, IO>), lds);
         if constexpr (IO == IO_F32 && NP == 3) {
             if (pipe == 2) { hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 3, 2, NP, IO>), grid, dim3(256), lds, s, q); return; }
             if (pipe == 3) {
                 constexpr size_t lds3 = (size_t)(2 * 2 * NP * (BN + 16) * 8) * sizeof(__bf16);       // the B images only
-                static bool attr3 = false;
-                if (!attr3) {
-                    (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 3, NP, IO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-                    attr3 = true;
-                }
+                PASTA_SET_LDS((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 3, NP, IO>), lds3);
                 hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 3, NP, IO>), grid, dim3(256), lds3, s, q);
                 return;
             }
@@ -1036,13 +1154,9 @@ static void launch_fwd_bf16_np(const ConvFwdParams& q, dim3 grid, hipStream_t s)
 template <int BM, int BN, int NP = 3>
 static void launch_fwd_bf16_isc(const ConvFwdParams& q, dim3 grid, hipStream_t s) {
     if (q.rows && q.ncls == 1 && rows_tile_ok(q.cls[0].P, q.cls[0].Q, BN)) {
-        constexpr int APT = (2 * 3 * BM + 255) / 256;
+        constexpr int APT = (2 * Arith<NP>::npa * BM + 255) / 256;
         constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 2 * Arith<NP>::npb * (BN + 16) * 8) * sizeof(__bf16);
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP, IO_F32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
+        PASTA_SET_LDS((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP, IO_F32, true>), lds);
         hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP, IO_F32, true>), grid, dim3(256), lds, s, q);
         return;
     }
@@ -1081,11 +1195,7 @@ static void launch_fwd_pair(const ConvFwdParams& p, hipStream_t s) {
     dim3 grid((unsigned)(2 * tiles), q.o_tiles, p.G);
     constexpr int APT = (2 * Arith<NP>::npa * BM + 255) / 256;
     constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 2 * Arith<NP>::npb * (BN + 16) * 8) * sizeof(__bf16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 2, NP, IO_F32, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    PASTA_SET_LDS((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 2, NP, IO_F32, false, true>), lds);
     hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 2, NP, IO_F32, false, true>), grid, dim3(256), lds, s, q);
 }
 

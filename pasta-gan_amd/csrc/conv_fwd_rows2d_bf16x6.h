@@ -30,7 +30,7 @@ namespace pasta {
 // on every live shape (248 / 304 / 318 / 324 against 255 / 310 / 325 / 328 TFLOP/s) although 34 % of the wave cycles are parked
 // at s_waitcnt / s_barrier -- the barrier count is not what parks them.
 // Also measured and dropped (round 3, profiles/r3_ab_wave128.txt, r3_ab_rows2d_pipe*.txt, r3_pipe_ablation.txt; the kernel is kept, out of
-// the build, as tools/experiments/conv_fwd_rows2d_pipe.h): FOUR waves of 64 x 128 outputs on the same tile (14 fragment reads per
+// the build; deleted in round 4, last in commit 7b449f3 as tools/experiments/conv_fwd_rows2d_pipe.h): FOUR waves of 64 x 128 outputs on the same tile (14 fragment reads per
 // 24 MFMAs instead of 10 per 12), one wave per SIMD -- equal to the eight waves within 2 % on every shape, with or without the fragments of
 // step g + 1 read behind the MFMAs of step g (two fragment sets, 253 + 128 registers, the order within a step pinned by
 // sched_group_barrier).  Its timing-only instances on the 512 -> 512 layer at 32 x 32: MFMAs + barriers alone 509 TFLOP/s, + fragment
@@ -110,10 +110,9 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
     // PASTA_MATH_F16X3: power-of-two scales of the two operands (every wave reduces the partial maxima itself)
     float x_scale = 1.f, out_scale = 1.f;
     if constexpr (HX) {
-        float sx, isx, sw, isw;
+        float sx, isx;
         scale_from_amax(amax_of_parts(p.x_amax), sx, isx);
-        scale_from_amax(amax_of_parts(p.w_amax) * p.w_gain, sw, isw);
-        x_scale = sx; out_scale = isx * isw;
+        x_scale = sx; out_scale = isx;                 // the weight rows carry their own scales: p.w_rowinv, applied per output row in the epilogue
     }
     float sb0[8], sb1[8];                               // the two staging register sets
     float sc0[ISC ? 8 : 1], sc1[ISC ? 8 : 1];           // ISC: the input scales of their channels
@@ -308,6 +307,24 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
     }
 
     const int OHW = p.OH * p.OW;
+    if constexpr (HX) {
+        // back to the operands' units: 1 / S_x for the tile, 1 / S_w per weight row (p.w_rowinv, written by the packing kernel).  The 32 row
+        // scales of this lane are fetched in one go in front of the stores (a load in front of every store cost 9 % of the kernel).
+        const float* const wri = p.w_rowinv + (int64_t)g * p.Og_pad + o_blk;
+        float ws[WMT][16];
+#pragma unroll
+        for (int a = 0; a < WMT; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) ws[a][r] = wri[(wm * WMT + a) * 32 + acc_row(r, lane)];
+#pragma unroll
+        for (int a = 0; a < WMT; a++)
+#pragma unroll
+            for (int b = 0; b < WNT; b++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    acc[a][b][r] = (acc[a][b][r] * out_scale) * ws[a][r];
+                }
+    }
     const bool has_noise = p.noise && p.ksplit == 1;
     const float nstr = has_noise ? p.noise_strength[0] : 0.f;
 #pragma unroll
@@ -327,7 +344,6 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
                 const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r16, lane);
                 if (o < p.Og) {
                     float v = acc[a][b][r16];
-                    if constexpr (HX) v *= out_scale;
                     v = conv_scale_noise(v, osb, o, nz);
                     if (has_res) v += io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES);
                     if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
@@ -351,11 +367,7 @@ static void launch_fwd_rows2d_np(const ConvFwdParams& q, dim3 grid, hipStream_t 
     constexpr int SEG = BN / R, SLOTS = (R + 2) * (SEG + 2);
     constexpr int APT = (2 * Arith<NP>::npa * BM + NT - 1) / NT;
     constexpr size_t lds = (size_t)(2 * APT * NT * 8 + 2 * 2 * Arith<NP>::npb * SLOTS * 8) * sizeof(__bf16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_fwd_rows2d_bf16x6_kernel<BM, BN, R, NP, IO, ISC, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    PASTA_SET_LDS((conv_fwd_rows2d_bf16x6_kernel<BM, BN, R, NP, IO, ISC, NT>), lds);
     hipLaunchKernelGGL((conv_fwd_rows2d_bf16x6_kernel<BM, BN, R, NP, IO, ISC, NT>), grid, dim3(NT), lds, s, q);
 }
 

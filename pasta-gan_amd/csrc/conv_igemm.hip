@@ -269,7 +269,8 @@ extern "C" int64_t pasta_conv2d_workspace(const pasta_conv_desc* d) {
         pack = pack > pk ? pack : pk;
         extra = kp + packed_input_floats(d);
     }
-    return (WS_AMAX_FLOATS + round_up((int)pack, 4) + partial + round_up((int)extra, 4)) * (int64_t)sizeof(float);
+    const int64_t rowinv = (int64_t)d->groups * round_up(Og, fwd_tile_bm(t));      // PASTA_MATH_F16X3: 1 / S_w per packed weight row
+    return (WS_AMAX_FLOATS + rowinv + round_up((int)pack, 4) + partial + round_up((int)extra, 4)) * (int64_t)sizeof(float);
 }
 
 extern "C" int pasta_conv2d_tile(const pasta_conv_desc* d) {
@@ -544,11 +545,15 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
     PASTA_CHECK(((uintptr_t)workspace & 15) == 0, "conv2d: workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
 
-    float* const ws_amax = (float*)workspace;                         // [2][AMAX_PARTS]: x, w
-    workspace = (float*)workspace + WS_AMAX_FLOATS;                  // packed weights and K-slice partial sums follow
+    float* const ws_amax = (float*)workspace;                         // [2][AMAX_PARTS]: partial |max| of x (second row: spare)
+    float* const ws_rowinv = ws_amax + WS_AMAX_FLOATS;                // [G][Og_pad]: 1 / S_w per packed weight row (PASTA_MATH_F16X3)
+    {
+        const FwdPlan pl = plan_fwd(d);
+        workspace = ws_rowinv + (int64_t)d->groups * round_up(d->C_out / d->groups, fwd_tile_bm(pl.tile));      // packed weights and K-slice partial sums follow
+    }
     ConvFwdParams p;
     p.x = (const float*)x; p.y = (float*)y; p.wp = (const float*)workspace; p.iscale = iscale; p.oscale = oscale;
-    p.x_amax = nullptr; p.w_amax = nullptr; p.w_gain = 1.f;
+    p.x_amax = nullptr; p.w_rowinv = nullptr;
     p.N = d->N; p.Cin = d->C_in; p.H = d->H; p.W = d->W;
     p.Cout = d->C_out; p.OH = d->OH; p.OW = d->OW;
     p.G = d->groups; p.Ig = d->C_in / d->groups; p.Og = d->C_out / d->groups;
@@ -565,7 +570,6 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
     p.partial = (float*)workspace + round_up((int)(((int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad * 3 + 1) / 2), 4);
     // bf16 pieces per operand; 0 = fp32 kernel.  An input scale rides in the staging of the six-product fp32-storage kernels only.
     p.bf16x6 = (plan.bf16x6 && (!iscale || isc_in_staging(d)) && !(plan.packed && (iscale || wmod_s))) ? math_pieces(d->math) : 0;
-    if (p.bf16x6 == NP_F16X3 && wmod_s) p.bf16x6 = 3;               // per-sample modulated weights: their |max| is not w's; six products
     p.io = d->io_dtype;
     if (p.io != IO_F32) {
         PASTA_CHECK(p.bf16x6, "conv2d: no 16-bit-storage kernel for this shape (pasta_conv2d_plan tells beforehand)");
@@ -575,8 +579,8 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
 
     const float wscale = d->wscale == 0.f ? 1.f : d->wscale;
     if (p.bf16x6 == NP_F16X3 && p.io == IO_F32) {
-        // operand scales: partial |max| of x (the caller's, or one pass here), times max |iscale| when the styles ride in the
-        // staging, and of w (a few MB at most)
+        // operand scale of x: partial |max| (the caller's, or one pass here), times max |iscale| when the styles ride in the staging.
+        // The weights carry one scale per output row, found by their packing kernel (no |max| of w is passed or cached).
         const float* xa = d->x_amax;
         if (!xa) {
             if (int e = tensor_amax(x, (int64_t)d->N * d->C_in * d->H * d->W, PASTA_F32, ws_amax, s)) return e;
@@ -586,12 +590,8 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
             hipLaunchKernelGGL(amax_times_kernel, dim3(1), dim3(256), 0, s, xa, iscale, d->N * d->C_in, ws_amax);
             xa = ws_amax;
         }
-        const float* wa = d->w_amax;
-        if (!wa) {
-            if (int e = tensor_amax(w, (int64_t)d->C_out * (d->C_in / d->groups) * d->kh * d->kw, PASTA_F32, ws_amax + AMAX_PARTS, s)) return e;
-            wa = ws_amax + AMAX_PARTS;
-        }
-        p.x_amax = xa; p.w_amax = wa; p.w_gain = fabsf(wscale);
+        p.x_amax = xa;
+        p.w_rowinv = ws_rowinv;
     }
     p.koff = nullptr;
     static const int xcd_order = getenv("PASTA_XCD_ORDER") ? atoi(getenv("PASTA_XCD_ORDER")) : 1;
@@ -623,10 +623,12 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
         const int64_t total = (int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad;
         int64_t blocks = ceil_div64(total, 256);
         if (blocks > 4096) blocks = 4096;
-        if (p.bf16x6)
+        if (p.bf16x6 == NP_F16X3 && p.io == IO_F32)         // two fp16 pieces, one scale per output row found on the way
+            hipLaunchKernelGGL(pack_weights_f16x3_kernel, dim3((unsigned)p.Og_pad, (unsigned)p.G), dim3(256), 0, s, w, (__bf16*)workspace, ws_rowinv,
+                               p.Ig, p.Og, p.Ig_pad, p.Og_pad, pk_kh, pk_kw, pk_tr, pk_flip, wscale, wmod_s, wmod_d);
+        else if (p.bf16x6)
             hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, (__bf16*)workspace, p.G, p.Ig, p.Og,
-                               p.Ig_pad, p.Og_pad, pk_kh, pk_kw, pk_tr, pk_flip, wscale, p.io == IO_F16 ? 1 : p.bf16x6 == NP_F16X3 ? 2 : 0, wmod_s, wmod_d,
-                               p.w_amax);
+                               p.Ig_pad, p.Og_pad, pk_kh, pk_kw, pk_tr, pk_flip, wscale, p.io == IO_F16 ? 1 : 0, wmod_s, wmod_d);
         else
             hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, (float*)workspace, p.G, p.Ig, p.Og,
                                p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip, wscale, wmod_s, wmod_d);

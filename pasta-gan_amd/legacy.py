@@ -17,6 +17,22 @@ import training.networks  # noqa: F401  (registers the persistent classes that p
 
 #----------------------------------------------------------------------------
 
+_FP16_OVERRIDES = dict(num_fp16_res=4, conv_clamp=256)     # what the reference's loader forces (legacy.py:45-59)
+
+def _with_fp16_blocks(net, generator):
+    """``net`` rebuilt from its recorded constructor arguments with the four highest resolutions in fp16 and the matching
+    clamp (a generator keeps them under ``synthesis_kwargs``); the original is returned when nothing changes."""
+    want = copy.deepcopy(net.init_kwargs)
+    target = want
+    if generator:
+        target = want['synthesis_kwargs'] = dnnlib.EasyDict(want.get('synthesis_kwargs') or {})
+    target.update(_FP16_OVERRIDES)
+    if want == net.init_kwargs:
+        return net
+    rebuilt = type(net)(**want).eval().requires_grad_(False)
+    misc.copy_params_and_buffers(net, rebuilt, require_all=True)
+    return rebuilt
+
 class _Unpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if module == 'dnnlib.tflib.network' and name == 'Network':
@@ -34,21 +50,8 @@ def load_network_pkl(f, force_fp16=False):
     assert isinstance(data['training_set_kwargs'], (dict, type(None)))
     assert isinstance(data['augment_pipe'], (torch.nn.Module, type(None)))
 
-    if force_fp16:      # rebuild with fp16 enabled in the four highest resolutions, as legacy.py:45-59
-        for key in ['G', 'D', 'G_ema']:
-            old = data[key]
-            kwargs = copy.deepcopy(old.init_kwargs)
-            if key.startswith('G'):
-                kwargs.synthesis_kwargs = dnnlib.EasyDict(kwargs.get('synthesis_kwargs', {}))
-                kwargs.synthesis_kwargs.num_fp16_res = 4
-                kwargs.synthesis_kwargs.conv_clamp = 256
-            else:
-                kwargs.num_fp16_res = 4
-                kwargs.conv_clamp = 256
-            if kwargs != old.init_kwargs:
-                new = type(old)(**kwargs).eval().requires_grad_(False)
-                misc.copy_params_and_buffers(old, new, require_all=True)
-                data[key] = new
+    if force_fp16:
+        data.update({key: _with_fp16_blocks(data[key], generator=(key != 'D')) for key in ('G', 'D', 'G_ema')})
     return data
 
 #----------------------------------------------------------------------------

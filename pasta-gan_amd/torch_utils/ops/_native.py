@@ -67,8 +67,9 @@ def amax_slot(like):
     return row
 
 def amax_attach(t, row):
-    """Hang the producer's row on the tensor it describes (valid for the tensor's current version)."""
-    if row is not None:
+    """Hang the producer's row on the tensor it describes (valid for the tensor's current version).  Inference tensors
+    (``torch.inference_mode()``) track no version, so nothing is attached and their consumers scan."""
+    if row is not None and not t.is_inference():
         try:
             t._pasta_amax = (t._version, t.data_ptr(), row)
         except AttributeError:

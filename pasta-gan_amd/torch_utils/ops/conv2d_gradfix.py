@@ -97,10 +97,22 @@ def _native16(kind, desc, has_iscale=False):
         _native16_cache[key] = hit
     return hit
 
-# PASTA_MATH_F16X3 (include/pasta_hip.h): the power-of-two operand scales come from the tensors' largest magnitudes.  A tensor
-# is scanned ONCE (``pasta_tensor_amax``: 256 partial maxima, one pass at HBM rate) and the result travels with the Python
-# tensor object for as long as its version stands: the forward input serves the forward launch and, from the saved tensor,
-# the weight gradient; a gradient serves the input-gradient and the weight-gradient launch of the same backward.
+# PASTA_MATH_F16X3 (include/pasta_hip.h): the power-of-two operand scales of the ACTIVATIONS come from the tensors' largest
+# magnitudes (the weights are scaled per output row by their packing kernel at every launch: nothing about a weight is cached).
+# A tensor is scanned by ``pasta_tensor_amax`` (256 partial maxima, one pass at HBM rate) or arrives with the maxima its
+# producer kernel left behind (_native.amax_attach), and the result travels with the Python tensor object while its version
+# stands: a forward input serves the forward launch and, from the saved tensor, the weight gradient; a gradient serves the
+# input-gradient and the weight-gradient launch of the same backward.
+#
+# What may be cached (round 4): the key (t._version, t.data_ptr()) cannot see a write that goes
+# around the version counter (``t.data.mul_()``, numpy / DLPack aliases).  The tensors such idioms are applied to are LEAVES a
+# caller holds: parameters (no longer scanned at all) and input batches.  So a scan result is attached only to
+#   * tensors with a ``grad_fn`` (results of recorded operations: only autograd-visible code writes them), and
+#   * tensors met inside a backward pass (gradients, saved activations being differentiated),
+# and a leaf met outside a backward pass -- an input batch, a parameter used as an activation, a no-grad intermediate of a
+# torch operator -- is scanned at every use (its maxima are never read from the object).  Producer rows are written by the
+# kernel that wrote the tensor and are trusted for that version.  Inference tensors (``torch.inference_mode()``) track no
+# version: nothing is cached on them or read back from them.
 AMAX_PARTS = 256
 _f16x3_cache = {}
 _SCAN_TRACE = {} if _os.environ.get('PASTA_AMAX_TRACE') else None
@@ -113,9 +125,24 @@ if _SCAN_TRACE is not None:
             print(f'amax scan x{n:5d}  {str(shape):28s} {src}', file=sys.stderr)
     _atexit.register(_dump_scans)
 
+# PASTA_CHECK_FINITE=1 (debug; synchronises): every convolution under the three-product arithmetic checks its output for
+# inf / NaN and raises -- what an operand scale taken from stale maxima (|v S| > 65504) or a non-finite operand produces.
+_CHECK_FINITE = _os.environ.get('PASTA_CHECK_FINITE', '0') == '1'
+
+_graph_task_id = getattr(torch._C, '_current_graph_task_id', None)
+
+def _in_backward():
+    return _graph_task_id is not None and _graph_task_id() != -1
+
+def _amax_cacheable(t):
+    """May a scan of ``t`` be attached to the tensor object (see the note above)?"""
+    if t.is_inference():
+        return False
+    return t.grad_fn is not None or _in_backward()
+
 def tensor_amax(t):
-    """[256] partial |max| of a contiguous fp32 GPU tensor (cached per tensor version)."""
-    hit = getattr(t, '_pasta_amax', None)
+    """[256] partial |max| of a contiguous fp32 GPU tensor; cached on the tensor only where no write can bypass the key."""
+    hit = None if t.is_inference() else getattr(t, '_pasta_amax', None)
     if hit is not None and hit[0] == t._version and hit[1] == t.data_ptr():
         return hit[2]
     if _SCAN_TRACE is not None:                        # diagnostic (PASTA_AMAX_TRACE=1): which tensors still cost a scan
@@ -127,17 +154,23 @@ def tensor_amax(t):
     parts = torch.empty([AMAX_PARTS], dtype=torch.float32, device=t.device)
     with torch.cuda.device(t.device):
         _native.check(_native.lib().pasta_tensor_amax(_native.ptr(t), t.numel(), 0, _native.ptr(parts), _native.stream()))
-    try:
-        t._pasta_amax = (t._version, t.data_ptr(), parts)
-    except AttributeError:
-        pass
+    if _amax_cacheable(t):
+        try:
+            t._pasta_amax = (t._version, t.data_ptr(), parts)
+        except AttributeError:
+            pass
     return parts
+
+def _check_finite(y, what):
+    if _CHECK_FINITE and not bool(torch.isfinite(y).all()):
+        raise RuntimeError(f'{what}: non-finite output under PASTA_MATH_F16X3 -- a non-finite operand, or an operand scale taken '
+                           f'from maxima that no longer describe the tensor (written behind the version counter?)')
 
 def _runs_f16x3(kind, desc, flags=0):
     """Does this launch run the three-product fp16 arithmetic (then it wants the operands' partial maxima)?"""
     if desc.math not in (0, MATH_CODES['f16x3']) or desc.io_dtype != 0:
         return False
-    key = (kind, flags & 1, desc.N, desc.C_in, desc.H, desc.W, desc.C_out, desc.OH, desc.OW, desc.kh, desc.kw, desc.stride, desc.pad_h,
+    key = (kind, flags & 9, desc.N, desc.C_in, desc.H, desc.W, desc.C_out, desc.OH, desc.OW, desc.kh, desc.kw, desc.stride, desc.pad_h,
            desc.pad_w, desc.groups, desc.transposed)
     hit = _f16x3_cache.get(key)
     if hit is None:
@@ -233,9 +266,10 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, 
         mod_d = _f32(wmod[1]).contiguous() if wmod[1] is not None else None
         assert mod_s.numel() == x.shape[1] and (mod_d is None or mod_d.numel() == c_out)
     x_amax = None
-    if wmod is None and _runs_f16x3('conv', desc, 1 if iscale is not None else 0):
-        x_amax, w_amax = tensor_amax(x), tensor_amax(w)       # w: a parameter is scanned once per optimiser step
-        desc.x_amax, desc.w_amax = x_amax.data_ptr(), w_amax.data_ptr()
+    f16x3 = _runs_f16x3('conv', desc, (1 if iscale is not None else 0) | (8 if wmod is not None else 0))
+    if f16x3:
+        x_amax = tensor_amax(x)                 # the weights are scaled per output row by their packing kernel: nothing to pass
+        desc.x_amax = x_amax.data_ptr()
     def launch():
         with torch.cuda.device(x.device):
             if wmod is not None:
@@ -253,6 +287,8 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, 
         # 'conv_isc': the launch passes an input scale (another kernel instance); flags = PASTA_PLAN_* of include/pasta_hip.h
         flags = (1 if iscale is not None else 0) | (2 if oscale is not None else 0) | (4 if ep is not None else 0) | (8 if wmod is not None else 0)
         launch_hook('conv' if iscale is None else 'conv_isc', desc, launch, flags)
+    if f16x3:
+        _check_finite(y, 'conv2d')
     if y_row is not None and y.dtype == out_dtype:
         _native.amax_attach(y, y_row)
     return y.to(out_dtype)
@@ -280,7 +316,8 @@ def _launch_wgrad(x, dy, cfg, w_shape, out_dtype=None):
     if nbytes < 0:
         _native.check(1)
     work = torch.empty([max(nbytes // 4, 4)], dtype=torch.float32, device=x.device)
-    if _runs_f16x3('wgrad', desc):
+    f16x3 = _runs_f16x3('wgrad', desc)
+    if f16x3:
         amax_x, amax_dy = tensor_amax(x), tensor_amax(dy)
         desc.x_amax, desc.dy_amax = amax_x.data_ptr(), amax_dy.data_ptr()
     def launch():
@@ -292,6 +329,8 @@ def _launch_wgrad(x, dy, cfg, w_shape, out_dtype=None):
         launch()
     else:
         launch_hook('wgrad', desc, launch, 0)
+    if f16x3:
+        _check_finite(dw, 'conv2d_wgrad')
     return dw.to(out_dtype)
 
 #----------------------------------------------------------------------------

@@ -102,7 +102,7 @@ class FlatGradReducer:
     def _on_grad(self, p):
         self._touched.add(p)
         b = self._where[p]
-        if b.launched:
+        if b.launched and self.collective:
             # the bucket left (pre-scaled by 1/world) when its expected count was reached: a gradient arriving now would be
             # added during or after the exchange and the replicas would diverge silently.  The count comes from
             # StyleGAN2Loss.backward_passes - a loss variant that calls backward() once more must say so there.
@@ -141,6 +141,7 @@ class FlatGradReducer:
             if b.work is not None:
                 b.work.wait()
                 b.work = None
+            b.launched = False              # the phase is over: a backward pass outside the begin / arm / finish protocol is not "late"
             for p, _ in b.params:
                 if p not in self._touched:
                     p.grad = None

@@ -550,12 +550,13 @@ def test_tensor_amax_partial_maxima(numel, offset):
     assert float(parts.min()) >= 0
     finite = x[torch.isfinite(x)]
     assert float(parts.max()) == float(finite.abs().max()) == 77.5
-    # cached front end
+    # cached front end (round 4: only on tensors no write can reach behind the version counter -- tests/test_f16x3_hardening_gpu.py)
     from torch_utils.ops import conv2d_gradfix as cg
-    t = torch.randn([4, 8, 16, 16], generator=g).cuda()
+    t = torch.randn([4, 8, 16, 16], generator=g).cuda().requires_grad_(True) * 1.0
     p1 = cg.tensor_amax(t)
     assert cg.tensor_amax(t) is p1                      # same version: no second scan
-    t.mul_(2)
+    with torch.no_grad():
+        t.mul_(2)
     p2 = cg.tensor_amax(t)
     assert p2 is not p1 and float(p2.max()) == float(t.abs().max())
 
@@ -585,10 +586,11 @@ def test_producer_side_maxima_match_a_scan():
         hit = getattr(t, '_pasta_amax', None)
         if name in ('scale_planes', 'mod_bias_act'):       # thousands of four-instruction waves: a commit per wave costs what the scan costs; the consumer scans
             assert hit is None, name
-            hit = (t._version, t.data_ptr(), cg.tensor_amax(t))
-        assert hit is not None and hit[0] == t._version and hit[1] == t.data_ptr(), name
-        assert float(hit[2].max()) == float(t.abs().max()), name
-        assert cg.tensor_amax(t) is hit[2], name                       # the convolution takes the producer's row
+            assert float(cg.tensor_amax(t).max()) == float(t.abs().max()), name
+        else:
+            assert hit is not None and hit[0] == t._version and hit[1] == t.data_ptr(), name
+            assert float(hit[2].max()) == float(t.abs().max()), name
+            assert cg.tensor_amax(t) is hit[2], name                   # the convolution takes the producer's row
         if t.shape[1] == 32:
             y = cg.conv2d(t, w, padding=1)
             ref = torch.nn.functional.conv2d(t.double(), w.double(), padding=1)
@@ -606,7 +608,7 @@ def test_producer_side_maxima_match_a_scan():
         y.square().mean().backward()
     finally:
         cg.tensor_amax = orig
-    assert seen and all(seen[i] for i in range(len(seen)) if i != 1), seen      # dz (and the saved x) arrive with their maxima; the weight is scanned once
+    assert seen == [True], seen      # the input-gradient launch: dz arrives with its producer's maxima; the weight is never scanned (its packing kernel scales it per row)
     # the SPADE backward with gamma | beta as halves of one tensor: dgamma | dbeta (the dy of ONE convolution's backward) carries its own row
     xs = x.clone().requires_grad_(True)
     gb = torch.cat([x * 0.1, x * 0.2], dim=1).requires_grad_(True)

@@ -110,6 +110,14 @@ def test_load_network_pkl():
     assert type(data['G_ema']) is type(G) and type(data['D']) is type(D)
     with pytest.raises(ValueError):
         legacy.load_network_pkl(io.BytesIO(pickle.dumps([1, 2, 3])))
+    # force_fp16 (reference legacy.py:45-59): every network is rebuilt with num_fp16_res = 4, conv_clamp = 256 and the same weights
+    buf.seek(0)
+    half = legacy.load_network_pkl(buf, force_fp16=True)
+    assert half['D'].init_kwargs['num_fp16_res'] == 4 and half['D'].init_kwargs['conv_clamp'] == 256 and half['D'].b256.use_fp16
+    assert half['G_ema'].init_kwargs['synthesis_kwargs']['num_fp16_res'] == 4 and G.init_kwargs['synthesis_kwargs'].get('num_fp16_res') is None
+    assert type(half['G']) is type(G) and not half['G'].training
+    sd, sd2 = D.state_dict(), half['D'].state_dict()
+    assert list(sd) == list(sd2) and all(torch.equal(sd[k], sd2[k]) for k in sd)
 
 
 @pytest.mark.gpu
