@@ -120,6 +120,12 @@ typedef struct pasta_conv_desc {
                                      (pasta_tensor_amax wrote them).  NULL: the launch computes them itself into its workspace
                                      (one extra pass over x).  A caller that uses a tensor in several launches (forward and
                                      weight gradient; input gradient and weight gradient) computes them once.            */
+    const void*  x2;              /* optional second input tensor of a POINTWISE convolution (kh = kw = 1, stride 1, fp32 storage, PASTA_MATH_F16X3):
+                                     x holds input channels [0, C1), x2 ([N, C_in - C1, H, W], contiguous) channels [C1, C_in) -- the convolution of
+                                     torch.cat([x, x2], 1) (the merge layers, networks.py:5698-5700) without forming it.  NULL: one tensor.  An error
+                                     where the pointwise kernel does not apply (pasta_conv2d_plan reports kernel 9 where it does)           */
+    const float* x2_amax;         /* partial |max| of x2, as x_amax                                                      */
+    int32_t      C1;              /* channels held by x when x2 is given                                                  */
     const float* dy_amax;         /* the same for dy (pasta_conv2d_wgrad only).  The WEIGHTS need nothing of the kind (ABI 17): their
                                      packing kernel finds one scale per output row itself at every launch, so no |max| of w is
                                      passed, cached or trusted across launches                                            */
@@ -187,7 +193,9 @@ int pasta_conv2d_tile(const pasta_conv_desc* d);
  * conv_t2_edge_kernel, and kernels 1 - 7 also run PASTA_MATH_F16X3), 8 conv_fwd_bf16x6_kernel in its packed-K mode (round 3: fewer than
  * 16 input channels, more than 32 output channels, at least 64 (channel, tap) pairs, planes above 8192 pixels -- the 7x7 RGB stems:
  * K runs over the pairs; the workspace then also holds the offset table and a zero-padded copy of the input, and two small
- * kernels fill them).  Any out pointer may be NULL. */
+ * kernels fill them), 9 conv1x1_f16x3_kernel (round 4: 1x1 stride-1 convolutions and their input gradients under PASTA_MATH_F16X3, fp32 tensors,
+ * >= 16 input and > 32 output channels, planes of a multiple of 128 / 256 pixels: 16-byte loads along the pixels, 32 channels per barrier pair,
+ * optionally over two input tensors -- pasta_conv_desc.x2).  Any out pointer may be NULL. */
 #define PASTA_PLAN_ISCALE   1
 #define PASTA_PLAN_OSCALE   2
 #define PASTA_PLAN_EPILOGUE 4

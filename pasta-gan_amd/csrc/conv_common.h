@@ -196,6 +196,7 @@ struct ConvFwdParams {
     const float* x; const float* wp; float* y;         // x, y (and res): elements of type `io` behind these pointers
     const float* iscale; const float* oscale;
     const float* x_amax;                                // PASTA_MATH_F16X3: AMAX_PARTS partial |max| of x
+    const float* x2; const float* x2_amax; int C1;      // conv1x1_f16x3_kernel: channels [C1, Cin) live in a second tensor x2 ([N, Cin - C1, H, W]); null = one tensor
     const float* w_rowinv;                              // PASTA_MATH_F16X3: [G][Og_pad] 1 / S_w of every packed weight row (pack_weights_f16x3_kernel)
     float* y_amax;                                      // optional (fused epilogue): zeroed partial |max| slots of y (common.h, amax_commit)
     int io;                                             // IO_F32 / IO_F16 / IO_BF16

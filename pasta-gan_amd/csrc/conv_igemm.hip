@@ -30,6 +30,7 @@
 #include "conv_fwd_f32.h"
 #include "conv_fwd_bf16x6.h"
 #include "conv_fwd_rows2d_bf16x6.h"
+#include "conv_fwd_1x1.h"
 #include "conv_wgrad_f32.h"
 #include "conv_wgrad_bf16x6.h"
 
@@ -311,7 +312,12 @@ extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int launch_flags, int
         const bool rows2d = plain6 && f.tile == T128x128 && rows2d_rows(d->OH, d->OW) > 0;
         const bool rows2d_256 = plain6 && f.tile == T64x256 && rows2d_rows256(d->OH, d->OW);
         const bool wide = rows2d && !has_iscale && fp32_equivalent(math_pieces(d->math)) && d->io_dtype == PASTA_F32 && rows2d_wide(d->OH, d->OW);
-        *kernel = !sb ? 0 : packed ? 8 : pair ? 3 : wide ? 7 : rows2d ? (rows2d_rows(d->OH, d->OW) == 4 ? 4 : 5) : rows2d_256 ? 6 : rows ? 2 : 1;
+        static const bool c1x1_on = !(getenv("PASTA_CONV1X1") && getenv("PASTA_CONV1X1")[0] == '0');
+        const int bn1 = (d->C_out / d->groups) <= 64 ? 256 : 128;
+        const bool c1x1 = c1x1_on && sb && math_pieces(d->math) == NP_F16X3 && d->io_dtype == PASTA_F32 && d->groups == 1 && d->kh == 1 && d->kw == 1 && d->stride == 1 &&
+                          !d->pad_h && !d->pad_w && !(launch_flags & (PASTA_PLAN_ISCALE | PASTA_PLAN_OSCALE)) && f.ksplit == 1 && !packed && d->C_in >= 16 &&
+                          d->C_out > 32 && d->OH == d->H && d->OW == d->W && ((int64_t)d->H * d->W) % bn1 == 0;
+        *kernel = !sb ? 0 : c1x1 ? 9 : packed ? 8 : pair ? 3 : wide ? 7 : rows2d ? (rows2d_rows(d->OH, d->OW) == 4 ? 4 : 5) : rows2d_256 ? 6 : rows ? 2 : 1;
     }
     return 0;
 }
@@ -554,6 +560,8 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
     ConvFwdParams p;
     p.x = (const float*)x; p.y = (float*)y; p.wp = (const float*)workspace; p.iscale = iscale; p.oscale = oscale;
     p.x_amax = nullptr; p.w_rowinv = nullptr;
+    p.x2 = (const float*)d->x2; p.x2_amax = nullptr; p.C1 = d->C1;
+    PASTA_CHECK(!d->x2 || (d->C1 > 0 && d->C1 < d->C_in && d->groups == 1 && !wmod_s), "conv2d: a second input tensor needs 0 < C1 < C_in, one group and plain weights");
     p.N = d->N; p.Cin = d->C_in; p.H = d->H; p.W = d->W;
     p.Cout = d->C_out; p.OH = d->OH; p.OW = d->OW;
     p.G = d->groups; p.Ig = d->C_in / d->groups; p.Og = d->C_out / d->groups;
@@ -592,6 +600,13 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
         }
         p.x_amax = xa;
         p.w_rowinv = ws_rowinv;
+        if (p.x2) {                                     // the second operand's maxima: the caller's, or one pass here (second row of ws_amax)
+            p.x2_amax = d->x2_amax;
+            if (!p.x2_amax) {
+                if (int e = tensor_amax(d->x2, (int64_t)d->N * (d->C_in - d->C1) * d->H * d->W, PASTA_F32, ws_amax + AMAX_PARTS, s)) return e;
+                p.x2_amax = ws_amax + AMAX_PARTS;
+            }
+        }
     }
     p.koff = nullptr;
     static const int xcd_order = getenv("PASTA_XCD_ORDER") ? atoi(getenv("PASTA_XCD_ORDER")) : 1;
@@ -634,6 +649,12 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
                                p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip, wscale, wmod_s, wmod_d);
     }
 
+    if (conv1x1_ok(p, d->kh, d->kw, d->stride, d->pad_h, d->pad_w)) {
+        launch_conv1x1(p, s);           // conv2d and conv_transpose2d coincide for 1x1 / stride 1 (the packing kernel reads either weight layout)
+        return launch_status("conv2d");
+    }
+    PASTA_CHECK(!p.x2, "conv2d: a second input tensor is served by the pointwise kernel only (1x1, stride 1, fp32 tensors, PASTA_MATH_F16X3, "
+                       ">= 16 input and > 32 output channels, planes that divide into 128- / 256-pixel tiles, no scale vectors or noise)");
     if (packed) {
         p.P = d->OH; p.Q = d->OW; p.oy0 = 0; p.ox0 = 0; p.osy = 1; p.osx = 1; p.isy = d->stride; p.isx = d->stride;
         p.T = 1; p.tap_dy[0] = 0; p.tap_dx[0] = 0; p.tap_slab[0] = 0;      // the window's corner in the padded plane; the taps are in koff

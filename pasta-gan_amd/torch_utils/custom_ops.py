@@ -121,7 +121,7 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(name, _c_i32) for name in (
         'N', 'C_in', 'H', 'W', 'C_out', 'OH', 'OW', 'kh', 'kw', 'stride',
         'pad_h', 'pad_w', 'groups', 'transposed', 'flip', 'math')] + [('wscale', _c_f32), ('io_dtype', _c_i32),
-                                                                      ('x_amax', _c_ptr), ('dy_amax', _c_ptr)]
+                                                                      ('x_amax', _c_ptr), ('x2', _c_ptr), ('x2_amax', _c_ptr), ('C1', _c_i32), ('dy_amax', _c_ptr)]
 
 class ConvEpilogue(ctypes.Structure):
     """Mirror of ``pasta_conv_epilogue`` (include/pasta_hip.h)."""

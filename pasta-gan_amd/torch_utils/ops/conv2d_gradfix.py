@@ -191,7 +191,7 @@ launch_hook = None
 def _f32(t):
     return t if t.dtype == torch.float32 else t.float()
 
-def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, noise=None):
+def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, noise=None, x2=None):
     """y = conv(x * iscale[n,c]) * oscale[n,c'] through ``pasta_conv2d_ex``; fp32 accumulation.  fp32 tensors run the
     split-bf16 (fp32-equivalent) or fp32 matrix-core kernels; fp16 / bf16 tensors stay 16-bit in HBM where a kernel exists
     (``_native16``) and are converted for the launch otherwise.
@@ -199,7 +199,9 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, 
     store; the residual ([N, C_out, OH, OW]) is added to the convolution before the bias.
     ``noise`` = (plane(s) [OH, OW] or [N, 1, OH, OW] fp32, strength scalar tensor): added after ``oscale`` (needs ``epilogue``).
     ``wmod`` = (styles [G, I], dcoefs [G, O] or None): ``w`` is ONE group's weight shared by all ``cfg.groups`` groups and
-    modulated per group by the packing kernel (``pasta_conv2d_modulated``)."""
+    modulated per group by the packing kernel (``pasta_conv2d_modulated``).
+    ``x2`` ([N, C2, H, W], pointwise convolutions only -- ``cat1x1_available``): the convolution runs over the channel concatenation
+    ``cat([x, x2], 1)`` without forming it (``pasta_conv_desc.x2``)."""
     _native.require_gpu(x, 'conv2d')
     if x.ndim != 4 or w.ndim != 4:
         raise RuntimeError('conv2d: x and w must be rank 4')
@@ -207,13 +209,14 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, 
     w = _f32(w).contiguous()
     kh, kw = w.shape[2], w.shape[3]
     shared = cfg.groups if wmod is not None else 1        # the weight tensor holds one group
+    c_in = x.shape[1] + (x2.shape[1] if x2 is not None else 0)
     if cfg.transposed:
-        if w.shape[0] * shared != x.shape[1]:
-            raise RuntimeError(f'conv_transpose2d: weight {tuple(w.shape)} does not match input channels {x.shape[1]}')
+        if w.shape[0] * shared != c_in:
+            raise RuntimeError(f'conv_transpose2d: weight {tuple(w.shape)} does not match input channels {c_in}')
         c_out = w.shape[1] * cfg.groups
     else:
-        if w.shape[1] * cfg.groups != x.shape[1]:
-            raise RuntimeError(f'conv2d: weight {tuple(w.shape)} does not match input channels {x.shape[1]} (groups={cfg.groups})')
+        if w.shape[1] * cfg.groups != c_in:
+            raise RuntimeError(f'conv2d: weight {tuple(w.shape)} does not match input channels {c_in} (groups={cfg.groups})')
         c_out = w.shape[0] * shared
     oh, ow = _out_hw(cfg, x.shape[2], x.shape[3], kh, kw)
     if oh < 1 or ow < 1:
@@ -225,7 +228,12 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, 
         io = x.dtype
     x = x.contiguous() if io is not torch.float32 else _f32(x).contiguous()
     y = torch.empty([x.shape[0], c_out, oh, ow], dtype=io, device=x.device)
-    desc = _desc(cfg, x.shape, c_out, oh, ow, kh, kw, io)
+    desc = _desc(cfg, (x.shape[0], c_in, x.shape[2], x.shape[3]), c_out, oh, ow, kh, kw, io)
+    if x2 is not None:
+        if io is not torch.float32 or x2.dtype != torch.float32 or x2.shape[0] != x.shape[0] or x2.shape[2:] != x.shape[2:]:
+            raise RuntimeError('conv2d: the second input tensor must be fp32 and match the first in batch and plane size')
+        x2 = x2.contiguous()
+        desc.x2, desc.C1 = x2.data_ptr(), int(x.shape[1])
     lib = _native.lib()
     nbytes = lib.pasta_conv2d_workspace(ctypes.byref(desc))
     if nbytes < 0:
@@ -267,9 +275,13 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, 
         assert mod_s.numel() == x.shape[1] and (mod_d is None or mod_d.numel() == c_out)
     x_amax = None
     f16x3 = _runs_f16x3('conv', desc, (1 if iscale is not None else 0) | (8 if wmod is not None else 0))
+    x2_amax = None
     if f16x3:
         x_amax = tensor_amax(x)                 # the weights are scaled per output row by their packing kernel: nothing to pass
         desc.x_amax = x_amax.data_ptr()
+        if x2 is not None:
+            x2_amax = tensor_amax(x2)
+            desc.x2_amax = x2_amax.data_ptr()
     def launch():
         with torch.cuda.device(x.device):
             if wmod is not None:
@@ -404,6 +416,79 @@ class _ConvBiasActHip(torch.autograd.Function):
         return dx, dw, db, None, None, dres
 
 FUSABLE_ACTS = ('linear', 'relu', 'lrelu')
+
+_cat1x1_cache = {}
+
+def cat1x1_available(x, x2, weight):
+    """Will ``conv2d_cat1x1_bias_act`` run as ONE launch over the two tensors (the pointwise kernel, pasta_conv2d_plan kernel 9)?"""
+    if not (x.device.type == 'cuda' and x.dtype == torch.float32 and x2.dtype == torch.float32 and x.ndim == 4 and x2.shape[0] == x.shape[0]
+            and x2.shape[2:] == x.shape[2:] and tuple(weight.shape[2:]) == (1, 1) and weight.shape[1] == x.shape[1] + x2.shape[1]
+            and conv_math in ('default', 'f16x3') and x.numel() > 0):
+        return False
+    key = (int(x.shape[0]), int(x.shape[1]), int(x2.shape[1]), int(x.shape[2]), int(x.shape[3]), int(weight.shape[0]))
+    hit = _cat1x1_cache.get(key)
+    if hit is None:
+        n, c1, c2, h, w_, o = key
+        desc = _desc(_Cfg((False, 1, 0, 0, 0, 0, 1, 1.0)), (n, c1 + c2, h, w_), o, h, w_, 1, 1)
+        kernel = ctypes.c_int()
+        hit = _native.lib().pasta_conv2d_plan(ctypes.byref(desc), 4, None, None, None, None, ctypes.byref(kernel)) == 0 and kernel.value == 9
+        _cat1x1_cache[key] = hit
+    return hit
+
+class _CatConv1x1BiasActHip(torch.autograd.Function):
+    """``bias_act(conv2d(cat([x, x2], 1), w), b)`` for a 1x1 weight in one launch over the two tensors; the backward is assembled from the
+    stand-alone differentiable pieces -- the two input gradients are two pointwise launches on the weight's channel slices (two
+    contiguous tensors, where the concatenation's backward hands out channel slices of one), the weight gradient two launches whose
+    results are concatenated (a few hundred KB)."""
+    @staticmethod
+    def forward(ctx, x, x2, w, b, wgain, act_cfg):
+        act, alpha, gain, clamp = act_cfg
+        from . import bias_act as ba
+        cfg = _Cfg((False, 1, 0, 0, 0, 0, 1, float(wgain)))
+        y = _launch_conv(x, w, cfg, epilogue=(b, ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, None), x2=x2)
+        keep_y = act != 'linear' or clamp >= 0
+        ctx.save_for_backward(x, x2, w, b, y if keep_y else None)
+        ctx.cfg, ctx.act_cfg = cfg, act_cfg
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import bias_act as ba
+        x, x2, w, b, y = ctx.saved_tensors
+        act, alpha, gain, clamp = ctx.act_cfg
+        cfg = ctx.cfg
+        dz = dy
+        dx = dx2 = dw = db = None
+        want_db = b is not None and ctx.needs_input_grad[3]
+        if act != 'linear' or gain != 1 or clamp >= 0:
+            if want_db:
+                dz, db = ba.grad_with_bias_grad(dy.contiguous(), y, (1, act, alpha, gain, clamp))
+            else:
+                dz = ba._BiasActHipGrad.apply(dy.contiguous(), None, None, y, (1, act, alpha, gain, clamp))
+        c1 = x.shape[1]
+        gcfg = _grad_cfg(cfg, x.shape[2:], dz.shape[2:], 1, 1)
+        if ctx.needs_input_grad[0]:
+            dx = _ConvHip.apply(dz, w[:, :c1], gcfg)
+        if ctx.needs_input_grad[1]:
+            dx2 = _ConvHip.apply(dz, w[:, c1:], gcfg)
+        if ctx.needs_input_grad[2] and not weight_gradients_disabled:
+            dw = torch.cat([_ConvWgradHip.apply(dz, x, cfg, (w.shape[0], c1, 1, 1), w.dtype),
+                            _ConvWgradHip.apply(dz, x2, cfg, (w.shape[0], w.shape[1] - c1, 1, 1), w.dtype)], dim=1)
+        if want_db and db is None:
+            db = ba._BiasSum.apply(dz, 1)
+        return dx, dx2, dw, db, None, None
+
+def conv2d_cat1x1_bias_act(x, x2, weight, bias=None, act='linear', alpha=None, gain=None, clamp=None, wgain=1.0):
+    """``bias_act(conv2d(torch.cat([x, x2], 1), weight), bias, ...)`` for a 1x1 ``weight`` without the concatenated tensor
+    (``cat1x1_available`` says whether the one-launch form exists for these shapes; otherwise the concatenation is formed)."""
+    from . import bias_act as ba
+    spec = ba.activation_funcs[act]
+    alpha = float(alpha if alpha is not None else spec.def_alpha)
+    gain = float(gain if gain is not None else spec.def_gain)
+    clampf = float(clamp if clamp is not None else -1)
+    if act in FUSABLE_ACTS and cat1x1_available(x, x2, weight):
+        return _CatConv1x1BiasActHip.apply(x, x2, weight, bias, float(wgain), (act, alpha, gain, clampf))
+    return conv2d_bias_act(torch.cat([x, x2], dim=1), weight, bias, act=act, alpha=alpha, gain=gain, clamp=clamp, wgain=wgain)
 
 def conv2d_bias_act(input, weight, bias=None, stride=1, padding=0, groups=1, act='linear', alpha=None, gain=None, clamp=None, wgain=1.0,
                     residual=None):

@@ -802,6 +802,22 @@ class Spade_ResBlockV2(torch.nn.Module):
         x = self._norm_then_conv(self.spade1, self.conv1, x, denorm_feat, half)
         return shortcut.add_(x)
 
+_MERGE_FUSED = _os.environ.get('PASTA_MERGE_FUSED', '1') != '0'         # A/B switch: 0 = torch.cat + one 1x1 convolution, as the reference
+
+def _merge_without_cat(layer, x, side):
+    """``layer(torch.cat([x, side], 1))`` for a 1x1 ``Conv2dLayer`` (networks.py:5698-5700) without the concatenated tensor: the
+    pointwise convolution kernel walks its K loop over the channels of ``x`` and then of ``side`` (conv2d_gradfix.conv2d_cat1x1_bias_act).
+    Against the concatenation: no 2 x 537 MB pass at 256 x 256 per call, no scan of the concatenated tensor for the operand scale, and
+    the two input gradients come back as two contiguous tensors instead of channel slices of one.  (Measured and dropped, round 4,
+    profiles/r4_ab_merge_split.txt: the same through linearity with the existing kernels -- conv(side, w[:, C:]) as the residual of
+    conv(x, w[:, :C]) -- was 0.4 ms per step SLOWER than the concatenation: two 64-row one-tap launches cost more than the copy.)"""
+    if (_MERGE_FUSED and layer.up == 1 and layer.down == 1 and layer.activation in conv2d_gradfix.FUSABLE_ACTS
+            and conv2d_gradfix.cat1x1_available(x, side, layer.weight)):
+        act_gain, act_clamp = _scaled_act(layer.activation, 1, layer.conv_clamp)
+        return conv2d_gradfix.conv2d_cat1x1_bias_act(x, side, _master_weight(layer.weight, x), None if layer.bias is None else layer.bias.to(x.dtype),
+                                                     act=layer.activation, gain=act_gain, clamp=act_clamp, wgain=layer.weight_gain)
+    return layer(torch.cat([x, side], dim=1))
+
 #----------------------------------------------------------------------------
 # Full-body generator: pose-seeded style pyramid, parsing-routed SPADE stage, texture block.
 
@@ -862,7 +878,7 @@ class _PoseStyleBlock(torch.nn.Module):
                 x = self.conv1(self.conv0(x, latents.pop(0), **styled), latents.pop(0), **styled)
                 if x.shape[2] > 16:
                     side = cat_feat[str(x.shape[2])].to(dtype=dtype, memory_format=memory_format)
-                    x = self.merge_conv(torch.cat([x, side], dim=1))
+                    x = _merge_without_cat(self.merge_conv, x, side)
 
         extras = (None,) * self.extra_outputs
         if img is not None:

@@ -42,3 +42,15 @@ def rel_err(a, b):
     b = torch.as_tensor(b).detach().to(torch.float64).cpu()
     assert a.shape == b.shape, (a.shape, b.shape)
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture(params=['f16x3', 'bf16x6'])
+def arith(request):
+    """Runs a parity test under the default three-product fp16 arithmetic AND under the six-product split-bf16 one, which stays
+    held to the bounds it met before the default changed: a test takes ``arith`` and chooses its bound by it."""
+    from torch_utils.ops import conv2d_gradfix
+    old, conv2d_gradfix.conv_math = conv2d_gradfix.conv_math, request.param
+    try:
+        yield request.param
+    finally:
+        conv2d_gradfix.conv_math = old

@@ -103,7 +103,7 @@ def test_oracle_discriminator_at_full_width():
     _gradnorms_ok(g, 'D.gradnorms', grads, 3 * TOL_GRAD)
 
 
-def _r1_check(g, logits, gx, pen, grads, tol_fwd, tol_grad):
+def _r1_check(g, logits, gx, pen, grads, tol_fwd, tol_grad, sample_slack=2):
     """Dreg phase against models_fullwidth_r1.npz: every parameter gradient here is a SECOND derivative (the loss is the R1
     term alone), |d logit / d img| ~ 1e-4 and the penalty ~ 7e-5: nothing degenerate."""
     from oracle import make_golden_fullwidth_r1 as R1
@@ -115,7 +115,7 @@ def _r1_check(g, logits, gx, pen, grads, tol_fwd, tol_grad):
     # MFMA 5.3e-4, fp16 x 3 1.05e-3 from the reference -- three fp32-class arithmetics, three sets of flipped slopes; any two differ
     # by 4e-3 at isolated pixels of the full tensor) while its L1 / L2 moments and the penalty -- where isolated pixels average
     # out -- meet the forward tolerance (measured 4e-6, 1.2e-5)
-    _summary_ok(g, 'Dr1.r1_grads', gx, 2 * tol_grad, R1.SAMPLES)
+    _summary_ok(g, 'Dr1.r1_grads', gx, sample_slack * tol_grad, R1.SAMPLES)
     m, mg = PF.summarize(gx, samples=R1.SAMPLES)['moments'], g['Dr1.r1_grads.moments']
     assert abs(m[1] - mg[1]) <= tol_fwd * abs(mg[1]) and abs(m[2] - mg[2]) <= tol_fwd * abs(mg[2])
     assert rel_err(pen, g['Dr1.r1_penalty']) < tol_fwd
@@ -212,7 +212,7 @@ def test_hip_discriminator_with_r1_at_full_width():
 
 
 @pytest.mark.gpu
-def test_hip_discriminator_r1_phase_at_full_width():
+def test_hip_discriminator_r1_phase_at_full_width(arith):
     """The Dreg phase exactly as the loss runs it (loss_wo_flow_fullbody.py:236-254: r1_grads under no_weight_gradients,
     then backward through them): weight gradients of the input-gradient convolutions at 512 / 256 / 128 / 64 channels."""
     from oracle import make_golden_fullwidth_r1 as R1
@@ -229,7 +229,8 @@ def test_hip_discriminator_r1_phase_at_full_width():
         gx, = torch.autograd.grad(outputs=[logits.sum()], inputs=[x], create_graph=True, only_inputs=True)
     pen = gx.square().sum([1, 2, 3])
     ((logits * 0 + pen * (R1.R1_GAMMA / 2)).mean() * R1.GAIN).backward()
-    _r1_check(g, logits, gx, pen, {k: sd[k].grad for k in names}, TOL_FWD, TOL_GRAD)
+    # split-bf16 (2.8e-4 measured) keeps the plain gradient tolerance on single samples of d logit / d img; the default gets the 2x of _r1_check
+    _r1_check(g, logits, gx, pen, {k: sd[k].grad for k in names}, TOL_FWD, TOL_GRAD, sample_slack=2 if arith == 'f16x3' else 1)
 
 
 @pytest.mark.gpu

@@ -67,7 +67,7 @@ def test_modulated_conv2d_golden(idx, fused):
     assert rel_err(dx, g[tag + '.dx']) < 1e-5 and rel_err(dw, g[tag + '.dw']) < 2e-5 and rel_err(ds, g[tag + '.ds']) < 2e-5
 
 
-def test_generator_full_golden():
+def test_generator_full_golden(arith):
     from training import networks
     g = load_golden('models_fullbody.npz')
     g64 = load_golden('models_fullbody_f64.npz')
@@ -84,7 +84,9 @@ def test_generator_full_golden():
     probe.backward()
     sd = dict(G.named_parameters())
     errs = [_grad_ok(g, g64, 'G.grad.' + k, sd[k].grad, TOL_GRAD) for k in GRAD_KEYS_G]
-    assert sum(e32 < TOL_GRAD for e32, _ in errs) >= len(errs) - 1          # at most one key needs the fp64 evaluation
+    # at most one key needs the fp64 evaluation, under either arithmetic (synthesis.b64.conv0.affine.weight: split-bf16 1.5e-3 and the
+    # three-product default 1.3e-3 from the reference's fp32 value, which is itself 1.25e-3 from the reference's fp64 value)
+    assert sum(e32 < TOL_GRAD for e32, _ in errs) >= len(errs) - 1, (arith, errs)
     G.eval()
     with torch.no_grad():
         img_e, fin_e, _ = G(*args, noise_mode='const')

@@ -68,7 +68,7 @@ def test_loss_terms_and_gradients(phase):
     assert np.median(np.abs(norms[big] / ref[big] - 1)) < 1e-4
 
 
-def test_two_iterations_of_the_loop():
+def test_two_iterations_of_the_loop(arith):
     from training.training_loop_wo_flow_fullbody import TrainingStep, fashion_config
 
     class Batch:                                   # TrainingStep only needs split()
@@ -102,9 +102,10 @@ def test_two_iterations_of_the_loop():
             size = abs(np.abs(ours).mean() / np.abs(ref).mean() - 1)
             print(f'{tag} {k}: cosine {cos:.4f}, size {size:.4f}')
             assert cos > 0.98, (tag, k, cos)
-            # 3 %: measured worst key (style_encoding.fc.weight, whose gradient is instance-norm cancellation residue, so many of its
-            # elements step by +-lr on rounding noise) 0.6 % fp32 MFMA, 1.9 % split-bf16, 2.7 % fp16 x 3 (gpurun_out/r3_two_it.log)
-            assert size < 0.03, (tag, k, size)
+            # measured worst key (style_encoding.fc.weight, whose gradient is instance-norm cancellation residue, so many of its
+            # elements step by +-lr on rounding noise) 0.6 % fp32 MFMA, 1.9 % split-bf16, 2.7 % fp16 x 3 (profiles/r3_two_iterations_by_arithmetic.txt):
+            # split-bf16 stays at the 2 % it met before the default changed, the three-product default is given 3 %
+            assert size < (0.03 if arith == 'f16x3' else 0.02), (tag, k, size, arith)
 
     check('b.G', dict(step.G.named_parameters()), init_G, DELTA_KEYS_G)
     check('b.D', dict(step.D.named_parameters()), init_D, DELTA_KEYS_D)
@@ -120,7 +121,7 @@ def test_two_iterations_of_the_loop():
     assert 0 < d_ema < 0.01 * d_live
 
 
-def test_merged_discriminator_pass_equals_separate_passes():
+def test_merged_discriminator_pass_equals_separate_passes(arith):
     """run_D_multi: one discriminator pass over several image batches, stacked so that every minibatch-std group stays
     inside its own batch, returns the logits (and, through them, the gradients) of the separate passes."""
     from training import networks
@@ -147,13 +148,15 @@ def test_merged_discriminator_pass_equals_separate_passes():
         # two differ by 3e-6 .. 1e-5 of their maximum -- unless a leaky-ReLU pre-activation within rounding of zero takes the other
         # slope in one of the two passes.  One such flip changes ONE sample's gradient, by as much as the unit's share of it:
         # measured 1.4e-4 (split-bf16, a 32x32-layer unit), 1.2e-5 (fp32 MFMA), 2.9e-2 (fp16 x 3, an 8x8-layer unit carrying the
-        # sample's largest gradient; tools/diag_f16x3_b.py traces it).  So: every sample within 3e-4 except at most one per
-        # batch of 24, and that one within 10 %.
+        # sample's largest gradient; tools/diag_f16x3_b.py traces it).  Over six input seeds no arithmetic is the one that flips more
+        # (profiles/r4_arith_seeds.txt: single samples of d logit / d img are 4.6e-3 / 2.8e-4 / 1.2e-3 off at their worst seed for
+        # fp16 x 3 / split-bf16 / fp32 MFMA).  So: split-bf16 keeps the bound it met before the default changed -- every sample within
+        # 3e-4 -- and the three-product default may have ONE sample per batch of 24 beyond it, within 10 %.
         pm = a.abs().amax(dim=[1, 2, 3]).clamp_min(1e-300)
         per_sample = ((b - a).abs().amax(dim=[1, 2, 3]) / pm).cpu()
-        assert float(per_sample.max()) < 0.1, per_sample
+        assert float(per_sample.max()) < (0.1 if arith == 'f16x3' else 3e-4), (arith, per_sample)
         flipped += int((per_sample >= 3e-4).sum())
-    assert flipped <= 1, flipped
+    assert flipped <= (1 if arith == 'f16x3' else 0), (arith, flipped)
 
 
 def test_ada_controller_moves_p_like_the_reference():
