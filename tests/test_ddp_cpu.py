@@ -128,17 +128,21 @@ def test_data_parallel_step_world_size_2(ddp_mode):
         assert msg == 'ok', f'rank {rank}: {msg}'
 
 
-def test_flat_reducer_refuses_a_gradient_after_its_bucket_left():
+def test_flat_reducer_refuses_a_gradient_after_its_bucket_left(tmp_path):
     """arm() told one backward pass, the loss makes two -> the second pass's gradients would be added to a
-    bucket that is already on the wire (pre-scaled).  The reducer must raise, not diverge silently."""
+    bucket that is already on the wire (pre-scaled).  Where an exchange happens the reducer must raise, not diverge silently;
+    where none happens (one rank, no forced collective) a late gradient is harmless and is accepted, and a
+    backward pass after finish() -- outside the begin / arm / finish protocol -- is not "late"."""
+    import torch.distributed as dist
     for p in (PKG, ROOT):
         if p not in sys.path:
             sys.path.insert(0, p)
     from training.grad_reducer import FlatGradReducer
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 4))
-    red = FlatGradReducer(net, world_size=1)
     x = torch.randn(3, 8)
+    # one rank, no exchange: nothing to protect
+    red = FlatGradReducer(net, world_size=1)
     red.begin()
     red.arm(2)
     net(x).sum().backward()
@@ -148,6 +152,23 @@ def test_flat_reducer_refuses_a_gradient_after_its_bucket_left():
     red.begin()
     red.arm(1)
     net(x).sum().backward()
-    with pytest.raises(RuntimeError, match='after its bucket was sent'):
-        net(x).sum().backward()
+    once = net[0].weight.grad.clone()
+    net(x).sum().backward()           # a second pass nobody announced: accumulated like any gradient
+    assert torch.allclose(net[0].weight.grad, 2 * once)
+    red.finish()
+    net(x).sum().backward()           # after the phase: not the reducer's business
     red.remove()
+    # the same with the collective in force (one-rank gloo group): the late gradient raises
+    dist.init_process_group('gloo', init_method='file://' + str(tmp_path / 'store'), rank=0, world_size=1)
+    try:
+        red = FlatGradReducer(net, world_size=1, force_collective=True)
+        red.begin()
+        red.arm(1)
+        net(x).sum().backward()
+        with pytest.raises(RuntimeError, match='after its bucket was sent'):
+            net(x).sum().backward()
+        red.finish()
+        net(x).sum().backward()       # launched flags are cleared when the phase ends
+        red.remove()
+    finally:
+        dist.destroy_process_group()
