@@ -88,7 +88,8 @@ class ConvMeter:
                       4: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,128,4,{_np()},{STORAGE_IO},false,256>'}, 5: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,128,2,{_np()},{STORAGE_IO},false,256>'},
                       6: {1: f'conv_fwd_rows2d_bf16x6_kernel<64,256,8,{_np()},{STORAGE_IO},false,256>'},
                       7: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,256,8,{_np()},0,false,512>'},
-                      9: {0: 'conv1x1_f16x3_kernel<128,128>', 1: 'conv1x1_f16x3_kernel<64,256>'}}[kernel.value][tile.value]     # <BM, BN, rows per tile, pieces, storage, input scale, threads>
+                      9: {0: 'conv1x1_f16x3_kernel<128,128>', 1: 'conv1x1_f16x3_kernel<64,256>'},
+                      10: {0: 'conv3x3s2_f16x3_kernel<128>', 1: 'conv3x3s2_f16x3_kernel<64>'}}[kernel.value][tile.value]     # <BM, BN, rows per tile, pieces, storage, input scale, threads>
             if isc and kernel.value != 0:       # the instance with the input scale: same family, another template argument (rocprofv3 names)
                 family = {1: family.replace(',3,3,0,false,false>', ',2,3,0,true,false>').replace(',3,4,0,false,false>', ',2,4,0,true,false>'), 2: family.replace(',false,false>', ',true,false>')}.get(
                     kernel.value, family.replace(',false,256>', ',true,256>'))

@@ -195,7 +195,9 @@ int pasta_conv2d_tile(const pasta_conv_desc* d);
  * K runs over the pairs; the workspace then also holds the offset table and a zero-padded copy of the input, and two small
  * kernels fill them), 9 conv1x1_f16x3_kernel (round 4: 1x1 stride-1 convolutions and their input gradients under PASTA_MATH_F16X3, fp32 tensors,
  * >= 16 input and > 32 output channels, planes of a multiple of 128 / 256 pixels: 16-byte loads along the pixels, 32 channels per barrier pair,
- * optionally over two input tensors -- pasta_conv_desc.x2).  Any out pointer may be NULL. */
+ * optionally over two input tensors -- pasta_conv_desc.x2), 10 conv3x3s2_f16x3_kernel (round 4: 3x3 stride-2 conv2d with pads 0 / 1 under PASTA_MATH_F16X3,
+ * fp32 tensors, >= 16 input and > 32 output channels, output widths 16 .. 128 .. that are powers of two: a round stages the input ROW segments of a kernel
+ * row once, de-interleaved by pixel parity, for its three taps).  Any out pointer may be NULL. */
 #define PASTA_PLAN_ISCALE   1
 #define PASTA_PLAN_OSCALE   2
 #define PASTA_PLAN_EPILOGUE 4

@@ -31,6 +31,7 @@
 #include "conv_fwd_bf16x6.h"
 #include "conv_fwd_rows2d_bf16x6.h"
 #include "conv_fwd_1x1.h"
+#include "conv_fwd_s2.h"
 #include "conv_wgrad_f32.h"
 #include "conv_wgrad_bf16x6.h"
 
@@ -317,7 +318,11 @@ extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int launch_flags, int
         const bool c1x1 = c1x1_on && sb && math_pieces(d->math) == NP_F16X3 && d->io_dtype == PASTA_F32 && d->groups == 1 && d->kh == 1 && d->kw == 1 && d->stride == 1 &&
                           !d->pad_h && !d->pad_w && !(launch_flags & (PASTA_PLAN_ISCALE | PASTA_PLAN_OSCALE)) && f.ksplit == 1 && !packed && d->C_in >= 16 &&
                           d->C_out > 32 && d->OH == d->H && d->OW == d->W && ((int64_t)d->H * d->W) % bn1 == 0;
-        *kernel = !sb ? 0 : c1x1 ? 9 : packed ? 8 : pair ? 3 : wide ? 7 : rows2d ? (rows2d_rows(d->OH, d->OW) == 4 ? 4 : 5) : rows2d_256 ? 6 : rows ? 2 : 1;
+        static const bool s2_on = !(getenv("PASTA_CONV_S2") && getenv("PASTA_CONV_S2")[0] == '0');
+        const bool s2k = s2_on && sb && !d->transposed && math_pieces(d->math) == NP_F16X3 && d->io_dtype == PASTA_F32 && d->groups == 1 && d->kh == 3 && d->kw == 3 &&
+                         d->stride == 2 && d->pad_h == d->pad_w && d->pad_h <= 1 && !(launch_flags & (PASTA_PLAN_ISCALE | PASTA_PLAN_OSCALE)) && f.ksplit == 1 && !packed &&
+                         d->C_in >= 16 && d->C_out > 32 && conv3x3s2_shape_ok(d->OH, d->OW);
+        *kernel = !sb ? 0 : c1x1 ? 9 : s2k ? 10 : packed ? 8 : pair ? 3 : wide ? 7 : rows2d ? (rows2d_rows(d->OH, d->OW) == 4 ? 4 : 5) : rows2d_256 ? 6 : rows ? 2 : 1;
     }
     return 0;
 }
@@ -669,6 +674,10 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
                 p.tap_dy[t] = r - d->pad_h; p.tap_dx[t] = c - d->pad_w; p.tap_slab[t] = t;
             }
         p.ncls = 1; p.cls[0] = {p.P, p.Q, 0, 0, p.T, 0};
+        if (conv3x3s2_ok(p, d->kh, d->kw, d->stride, d->pad_h, d->pad_w, d->transposed)) {
+            launch_conv3x3s2(p, s);
+            return launch_status("conv2d");
+        }
         detect_tap_rows(p, p.T);
         dispatch_fwd(tile, p, s);
     } else {

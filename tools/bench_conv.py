@@ -17,6 +17,9 @@ SHAPES = [  # name, N, Cin, H, Cout, k, stride, transposed
     ('b256 64->64 3x3 @256', 16, 64, 256, 64, 3, 1, False),
     ('down 64->128 3x3 s2 @257 p0', 16, 64, 257, 128, 3, 2, False, 0),      # discriminator: blur to 257, then stride 2 without padding
     ('enc 64->128 3x3 s2 @256 p1', 16, 64, 256, 128, 3, 2, False),
+    ('down 128->256 3x3 s2 @129 p0', 16, 128, 129, 256, 3, 2, False, 0),
+    ('down 256->512 3x3 s2 @65 p0', 16, 256, 65, 512, 3, 2, False, 0),
+    ('down 64->128 3x3 s2 @257 p0 x48', 48, 64, 257, 128, 3, 2, False, 0),
     ('b64 256->256 3x3 @64', 16, 256, 64, 256, 3, 1, False),
     ('b32 512->512 3x3 @32', 16, 512, 32, 512, 3, 1, False),
     ('b16 512->512 3x3 @16', 16, 512, 16, 512, 3, 1, False),
@@ -27,6 +30,10 @@ SHAPES = [  # name, N, Cin, H, Cout, k, stride, transposed
     ('up 256->128 3x3 T2 @64', 16, 256, 64, 128, 3, 2, True),
     ('up 512->256 3x3 T2 @32', 16, 512, 32, 256, 3, 2, True),
     ('merge 192->128 1x1 @128', 16, 192, 128, 128, 1, 1, False),
+    ('merge 128->64 1x1 @256', 16, 128, 256, 64, 1, 1, False),
+    ('skip 64->64 1x1 @256', 16, 64, 256, 64, 1, 1, False),
+    ('skip 128->128 1x1 @128', 16, 128, 128, 128, 1, 1, False),
+    ('merge 320->256 1x1 @64', 16, 320, 64, 256, 1, 1, False),
     ('skip 64->128 1x1 @128', 16, 64, 128, 128, 1, 1, False),
     ('torgb 64->3 1x1 @256', 16, 64, 256, 3, 1, 1, False),
     ('stem 3->64 7x7 @256', 16, 3, 256, 64, 7, 1, False),
