@@ -279,12 +279,40 @@ def run_infer(args, device):
     meter.enabled = conv.enabled = False
     upfirdn2d.launch_hook = conv2d_gradfix.launch_hook = None
     assert all(torch.isfinite(t).all() for t in out[:2])
+    graph_line = None
+    if args.graph:
+        # the same forward captured once as a hipGraph and replayed -- what the host's launch work is worth here.
+        # Everything the forward allocates comes from torch's capture pool; the rows of producer-side maxima are zeroed INSIDE the graph
+        # (torch_utils/ops/_native.py, amax_slot), so a replay starts from the same state as an eager call.
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()                                  # once on the capture stream (lazy initialisations, caches)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                gout = step()
+            g.replay(); torch.cuda.synchronize()
+            same = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(gout[:2], out[:2]))
+            tg = time.perf_counter()
+            for _ in range(args.steps):
+                g.replay()
+            torch.cuda.synchronize()
+            tg = time.perf_counter() - tg
+            graph_line = {'value': round(args.steps * batch / tg, 2), 'unit': 'images/sec', 'ms_per_step': round(1000 * tg / args.steps, 2),
+                          'max_rel_difference_from_eager': same, 'note': 'the timed eager forward captured once (torch.cuda.CUDAGraph = hipGraph) and replayed'}
+        except Exception as e:  # noqa: BLE001  (a measurement, never the headline: report why it could not be taken)
+            graph_line = {'error': f'{type(e).__name__}: {e}'[:400]}
     line = {'metric': f'generator inference images/sec at {res}x{res * 5 // 8 if res == 512 else 192} (tensor {res}x{res}), batch {batch}', 'value': round(args.steps * batch / dt, 2),
             'unit': 'images/sec', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000 * dt / args.steps, 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'conv_math': conv2d_gradfix.conv_math, 'data': 'synthetic',
             'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
             'config': {'workload': f'BASELINE config 4: generator inference, eval mode, per-sample modulated weights (grouped convolution, groups = batch), '
                                    f'noise_mode const, cfg=fashion widths, random-init weights; {cls_note}', 'global_batch': batch, 'parallelism': 'dp1 (single process)'}}
+    if graph_line is not None:
+        line['hipgraph_replay'] = graph_line
     tab = meter.table()
     if tab:
         nbytes, ms = sum(v[2] for v in tab.values()), sum(v[1] for v in tab.values())
@@ -390,6 +418,7 @@ def main():
     ap.add_argument('--no-variants', action='store_true', help='skip the two reduced-precision side measurements (fp16 discriminator blocks as in '
                     'the reference train script; bf16 activation storage = BASELINE config 5) that a default single-GPU run appends as `also_measured`')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='--mode infer: also capture the forward as a hipGraph and time its replay (reported as hipgraph_replay)')
     ap.add_argument('--no-meter', action='store_true', help='do not bracket convolution launches with events')
     ap.add_argument('--by-shape', action='store_true', help='also print a per-shape convolution table to stderr')
     ap.add_argument('--by-shape-top', type=int, default=40, help='rows of that table')

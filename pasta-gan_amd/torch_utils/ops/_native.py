@@ -58,6 +58,9 @@ def amax_slot(like):
         return None
     if conv2d_gradfix.conv_math not in ('default', 'f16x3') or like.dtype != torch.float32 or like.device.type != 'cuda':
         return None
+    if torch.cuda.is_current_stream_capturing():
+        # under hipGraph capture the row must be zeroed by a node of the graph itself: a replay reuses the same memory, and maxima only grow
+        return torch.zeros([256], dtype=torch.float32, device=like.device)
     pool = _amax_pools.get(like.device)
     if pool is None or pool[1] >= _AMAX_ROWS:
         pool = [torch.zeros([_AMAX_ROWS, 256], dtype=torch.float32, device=like.device), 0]      # one fill per 1024 tensors
