@@ -29,6 +29,9 @@ namespace pasta {
 // tile (four weight buffers; the weights of the next pair fetched when a pair begins, stored when it ends; 246 VGPRs): 2 % SLOWER
 // on every live shape (248 / 304 / 318 / 324 against 255 / 310 / 325 / 328 TFLOP/s) although 34 % of the wave cycles are parked
 // at s_waitcnt / s_barrier -- the barrier count is not what parks them.
+// Measured and dropped (round 4, profiles/r4_ab_fragment_prefetch.txt; "ab" = without): the ACTIVATION fragments of tap S + 1 read at the end of
+// step S, in front of the barrier (the B image of a chunk is complete when the chunk begins), so that only the six weight-fragment reads stand
+// between the barrier and the first MFMA group: 327.0 -> 324.4 TFLOP/s in the training step, 316.5 -> 313.7 on 256 -> 128 at 128 x 128: 0.8 % SLOWER.
 // Also measured and dropped (round 3, profiles/r3_ab_wave128.txt, r3_ab_rows2d_pipe*.txt, r3_pipe_ablation.txt; the kernel is kept, out of
 // the build; deleted in round 4, last in commit 7b449f3 as tools/experiments/conv_fwd_rows2d_pipe.h): FOUR waves of 64 x 128 outputs on the same tile (14 fragment reads per
 // 24 MFMAs instead of 10 per 12), one wave per SIMD -- equal to the eight waves within 2 % on every shape, with or without the fragments of

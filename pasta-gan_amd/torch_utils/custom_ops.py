@@ -193,6 +193,8 @@ def get_plugin(module_name='pasta_hip', sources=None, **build_kwargs):
         if module_name in _cached_plugins:
             return _cached_plugins[module_name]
         lib_path = build(**build_kwargs)
+        # same-box A/B of two builds (tools/ab_lib.sh): PASTA_LIB_AB names another library built from THIS tree with other compile flags
+        lib_path = os.environ.get('PASTA_LIB_AB') or lib_path
         lib = ctypes.CDLL(lib_path)
         for name, (restype, argtypes) in ABI.items():
             fn = getattr(lib, name)       # AttributeError here = header/library mismatch
