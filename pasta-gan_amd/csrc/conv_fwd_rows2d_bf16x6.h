@@ -32,6 +32,9 @@ namespace pasta {
 // Measured and dropped (round 4, profiles/r4_ab_fragment_prefetch.txt; "ab" = without): the ACTIVATION fragments of tap S + 1 read at the end of
 // step S, in front of the barrier (the B image of a chunk is complete when the chunk begins), so that only the six weight-fragment reads stand
 // between the barrier and the first MFMA group: 327.0 -> 324.4 TFLOP/s in the training step, 316.5 -> 313.7 on 256 -> 128 at 128 x 128: 0.8 % SLOWER.
+// Measured and dropped (round 4, profiles/r4_ab_rows2d_64x256_eight_waves.txt): EIGHT waves of 32 rows x 64 pixels on the 64 x 256 tile (1.33 staging units
+// per thread and chunk instead of 2.66; 168 VGPRs, one workgroup per CU): 64 -> 64 at 256 x 256 0.400 -> 0.460 ms forward, 0.360 -> 0.431 ms input gradient,
+// step 153.2 -> 155.2 ms -- a B fragment then serves one MFMA instead of two, and one workgroup per CU leaves nothing to overlap with.
 // Also measured and dropped (round 3, profiles/r3_ab_wave128.txt, r3_ab_rows2d_pipe*.txt, r3_pipe_ablation.txt; the kernel is kept, out of
 // the build; deleted in round 4, last in commit 7b449f3 as tools/experiments/conv_fwd_rows2d_pipe.h): FOUR waves of 64 x 128 outputs on the same tile (14 fragment reads per
 // 24 MFMAs instead of 10 per 12), one wave per SIMD -- equal to the eight waves within 2 % on every shape, with or without the fragments of
