@@ -49,7 +49,7 @@ def bf16x6_pair_names():    # stride-2 conv_transpose2d on the row-reuse kernel'
 
 TILE_NAMES = {0: 'conv_fwd_kernel<128,128,2,2,8,4>', 1: 'conv_fwd_kernel<64,256,2,2,8,4>',
               2: 'conv_fwd_kernel<32,256,1,2,8>', 3: 'conv_fwd_kernel<64,64,1,1,8>'}
-WGRAD_NAMES = {0: 'conv_wgrad_kernel', 1: 'conv_wgrad_smallcin_kernel', 2: 'conv_wgrad3x3_bf16x6_kernel', 3: 'conv_wgrad3x3s2_bf16x6_kernel', 4: 'conv_wgrad1x1_bf16x6_kernel'}
+WGRAD_NAMES = {0: 'conv_wgrad_kernel', 1: 'conv_wgrad_smallcin_kernel', 2: 'conv_wgrad3x3_bf16x6_kernel', 3: 'conv_wgrad3x3s2_bf16x6_kernel', 4: 'conv_wgrad1x1_bf16x6_kernel', 5: 'wgrad1x1_fewcin_kernel'}
 
 
 class ConvMeter:

@@ -767,7 +767,8 @@ extern "C" int pasta_conv2d_wgrad_plan(const pasta_conv_desc* d, int* kernel) {
     if (int e = check_desc(d, "conv2d_wgrad_plan")) return e;
     const int Ig = d->C_in / d->groups, Og = d->C_out / d->groups;
     int k = 0;
-    if (plan_wgrad_small(d).use) k = 1;
+    if (plan_wgrad1x1_fewcin(d, plan_wgrad_small(d))) k = 5;
+    else if (plan_wgrad_small(d).use) k = 1;
     else {
         const WgradPlan w = d->transposed ? plan_wgrad(d->N, d->H, d->W, d->groups, Ig, Og, d->kh, d->kw, d->stride)
                                           : plan_wgrad(d->N, d->OH, d->OW, d->groups, Og, Ig, d->kh, d->kw, d->stride);
@@ -808,6 +809,20 @@ extern "C" int pasta_conv2d_wgrad(const void* xv, const void* dyv, float* dw, co
 
     const WgradSmallPlan ws = plan_wgrad_small(d);
     PASTA_CHECK(d->io_dtype == PASTA_F32 || !ws.use, "conv2d_wgrad: no 16-bit-storage kernel for this shape (pasta_conv2d_wgrad_plan tells beforehand)");
+    if (const int fks = plan_wgrad1x1_fewcin(d, ws)) {
+        // few input channels, 1x1: one bandwidth-bound pass over dy with plain FMAs (conv_wgrad_f32.h)
+        const int64_t total = (int64_t)d->N * ((int64_t)d->H * d->W / 4);
+        const int64_t per = (total + fks - 1) / fks;
+        const int a_pad = ws.a_tiles * 64, bpad = ws.nb * 32;
+        const dim3 grid((unsigned)fks, (unsigned)((d->C_out + 7) / 8));
+#define PASTA_FEW(CI_) case CI_: hipLaunchKernelGGL((wgrad1x1_fewcin_kernel<CI_>), grid, dim3(256), 0, s, dy, x, (float*)workspace, d->N, d->C_out, d->H * d->W, per, a_pad, bpad); break;
+        switch (d->C_in) { PASTA_FEW(1) PASTA_FEW(2) PASTA_FEW(3) PASTA_FEW(4) PASTA_FEW(5) PASTA_FEW(6) PASTA_FEW(7) PASTA_FEW(8) }
+#undef PASTA_FEW
+        const int totw = d->C_out * ws.bprime;
+        hipLaunchKernelGGL(wgrad_smallcin_reduce_kernel, dim3((unsigned)((totw + 255) / 256)), dim3(256), 0, s, (const float*)workspace, dw,
+                           fks, d->C_out, ws.bprime, a_pad, bpad, d->wscale == 0.f ? 1.f : d->wscale);
+        return launch_status("conv2d_wgrad(few-channel 1x1)");
+    }
     if (ws.use) {
         WgradSmallParams q;
         q.S = dy; q.L = x; q.slab = (float*)workspace;

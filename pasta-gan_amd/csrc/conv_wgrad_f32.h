@@ -416,5 +416,76 @@ static WgradSmallPlan plan_wgrad_small(const pasta_conv_desc* d) {
     return w;
 }
 
+//------------------------------------------------------------------------------------
+// Pointwise weight gradient with very few input channels (round 4: the discriminator's fromrgb, 3 -> 64 over 48 stacked images, the pose /
+// parsing stems): dW[o][i] = sum_{n, pixel} dy[n, o, pixel] x[n, i, pixel] is ONE pass over dy (805 MB for the fromrgb layer) and 3 .. 8
+// multiply-adds per element -- bandwidth-bound, and the (channel, tap)-pair MFMA kernel above, built for 7 x 7 x 3 = 147 columns, runs it at
+// 1.3 TB/s with three of 32 columns filled (0.67 ms; profiles/r4_byshape_classes.txt).  Here: plain fp32 FMAs; a thread takes four
+// consecutive pixels (16-byte loads) of eight output channels and all CI input channels per trip -- CI + 8 loads in flight -- and keeps
+// 8 x CI sums; a workgroup walks one K slice (pixel quads of the whole batch) for one group of eight output channels; sums are combined by
+// wave shuffles and a fixed-order pass over the four waves (bitwise reproducible) and land in the slab layout of the kernel above, whose
+// reduction kernel finishes the job.
+template <int CI>
+__global__ __launch_bounds__(256) void wgrad1x1_fewcin_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ slab,
+                                                              int N, int Co, int HW, int64_t quads_per_slice, int a_pad, int bpad) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int og = blockIdx.y * 8;
+    const int hwq = HW >> 2;
+    const int64_t total = (int64_t)N * hwq;
+    const int64_t q0 = (int64_t)blockIdx.x * quads_per_slice;
+    const int64_t q1 = q0 + quads_per_slice < total ? q0 + quads_per_slice : total;
+    float acc[8][CI];
+#pragma unroll
+    for (int o = 0; o < 8; o++)
+#pragma unroll
+        for (int i = 0; i < CI; i++) acc[o][i] = 0.f;
+    for (int64_t q = q0 + tid; q < q1; q += 256) {
+        const int n = (int)(q / hwq);
+        const int off = (int)(q - (int64_t)n * hwq) * 4;
+        float4 xv[CI], dv[8];
+#pragma unroll
+        for (int i = 0; i < CI; i++) xv[i] = *(const float4*)(x + ((int64_t)n * CI + i) * HW + off);
+#pragma unroll
+        for (int o = 0; o < 8; o++) {
+            const int oc = og + o < Co ? og + o : Co - 1;          // rows beyond C_out re-read the last one; their sums are not stored
+            dv[o] = *(const float4*)(dy + ((int64_t)n * Co + oc) * HW + off);
+        }
+#pragma unroll
+        for (int o = 0; o < 8; o++)
+#pragma unroll
+            for (int i = 0; i < CI; i++) {
+                float a = acc[o][i];
+                a = fmaf(dv[o].x, xv[i].x, a); a = fmaf(dv[o].y, xv[i].y, a); a = fmaf(dv[o].z, xv[i].z, a); a = fmaf(dv[o].w, xv[i].w, a);
+                acc[o][i] = a;
+            }
+    }
+    __shared__ float part[4][8 * CI];
+#pragma unroll
+    for (int o = 0; o < 8; o++)
+#pragma unroll
+        for (int i = 0; i < CI; i++) {
+            float v = acc[o][i];
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, 64);
+            if (lane == 0) part[wave][o * CI + i] = v;
+        }
+    __syncthreads();
+    if (tid < 8 * CI) {
+        const int o = tid / CI, i = tid - o * CI;
+        if (og + o < Co)
+            slab[((int64_t)blockIdx.x * a_pad + og + o) * bpad + i] = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
+    }
+}
+
+// Does the few-channel pointwise kernel take this weight gradient, and with how many K slices (<= the slab the small-cin plan reserved)?
+static int plan_wgrad1x1_fewcin(const pasta_conv_desc* d, const WgradSmallPlan& ws) {
+    static const bool enabled = !(getenv("PASTA_WGRAD_FEWCIN") && getenv("PASTA_WGRAD_FEWCIN")[0] == '0');         // A/B switch
+    if (!enabled || !ws.use || d->kh != 1 || d->kw != 1 || d->pad_h || d->pad_w || d->io_dtype != PASTA_F32 || d->C_in > 8) return 0;
+    const int64_t hw = (int64_t)d->H * d->W;
+    if (hw % 4 || d->OH != d->H || d->OW != d->W) return 0;
+    int64_t ks = (int64_t)d->N * (hw / 4) / (256 * 8);          // at least eight trips per thread
+    ks = ks < 1 ? 1 : ks > 256 ? 256 : ks;
+    return (int)(ks < ws.ksplit ? ks : ws.ksplit);
+}
 
 }  // namespace pasta

@@ -113,3 +113,24 @@ def test_merge_layer_of_a_synthesis_block_uses_it():
     assert _rel(y1, y0) < 2e-6
     for u, v in zip(g1, g0):
         assert _rel(u, v) < 1e-5
+
+
+@pytest.mark.parametrize('n,ci,co,h,w', [(5, 3, 64, 32, 32), (2, 6, 64, 64, 48), (3, 8, 128, 16, 16), (2, 1, 9, 8, 12), (4, 3, 70, 10, 6), (2, 3, 64, 15, 15)])
+def test_few_channel_pointwise_weight_gradient(n, ci, co, h, w):
+    """wgrad1x1_fewcin_kernel (the discriminator's fromrgb, the 6-channel pose stem): against fp64; planes that are not a multiple of four
+    pixels stay on the (channel, tap)-pair kernel."""
+    from torch_utils import custom_ops
+    from torch_utils.ops import conv2d_gradfix as cg
+    desc = custom_ops.ConvDesc(N=n, C_in=ci, H=h, W=w, C_out=co, OH=h, OW=w, kh=1, kw=1, stride=1, pad_h=0, pad_w=0, groups=1, transposed=0, flip=0, math=0)
+    k = ctypes.c_int()
+    assert custom_ops.get_plugin().pasta_conv2d_wgrad_plan(ctypes.byref(desc), ctypes.byref(k)) == 0
+    assert (k.value == 5) == ((h * w) % 4 == 0)
+    g = torch.Generator().manual_seed(n + ci + co)
+    x = torch.randn([n, ci, h, w], generator=g)
+    wt = torch.randn([co, ci, 1, 1], generator=g)
+    dy = torch.randn([n, co, h, w], generator=g)
+    w64 = wt.double().requires_grad_(True)
+    rw, = torch.autograd.grad(torch.nn.functional.conv2d(x.double(), w64), w64, dy.double())
+    wc = wt.cuda().requires_grad_(True)
+    gw, = torch.autograd.grad(cg.conv2d(x.cuda(), wc, wgain=0.25), wc, dy.cuda())
+    assert gw.shape == rw.shape and _rel(gw, rw * 0.25) < 2e-6
