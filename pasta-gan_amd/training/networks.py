@@ -62,13 +62,17 @@ class _SpadeModulate(torch.autograd.Function):
     output of ONE convolution with the concatenated conv_gamma / conv_beta weights); its gradient comes back as one tensor,
     so the two input gradients of that convolution accumulate inside its K loop instead of in an addition pass."""
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, post):
+    def forward(ctx, x, gamma, beta, eps, post, shared=None):
         n, c, h, w = x.shape
-        x, gamma = x.contiguous(), gamma.contiguous()
+        x = x.contiguous()
         fused = beta is None
+        if fused and gamma.shape == (n, 2 * c, h, w) and gamma.stride()[1:] == (h * w, w, 1) and gamma.stride(0) >= 2 * c * h * w:
+            pass            # gamma | beta as a channel slice of a wider tensor (the block's batched convolution): read at its sample stride
+        else:
+            gamma, shared = gamma.contiguous(), None
         if fused:
             assert gamma.shape == (n, 2 * c, h, w)
-            beta_ptr, gstride = gamma.data_ptr() + x.element_size() * c * h * w, 2 * c * h * w
+            beta_ptr, gstride = gamma.data_ptr() + x.element_size() * c * h * w, gamma.stride(0)
         else:
             beta = beta.contiguous()
             beta_ptr, gstride = beta.data_ptr(), 0
@@ -83,7 +87,7 @@ class _SpadeModulate(torch.autograd.Function):
         _native.check(st)
         _native.amax_attach(out, row)
         ctx.save_for_backward(x, gamma, stats, beta if (act == 2 and not fused) else None)
-        ctx.post, ctx.fused = post, fused
+        ctx.post, ctx.fused, ctx.shared = post, fused, shared
         return out
 
     @staticmethod
@@ -98,21 +102,28 @@ class _SpadeModulate(torch.autograd.Function):
         lib = _native.lib()
         if ctx.fused:       # gamma | beta and their gradients as channel halves of one tensor each
             half = x.element_size() * c * h * w
-            dgb = torch.empty_like(gamma) if ctx.needs_input_grad[1] else None
-            grow = _native.amax_slot(dgb) if dgb is not None else None         # dgamma | dbeta is the dy of ONE convolution's backward
+            dgb = grow = None
+            if ctx.needs_input_grad[1]:
+                if ctx.shared is not None:      # this block's slice of the gradient of the batched gamma | beta convolution (_SharedGrad)
+                    holder, idx = ctx.shared
+                    dgb, grow = holder.view(idx), holder.row
+                else:
+                    dgb = torch.empty([n, 2 * c, h, w], dtype=x.dtype, device=x.device)
+                    grow = _native.amax_slot(dgb)                           # dgamma | dbeta is the dy of ONE convolution's backward
             if dx is not None or dgb is not None:
                 with torch.cuda.device(x.device):
                     st = lib.pasta_spade_norm_bwd(_native.ptr(dout), _native.ptr(x), _native.ptr(gamma), _native.ptr(stats), _native.ptr(dx),
                                                   _native.ptr(dgb), dgb.data_ptr() + half if dgb is not None else None,
                                                   _native.dtype_code(x, 'spade_norm_bwd'), n * c, h * w,
-                                                  gamma.data_ptr() + half, act, float(gain), float(clamp), c, 2 * c * h * w, 2 * c * h * w,
+                                                  gamma.data_ptr() + half, act, float(gain), float(clamp), c, gamma.stride(0),
+                                                  dgb.stride(0) if dgb is not None else 2 * c * h * w,
                                                   _native.stream(), _native.ptr(row), _native.ptr(grow))
                 _native.check(st)
                 if dx is not None:
                     _native.amax_attach(dx, row)
-                if dgb is not None:
+                if dgb is not None and ctx.shared is None:
                     _native.amax_attach(dgb, grow)
-            return dx, dgb, None, None, None
+            return dx, dgb, None, None, None, None
         dgamma = torch.empty_like(x) if ctx.needs_input_grad[1] else None
         # without a fused activation d/dbeta is dout itself; with one it is dout through the activation, written by the kernel
         dbeta = None
@@ -129,9 +140,45 @@ class _SpadeModulate(torch.autograd.Function):
             _native.check(st)
             if dx is not None:
                 _native.amax_attach(dx, row)
-        return dx, dgamma, (dbeta if ctx.needs_input_grad[2] else None), None, None
+        return dx, dgamma, (dbeta if ctx.needs_input_grad[2] else None), None, None, None
 
-def spade_modulate(x, gamma, beta, eps=1e-5, relu_gain=None, clamp=None):
+class _SharedGrad:
+    """ONE gradient tensor written in channel slices by several backward nodes: the three SPADE normalisations of a residual block leave
+    dgamma | dbeta of their group in channels [g 2C, (g + 1) 2C) of the dy of the block's batched gamma | beta convolution, so that convolution's
+    backward is one input-gradient and one weight-gradient launch and nothing is concatenated or added.  One row of producer maxima serves
+    the three writers (a maximum does not care about the order)."""
+    def __init__(self, like, groups):
+        self.shape, self.dtype, self.device, self.groups = tuple(like.shape), like.dtype, like.device, groups
+        self.buf = self.row = None
+
+    def view(self, g):
+        if self.buf is None:
+            self.buf = torch.empty(self.shape, dtype=self.dtype, device=self.device)
+            self.row = _native.amax_slot(self.buf)
+        c = self.shape[1] // self.groups
+        return self.buf.narrow(1, g * c, c)
+
+class _SplitGroups(torch.autograd.Function):
+    """``t -> (t[:, 0:c], t[:, c:2c], ...)`` as views; the backward hands back the shared gradient buffer when every slice gradient it receives IS
+    that buffer's slice (what ``_SpadeModulate`` writes), else it assembles the gradient the ordinary way."""
+    @staticmethod
+    def forward(ctx, t, holder):
+        ctx.holder = holder
+        ctx.set_materialize_grads(False)
+        c = t.shape[1] // holder.groups
+        return tuple(t.narrow(1, g * c, c) for g in range(holder.groups))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        h, ctx.holder = ctx.holder, None
+        if h.buf is not None and all(g is not None and g.data_ptr() == h.view(i).data_ptr() and g.shape == h.view(i).shape and g.stride() == h.view(i).stride()
+                                     for i, g in enumerate(grads)):
+            return _native.amax_attach(h.buf, h.row), None
+        c = h.shape[1] // h.groups
+        parts = [g if g is not None else torch.zeros([h.shape[0], c, *h.shape[2:]], dtype=h.dtype, device=h.device) for g in grads]
+        return torch.cat(parts, dim=1), None
+
+def spade_modulate(x, gamma, beta, eps=1e-5, relu_gain=None, clamp=None, shared=None):
     """InstanceNorm(x) * (1 + gamma) + beta; ``relu_gain`` not None additionally applies ``min(relu(.) * relu_gain, clamp)``
     in the same pass (the activation of the Spade_Conv2dLayer that consumes the result).  ``beta=None``: ``gamma`` holds
     gamma | beta as the two channel halves of a [N, 2C, H, W] tensor."""
@@ -139,7 +186,7 @@ def spade_modulate(x, gamma, beta, eps=1e-5, relu_gain=None, clamp=None):
     if x.dtype not in _HIP_DTYPES or gamma.dtype != x.dtype or (beta is not None and beta.dtype != x.dtype):
         raise RuntimeError('spade_modulate: x, gamma and beta must share one of float32 / float16 / bfloat16')
     post = (0, 1.0, -1.0) if relu_gain is None else (2, float(relu_gain), float(clamp if clamp is not None else -1))
-    return _SpadeModulate.apply(x, gamma, beta, eps, post)
+    return _SpadeModulate.apply(x, gamma, beta, eps, post, shared)
 
 #----------------------------------------------------------------------------
 
@@ -743,7 +790,10 @@ class Spade_Norm_Block(torch.nn.Module):
         return (actv.dtype in _HIP_DTYPES and g.weight.shape == b.weight.shape and g.bias is None and b.bias is None
                 and (g.up, g.down, g.padding, g.weight_gain) == (b.up, b.down, b.padding, b.weight_gain) and g.up == g.down == 1)
 
-    def forward(self, x, denorm_feats, post_act=None):
+    def forward(self, x, denorm_feats, post_act=None, gb=None):
+        relu_gain, clamp = post_act if post_act is not None else (None, None)      # the consuming layer's activation, same pass
+        if gb is not None:          # (gamma | beta slice, shared gradient holder, group index) from the block's batched convolutions
+            return spade_modulate(x, gb[0], None, eps=self.param_free_norm.eps, relu_gain=relu_gain, clamp=clamp, shared=(gb[1], gb[2]))
         mlp = self.conv_mlp         # no activation in front, nn.ReLU behind (:4373-4374): the ReLU rides in the epilogue
         actv = conv2d_resample.conv2d_resample_bias_act(x=denorm_feats, b=None, act='relu', gain=1, **mlp._resample_args(denorm_feats))
         if self._twin_convs(actv):
@@ -755,7 +805,6 @@ class Spade_Norm_Block(torch.nn.Module):
             beta = None
         else:
             gamma, beta = self.conv_gamma(actv, no_act=True), self.conv_beta(actv, no_act=True)
-        relu_gain, clamp = post_act if post_act is not None else (None, None)      # the consuming layer's activation, same pass
         return spade_modulate(x, gamma, beta, eps=self.param_free_norm.eps, relu_gain=relu_gain, clamp=clamp)
 
 @persistence.persistent_class
@@ -781,27 +830,50 @@ class Spade_ResBlockV2(torch.nn.Module):
         self.spade1 = Spade_Norm_Block(feat_channels, out_channels)
 
     @staticmethod
-    def _norm_then_conv(norm, conv, x, feat, gain, residual=None):
+    def _norm_then_conv(norm, conv, x, feat, gain, residual=None, gb=None):
         """conv(norm(x, feat), gain) [+ residual]; the activation in front of the convolution is applied by the SPADE kernel when
         the layer allows it (bias-free relu)."""
         post = conv.fusable_activation(gain)
         if post is None:
-            return conv(norm(x, feat), gain=gain, residual=residual)
-        return conv(norm(x, feat, post_act=post), no_act=True, residual=residual)
+            return conv(norm(x, feat, gb=gb), gain=gain, residual=residual)
+        return conv(norm(x, feat, post_act=post, gb=gb), no_act=True, residual=residual)
+
+    def _batched_gamma_beta(self, feat):
+        """gamma | beta of the block's THREE normalisations from two launches (round 4): their ``conv_mlp`` layers read the same
+        feature map (networks.py:4373), so one convolution over the concatenated weights computes the three hidden maps, and one GROUPED
+        convolution (three groups) over the six concatenated gamma / beta weights the three gamma | beta pairs.  Backwards that is ONE input
+        gradient into the feature map per block instead of three that autograd then adds (two 268 MB additions per block), and the three
+        normalisations write their dgamma | dbeta as slices of one tensor (``_SharedGrad``).  None where the layers do not line up."""
+        norms = (self.spade_skip, self.spade0, self.spade1)
+        ok = (_SPADE_BATCH and feat.dtype == torch.float32 and feat.device.type == 'cuda' and all(n._twin_convs(feat) for n in norms)
+              and len({tuple(n.conv_mlp.weight.shape) for n in norms}) == 1 and len({tuple(n.conv_gamma.weight.shape) for n in norms}) == 1
+              and all(n.conv_mlp.up == n.conv_mlp.down == 1 and n.conv_mlp.bias is None for n in norms)
+              and len({(n.conv_mlp.weight_gain, n.conv_gamma.weight_gain, n.conv_mlp.padding, n.conv_gamma.padding) for n in norms}) == 1)
+        if not ok:
+            return None
+        mlp, g = norms[0].conv_mlp, norms[0].conv_gamma
+        actv = conv2d_resample.conv2d_resample_bias_act(x=feat, w=torch.cat([n.conv_mlp.weight for n in norms], dim=0), b=None, act='relu', gain=1,
+                                                        f=mlp.resample_filter, padding=mlp.padding, flip_weight=True, wgain=mlp.weight_gain)
+        w_gb = torch.cat([w for n in norms for w in (n.conv_gamma.weight, n.conv_beta.weight)], dim=0)
+        gb_all = conv2d_gradfix.conv2d(actv, w_gb, padding=g.padding, groups=3, wgain=g.weight_gain)
+        holder = _SharedGrad(gb_all, 3)
+        return [(v, holder, i) for i, v in enumerate(_SplitGroups.apply(gb_all, holder))]
 
     def forward(self, x, denorm_feat):
         half = np.sqrt(0.5)
         x = self.conv(x, no_act=True)
-        shortcut = self._norm_then_conv(self.spade_skip, self.skip, x, denorm_feat, half)
-        x = self._norm_then_conv(self.spade0, self.conv0, x, denorm_feat, 1)
+        gb = self._batched_gamma_beta(denorm_feat) or (None, None, None)
+        shortcut = self._norm_then_conv(self.spade_skip, self.skip, x, denorm_feat, half, gb=gb[0])
+        x = self._norm_then_conv(self.spade0, self.conv0, x, denorm_feat, 1, gb=gb[1])
         if x.dtype == torch.float32 and x.device.type == 'cuda' and self.conv1.up == 1 and self.conv1.down == 1:
             # shortcut + conv1(.): the sum is formed in conv1's epilogue (the layers are activation-FIRST: the convolution is the last step).
             # fp32 storage only: in 16-bit storage the reference rounds conv1's output to the storage type BEFORE the addition, and the
             # config-5 fixtures (tests/test_config5_gpu.py) hold this path to that sequence of roundings
-            return self._norm_then_conv(self.spade1, self.conv1, x, denorm_feat, half, residual=shortcut)
-        x = self._norm_then_conv(self.spade1, self.conv1, x, denorm_feat, half)
+            return self._norm_then_conv(self.spade1, self.conv1, x, denorm_feat, half, residual=shortcut, gb=gb[2])
+        x = self._norm_then_conv(self.spade1, self.conv1, x, denorm_feat, half, gb=gb[2])
         return shortcut.add_(x)
 
+_SPADE_BATCH = _os.environ.get('PASTA_SPADE_BATCH', '1') != '0'         # A/B switch: 0 = three conv_mlp and three gamma | beta convolutions per SPADE residual block
 _MERGE_FUSED = _os.environ.get('PASTA_MERGE_FUSED', '1') != '0'         # A/B switch: 0 = torch.cat + one 1x1 convolution, as the reference
 
 def _merge_without_cat(layer, x, side):

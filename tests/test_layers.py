@@ -88,3 +88,32 @@ def test_hip_layers_match_reference(idx):
         short = k[len(case['name']) + 1:]
         ref = g[k]
         assert rel_err(res[short], ref) < TOL or float(np.abs(ref).max()) == 0.0, (case['name'], short, rel_err(res[short], ref))
+
+
+@pytest.mark.gpu
+def test_spade_block_batched_convolutions_equal_the_separate_ones():
+    """Spade_ResBlockV2 with the three conv_mlp / gamma | beta convolutions of its normalisations batched into two launches (round 4) against
+    the same block running them one by one (``networks._SPADE_BATCH = False``): output and every gradient, feature map included."""
+    import torch
+    from training import networks
+    g = torch.Generator().manual_seed(11)
+    blk = networks.Spade_ResBlockV2(32, 32, conv_clamp=256, resolution=64, feat_channels=48).cuda()
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.copy_(torch.randn(p.shape, generator=g).to(p.device) * (0.3 if p.ndim > 1 else 0.1))
+    x = torch.randn([3, 32, 64, 64], generator=g).cuda().requires_grad_(True)
+    feat = torch.randn([3, 48, 64, 64], generator=g).cuda().requires_grad_(True)
+    dy = torch.randn([3, 32, 64, 64], generator=g).cuda()
+    params = list(blk.parameters())
+    def run(batched):
+        old, networks._SPADE_BATCH = networks._SPADE_BATCH, batched
+        try:
+            y = blk(x, feat)
+            return (y,) + torch.autograd.grad(y, [x, feat] + params, dy)
+        finally:
+            networks._SPADE_BATCH = old
+    a, b = run(True), run(False)
+    rel = lambda u, v: float((u.double() - v.double()).abs().max() / (v.double().abs().max() + 1e-30))
+    assert rel(a[0], b[0]) < 2e-6
+    for i, (u, v) in enumerate(zip(a[1:], b[1:])):
+        assert u.shape == v.shape and rel(u, v) < 2e-5, i
