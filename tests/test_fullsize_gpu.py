@@ -29,6 +29,9 @@ CONV_SHAPES = [  # x shape, w shape, kwargs -- one of each kernel family at full
     ([16, 3, 256, 256], [64, 3, 7, 7], dict(padding=3)),                           # RGB stem: 4-channel K chunks, small-Cin wgrad
     ([16, 64, 256, 256], [3, 64, 1, 1], dict()),                                   # ToRGB
     ([16, 64, 256, 256], [128, 64, 1, 1], dict(down=2)),                           # discriminator skip
+    ([16, 128, 256, 256], [64, 128, 1, 1], dict()),                                # round 4: pointwise kernel, 64-row tile (and the 128-row one for its input gradient)
+    ([48, 3, 256, 256], [64, 3, 1, 1], dict()),                                    # fromrgb over the stacked discriminator batch: few-channel pointwise weight gradient
+    ([16, 128, 129, 129], [256, 128, 3, 3], dict(down=2, padding=1)),              # stride-2 kernel on two tile rows of 64
 ]
 
 
@@ -121,3 +124,25 @@ def test_one_training_iteration_batch16():
     assert moved_d == len(d0)
     assert moved_g >= len(g0) - 6            # b4.const and the texture block's unused parsing / conv0-less parameters never get gradients
     assert all(torch.isfinite(p).all() for p in step.G.parameters()) and all(torch.isfinite(p).all() for p in step.D.parameters())
+
+
+def test_merge_layer_over_two_tensors_full_size():
+    """The synthesis blocks' merge at 256 x 256 (networks.py:5698-5700) as ONE pointwise launch over (x, side): equal to the convolution of the
+    concatenation, and adjoint to its three gradients."""
+    from torch_utils.ops import conv2d_gradfix as cg
+    g = torch.Generator(device='cuda').manual_seed(77)
+    x = torch.randn([16, 64, 256, 256], device='cuda', generator=g).requires_grad_(True)
+    side = (torch.randn([16, 64, 256, 256], device='cuda', generator=g) * 0.1).requires_grad_(True)
+    w = (torch.randn([64, 128, 1, 1], device='cuda', generator=g) / np.sqrt(128)).requires_grad_(True)
+    b = torch.randn([64], device='cuda', generator=g).requires_grad_(True)
+    assert cg.cat1x1_available(x, side, w)
+    y = cg.conv2d_cat1x1_bias_act(x, side, w, b, act='linear', clamp=256)
+    with torch.no_grad():
+        ref = cg.conv2d_bias_act(torch.cat([x, side], dim=1), w, b, act='linear', clamp=256)
+    assert float((y - ref).abs().max() / ref.abs().max()) < 2e-6
+    dy = torch.randn(y.shape, device='cuda', generator=g)
+    dx, ds, dw, db = torch.autograd.grad(y, [x, side, w, b], dy)
+    # y is affine in (x, side) jointly with w: <dy, y - bias> = <dx, x> + <ds, side> = <dw, w>   (no clamp is active at these magnitudes)
+    assert float(y.abs().max()) < 256
+    lhs = _dot(dy, y) - _dot(db, b)
+    assert _rel(_dot(dx, x) + _dot(ds, side), lhs) < 2e-4 and _rel(_dot(dw, w), lhs) < 2e-4
