@@ -191,7 +191,7 @@ launch_hook = None
 def _f32(t):
     return t if t.dtype == torch.float32 else t.float()
 
-def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, noise=None, x2=None):
+def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, noise=None, x2=None, used=None):
     """y = conv(x * iscale[n,c]) * oscale[n,c'] through ``pasta_conv2d_ex``; fp32 accumulation.  fp32 tensors run the
     split-bf16 (fp32-equivalent) or fp32 matrix-core kernels; fp16 / bf16 tensors stay 16-bit in HBM where a kernel exists
     (``_native16``) and are converted for the launch otherwise.
@@ -201,7 +201,10 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, 
     ``wmod`` = (styles [G, I], dcoefs [G, O] or None): ``w`` is ONE group's weight shared by all ``cfg.groups`` groups and
     modulated per group by the packing kernel (``pasta_conv2d_modulated``).
     ``x2`` ([N, C2, H, W], pointwise convolutions only -- ``cat1x1_available``): the convolution runs over the channel concatenation
-    ``cat([x, x2], 1)`` without forming it (``pasta_conv_desc.x2``)."""
+    ``cat([x, x2], 1)`` without forming it (``pasta_conv_desc.x2``).
+    ``used`` (dict, optional): receives ``'x_amax'`` / ``'x2_amax'`` = the partial maxima the launch took for its activations, so that the
+    autograd node can hand them to the weight gradient of the SAME saved tensor (a saved non-leaf tensor comes back from autograd as a new
+    Python object without the attribute the maxima travel on: it would be scanned a second time)."""
     _native.require_gpu(x, 'conv2d')
     if x.ndim != 4 or w.ndim != 4:
         raise RuntimeError('conv2d: x and w must be rank 4')
@@ -282,6 +285,8 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, 
         if x2 is not None:
             x2_amax = tensor_amax(x2)
             desc.x2_amax = x2_amax.data_ptr()
+        if used is not None:
+            used['x_amax'], used['x2_amax'] = x_amax, x2_amax
     def launch():
         with torch.cuda.device(x.device):
             if wmod is not None:
@@ -305,7 +310,7 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, 
         _native.amax_attach(y, y_row)
     return y.to(out_dtype)
 
-def _launch_wgrad(x, dy, cfg, w_shape, out_dtype=None):
+def _launch_wgrad(x, dy, cfg, w_shape, out_dtype=None, x_amax=None):
     """dw of ``conv(x, w)`` given dy through ``pasta_conv2d_wgrad``; the gradient comes out fp32 (weights are fp32 masters)
     and is returned as ``out_dtype`` (default: dy's)."""
     _native.require_gpu(x, 'conv2d_wgrad')
@@ -330,7 +335,8 @@ def _launch_wgrad(x, dy, cfg, w_shape, out_dtype=None):
     work = torch.empty([max(nbytes // 4, 4)], dtype=torch.float32, device=x.device)
     f16x3 = _runs_f16x3('wgrad', desc)
     if f16x3:
-        amax_x, amax_dy = tensor_amax(x), tensor_amax(dy)
+        # x_amax: the maxima the forward launch took for this very tensor (autograd has checked that it was not written since)
+        amax_x, amax_dy = (x_amax if x_amax is not None and x.dtype == torch.float32 else tensor_amax(x)), tensor_amax(dy)
         desc.x_amax, desc.dy_amax = amax_x.data_ptr(), amax_dy.data_ptr()
     def launch():
         with torch.cuda.device(x.device):
@@ -358,9 +364,10 @@ def _grad_cfg(cfg, x_hw, y_hw, kh, kw):
 class _ConvHip(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, cfg):
-        y = _launch_conv(x, w, cfg)
+        used = {}
+        y = _launch_conv(x, w, cfg, used=used)
         ctx.save_for_backward(x, w)
-        ctx.cfg = cfg
+        ctx.cfg, ctx.x_amax = cfg, (used.get('x_amax') if x.dtype == torch.float32 else None)
         return y
 
     @staticmethod
@@ -373,7 +380,7 @@ class _ConvHip(torch.autograd.Function):
             dx = _ConvHip.apply(dy, w, gcfg)
             assert dx.shape == x.shape
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
-            dw = _ConvWgradHip.apply(dy, x, cfg, tuple(w.shape), w.dtype)
+            dw = _ConvWgradHip.apply(dy, x, cfg, tuple(w.shape), w.dtype, ctx.x_amax)
         return dx, dw, None
 
 class _ConvBiasActHip(torch.autograd.Function):
@@ -384,12 +391,13 @@ class _ConvBiasActHip(torch.autograd.Function):
     def forward(ctx, x, w, b, cfg, act_cfg, res=None):
         act, alpha, gain, clamp = act_cfg
         from . import bias_act as ba
-        y = _launch_conv(x, w, cfg, epilogue=(b, ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, res))
+        used = {}
+        y = _launch_conv(x, w, cfg, epilogue=(b, ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, res), used=used)
         # y is needed by the backward only as the activation / clamp mask; a linear, unclamped layer (the residual
         # skips, whose output the blocks then update in place) must not pin it
         keep_y = act != 'linear' or clamp >= 0
         ctx.save_for_backward(x, w, b, y if keep_y else None)
-        ctx.cfg, ctx.act_cfg = cfg, act_cfg
+        ctx.cfg, ctx.act_cfg, ctx.x_amax = cfg, act_cfg, (used.get('x_amax') if x.dtype == torch.float32 else None)
         return y
 
     @staticmethod
@@ -409,7 +417,7 @@ class _ConvBiasActHip(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _ConvHip.apply(dz, w, _grad_cfg(cfg, x.shape[2:], dz.shape[2:], w.shape[2], w.shape[3]))
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
-            dw = _ConvWgradHip.apply(dz, x, cfg, tuple(w.shape), w.dtype)
+            dw = _ConvWgradHip.apply(dz, x, cfg, tuple(w.shape), w.dtype, ctx.x_amax)
         if want_db and db is None:
             db = ba._BiasSum.apply(dz, 1)
         dres = dz if len(ctx.needs_input_grad) > 5 and ctx.needs_input_grad[5] else None     # the residual enters before the activation
@@ -445,10 +453,11 @@ class _CatConv1x1BiasActHip(torch.autograd.Function):
         act, alpha, gain, clamp = act_cfg
         from . import bias_act as ba
         cfg = _Cfg((False, 1, 0, 0, 0, 0, 1, float(wgain)))
-        y = _launch_conv(x, w, cfg, epilogue=(b, ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, None), x2=x2)
+        used = {}
+        y = _launch_conv(x, w, cfg, epilogue=(b, ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, None), x2=x2, used=used)
         keep_y = act != 'linear' or clamp >= 0
         ctx.save_for_backward(x, x2, w, b, y if keep_y else None)
-        ctx.cfg, ctx.act_cfg = cfg, act_cfg
+        ctx.cfg, ctx.act_cfg, ctx.amax = cfg, act_cfg, (used.get('x_amax'), used.get('x2_amax'))
         return y
 
     @staticmethod
@@ -472,8 +481,8 @@ class _CatConv1x1BiasActHip(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dx2 = _ConvHip.apply(dz, w[:, c1:], gcfg)
         if ctx.needs_input_grad[2] and not weight_gradients_disabled:
-            dw = torch.cat([_ConvWgradHip.apply(dz, x, cfg, (w.shape[0], c1, 1, 1), w.dtype),
-                            _ConvWgradHip.apply(dz, x2, cfg, (w.shape[0], w.shape[1] - c1, 1, 1), w.dtype)], dim=1)
+            dw = torch.cat([_ConvWgradHip.apply(dz, x, cfg, (w.shape[0], c1, 1, 1), w.dtype, ctx.amax[0]),
+                            _ConvWgradHip.apply(dz, x2, cfg, (w.shape[0], w.shape[1] - c1, 1, 1), w.dtype, ctx.amax[1])], dim=1)
         if want_db and db is None:
             db = ba._BiasSum.apply(dz, 1)
         return dx, dx2, dw, db, None, None
@@ -593,8 +602,8 @@ class _DemodCoefs(torch.autograd.Function):
 
 class _ConvWgradHip(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, dy, x, cfg, w_shape, w_dtype=None):
-        dw = _launch_wgrad(x, dy, cfg, w_shape, w_dtype)
+    def forward(ctx, dy, x, cfg, w_shape, w_dtype=None, x_amax=None):
+        dw = _launch_wgrad(x, dy, cfg, w_shape, w_dtype, x_amax=x_amax)
         ctx.save_for_backward(dy, x)
         ctx.cfg = cfg
         return dw
@@ -611,7 +620,7 @@ class _ConvWgradHip(torch.autograd.Function):
             gcfg = _grad_cfg(cfg, x.shape[2:], dy.shape[2:], d_dw.shape[2], d_dw.shape[3])
             d_x = _ConvHip.apply(dy, d_dw, gcfg)
             assert d_x.shape == x.shape
-        return d_dy, d_x, None, None, None
+        return d_dy, d_x, None, None, None, None
 
 #----------------------------------------------------------------------------
 
