@@ -333,6 +333,24 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
     }
     const bool has_noise = p.noise && p.ksplit == 1;
     const float nstr = has_noise ? p.noise_strength[0] : 0.f;
+    // What an output ROW brings to the epilogue -- bias, output scale -- depends on (a, r16) only: fetched once, in front of the stores, like
+    // the row scales above; the residual of a 32 x 32 sub-tile is fetched as sixteen loads in a row and then stored over.  (One load in
+    // front of every store serialises on the memory counter: the input-gradient launches that carry another consumer's gradient as residual
+    // ran 4 % SLOWER than launch + torch addition that way, profiles/r4_ab_grad_join.txt.)
+    const bool fused = p.ksplit == 1;
+    const bool has_res = p.res && fused;
+    const float* osb = (p.oscale && fused) ? p.oscale + (int64_t)n_img * p.Cout + (int64_t)g * p.Og : nullptr;
+    const float* bsb = (p.act && fused && p.bias) ? p.bias + g * p.Og : nullptr;
+    float row_b[WMT][16], row_s[WMT][16];
+#pragma unroll
+    for (int a = 0; a < WMT; a++)
+#pragma unroll
+        for (int r16 = 0; r16 < 16; r16++) {
+            const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r16, lane);
+            const int oc = o < p.Og ? o : p.Og - 1;
+            row_b[a][r16] = bsb ? bsb[oc] : 0.f;
+            row_s[a][r16] = osb ? osb[oc] : 1.f;
+        }
 #pragma unroll
     for (int b = 0; b < WNT; b++) {
         const int t = (wn * WNT + b) * 32 + jl;
@@ -341,22 +359,29 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
         const int64_t yoff = ((int64_t)n_img * p.Cout + (int64_t)g * p.Og) * OHW + plane_off;
         const float nz = has_noise ? p.noise[(p.noise_ps ? (int64_t)n_img * OHW : 0) + plane_off] * nstr : 0.f;
         float* pb = p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW + yoff : nullptr;
-        const bool has_res = p.res && p.ksplit == 1;
-        const float* osb = (p.oscale && p.ksplit == 1) ? p.oscale + (int64_t)n_img * p.Cout + (int64_t)g * p.Og : nullptr;
 #pragma unroll
-        for (int a = 0; a < WMT; a++)
+        for (int a = 0; a < WMT; a++) {
+            float rv[16];
+            if (has_res) {
+#pragma unroll
+                for (int r16 = 0; r16 < 16; r16++) {
+                    const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r16, lane);
+                    rv[r16] = o < p.Og ? io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES) : 0.f;
+                }
+            }
 #pragma unroll
             for (int r16 = 0; r16 < 16; r16++) {
                 const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r16, lane);
                 if (o < p.Og) {
                     float v = acc[a][b][r16];
-                    v = conv_scale_noise(v, osb, o, nz);
-                    if (has_res) v += io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES);
-                    if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
+                    v = osb ? fmaf(v, row_s[a][r16], nz) : v + nz;
+                    if (has_res) v += rv[r16];
+                    if (p.act && fused) v = conv_epilogue(v, row_b[a][r16], p.act, p.alpha, p.gain, p.clamp);
                     if (pb) pb[(int64_t)o * OHW] = v;
                     else { io_st<IO>(p.y, yoff + (int64_t)o * OHW, v); if (p.y_amax) amax_take(y_am, v); }
                 }
             }
+        }
     }
     if (p.ksplit == 1) amax_commit(y_am, y_slot);
 }

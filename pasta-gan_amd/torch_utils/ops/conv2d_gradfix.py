@@ -386,9 +386,13 @@ class _ConvHip(torch.autograd.Function):
 class _ConvBiasActHip(torch.autograd.Function):
     """y = bias_act(conv(x, w), b) with the bias / activation / gain / clamp applied in the convolution's epilogue.
     The backward is assembled from the stand-alone differentiable pieces (bias_act gradient kernel, input- and
-    weight-gradient convolutions), so gradients of any order keep working."""
+    weight-gradient convolutions), so gradients of any order keep working.
+
+    ``passthrough=True`` returns ``(y, x)``: the second output is the input again, to be handed to the OTHER consumers of ``x`` (a
+    residual block's skip branch).  Their gradient then arrives here as ``dxp`` and joins this layer's input gradient in the epilogue of
+    the input-gradient launch (one read of it) -- instead of autograd adding two full tensors afterwards (two reads and a write)."""
     @staticmethod
-    def forward(ctx, x, w, b, cfg, act_cfg, res=None):
+    def forward(ctx, x, w, b, cfg, act_cfg, res=None, passthrough=False):
         act, alpha, gain, clamp = act_cfg
         from . import bias_act as ba
         used = {}
@@ -398,12 +402,17 @@ class _ConvBiasActHip(torch.autograd.Function):
         keep_y = act != 'linear' or clamp >= 0
         ctx.save_for_backward(x, w, b, y if keep_y else None)
         ctx.cfg, ctx.act_cfg, ctx.x_amax = cfg, act_cfg, (used.get('x_amax') if x.dtype == torch.float32 else None)
+        if passthrough:
+            ctx.set_materialize_grads(False)        # an unused output's gradient arrives as None, not as a tensor of zeros
+            return y, x
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dxp=None):
         from . import bias_act as ba
         x, w, b, y = ctx.saved_tensors
+        if dy is None:                              # only the pass-through output was differentiated
+            return dxp, None, None, None, None, None, None
         act, alpha, gain, clamp = ctx.act_cfg
         cfg = ctx.cfg
         dz = dy
@@ -415,13 +424,22 @@ class _ConvBiasActHip(torch.autograd.Function):
             else:
                 dz = ba._BiasActHipGrad.apply(dy.contiguous(), None, None, y, (1, act, alpha, gain, clamp))
         if ctx.needs_input_grad[0]:
-            dx = _ConvHip.apply(dz, w, _grad_cfg(cfg, x.shape[2:], dz.shape[2:], w.shape[2], w.shape[3]))
+            gcfg = _grad_cfg(cfg, x.shape[2:], dz.shape[2:], w.shape[2], w.shape[3])
+            if dxp is not None and dxp.dtype == dz.dtype:
+                dx = _ConvBiasActHip.apply(dz, w, None, gcfg, _LINEAR_EPILOGUE, dxp)
+            else:
+                dx = _ConvHip.apply(dz, w, gcfg)
+                if dxp is not None:
+                    dx = dx + dxp
+            assert dx.shape == x.shape
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
             dw = _ConvWgradHip.apply(dz, x, cfg, tuple(w.shape), w.dtype, ctx.x_amax)
         if want_db and db is None:
             db = ba._BiasSum.apply(dz, 1)
-        dres = dz if len(ctx.needs_input_grad) > 5 and ctx.needs_input_grad[5] else None     # the residual enters before the activation
-        return dx, dw, db, None, None, dres
+        dres = dz if ctx.needs_input_grad[5] else None     # the residual enters before the activation
+        return dx, dw, db, None, None, dres, None
+
+_LINEAR_EPILOGUE = ('linear', 0.0, 1.0, -1.0)      # (act, alpha, gain, clamp) of an epilogue that only adds the residual
 
 FUSABLE_ACTS = ('linear', 'relu', 'lrelu')
 
@@ -500,9 +518,10 @@ def conv2d_cat1x1_bias_act(x, x2, weight, bias=None, act='linear', alpha=None, g
     return conv2d_bias_act(torch.cat([x, x2], dim=1), weight, bias, act=act, alpha=alpha, gain=gain, clamp=clamp, wgain=wgain)
 
 def conv2d_bias_act(input, weight, bias=None, stride=1, padding=0, groups=1, act='linear', alpha=None, gain=None, clamp=None, wgain=1.0,
-                    residual=None):
+                    residual=None, passthrough=False):
     """``bias_act(conv2d(input, weight) [+ residual], bias, act, alpha, gain, clamp)`` in one launch (fp32 GPU tensors,
-    act in FUSABLE_ACTS); other cases run the ops separately."""
+    act in FUSABLE_ACTS); other cases run the ops separately.  ``passthrough=True`` returns ``(y, input')`` where ``input'`` is the
+    input again, for its other consumers: see ``_ConvBiasActHip``."""
     from . import bias_act as ba
     spec = ba.activation_funcs[act]
     alpha = float(alpha if alpha is not None else spec.def_alpha)
@@ -513,11 +532,15 @@ def conv2d_bias_act(input, weight, bias=None, stride=1, padding=0, groups=1, act
         ph, pw = _pair(padding)
         assert sh == sw
         cfg = _Cfg((False, sh, ph, pw, 0, 0, int(groups), float(wgain)))
-        return _ConvBiasActHip.apply(input, weight, bias, cfg, (act, alpha, gain, clampf), residual)
+        if passthrough and torch.is_grad_enabled() and input.requires_grad:
+            return _ConvBiasActHip.apply(input, weight, bias, cfg, (act, alpha, gain, clampf), residual, True)
+        y = _ConvBiasActHip.apply(input, weight, bias, cfg, (act, alpha, gain, clampf), residual)
+        return (y, input) if passthrough else y
     y = conv2d(input, weight, stride=stride, padding=padding, groups=groups, wgain=wgain)
     if residual is not None:
         y = y + residual
-    return ba.bias_act(y, bias, act=act, alpha=alpha, gain=gain, clamp=clamp)
+    y = ba.bias_act(y, bias, act=act, alpha=alpha, gain=gain, clamp=clamp)
+    return (y, input) if passthrough else y
 
 def modulated_conv2d_forward(x, weight, styles, dcoefs=None, stride=1, padding=0, transposed=False, per_sample=False, tail=None):
     """FORWARD-ONLY modulated convolution (networks.py:36-94) in one launch -- no autograd graph is recorded; the training

@@ -35,14 +35,19 @@ def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_w
 #----------------------------------------------------------------------------
 
 def conv2d_resample_bias_act(x, w, b=None, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False,
-                             act='linear', alpha=None, gain=None, clamp=None, wgain=1.0, residual=None):
+                             act='linear', alpha=None, gain=None, clamp=None, wgain=1.0, residual=None, passthrough=False):
     """``bias_act(conv2d_resample(x, w, ...), b, act, alpha, gain, clamp)`` -- the body of ``Conv2dLayer.forward``
     (reference training/networks.py:170-179). When the dense convolution is the last step of the resampling
     decomposition (no upsampling), bias / activation / gain / clamp ride in its epilogue; otherwise the two ops run
     one after the other. ``wgain``: the convolution uses ``w * wgain`` (``Conv2dLayer``'s weight gain) without a
     multiplication kernel of its own.  ``residual`` (extension, shape of the output): added to the convolution before
-    the bias -- also in the epilogue when the convolution is fused."""
+    the bias -- also in the epilogue when the convolution is fused.  ``passthrough=True`` (extension) returns ``(y, x')``: ``x'`` is ``x``
+    again, to be given to the other consumers of ``x`` so that their gradient joins this layer's input gradient in that launch's epilogue
+    (``conv2d_gradfix._ConvBiasActHip``; where the convolution does not read ``x`` itself -- resampling layers -- ``x'`` is plainly ``x``)."""
     from . import bias_act
+    if passthrough and (up != 1 or down != 1):
+        return conv2d_resample_bias_act(x, w, b=b, f=f, up=up, down=down, padding=padding, groups=groups, flip_weight=flip_weight, flip_filter=flip_filter,
+                                        act=act, alpha=alpha, gain=gain, clamp=clamp, wgain=wgain, residual=residual), x
     if up == 1 and x.dtype in conv2d_gradfix.IO_CODES and x.device.type == 'cuda' and act in conv2d_gradfix.FUSABLE_ACTS:
         out_channels, in_channels_per_group, kh, kw = _get_weight_shape(w)
         fw, fh = _get_filter_size(f)
@@ -60,7 +65,11 @@ def conv2d_resample_bias_act(x, w, b=None, f=None, up=1, down=1, padding=0, grou
             x = upfirdn2d.upfirdn2d(x=x, f=f, padding=[px0, px1, py0, py1], flip_filter=flip_filter)
             return conv2d_gradfix.conv2d_bias_act(x, wc, b, stride=down, groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp, wgain=wgain, residual=residual)
         if px0 == px1 and py0 == py1 and px0 >= 0 and py0 >= 0:
-            return conv2d_gradfix.conv2d_bias_act(x, wc, b, padding=[py0, px0], groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp, wgain=wgain, residual=residual)
+            return conv2d_gradfix.conv2d_bias_act(x, wc, b, padding=[py0, px0], groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp, wgain=wgain,
+                                                  residual=residual, passthrough=passthrough)
+    if passthrough:
+        return conv2d_resample_bias_act(x, w, b=b, f=f, up=up, down=down, padding=padding, groups=groups, flip_weight=flip_weight, flip_filter=flip_filter,
+                                        act=act, alpha=alpha, gain=gain, clamp=clamp, wgain=wgain, residual=residual), x
     x = conv2d_resample(x=x, w=w, f=f, up=up, down=down, padding=padding, groups=groups, flip_weight=flip_weight, flip_filter=flip_filter,
                         wgain=wgain)
     if residual is not None:

@@ -532,10 +532,12 @@ class _FilteredConv(torch.nn.Module):
 class Conv2dLayer(_FilteredConv):
     """conv2d_resample -> bias_act, bias / activation / gain / clamp in the convolution's epilogue where the dense
     convolution is the last step (networks.py:132-179)."""
-    def forward(self, x, gain=1):
+    def forward(self, x, gain=1, passthrough=False):
+        """``passthrough=True`` (own extension) returns ``(y, x')``: hand ``x'`` instead of ``x`` to the other consumers of ``x`` (a residual
+        block's skip branch) and their gradient is added in the epilogue of this layer's input-gradient launch (conv2d_gradfix._ConvBiasActHip)."""
         act_gain, act_clamp = _scaled_act(self.activation, gain, self.conv_clamp)
         return conv2d_resample.conv2d_resample_bias_act(x=x, b=(None if self.bias is None else self.bias.to(x.dtype)), act=self.activation,
-                                                        gain=act_gain, clamp=act_clamp, **self._resample_args(x))
+                                                        gain=act_gain, clamp=act_clamp, passthrough=passthrough, **self._resample_args(x))
 
 @persistence.persistent_class
 class Spade_Conv2dLayer(_FilteredConv):
@@ -696,6 +698,14 @@ class ToRGBLayerV18(_StyledHeads):
 #----------------------------------------------------------------------------
 # Encoders.
 
+# A/B switch: 0 = every consumer of a multi-consumer tensor returns its own input gradient and autograd adds them (two reads and a write per addition)
+_GRAD_JOIN = _os.environ.get('PASTA_GRAD_JOIN', '1') != '0'
+
+def _layer_and_input(layer, x):
+    """``(layer(x), x')`` for a tensor with further consumers: give them ``x'`` (= ``x``), and their gradient is added in the epilogue of
+    the layer's input-gradient launch instead of by a pass of its own (``Conv2dLayer.forward(passthrough=True)``)."""
+    return layer(x, passthrough=True) if _GRAD_JOIN else (layer(x), x)
+
 @persistence.persistent_class
 class ResBlock(torch.nn.Module):
     """sqrt(1/2) * (1x1 skip + 3x3 -> 3x3), resampling in skip and first 3x3 (networks.py:528-558).  ``kernel_size`` is
@@ -711,8 +721,9 @@ class ResBlock(torch.nn.Module):
 
     def forward(self, x):
         half = np.sqrt(0.5)
+        h, x = _layer_and_input(self.conv0, x)          # x again: the skip branch's gradient joins conv0's input gradient in that launch
         shortcut = self.skip(x, gain=half)
-        return shortcut.add_(self.conv1(self.conv0(x), gain=half))
+        return shortcut.add_(self.conv1(h, gain=half))
 
 # channel multipliers (in, out) of the pose encoder's stride-2 stages (networks.py:564-565); the table continues at
 # 8 -> 8 for pyramids deeper than the reference's six stages (512^2 and up, own generalisation)
@@ -850,28 +861,40 @@ class Spade_ResBlockV2(torch.nn.Module):
               and all(n.conv_mlp.up == n.conv_mlp.down == 1 and n.conv_mlp.bias is None for n in norms)
               and len({(n.conv_mlp.weight_gain, n.conv_gamma.weight_gain, n.conv_mlp.padding, n.conv_gamma.padding) for n in norms}) == 1)
         if not ok:
-            return None
+            return None, feat
         mlp, g = norms[0].conv_mlp, norms[0].conv_gamma
+        # (the feature map again as second result: the next SPADE block reads IT, and its gradient joins this convolution's input gradient
+        # in that launch's epilogue -- the three blocks' gradients into the map without the two 268 MB additions autograd would make)
         actv = conv2d_resample.conv2d_resample_bias_act(x=feat, w=torch.cat([n.conv_mlp.weight for n in norms], dim=0), b=None, act='relu', gain=1,
-                                                        f=mlp.resample_filter, padding=mlp.padding, flip_weight=True, wgain=mlp.weight_gain)
+                                                        f=mlp.resample_filter, padding=mlp.padding, flip_weight=True, wgain=mlp.weight_gain,
+                                                        passthrough=_GRAD_JOIN)
+        if _GRAD_JOIN:
+            actv, feat = actv
         w_gb = torch.cat([w for n in norms for w in (n.conv_gamma.weight, n.conv_beta.weight)], dim=0)
         gb_all = conv2d_gradfix.conv2d(actv, w_gb, padding=g.padding, groups=3, wgain=g.weight_gain)
         holder = _SharedGrad(gb_all, 3)
-        return [(v, holder, i) for i, v in enumerate(_SplitGroups.apply(gb_all, holder))]
+        return [(v, holder, i) for i, v in enumerate(_SplitGroups.apply(gb_all, holder))], feat
 
-    def forward(self, x, denorm_feat):
+    def forward(self, x, denorm_feat, return_feat=False):
+        """``return_feat=True`` (own extension): returns ``(y, feat')`` -- ``feat'`` is the feature map for the NEXT block that reads it (see
+        ``_batched_gamma_beta``)."""
+        y = self._forward(x, denorm_feat)
+        return y if return_feat else y[0]
+
+    def _forward(self, x, denorm_feat):
         half = np.sqrt(0.5)
         x = self.conv(x, no_act=True)
-        gb = self._batched_gamma_beta(denorm_feat) or (None, None, None)
+        gb, feat_next = self._batched_gamma_beta(denorm_feat)
+        gb = gb or (None, None, None)
         shortcut = self._norm_then_conv(self.spade_skip, self.skip, x, denorm_feat, half, gb=gb[0])
         x = self._norm_then_conv(self.spade0, self.conv0, x, denorm_feat, 1, gb=gb[1])
         if x.dtype == torch.float32 and x.device.type == 'cuda' and self.conv1.up == 1 and self.conv1.down == 1:
             # shortcut + conv1(.): the sum is formed in conv1's epilogue (the layers are activation-FIRST: the convolution is the last step).
             # fp32 storage only: in 16-bit storage the reference rounds conv1's output to the storage type BEFORE the addition, and the
             # config-5 fixtures (tests/test_config5_gpu.py) hold this path to that sequence of roundings
-            return self._norm_then_conv(self.spade1, self.conv1, x, denorm_feat, half, residual=shortcut, gb=gb[2])
+            return self._norm_then_conv(self.spade1, self.conv1, x, denorm_feat, half, residual=shortcut, gb=gb[2]), feat_next
         x = self._norm_then_conv(self.spade1, self.conv1, x, denorm_feat, half, gb=gb[2])
-        return shortcut.add_(x)
+        return shortcut.add_(x), feat_next
 
 _SPADE_BATCH = _os.environ.get('PASTA_SPADE_BATCH', '1') != '0'         # A/B switch: 0 = three conv_mlp and three gamma | beta convolutions per SPADE residual block
 _MERGE_FUSED = _os.environ.get('PASTA_MERGE_FUSED', '1') != '0'         # A/B switch: 0 = torch.cat + one 1x1 convolution, as the reference
@@ -1093,7 +1116,7 @@ class _PatchRoutedSynthesis(torch.nn.Module):
             feat = torch.cat([self._spade_fill(*pu), self._spade_fill(*pl)], dim=1)
         x, img_below = keep
         for i in (1, 2, 3):
-            x = getattr(self, f'spade_b{self.spade_resolution}_{i}')(x, feat)
+            x, feat = getattr(self, f'spade_b{self.spade_resolution}_{i}')(x, feat, return_feat=True)
         texture = getattr(self, f'texture_b{self.img_resolution}')
         return texture(x, img_below, top_rows, pose_feat, cat_feat, force_fp32=(self.act_dtype is None), **block_kwargs)[1]
 
@@ -1226,8 +1249,9 @@ class DiscriminatorBlock(torch.nn.Module):
             img = upfirdn2d.downsample2d(img, self.resample_filter) if self.architecture == 'skip' else None
         if self.architecture == 'resnet':
             half = np.sqrt(0.5)
+            h, x = _layer_and_input(self.conv0, x)      # x again: the skip branch's gradient joins conv0's input gradient in that launch
             shortcut = self.skip(x, gain=half)
-            x = shortcut.add_(self.conv1(self.conv0(x), gain=half))
+            x = shortcut.add_(self.conv1(h, gain=half))
         else:
             x = self.conv1(self.conv0(x))
         assert x.dtype == dtype
