@@ -267,6 +267,18 @@ int pasta_conv2d_wgrad(const void* x, const void* dy, float* dw,
                        const pasta_conv_desc* d, void* workspace,
                        int64_t workspace_bytes, void* stream);
 
+/* Weight gradient AND style gradient of the shared-weight modulated convolution  y = conv(x * styles[n, i], w)  (training/networks.py:72-76, the
+ * training branch of modulated_conv2d) WITHOUT the tensor x * styles: the weight-gradient kernels run on the unmodulated x with K slices that do
+ * not straddle samples, and the reduction forms  dw[o,i,t] = wscale sum_n styles[n,i] Dw_n[o,i,t]  and  dstyles[n,i] = sum_{o,t} wscale w[o,i,t] Dw_n[o,i,t]
+ * (Dw_n: sample n's gradient with respect to the weight it saw).  With the forward launched as pasta_conv2d(x, w, iscale = styles) and the input
+ * gradient as pasta_conv2d(dy, w, oscale = styles) the reference's  x * styles  (one pass to form it, its saved copy, one pass to scale the input
+ * gradient back, two reads for sum_hw dx x) is gone from the training step.  d, x, dy, x_amax / dy_amax as for pasta_conv2d_wgrad (x_amax: of the
+ * UNMODULATED x); styles: [N, C_in] fp32; w: the weight; dw: its gradient; dstyles: [N, C_in].  fp32 storage, groups == 1, N <= 32, the split kernels'
+ * shapes (pasta_conv2d_wgrad_plan kernels 2 - 4): pasta_conv2d_wgrad_modulated_workspace returns -1 where it does not apply (ABI 18). */
+int64_t pasta_conv2d_wgrad_modulated_workspace(const pasta_conv_desc* d);
+int pasta_conv2d_wgrad_modulated(const void* x, const void* dy, const float* styles, const float* w, float* dw, float* dstyles,
+                                 const pasta_conv_desc* d, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Modulated-convolution helpers (training/networks.py:36-94).
  * ------------------------------------------------------------------------- */

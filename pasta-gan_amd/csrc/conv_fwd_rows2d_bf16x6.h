@@ -455,12 +455,13 @@ static bool try_fwd_rows2d(const ConvFwdParams& p, hipStream_t s) {
     ConvFwdParams q = p;
     q.rows_y0 = ymin;
     if constexpr (BN == 128) {
-        if (rows2d_wide(p.cls[0].P, p.cls[0].Q) && (p.bf16x6 == 3 || p.bf16x6 == NP_F16X3) && p.io == IO_F32 && !p.iscale) {
+        if (rows2d_wide(p.cls[0].P, p.cls[0].Q) && (p.bf16x6 == 3 || p.bf16x6 == NP_F16X3) && p.io == IO_F32 && (!p.iscale || p.bf16x6 == NP_F16X3)) {
             ConvFwdParams w8 = q;
             w8.o_tiles = (p.Og + BM - 1) / BM;
             const int64_t tiles = (int64_t)p.N * (p.cls[0].P / 8) * (p.cls[0].Q / 32);
             const dim3 grid8((unsigned)tiles, w8.o_tiles * w8.ksplit, p.G);
-            if (p.bf16x6 == NP_F16X3) launch_fwd_rows2d_np<128, 256, 8, NP_F16X3, IO_F32, false, 512>(w8, grid8, s);
+            if (p.bf16x6 == NP_F16X3 && p.iscale) launch_fwd_rows2d_np<128, 256, 8, NP_F16X3, IO_F32, true, 512>(w8, grid8, s);      // the training step's modulated layers (round 4)
+            else if (p.bf16x6 == NP_F16X3) launch_fwd_rows2d_np<128, 256, 8, NP_F16X3, IO_F32, false, 512>(w8, grid8, s);
             else launch_fwd_rows2d_np<128, 256, 8, 3, IO_F32, false, 512>(w8, grid8, s);
             return true;
         }

@@ -173,7 +173,9 @@ struct WgradPlan {
     int64_t slab_floats; size_t lds_bytes;
 };
 
-static WgradPlan plan_wgrad(int N, int P, int Q, int G, int Ag, int Bg, int kh, int kw, int st) {
+// ks_multiple > 1 (pasta_conv2d_wgrad_modulated: the batch size): the number of K slices is rounded UP to a multiple of it, so that no slice
+// straddles two samples (the chunks are numbered sample-major and N divides their count where the caller checked)
+static WgradPlan plan_wgrad(int N, int P, int Q, int G, int Ag, int Bg, int kh, int kw, int st, int ks_multiple = 1) {
     WgradPlan w;
     if (kh == 3 && kw == 3) { w.TR = 3; w.TS = 3; }
     else if (kw == 7) { w.TR = 1; w.TS = 7; }
@@ -206,6 +208,7 @@ static WgradPlan plan_wgrad(int N, int P, int Q, int G, int Ag, int Bg, int kh, 
     if (ks > w.chunks_total / 8) ks = w.chunks_total / 8; // at least eight chunks per slice
     if (ks < 1) ks = 1;
     if (ks > 1024) ks = 1024;
+    if (ks_multiple > 1) ks = (ks + ks_multiple - 1) / ks_multiple * ks_multiple;
     w.ksplit = (int)ks;
     w.slab_floats = (int64_t)w.ksplit * G * kh * kw * w.a_tiles * BA * w.b_tiles * BB;
     const int lwid = (cw - 1) * st + w.TS, lpitch = lwid | 1, lch = (chh * w.TR * lpitch) | 1;
@@ -312,7 +315,7 @@ extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int launch_flags, int
         const bool plain6 = sb && d->stride == 1 && d->kw == 3 && d->kh == 3;
         const bool rows2d = plain6 && f.tile == T128x128 && rows2d_rows(d->OH, d->OW) > 0;
         const bool rows2d_256 = plain6 && f.tile == T64x256 && rows2d_rows256(d->OH, d->OW);
-        const bool wide = rows2d && !has_iscale && fp32_equivalent(math_pieces(d->math)) && d->io_dtype == PASTA_F32 && rows2d_wide(d->OH, d->OW);
+        const bool wide = rows2d && (!has_iscale || math_pieces(d->math) == NP_F16X3) && fp32_equivalent(math_pieces(d->math)) && d->io_dtype == PASTA_F32 && rows2d_wide(d->OH, d->OW);
         static const bool c1x1_on = !(getenv("PASTA_CONV1X1") && getenv("PASTA_CONV1X1")[0] == '0');
         const int bn1 = (d->C_out / d->groups) <= 64 ? 256 : 128;
         const bool c1x1 = c1x1_on && sb && math_pieces(d->math) == NP_F16X3 && d->io_dtype == PASTA_F32 && d->groups == 1 && d->kh == 1 && d->kw == 1 && d->stride == 1 &&
@@ -793,13 +796,58 @@ extern "C" int64_t pasta_conv2d_wgrad_workspace(const pasta_conv_desc* d) {
     return (WS_AMAX_FLOATS + w.slab_floats) * (int64_t)sizeof(float);
 }
 
+namespace pasta {
+// Can the weight gradient of a MODULATED convolution come from the plain kernels with sample-aligned K slices (pasta_conv2d_wgrad_modulated)?
+// The main split kernels only (3x3 stride 1 / stride 2, pointwise), fp32 storage, one group, up to 32 samples that the chunk count divides into.
+static bool wgrad_modulated_ok(const pasta_conv_desc* d, WgradPlan* out) {
+    if (d->groups != 1 || d->io_dtype != PASTA_F32 || d->N < 1 || d->N > 32 || plan_wgrad_small(d).use) return false;
+    const int Ig = d->C_in, Og = d->C_out;
+    const WgradPlan w = d->transposed ? plan_wgrad(d->N, d->H, d->W, 1, Ig, Og, d->kh, d->kw, d->stride, d->N)
+                                      : plan_wgrad(d->N, d->OH, d->OW, 1, Og, Ig, d->kh, d->kw, d->stride, d->N);
+    if (!(wgrad_bf16x6(d, w) || wgrad_s2_bf16x6(d, w) || (wgrad_1x1_bf16x6(d, w) && !(w.TR == 3 && w.TS == 3) && w.TS != 7 && w.TS != 4))) return false;
+    const int P = d->transposed ? d->H : d->OH;
+    const int chh = w.kp >> w.cw_log2;
+    if (P % chh != 0 || w.chunks_total % d->N != 0 || w.ksplit > w.chunks_total) return false;     // whole chunks per sample, at least one chunk per slice
+    if (out) *out = w;
+    return true;
+}
+// partial-ds blocks of wgrad_reduce_modulated_kernel: (16-row a blocks | 64-column b tiles when the modulated index is a) x taps
+static int wgrad_modulated_blocks(const pasta_conv_desc* d, const WgradPlan& w) {
+    const int Ap = w.a_tiles * 64 * w.WA, Bp = w.b_tiles * 64 * w.WB;
+    return (d->transposed ? Bp / 64 : Ap / wgrad_mod_rows(Ap, Bp, d->kh * d->kw)) * d->kh * d->kw;
+}
+static int wgrad_run(const void* xv, const void* dyv, float* dw, const pasta_conv_desc* d, void* workspace, int64_t workspace_bytes, void* stream,
+                     const float* mod_s, const float* mod_w, float* ds);
+}  // namespace pasta
+
+extern "C" int64_t pasta_conv2d_wgrad_modulated_workspace(const pasta_conv_desc* d) {
+    using namespace pasta;
+    if (check_desc(d, "conv2d_wgrad_modulated_workspace")) return -1;
+    WgradPlan w;
+    if (!wgrad_modulated_ok(d, &w)) return -1;
+    // [amax rows][slabs][partial ds: one [N][C_in] block per workgroup row of wgrad_reduce_modulated_kernel]
+    return (WS_AMAX_FLOATS + w.slab_floats + (int64_t)wgrad_modulated_blocks(d, w) * d->N * d->C_in) * (int64_t)sizeof(float);
+}
+
 extern "C" int pasta_conv2d_wgrad(const void* xv, const void* dyv, float* dw, const pasta_conv_desc* d, void* workspace,
                                   int64_t workspace_bytes, void* stream) {
+    return pasta::wgrad_run(xv, dyv, dw, d, workspace, workspace_bytes, stream, nullptr, nullptr, nullptr);
+}
+
+extern "C" int pasta_conv2d_wgrad_modulated(const void* x, const void* dy, const float* styles, const float* w, float* dw, float* dstyles,
+                                            const pasta_conv_desc* d, void* workspace, int64_t workspace_bytes, void* stream) {
     using namespace pasta;
+    PASTA_CHECK(styles && w && dstyles, "conv2d_wgrad_modulated: null pointer");
+    return wgrad_run(x, dy, dw, d, workspace, workspace_bytes, stream, styles, w, dstyles);
+}
+
+int pasta::wgrad_run(const void* xv, const void* dyv, float* dw, const pasta_conv_desc* d, void* workspace, int64_t workspace_bytes, void* stream,
+                     const float* mod_s, const float* mod_w, float* ds) {
     if (int e = check_desc(d, "conv2d_wgrad")) return e;
     const float* x = (const float*)xv; const float* dy = (const float*)dyv;       // elements of d->io_dtype behind these pointers
     PASTA_CHECK(x && dy && dw, "conv2d_wgrad: null pointer");
-    const int64_t need = pasta_conv2d_wgrad_workspace(d);
+    const int64_t need = mod_s ? pasta_conv2d_wgrad_modulated_workspace(d) : pasta_conv2d_wgrad_workspace(d);
+    PASTA_CHECK(need >= 0, "conv2d_wgrad_modulated: this shape has no sample-aligned split kernel (pasta_conv2d_wgrad_modulated_workspace tells beforehand)");
     PASTA_CHECK(workspace && workspace_bytes >= need, "conv2d_wgrad: workspace of %lld bytes needed, %lld given", (long long)need, (long long)workspace_bytes);
     hipStream_t s = (hipStream_t)stream;
     const int Ig = d->C_in / d->groups, Og = d->C_out / d->groups;
@@ -807,7 +855,7 @@ extern "C" int pasta_conv2d_wgrad(const void* xv, const void* dyv, float* dw, co
     float* const ws_amax = (float*)workspace;                         // [2][AMAX_PARTS]: x, dy
     workspace = (float*)workspace + WS_AMAX_FLOATS;                  // the partial slabs follow
 
-    const WgradSmallPlan ws = plan_wgrad_small(d);
+    const WgradSmallPlan ws = mod_s ? WgradSmallPlan{} : plan_wgrad_small(d);
     PASTA_CHECK(d->io_dtype == PASTA_F32 || !ws.use, "conv2d_wgrad: no 16-bit-storage kernel for this shape (pasta_conv2d_wgrad_plan tells beforehand)");
     if (const int fks = plan_wgrad1x1_fewcin(d, ws)) {
         // few input channels, 1x1: one bandwidth-bound pass over dy with plain FMAs (conv_wgrad_f32.h)
@@ -850,7 +898,7 @@ extern "C" int pasta_conv2d_wgrad(const void* xv, const void* dyv, float* dw, co
         p.S = x;  p.SC = d->C_in;  p.P = d->H; p.Q = d->W; p.Ag = Ig;
         p.L = dy; p.LC = d->C_out; p.LH = d->OH; p.LW = d->OW; p.Bg = Og;
     }
-    const WgradPlan w = plan_wgrad(p.N, p.P, p.Q, p.G, p.Ag, p.Bg, p.kh, p.kw, p.st);
+    const WgradPlan w = plan_wgrad(p.N, p.P, p.Q, p.G, p.Ag, p.Bg, p.kh, p.kw, p.st, mod_s ? d->N : 1);
     p.cw_log2 = w.cw_log2; p.rows_total = w.rows_total; p.qblocks = w.qblocks; p.chunks_total = w.chunks_total;
     p.ksplit = w.ksplit; p.a_tiles = w.a_tiles; p.b_tiles = w.b_tiles; p.tap_groups_r = w.tgr; p.tap_groups_s = w.tgs;
     // measured (profiles/r3_ab_wgrad_xcd.txt): 256 -> 128 at 128^2 298.6 -> 303.4 TFLOP/s, stride 2 at 256^2 143 -> 154, at 257^2 140.7 -> 143.4,
@@ -918,6 +966,22 @@ extern "C" int pasta_conv2d_wgrad(const void* xv, const void* dyv, float* dw, co
 #undef PASTA_WGRAD
 #undef PASTA_WGRAD1
 #undef PASTA_NP
+    if (mod_s) {
+        // slices [n m, (n + 1) m) hold sample n's gradient with respect to the modulated weight: dw = sum_n s[n, i] (.), ds[n, i] = sum_{o, taps} w (.)
+        const int Ap = w.a_tiles * 64 * w.WA, Bp = w.b_tiles * 64 * w.WB;
+        float* const dsp = (float*)workspace + w.slab_floats;
+        const float wsc = d->wscale == 0.f ? 1.f : d->wscale;
+        const int wg_rows = wgrad_mod_rows(Ap, Bp, p.kh * p.kw);
+        const dim3 grid((unsigned)(Bp / 64), (unsigned)(Ap / wg_rows), (unsigned)(p.kh * p.kw));
+        if (d->transposed) hipLaunchKernelGGL((wgrad_reduce_modulated_kernel<true>), grid, dim3(256), 0, s, (const float*)workspace, mod_s, mod_w, dw, dsp, w.ksplit, d->N,
+                                              p.Ag, p.Bg, Ap, Bp, p.kh, p.kw, d->flip, wsc, wg_rows);
+        else               hipLaunchKernelGGL((wgrad_reduce_modulated_kernel<false>), grid, dim3(256), 0, s, (const float*)workspace, mod_s, mod_w, dw, dsp, w.ksplit, d->N,
+                                              p.Ag, p.Bg, Ap, Bp, p.kh, p.kw, d->flip, wsc, wg_rows);
+        const int tiles = wgrad_modulated_blocks(d, w);
+        const int nc = d->N * d->C_in;
+        hipLaunchKernelGGL(sum_blocks_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, (const float*)dsp, ds, tiles, nc);
+        return launch_status("conv2d_wgrad_modulated");
+    }
     {
         const int64_t total = (int64_t)p.G * p.kh * p.kw * p.Ag * p.Bg;
         int64_t rb = ceil_div64(total, 256);

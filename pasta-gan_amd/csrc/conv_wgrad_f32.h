@@ -235,6 +235,109 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 //------------------------------------------------------------------------------------
+// Weight gradient AND style gradient of a modulated convolution y = conv(x * s[n, i], w) (networks.py:72-76) from the weight-gradient kernels run on
+// the UNMODULATED x (pasta_conv2d_wgrad_modulated): the K slices are sample-aligned -- slices [n m, (n + 1) m), m = ksplit / N, sum to Dw_n, sample n's
+// gradient with respect to the weight it saw, w s[n, i] -- so
+//     dw[o, i, t] = wscale sum_n s[n, i] Dw_n[o, i, t]            ds[n, i] = sum_{o, t} wscale w[o, i, t] Dw_n[o, i, t]
+// and neither x * s (a pass over the activation to form it, one to scan it, one to scale the input gradient back) nor the plane products
+// sum_hw dx x (two reads) exist.  Workgroup = (64 b, 16 or 4 a, one tap); wave = four rows a or one, lanes along b (the slab's contiguous index).
+// MOD_A: the modulated (input) channel is the a index (conv_transpose2d: weight [I, O, kh, kw]).  Partial ds per workgroup row:
+// dsp[(a block * KK + t)][n][b] (MOD_A: dsp[(b tile * KK + t)][n][a]), summed in a fixed order by sum_blocks_kernel.  N <= 32.
+// rows a per workgroup: 16, or 4 where 16 would leave the grid below 512 workgroups (the 64- and 128-channel layers: 75 MB of slabs each)
+static int wgrad_mod_rows(int Ap, int Bp, int KK) { return (int64_t)(Bp / 64) * (Ap / 16) * KK >= 512 ? 16 : 4; }
+template <bool MOD_A>
+__global__ __launch_bounds__(256) void wgrad_reduce_modulated_kernel(const float* __restrict__ slab, const float* __restrict__ sty, const float* __restrict__ w,
+                                                                     float* __restrict__ dw, float* __restrict__ dsp, int ksplit, int N,
+                                                                     int Ag, int Bg, int Ap, int Bp, int kh, int kw, int flip, float wscale, int wg_rows) {
+    constexpr int MAXN = 32;
+    const int ROWS = wg_rows / 4;                                    // rows a per wave
+    const int KK = kh * kw;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 64 + lane;
+    const int t = blockIdx.z;
+    const int m = ksplit / N;
+    const int C = MOD_A ? Ag : Bg;                                   // modulated channels
+    const int64_t slab_stride = (int64_t)KK * Ap * Bp;
+    int ty = t / kw, tx = t - ty * kw;
+    if (flip) { ty = kh - 1 - ty; tx = kw - 1 - tx; }
+    float dsacc[MAXN];
+#pragma unroll
+    for (int n = 0; n < MAXN; n++) dsacc[n] = 0.f;
+    __shared__ float red[4][MAXN][64];
+    for (int j = 0; j < ROWS; j++) {
+        const int a = blockIdx.y * wg_rows + wave * ROWS + j;
+        const bool live = a < Ag && b < Bg;
+        const float* src = slab + ((int64_t)t * Ap + a) * Bp + b;   // a < Ap, b < Bp: inside the padded slab
+        const int64_t widx = (((int64_t)a * Bg + b) * kh + ty) * kw + tx;
+        const float wv = live ? w[widx] * wscale : 0.f;
+        float dwsum = 0.f;
+        // four samples at a time, their slices four at a time: sixteen independent loads in flight, every sum in a fixed order
+#pragma unroll
+        for (int n0 = 0; n0 < MAXN; n0 += 4) {
+            if (n0 < N) {
+                float pn[4] = {0.f, 0.f, 0.f, 0.f};
+                const float* sp[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) sp[q] = src + (int64_t)((n0 + q < N ? n0 + q : n0) * m) * slab_stride;
+                int k = 0;
+                for (; k + 4 <= m; k += 4) {
+                    float r[4][4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+#pragma unroll
+                        for (int u = 0; u < 4; u++) r[q][u] = sp[q][(int64_t)(k + u) * slab_stride];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) pn[q] += (r[q][0] + r[q][1]) + (r[q][2] + r[q][3]);
+                }
+                for (; k < m; k++) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) pn[q] += sp[q][(int64_t)k * slab_stride];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int n = n0 + q;
+                    const float v = (live && n < N) ? pn[q] : 0.f;
+                    const float sc = (live && n < N) ? sty[n * C + (MOD_A ? a : b)] : 0.f;
+                    dwsum = fmaf(sc, v, dwsum);
+                    if constexpr (MOD_A) {
+                        float z = wv * v;                             // this row's share of ds[n, a]: summed over the b lanes now
+#pragma unroll
+                        for (int off = 32; off >= 1; off >>= 1) z += __shfl_xor(z, off, 64);
+                        if (lane == 0 && a < Ag && n < N) dsp[((int64_t)(blockIdx.x * KK + t) * N + n) * C + a] = z;
+                    } else {
+                        dsacc[n] = fmaf(wv, v, dsacc[n]);
+                    }
+                }
+            }
+        }
+        if (live) dw[widx] = dwsum * wscale;
+    }
+    if constexpr (!MOD_A) {
+#pragma unroll
+        for (int n = 0; n < MAXN; n++) if (n < N) red[wave][n][lane] = dsacc[n];
+        __syncthreads();
+        // four waves' partial sums in a fixed order; thread -> (n, b): 64 lanes along b, waves stride n
+        for (int n = wave; n < N; n += 4) {
+            const float v = (red[0][n][lane] + red[1][n][lane]) + (red[2][n][lane] + red[3][n][lane]);
+            if (b < Bg) dsp[((int64_t)(blockIdx.y * KK + t) * N + n) * C + b] = v;
+        }
+    }
+}
+
+// out[i] = sum_k blocks[k][i] in the order of k (bitwise reproducible)
+__global__ __launch_bounds__(256) void sum_blocks_kernel(const float* __restrict__ blocks, float* __restrict__ out, int nblocks, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= nblocks; k += 4) {
+        v0 += blocks[(int64_t)k * n + i]; v1 += blocks[(int64_t)(k + 1) * n + i]; v2 += blocks[(int64_t)(k + 2) * n + i]; v3 += blocks[(int64_t)(k + 3) * n + i];
+    }
+    for (; k < nblocks; k++) v0 += blocks[(int64_t)k * n + i];
+    out[i] = (v0 + v1) + (v2 + v3);
+}
+
+//------------------------------------------------------------------------------------
 // Weight gradient when the input has very few channels (RGB / pose stems: 3 or 6 channels, up to 7x7):
 // the (channel, tap) pairs become the GEMM's column index b' = (i*kh + r)*kw + s, so a 7x7x3 kernel fills
 // 147 of 160 MFMA columns instead of 3 of 64.  conv2d, stride 1, groups 1 only.

@@ -158,6 +158,8 @@ ABI = {
     'pasta_conv2d':       (ctypes.c_int, [_c_ptr] * 5 + [ctypes.POINTER(ConvDesc), _c_ptr, _c_i64, _c_ptr]),
     'pasta_conv2d_ex':    (ctypes.c_int, [_c_ptr] * 5 + [ctypes.POINTER(ConvEpilogue), ctypes.POINTER(ConvDesc), _c_ptr, _c_i64, _c_ptr]),
     'pasta_conv2d_wgrad': (ctypes.c_int, [_c_ptr] * 3 + [ctypes.POINTER(ConvDesc), _c_ptr, _c_i64, _c_ptr]),
+    'pasta_conv2d_wgrad_modulated': (ctypes.c_int, [_c_ptr] * 6 + [ctypes.POINTER(ConvDesc), _c_ptr, _c_i64, _c_ptr]),
+    'pasta_conv2d_wgrad_modulated_workspace': (_c_i64, [ctypes.POINTER(ConvDesc)]),
     'pasta_conv2d_modulated': (ctypes.c_int, [_c_ptr] * 5 + [ctypes.POINTER(ConvEpilogue), ctypes.POINTER(ConvDesc), _c_ptr, _c_i64, _c_ptr]),
     'pasta_tensor_amax':  (ctypes.c_int, [_c_ptr, _c_i64, ctypes.c_int, _c_ptr, _c_ptr]),
     'pasta_demod_coefs':  (ctypes.c_int, [_c_ptr] * 3 + [ctypes.c_int] * 4 + [_c_f32, _c_ptr]),

@@ -588,6 +588,93 @@ def modulated_conv2d_forward(x, weight, styles, dcoefs=None, stride=1, padding=0
         return _launch_conv(x, weight, cfg, iscale=styles)
     return _launch_conv(x, weight, cfg, iscale=styles, oscale=dcoefs, epilogue=epilogue, noise=noise)
 
+#----------------------------------------------------------------------------
+# Shared-weight modulated convolution of the TRAINING path, y = conv(x * s[n, i], w)  (networks.py:72-76), without the tensor x * s:
+#   forward          conv(x, w) with the styles multiplied onto the activations in the kernel's staging (``iscale``),
+#   input gradient   conv^T(dy, w) with the styles as the output scale of the launch's epilogue (``oscale``),
+#   weight gradient  the plain weight-gradient kernels on the UNMODULATED x with sample-aligned K slices, whose reduction forms
+#                    dw = sum_n s[n, i] Dw_n and ds[n, i] = sum_{o, taps} w Dw_n  (pasta_conv2d_wgrad_modulated),
+# instead of scale_planes (a read and a write of the activation) + a scan of x * s for its operand scale + scale_planes of the input
+# gradient + plane_dot(dx, x) (two reads): seven passes over the activation per modulated layer.  
+
+_MODCONV = _os.environ.get('PASTA_MODCONV_TRAIN', '1') != '0'         # A/B switch: 0 = scale_planes + the plain convolution, as before
+_modconv_cache = {}
+
+def modconv_available(x, weight, styles, stride=1, padding=0, transposed=False):
+    """Does ``modulated_conv2d_shared`` run natively for these operands (else the caller scales the planes itself)?"""
+    if not (_MODCONV and x.device.type == 'cuda' and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.ndim == 4 and x.numel() > 0
+            and conv_math in ('default', 'f16x3') and not transposed and stride == 1):
+        return False
+    ph, pw = _pair(padding)
+    key = (tuple(x.shape), tuple(weight.shape), ph, pw)
+    hit = _modconv_cache.get(key)
+    if hit is None:
+        cfg = _Cfg((False, 1, ph, pw, 0, 0, 1, 1.0))
+        kh, kw = int(weight.shape[2]), int(weight.shape[3])
+        oh, ow = _out_hw(cfg, x.shape[2], x.shape[3], kh, kw)
+        desc = _desc(cfg, x.shape, int(weight.shape[0]), oh, ow, kh, kw, kind='wgrad')
+        hit = _native.lib().pasta_conv2d_wgrad_modulated_workspace(ctypes.byref(desc)) >= 0
+        _modconv_cache[key] = hit
+    return hit
+
+def _launch_wgrad_modulated(x, dy, cfg, styles, w, x_amax=None):
+    """(dw, dstyles) of ``conv(x * styles, w)`` given dy: pasta_conv2d_wgrad_modulated."""
+    _native.require_gpu(x, 'conv2d_wgrad_modulated')
+    kh, kw = int(w.shape[2]), int(w.shape[3])
+    x, dy = _f32(x).contiguous(), _f32(dy).contiguous()
+    styles, w32 = _f32(styles).contiguous(), _f32(w).contiguous()
+    desc = _desc(cfg, x.shape, dy.shape[1], dy.shape[2], dy.shape[3], kh, kw, kind='wgrad')
+    lib = _native.lib()
+    nbytes = lib.pasta_conv2d_wgrad_modulated_workspace(ctypes.byref(desc))
+    if nbytes < 0:
+        raise RuntimeError('conv2d_wgrad_modulated: no sample-aligned weight-gradient kernel for this shape (modconv_available tells beforehand)')
+    work = torch.empty([max(nbytes // 4, 4)], dtype=torch.float32, device=x.device)
+    dw = torch.empty(list(w.shape), dtype=torch.float32, device=x.device)
+    ds = torch.empty([x.shape[0], x.shape[1]], dtype=torch.float32, device=x.device)
+    amax_x, amax_dy = (x_amax if x_amax is not None else tensor_amax(x)), tensor_amax(dy)
+    desc.x_amax, desc.dy_amax = amax_x.data_ptr(), amax_dy.data_ptr()
+    def launch():
+        with torch.cuda.device(x.device):
+            _native.check(lib.pasta_conv2d_wgrad_modulated(_native.ptr(x), _native.ptr(dy), _native.ptr(styles), _native.ptr(w32), _native.ptr(dw), _native.ptr(ds),
+                                                           ctypes.byref(desc), _native.ptr(work), work.numel() * 4, _native.stream()))
+    if launch_hook is None:
+        launch()
+    else:
+        launch_hook('wgrad', desc, launch, 0)
+    return dw, ds
+
+class _ModConvHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, s, cfg):
+        used = {}
+        y = _launch_conv(x, w, cfg, iscale=s, used=used)
+        ctx.save_for_backward(x, w, s)
+        ctx.cfg, ctx.x_amax = cfg, used.get('x_amax')
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, w, s = ctx.saved_tensors
+        cfg = ctx.cfg
+        dx = dw = ds = None
+        dy = dy.contiguous()
+        if ctx.needs_input_grad[0]:
+            dx = _launch_conv(dy, w, _grad_cfg(cfg, x.shape[2:], dy.shape[2:], w.shape[2], w.shape[3]), oscale=s)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dw, ds = _launch_wgrad_modulated(x, dy, cfg, s, w, x_amax=ctx.x_amax)
+            dw = dw.to(w.dtype) if ctx.needs_input_grad[1] and not weight_gradients_disabled else None
+            ds = ds.to(s.dtype) if ctx.needs_input_grad[2] else None
+        return dx, dw, ds, None
+
+def modulated_conv2d_shared(x, weight, styles, padding=0):
+    """``conv2d(x * styles[:, :, None, None], weight, padding=padding)`` for the training path (where ``modconv_available``); first derivatives only,
+    like the reference's own fused op would be used (the generator has no second-order phase: networks.py / loss_wo_flow_fullbody.py run no
+    path-length regularisation).  ``styles``: [N, C_in]."""
+    ph, pw = _pair(padding)
+    cfg = _Cfg((False, 1, ph, pw, 0, 0, 1, 1.0))
+    return _ModConvHip.apply(x, weight, styles.to(torch.float32).reshape(x.shape[0], x.shape[1]), cfg)
+
 def demod_coefs(weight, styles):
     """``rsqrt(sum_{i,kh,kw} (weight[o,i] * styles[n,i])^2 + 1e-8)`` [N, O] (networks.py:65-68) by ``pasta_demod_coefs``: one
     workgroup per output channel, wavefront-shuffle reduction; differentiable to any order (the backward is written in

@@ -387,7 +387,13 @@ def _modulate_and_convolve(x, weight, styles, up, down, padding, resample_filter
     """Shared-weight form of the modulated convolution up to, not including, the demodulation (networks.py:72-76):
     returns conv(x * s) and the demodulation coefficients (None without demodulation)."""
     dcoefs = _demodulation(weight, styles) if demodulate else None
-    y = conv2d_resample.conv2d_resample(x=scale_planes(x, styles), w=_master_weight(weight, x), f=resample_filter, up=up, down=down,
+    w = _master_weight(weight, x)
+    if up == 1 and down == 1 and isinstance(padding, int) and (flip_weight or tuple(w.shape[2:]) == (1, 1)) and \
+            conv2d_gradfix.modconv_available(x, w, styles, padding=padding):
+        # the styles ride in the staging of the forward launch, in the epilogue of the input gradient and in the reduction of the weight
+        # gradient: x * styles is never formed (conv2d_gradfix.modulated_conv2d_shared)
+        return conv2d_gradfix.modulated_conv2d_shared(x, w, styles, padding=padding), dcoefs
+    y = conv2d_resample.conv2d_resample(x=scale_planes(x, styles), w=w, f=resample_filter, up=up, down=down,
                                         padding=padding, flip_weight=flip_weight)
     return y, dcoefs
 
