@@ -166,22 +166,41 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16x3_kernel(ConvFwdParams p) 
                 for (int r = 0; r < 16; r++) acc[a][b][r] = (acc[a][b][r] * isx) * ws[a][r];
     }
     const int64_t ybase = (int64_t)n_img * p.Cout * HW + (pix_blk - (int64_t)n_img * HW);
+    // bias per output row and the residual of a 32 x 32 sub-tile are fetched in front of the stores (a load in front of every store serialises on
+    // the memory counter: conv_fwd_rows2d_bf16x6.h)
+    float row_b[WMT][16];
+#pragma unroll
+    for (int a = 0; a < WMT; a++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
+            row_b[a][r] = (p.act && p.bias) ? p.bias[o < p.Og ? o : p.Og - 1] : 0.f;
+        }
 #pragma unroll
     for (int b = 0; b < WNT; b++) {
         const int64_t yoff = ybase + (wn * WNT + b) * 32 + jl;
 #pragma unroll
-        for (int a = 0; a < WMT; a++)
+        for (int a = 0; a < WMT; a++) {
+            float rv[16];
+            if (p.res) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
+                    rv[r] = o < p.Og ? p.res[yoff + (int64_t)o * HW] : 0.f;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
                 if (o < p.Og) {
                     float v = acc[a][b][r];
-                    if (p.res) v += p.res[yoff + (int64_t)o * HW];
-                    if (p.act) v = conv_epilogue(v, p.bias ? p.bias[o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
+                    if (p.res) v += rv[r];
+                    if (p.act) v = conv_epilogue(v, row_b[a][r], p.act, p.alpha, p.gain, p.clamp);
                     p.y[yoff + (int64_t)o * HW] = v;
                     if (p.y_amax) amax_take(y_am, v);
                 }
             }
+        }
     }
     amax_commit(y_am, y_slot);
 }

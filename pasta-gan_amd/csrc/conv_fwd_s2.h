@@ -200,24 +200,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_f16x3_kernel(ConvFwdParams p
                 for (int r = 0; r < 16; r++) acc[a][b][r] = (acc[a][b][r] * isx) * ws[a][r];
     }
     const int OHW = OH * OW;
+    float row_b[WMT][16];                                // bias per output row, fetched in front of the stores (conv_fwd_rows2d_bf16x6.h)
+#pragma unroll
+    for (int a = 0; a < WMT; a++)
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) {
+            const int o = o_blk + (wm * WMT + a) * 32 + acc_row(rr, lane);
+            row_b[a][rr] = (p.act && p.bias) ? p.bias[o < p.Og ? o : p.Og - 1] : 0.f;
+        }
 #pragma unroll
     for (int b = 0; b < WNT_; b++) {
         const int t = wn * WN_PIX + b * 32 + jl;
         const int r = t >> seg_log2, c = t & (SEG - 1);
         const int64_t yoff = (int64_t)n_img * p.Cout * OHW + (p0 + r) * OW + q0 + c;
 #pragma unroll
-        for (int a = 0; a < WMT; a++)
+        for (int a = 0; a < WMT; a++) {
+            float rv[16];
+            if (p.res) {
+#pragma unroll
+                for (int rr = 0; rr < 16; rr++) {
+                    const int o = o_blk + (wm * WMT + a) * 32 + acc_row(rr, lane);
+                    rv[rr] = o < p.Og ? p.res[yoff + (int64_t)o * OHW] : 0.f;
+                }
+            }
 #pragma unroll
             for (int rr = 0; rr < 16; rr++) {
                 const int o = o_blk + (wm * WMT + a) * 32 + acc_row(rr, lane);
                 if (o < p.Og) {
                     float v = acc[a][b][rr];
-                    if (p.res) v += p.res[yoff + (int64_t)o * OHW];
-                    if (p.act) v = conv_epilogue(v, p.bias ? p.bias[o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
+                    if (p.res) v += rv[rr];
+                    if (p.act) v = conv_epilogue(v, row_b[a][rr], p.act, p.alpha, p.gain, p.clamp);
                     p.y[yoff + (int64_t)o * OHW] = v;
                     if (p.y_amax) amax_take(y_am, v);
                 }
             }
+        }
     }
     amax_commit(y_am, y_slot);
 }

@@ -533,7 +533,11 @@ def conv2d_bias_act(input, weight, bias=None, stride=1, padding=0, groups=1, act
         assert sh == sw
         cfg = _Cfg((False, sh, ph, pw, 0, 0, int(groups), float(wgain)))
         if passthrough and torch.is_grad_enabled() and input.requires_grad:
-            return _ConvBiasActHip.apply(input, weight, bias, cfg, (act, alpha, gain, clampf), residual, True)
+            y, again = _ConvBiasActHip.apply(input, weight, bias, cfg, (act, alpha, gain, clampf), residual, True)
+            hit = getattr(input, '_pasta_amax', None)      # the view autograd made of the input is the same data at the same version: its maxima go along
+            if hit is not None and not again.is_inference():
+                again._pasta_amax = hit
+            return y, again
         y = _ConvBiasActHip.apply(input, weight, bias, cfg, (act, alpha, gain, clampf), residual)
         return (y, input) if passthrough else y
     y = conv2d(input, weight, stride=stride, padding=padding, groups=groups, wgain=wgain)

@@ -538,12 +538,25 @@ class _FilteredConv(torch.nn.Module):
 class Conv2dLayer(_FilteredConv):
     """conv2d_resample -> bias_act, bias / activation / gain / clamp in the convolution's epilogue where the dense
     convolution is the last step (networks.py:132-179)."""
-    def forward(self, x, gain=1, passthrough=False):
+    def forward(self, x, gain=1, passthrough=False, add=None):
         """``passthrough=True`` (own extension) returns ``(y, x')``: hand ``x'`` instead of ``x`` to the other consumers of ``x`` (a residual
-        block's skip branch) and their gradient is added in the epilogue of this layer's input-gradient launch (conv2d_gradfix._ConvBiasActHip)."""
+        block's skip branch) and their gradient is added in the epilogue of this layer's input-gradient launch (conv2d_gradfix._ConvBiasActHip).
+        ``add`` (own extension; shape of the output): returns ``layer(x, gain) + add`` -- for a linear, bias-free, unclamped layer on fp32 GPU
+        tensors (the skip branch of the residual blocks) the sum is formed in the convolution's epilogue, the gain folded into the weight
+        gain; otherwise by ``add_`` as the reference writes it (networks.py:557, :994)."""
+        if add is not None:
+            if _SKIP_ADD_FUSED and self.activation == 'linear' and self.bias is None and self.conv_clamp is None and x.dtype == torch.float32 \
+                    and x.device.type == 'cuda' and self.up == 1 and not passthrough:
+                args = self._resample_args(x)
+                args['wgain'] = args['wgain'] * float(gain)
+                return conv2d_resample.conv2d_resample_bias_act(x=x, b=None, act='linear', gain=1, clamp=None, residual=add, **args)
+            return self.forward(x, gain=gain, passthrough=passthrough).add_(add)
         act_gain, act_clamp = _scaled_act(self.activation, gain, self.conv_clamp)
         return conv2d_resample.conv2d_resample_bias_act(x=x, b=(None if self.bias is None else self.bias.to(x.dtype)), act=self.activation,
                                                         gain=act_gain, clamp=act_clamp, passthrough=passthrough, **self._resample_args(x))
+
+# A/B switch: 0 = ``shortcut.add_(...)`` as the reference writes the residual blocks; 1 = the sum in the skip convolution's epilogue
+_SKIP_ADD_FUSED = _os.environ.get('PASTA_SKIP_ADD_FUSED', '1') != '0'
 
 @persistence.persistent_class
 class Spade_Conv2dLayer(_FilteredConv):
@@ -728,8 +741,7 @@ class ResBlock(torch.nn.Module):
     def forward(self, x):
         half = np.sqrt(0.5)
         h, x = _layer_and_input(self.conv0, x)          # x again: the skip branch's gradient joins conv0's input gradient in that launch
-        shortcut = self.skip(x, gain=half)
-        return shortcut.add_(self.conv1(h, gain=half))
+        return self.skip(x, gain=half, add=self.conv1(h, gain=half))      # skip(x) + conv1(.): the sum in the skip convolution's epilogue
 
 # channel multipliers (in, out) of the pose encoder's stride-2 stages (networks.py:564-565); the table continues at
 # 8 -> 8 for pyramids deeper than the reference's six stages (512^2 and up, own generalisation)
@@ -1256,8 +1268,7 @@ class DiscriminatorBlock(torch.nn.Module):
         if self.architecture == 'resnet':
             half = np.sqrt(0.5)
             h, x = _layer_and_input(self.conv0, x)      # x again: the skip branch's gradient joins conv0's input gradient in that launch
-            shortcut = self.skip(x, gain=half)
-            x = shortcut.add_(self.conv1(h, gain=half))
+            x = self.skip(x, gain=half, add=self.conv1(h, gain=half))     # skip(x) + conv1(.): the sum in the skip convolution's epilogue
         else:
             x = self.conv1(self.conv0(x))
         assert x.dtype == dtype

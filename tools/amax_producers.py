@@ -18,6 +18,7 @@ def spy(t):
             # no graph (backward pass or no_grad): name the caller chain instead
             fr = [f.name for f in traceback.extract_stack(limit=12)][:-2]
             who = 'nograd:' + '>'.join(n for n in fr if n not in ('apply', '_call_impl', '_wrapped_call_impl', 'forward', 'launch', '<module>'))[-90:]
+        who += ' ' + str(tuple(t.shape))
         if isinstance(t, torch.nn.Parameter): who = 'Parameter'
         stats[who][0] += 1; stats[who][1] += t.numel() * 4
     return orig(t)
