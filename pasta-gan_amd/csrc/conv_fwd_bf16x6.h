@@ -474,19 +474,43 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
         const bool has_res = p.res && p.ksplit == 1;
         const float* osb = (p.oscale && p.ksplit == 1) ? p.oscale + (int64_t)n * p.Cout + (int64_t)g * p.Og : nullptr;
 #pragma unroll
-        for (int a = 0; a < WMT; a++)
+        for (int a = 0; a < WMT; a++) {
+            // what the sixteen stores of a 32 x 32 sub-tile need from memory -- output scale, residual, bias -- is fetched in front of them
+            // (a load in front of every store serialises on the memory counter: conv_fwd_rows2d_bf16x6.h)
+            // (one operand kind at a time through the same sixteen registers: three arrays side by side spill on the three-workgroup tiles)
+            float tv[16];
+            const bool has_bias = p.act && p.ksplit == 1 && p.bias;
+            if (osb) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) { const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane); tv[r] = osb[o < p.Og ? o : p.Og - 1]; }
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[a][b][r] = fmaf(acc[a][b][r], tv[r], nz);
+            } else if (has_noise) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[a][b][r] += nz;
+            }
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
+                    tv[r] = o < p.Og ? io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES) : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[a][b][r] += tv[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) { const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane); tv[r] = has_bias ? p.bias[g * p.Og + (o < p.Og ? o : p.Og - 1)] : 0.f; }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
                 if (o < p.Og) {
                     float v = acc[a][b][r];
-                    v = conv_scale_noise(v, osb, o, nz);
-                    if (has_res) v += io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES);
-                    if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
+                    if (p.act && p.ksplit == 1) v = conv_epilogue(v, tv[r], p.act, p.alpha, p.gain, p.clamp);
                     if (pb) pb[(int64_t)o * OHW] = v;
                     else { io_st<IO>(p.y, yoff + (int64_t)o * OHW, v); if (p.y_amax) amax_take(y_am, v); }
                 }
             }
+        }
     }
     if (p.ksplit == 1) amax_commit(y_am, y_slot);
 }
@@ -1093,19 +1117,43 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
         const bool has_res = p.res && p.ksplit == 1;
         const float* osb = (p.oscale && p.ksplit == 1) ? p.oscale + (int64_t)n * p.Cout + (int64_t)g * p.Og : nullptr;
 #pragma unroll
-        for (int a = 0; a < WMT; a++)
+        for (int a = 0; a < WMT; a++) {
+            // what the sixteen stores of a 32 x 32 sub-tile need from memory -- output scale, residual, bias -- is fetched in front of them
+            // (a load in front of every store serialises on the memory counter: conv_fwd_rows2d_bf16x6.h)
+            // (one operand kind at a time through the same sixteen registers: three arrays side by side spill on the three-workgroup tiles)
+            float tv[16];
+            const bool has_bias = p.act && p.ksplit == 1 && p.bias;
+            if (osb) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) { const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane); tv[r] = osb[o < p.Og ? o : p.Og - 1]; }
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[a][b][r] = fmaf(acc[a][b][r], tv[r], nz);
+            } else if (has_noise) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[a][b][r] += nz;
+            }
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
+                    tv[r] = o < p.Og ? io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES) : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[a][b][r] += tv[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) { const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane); tv[r] = has_bias ? p.bias[g * p.Og + (o < p.Og ? o : p.Og - 1)] : 0.f; }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
                 if (o < p.Og) {
                     float v = acc[a][b][r];
-                    v = conv_scale_noise(v, osb, o, nz);
-                    if (has_res) v += io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES);
-                    if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
+                    if (p.act && p.ksplit == 1) v = conv_epilogue(v, tv[r], p.act, p.alpha, p.gain, p.clamp);
                     if (pb) pb[(int64_t)o * OHW] = v;
                     else { io_st<IO>(p.y, yoff + (int64_t)o * OHW, v); if (p.y_amax) amax_take(y_am, v); }
                 }
             }
+        }
     }
     if (p.ksplit == 1) amax_commit(y_am, y_slot);
 }
