@@ -77,8 +77,11 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __r
 constexpr int PACK_ROW_LDS = 8192;          // floats of a row kept in LDS; longer rows are re-read from global memory (L2)
 __global__ __launch_bounds__(256) void pack_weights_f16x3_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, float* __restrict__ rowinv,
                                                                  int Ig, int Og, int Ig_pad, int Og_pad, int kh, int kw, int transposed, int flip,
-                                                                 float wscale, const float* __restrict__ mod_s, const float* __restrict__ mod_d) {
-    const int g = blockIdx.y, o = blockIdx.x;               // one packed row
+                                                                 float wscale, const float* __restrict__ mod_s, const float* __restrict__ mod_d, int pack_xcd_rows) {
+    // one packed row.  Eight consecutive rows share every 128-byte line of the packed layout ([...][O_pad][8 x 2 bytes]) and workgroups go round-robin
+    // to the eight XCDs: XCD x takes the rows [x O_pad / 8, (x + 1) O_pad / 8), so that the sixteen-byte stores of a line meet in ONE L2 and leave it
+    // as a whole line (O_pad is a multiple of 64)
+    const int g = blockIdx.y, o = pack_xcd_rows ? (int)(blockIdx.x & 7u) * (Og_pad >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int taps = kh * kw, NC = Ig_pad / 16, K = Ig * taps;
     const int tid = threadIdx.x;
     const int gs = mod_s ? 0 : g;

@@ -646,9 +646,11 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
         const int64_t total = (int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad;
         int64_t blocks = ceil_div64(total, 256);
         if (blocks > 4096) blocks = 4096;
-        if (p.bf16x6 == NP_F16X3 && p.io == IO_F32)         // two fp16 pieces, one scale per output row found on the way
+        if (p.bf16x6 == NP_F16X3 && p.io == IO_F32) {       // two fp16 pieces, one scale per output row found on the way
+            static const int pack_xcd = getenv("PASTA_PACK_XCD") ? atoi(getenv("PASTA_PACK_XCD")) : 1;      // A/B switch: 0 = row = workgroup index
             hipLaunchKernelGGL(pack_weights_f16x3_kernel, dim3((unsigned)p.Og_pad, (unsigned)p.G), dim3(256), 0, s, w, (__bf16*)workspace, ws_rowinv,
-                               p.Ig, p.Og, p.Ig_pad, p.Og_pad, pk_kh, pk_kw, pk_tr, pk_flip, wscale, wmod_s, wmod_d);
+                               p.Ig, p.Og, p.Ig_pad, p.Og_pad, pk_kh, pk_kw, pk_tr, pk_flip, wscale, wmod_s, wmod_d, (p.Og_pad & 63) == 0 ? pack_xcd : 0);
+        }
         else if (p.bf16x6)
             hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, (__bf16*)workspace, p.G, p.Ig, p.Og,
                                p.Ig_pad, p.Og_pad, pk_kh, pk_kw, pk_tr, pk_flip, wscale, p.io == IO_F16 ? 1 : 0, wmod_s, wmod_d);
