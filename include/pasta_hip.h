@@ -334,8 +334,11 @@ int pasta_spade_norm_bwd(const void* dout, const void* x, const void* gamma,
                          const float* stats, void* dx, void* dgamma,
                          void* dbeta, int dtype, int64_t planes, int64_t HW,
                          const void* beta, int act, float gain, float clamp, int C, int64_t gb_stride, int64_t dgb_stride,
-                         void* stream, float* dx_amax, float* dgb_amax);     /* dgb_amax: |max| over what is written to dgamma AND dbeta (they
+                         void* stream, float* dx_amax, float* dgb_amax,      /* dgb_amax: |max| over what is written to dgamma AND dbeta (they
                                                                                feed one convolution when they are halves of one tensor) */
+                         const void* dx_add);                                /* ABI 18, optional ([planes, HW] like dx): added to dx on its way out -- the
+                                                                               gradient another consumer of x returned (a block's second normalisation
+                                                                               of the same tensor), instead of an addition pass over both */
 
 /* ------------------------------------------------------------------------- *
  * Garment features of the SPADE stage (training/networks.py:5777-5800, get_spade_feat): fp32, NCHW.

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const T* __restric
                                                               T* __restrict__ dbeta, int64_t planes, int64_t HW,
                                                               const T* __restrict__ beta, int act, float gain, float clamp,
                                                               int C, int64_t gb_ns, int64_t dgb_ns, float* __restrict__ dx_amax,
-                                                              float* __restrict__ dgb_amax) {
+                                                              float* __restrict__ dgb_amax, const T* __restrict__ dx_add) {
     __shared__ float red[16];
     uint32_t am = 0, am2 = 0;                       // |max| of dx; of everything written to dgamma and dbeta (one tensor when they are halves)
     const AmaxSlot aslot = amax_begin(dx_amax);
@@ -236,6 +236,7 @@ __global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const T* __restric
                     o.y = rstd * (t[k * 4 + 1] - m1 - xh[k * 4 + 1] * m2);
                     o.z = rstd * (t[k * 4 + 2] - m1 - xh[k * 4 + 2] * m2);
                     o.w = rstd * (t[k * 4 + 3] - m1 - xh[k * 4 + 3] * m2);
+                    if (dx_add) { const float4 c = ld4<T>(dx_add + base + 4 * (k * 1024 + tid)); o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }     // another consumer's gradient of x
                     st4<T>(dx + base + 4 * (k * 1024 + tid), o);
                     if (dx_amax) { amax_take(am, o.x); amax_take(am, o.y); amax_take(am, o.z); amax_take(am, o.w); }
                 }
@@ -259,7 +260,8 @@ __global__ __launch_bounds__(1024) void spade_norm_bwd_kernel(const T* __restric
                     const float gi = gamma ? ld<T>(gamma + gb + i) : 0.f;
                     float d = pre(ld<T>(dout + base + i), h, gi, (act == 2 && beta) ? ld<T>(beta + gb + i) : 0.f);
                     float tt = d * (1.f + gi);
-                    const float o = rstd * (tt - m1 - h * m2);
+                    float o = rstd * (tt - m1 - h * m2);
+                    if (dx_add) o += ld<T>(dx_add + base + i);
                     st<T>(dx + base + i, o);
                     if (dx_amax) amax_take(am, o);
                 }
@@ -620,9 +622,11 @@ extern "C" int pasta_spade_norm(const void* x, const void* gamma, const void* be
 
 extern "C" int pasta_spade_norm_bwd(const void* dout, const void* x, const void* gamma, const float* stats, void* dx,
                                     void* dgamma, void* dbeta, int dtype, int64_t planes, int64_t HW, const void* beta, int act, float gain,
-                                    float clamp, int C, int64_t gb_stride, int64_t dgb_stride, void* stream, float* dx_amax, float* dgb_amax) {
+                                    float clamp, int C, int64_t gb_stride, int64_t dgb_stride, void* stream, float* dx_amax, float* dgb_amax,
+                                    const void* dx_add) {
     using namespace pasta;
     PASTA_CHECK(dout && x && stats, "spade_norm_bwd: null pointer");
+    PASTA_CHECK(!dx_add || dx, "spade_norm_bwd: dx_add without dx");
     PASTA_CHECK(act == 0 || act == 1 || act == 2, "spade_norm_bwd: fused activation code %d (0/1 = none, 2 = relu)", act);
     PASTA_CHECK(act != 2 || dbeta || !dgamma, "spade_norm_bwd: dbeta buffer required with a fused activation");
     PASTA_CHECK(planes >= 1 && HW >= 1, "spade_norm_bwd: empty tensor");
@@ -631,9 +635,9 @@ extern "C" int pasta_spade_norm_bwd(const void* dout, const void* x, const void*
     PASTA_CHECK(gb_ns >= (int64_t)C * HW && dgb_ns >= (int64_t)C * HW, "spade_norm_bwd: sample stride below C * HW");
     int grid = (int)(planes < 65535 ? planes : 65535);
     hipStream_t s = (hipStream_t)stream;
-    const bool al = (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dout | (uintptr_t)dx | (uintptr_t)dgamma | (uintptr_t)dbeta | (uintptr_t)beta) & 15) == 0 &&
+    const bool al = (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dout | (uintptr_t)dx | (uintptr_t)dgamma | (uintptr_t)dbeta | (uintptr_t)beta | (uintptr_t)dx_add) & 15) == 0 &&
                     gb_ns % 4 == 0 && dgb_ns % 4 == 0;
-#define PASTA_ARGS(T) (const T*)dout, (const T*)x, (const T*)gamma, stats, (T*)dx, (T*)dgamma, (T*)dbeta, planes, HW, (const T*)beta, act, gain, clamp, C, gb_ns, dgb_ns, dx_amax, dgb_amax
+#define PASTA_ARGS(T) (const T*)dout, (const T*)x, (const T*)gamma, stats, (T*)dx, (T*)dgamma, (T*)dbeta, planes, HW, (const T*)beta, act, gain, clamp, C, gb_ns, dgb_ns, dx_amax, dgb_amax, (const T*)dx_add
 #define PASTA_L(T)                                                                                                            \
     if (HW == 16384 && al) hipLaunchKernelGGL((spade_norm_bwd_kernel<T, 16>), dim3(grid), dim3(1024), 0, s, PASTA_ARGS(T));  \
     else if (HW == 4096 && al) hipLaunchKernelGGL((spade_norm_bwd_kernel<T, 4>), dim3(grid), dim3(1024), 0, s, PASTA_ARGS(T)); \

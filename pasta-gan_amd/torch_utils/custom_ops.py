@@ -172,7 +172,7 @@ ABI = {
                                               ctypes.c_float, ctypes.c_float, _c_ptr, _c_ptr]),
     'pasta_masked_mean_fill': (ctypes.c_int, [_c_ptr] * 5 + [ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, _c_i64, ctypes.c_int, _c_ptr, _c_ptr]),
     'pasta_spade_norm':   (ctypes.c_int, [_c_ptr] * 5 + [ctypes.c_int, _c_i64, _c_i64, _c_f32, ctypes.c_int, _c_f32, _c_f32, ctypes.c_int, _c_i64, _c_ptr, _c_ptr]),
-    'pasta_spade_norm_bwd': (ctypes.c_int, [_c_ptr] * 7 + [ctypes.c_int, _c_i64, _c_i64, _c_ptr, ctypes.c_int, _c_f32, _c_f32, ctypes.c_int, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr]),
+    'pasta_spade_norm_bwd': (ctypes.c_int, [_c_ptr] * 7 + [ctypes.c_int, _c_i64, _c_i64, _c_ptr, ctypes.c_int, _c_f32, _c_f32, ctypes.c_int, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     'pasta_ada_matrices': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, ctypes.c_int, ctypes.c_int, _c_ptr, ctypes.POINTER(AdaConfig)] +
                                          [ctypes.c_int] * 4 + [_c_f32, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     'pasta_ada_theta':    (ctypes.c_int, [_c_ptr, _c_i64, ctypes.POINTER(_c_f32), ctypes.POINTER(_c_f32), _c_ptr, _c_ptr]),

@@ -62,8 +62,12 @@ class _SpadeModulate(torch.autograd.Function):
     output of ONE convolution with the concatenated conv_gamma / conv_beta weights); its gradient comes back as one tensor,
     so the two input gradients of that convolution accumulate inside its K loop instead of in an addition pass."""
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, post, shared=None):
+    def forward(ctx, x, gamma, beta, eps, post, shared=None, passthrough=False):
+        """``passthrough=True`` returns ``(out, x)``: the second output is ``x`` again, for the block's OTHER normalisation of the same tensor,
+        whose input gradient then arrives here as ``dxp`` and is added to ``dx`` by the backward kernel on its way out (``dx_add``) instead of
+        by an addition pass of autograd over both."""
         n, c, h, w = x.shape
+        x_in = x
         x = x.contiguous()
         fused = beta is None
         if fused and gamma.shape == (n, 2 * c, h, w) and gamma.stride()[1:] == (h * w, w, 1) and gamma.stride(0) >= 2 * c * h * w:
@@ -88,16 +92,23 @@ class _SpadeModulate(torch.autograd.Function):
         _native.amax_attach(out, row)
         ctx.save_for_backward(x, gamma, stats, beta if (act == 2 and not fused) else None)
         ctx.post, ctx.fused, ctx.shared = post, fused, shared
+        if passthrough:
+            ctx.set_materialize_grads(False)
+            return out, x_in
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dout):
+    def backward(ctx, dout, dxp=None):
         x, gamma, stats, beta = ctx.saved_tensors
         act, gain, clamp = ctx.post
         n, c, h, w = x.shape
+        if dout is None:                            # only the pass-through output was differentiated
+            return dxp, None, None, None, None, None, None
         dout = dout.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        if dxp is not None:
+            dxp = dxp.to(x.dtype).contiguous() if dx is not None else None
         row = _native.amax_slot(dx) if dx is not None else None
         lib = _native.lib()
         if ctx.fused:       # gamma | beta and their gradients as channel halves of one tensor each
@@ -117,13 +128,15 @@ class _SpadeModulate(torch.autograd.Function):
                                                   _native.dtype_code(x, 'spade_norm_bwd'), n * c, h * w,
                                                   gamma.data_ptr() + half, act, float(gain), float(clamp), c, gamma.stride(0),
                                                   dgb.stride(0) if dgb is not None else 2 * c * h * w,
-                                                  _native.stream(), _native.ptr(row), _native.ptr(grow))
+                                                  _native.stream(), _native.ptr(row), _native.ptr(grow), _native.ptr(dxp))
                 _native.check(st)
                 if dx is not None:
                     _native.amax_attach(dx, row)
                 if dgb is not None and ctx.shared is None:
                     _native.amax_attach(dgb, grow)
-            return dx, dgb, None, None, None, None
+            elif dxp is not None:
+                dx = dxp
+            return dx, dgb, None, None, None, None, None
         dgamma = torch.empty_like(x) if ctx.needs_input_grad[1] else None
         # without a fused activation d/dbeta is dout itself; with one it is dout through the activation, written by the kernel
         dbeta = None
@@ -136,11 +149,11 @@ class _SpadeModulate(torch.autograd.Function):
                 st = lib.pasta_spade_norm_bwd(_native.ptr(dout), _native.ptr(x), _native.ptr(gamma), _native.ptr(stats),
                                               _native.ptr(dx), _native.ptr(dgamma), _native.ptr(dbeta if act == 2 else None),
                                               _native.dtype_code(x, 'spade_norm_bwd'), n * c, h * w, _native.ptr(beta), act, float(gain), float(clamp), c, 0, 0, _native.stream(),
-                                              _native.ptr(row), None)
+                                              _native.ptr(row), None, _native.ptr(dxp))
             _native.check(st)
             if dx is not None:
                 _native.amax_attach(dx, row)
-        return dx, dgamma, (dbeta if ctx.needs_input_grad[2] else None), None, None, None
+        return dx, dgamma, (dbeta if ctx.needs_input_grad[2] else None), None, None, None, None
 
 class _SharedGrad:
     """ONE gradient tensor written in channel slices by several backward nodes: the three SPADE normalisations of a residual block leave
@@ -178,7 +191,7 @@ class _SplitGroups(torch.autograd.Function):
         parts = [g if g is not None else torch.zeros([h.shape[0], c, *h.shape[2:]], dtype=h.dtype, device=h.device) for g in grads]
         return torch.cat(parts, dim=1), None
 
-def spade_modulate(x, gamma, beta, eps=1e-5, relu_gain=None, clamp=None, shared=None):
+def spade_modulate(x, gamma, beta, eps=1e-5, relu_gain=None, clamp=None, shared=None, passthrough=False):
     """InstanceNorm(x) * (1 + gamma) + beta; ``relu_gain`` not None additionally applies ``min(relu(.) * relu_gain, clamp)``
     in the same pass (the activation of the Spade_Conv2dLayer that consumes the result).  ``beta=None``: ``gamma`` holds
     gamma | beta as the two channel halves of a [N, 2C, H, W] tensor."""
@@ -186,6 +199,10 @@ def spade_modulate(x, gamma, beta, eps=1e-5, relu_gain=None, clamp=None, shared=
     if x.dtype not in _HIP_DTYPES or gamma.dtype != x.dtype or (beta is not None and beta.dtype != x.dtype):
         raise RuntimeError('spade_modulate: x, gamma and beta must share one of float32 / float16 / bfloat16')
     post = (0, 1.0, -1.0) if relu_gain is None else (2, float(relu_gain), float(clamp if clamp is not None else -1))
+    if passthrough:         # (out, x'): x' = x for the other normalisation of the same tensor (_SpadeModulate.forward)
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _SpadeModulate.apply(x, gamma, beta, eps, post, shared, True)
+        return _SpadeModulate.apply(x, gamma, beta, eps, post, shared), x
     return _SpadeModulate.apply(x, gamma, beta, eps, post, shared)
 
 #----------------------------------------------------------------------------
@@ -819,10 +836,11 @@ class Spade_Norm_Block(torch.nn.Module):
         return (actv.dtype in _HIP_DTYPES and g.weight.shape == b.weight.shape and g.bias is None and b.bias is None
                 and (g.up, g.down, g.padding, g.weight_gain) == (b.up, b.down, b.padding, b.weight_gain) and g.up == g.down == 1)
 
-    def forward(self, x, denorm_feats, post_act=None, gb=None):
+    def forward(self, x, denorm_feats, post_act=None, gb=None, passthrough=False):
         relu_gain, clamp = post_act if post_act is not None else (None, None)      # the consuming layer's activation, same pass
         if gb is not None:          # (gamma | beta slice, shared gradient holder, group index) from the block's batched convolutions
-            return spade_modulate(x, gb[0], None, eps=self.param_free_norm.eps, relu_gain=relu_gain, clamp=clamp, shared=(gb[1], gb[2]))
+            return spade_modulate(x, gb[0], None, eps=self.param_free_norm.eps, relu_gain=relu_gain, clamp=clamp, shared=(gb[1], gb[2]),
+                                  passthrough=passthrough)
         mlp = self.conv_mlp         # no activation in front, nn.ReLU behind (:4373-4374): the ReLU rides in the epilogue
         actv = conv2d_resample.conv2d_resample_bias_act(x=denorm_feats, b=None, act='relu', gain=1, **mlp._resample_args(denorm_feats))
         if self._twin_convs(actv):
@@ -834,7 +852,7 @@ class Spade_Norm_Block(torch.nn.Module):
             beta = None
         else:
             gamma, beta = self.conv_gamma(actv, no_act=True), self.conv_beta(actv, no_act=True)
-        return spade_modulate(x, gamma, beta, eps=self.param_free_norm.eps, relu_gain=relu_gain, clamp=clamp)
+        return spade_modulate(x, gamma, beta, eps=self.param_free_norm.eps, relu_gain=relu_gain, clamp=clamp, passthrough=passthrough)
 
 @persistence.persistent_class
 class Spade_ResBlockV2(torch.nn.Module):
@@ -859,13 +877,17 @@ class Spade_ResBlockV2(torch.nn.Module):
         self.spade1 = Spade_Norm_Block(feat_channels, out_channels)
 
     @staticmethod
-    def _norm_then_conv(norm, conv, x, feat, gain, residual=None, gb=None):
+    def _norm_then_conv(norm, conv, x, feat, gain, residual=None, gb=None, passthrough=False):
         """conv(norm(x, feat), gain) [+ residual]; the activation in front of the convolution is applied by the SPADE kernel when
-        the layer allows it (bias-free relu)."""
+        the layer allows it (bias-free relu).  ``passthrough``: returns ``(result, x')`` with ``x'`` = ``x`` for the block's other
+        normalisation of the same tensor (its gradient joins this one's in the backward kernel: ``_SpadeModulate``)."""
         post = conv.fusable_activation(gain)
-        if post is None:
-            return conv(norm(x, feat, gb=gb), gain=gain, residual=residual)
-        return conv(norm(x, feat, post_act=post, gb=gb), no_act=True, residual=residual)
+        h = norm(x, feat, gb=gb, passthrough=passthrough) if post is None else norm(x, feat, post_act=post, gb=gb, passthrough=passthrough)
+        again = None
+        if passthrough:
+            h, again = h
+        y = conv(h, gain=gain, residual=residual) if post is None else conv(h, no_act=True, residual=residual)
+        return (y, again) if passthrough else y
 
     def _batched_gamma_beta(self, feat):
         """gamma | beta of the block's THREE normalisations from two launches (round 4): their ``conv_mlp`` layers read the same
@@ -904,8 +926,12 @@ class Spade_ResBlockV2(torch.nn.Module):
         x = self.conv(x, no_act=True)
         gb, feat_next = self._batched_gamma_beta(denorm_feat)
         gb = gb or (None, None, None)
+        # x feeds two normalisations: the first hands it on (x again), so that the second one's input gradient is added by the first one's
+        # backward kernel on its way out instead of by an addition pass over two 134 MB tensors (and the sum arrives with its maxima)
+        h0, x = self._norm_then_conv(self.spade0, self.conv0, x, denorm_feat, 1, gb=gb[1], passthrough=True) if _GRAD_JOIN else \
+            (self._norm_then_conv(self.spade0, self.conv0, x, denorm_feat, 1, gb=gb[1]), x)
         shortcut = self._norm_then_conv(self.spade_skip, self.skip, x, denorm_feat, half, gb=gb[0])
-        x = self._norm_then_conv(self.spade0, self.conv0, x, denorm_feat, 1, gb=gb[1])
+        x = h0
         if x.dtype == torch.float32 and x.device.type == 'cuda' and self.conv1.up == 1 and self.conv1.down == 1:
             # shortcut + conv1(.): the sum is formed in conv1's epilogue (the layers are activation-FIRST: the convolution is the last step).
             # fp32 storage only: in 16-bit storage the reference rounds conv1's output to the storage type BEFORE the addition, and the
