@@ -49,7 +49,10 @@ int pasta_upfirdn2d(const void* x, const float* f, void* y, int dtype,
                     const int32_t out_size[4], const int64_t out_stride[4],
                     int upx, int upy, int downx, int downy,
                     int padx0, int padx1, int pady0, int pady1,
-                    int flip, float gain, void* stream, float* y_amax);
+                    int flip, float gain, void* stream, float* y_amax,
+                    const void* y_add);     /* ABI 18, optional: a tensor with y's shape, strides and type, added to the result on its way out.  The
+                                               gradient of upfirdn2d is upfirdn2d (upfirdn2d.py:246-264): when x has further consumers their gradient
+                                               rides here instead of in an addition pass over two tensors */
 
 /* ------------------------------------------------------------------------- *
  * bias_act -- fused bias + activation + gain + clamp, and its 1st/2nd grads.

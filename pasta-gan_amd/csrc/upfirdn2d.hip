@@ -45,6 +45,8 @@ struct UpfirdnParams {
     int flip;
     float gain;
     float* y_amax;                // optional: PASTA_AMAX_PARTS zeroed floats that receive the largest finite |y| (common.h)
+    const void* y_add;            // optional: a tensor laid out like y, added to the result on its way out (ABI 18: another consumer's gradient
+                                  // when this launch is the backward of a tensor with several consumers)
 };
 
 //------------------------------------------------------------------------------------
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(UpfirdnParams p)
             }
         }
         v *= (A)p.gain;
+        if (p.y_add) v += (A)ld<T>((const T*)p.y_add + n * p.osn + c * p.osc + oy * p.osy + ox * p.osx);
         st<T>((T*)p.y + n * p.osn + c * p.osc + oy * p.osy + ox * p.osx, v);
         if (p.y_amax) amax_take(am, (float)v);
     }
@@ -189,6 +192,14 @@ __global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p,
                 acc[b][a] = v * p.gain;
             }
         const int ox = tile_x * TOW + tx * MX, oy = tile_y * TOH + ty * MY;
+        const T* ap = p.y_add ? (const T*)p.y_add + (int64_t)plane * p.outH * p.outW : nullptr;
+        if (ap) {                                       // the addend of this thread's outputs, fetched in one go in front of the stores
+#pragma unroll
+            for (int b = 0; b < MY; b++)
+#pragma unroll
+                for (int a = 0; a < MX; a++)
+                    if (oy + b < p.outH && ox + a < p.outW) acc[b][a] += ld<T>(ap + (int64_t)(oy + b) * p.outW + ox + a);
+        }
 #pragma unroll
         for (int b = 0; b < MY; b++) {
             if (oy + b >= p.outH) break;
@@ -208,8 +219,10 @@ __global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p,
                 for (int jy = 0; jy < FH; jy++)
 #pragma unroll
                     for (int jx = 0; jx < FW; jx++) v = fmaf(g[jy][jx], sx[(yy + jy) * LDW + xx + jx], v);
-                st<T>(yp + (int64_t)(tile_y * TOH + yy) * p.outW + tile_x * TOW + xx, v * p.gain);
-                if (p.y_amax) amax_take(am, v * p.gain);
+                v *= p.gain;
+                if (ap) v += ld<T>(ap + (int64_t)(tile_y * TOH + yy) * p.outW + tile_x * TOW + xx);
+                st<T>(yp + (int64_t)(tile_y * TOH + yy) * p.outW + tile_x * TOW + xx, v);
+                if (p.y_amax) amax_take(am, v);
             };
             if (ex) {
 #pragma unroll
@@ -277,8 +290,10 @@ __global__ __launch_bounds__(256) void upfirdn2d_small_kernel(UpfirdnParams p, i
                         v = fmaf(ok ? sp[iy * p.inW + ix] : 0.f, g[ty][tx], v);
                     }
                 }
-                st<T>(yp + e, v * p.gain);
-                if (p.y_amax) amax_take(am, v * p.gain);
+                v *= p.gain;
+                if (p.y_add) v += ld<T>((const T*)p.y_add + (int64_t)p0 * out_sz + e);
+                st<T>(yp + e, v);
+                if (p.y_amax) amax_take(am, v);
             } else {
                 const int ux0 = ox * p.downx - p.padx0, uy0 = oy * p.downy - p.pady0;
                 for (int ty = posmod(-uy0, p.upy); ty < p.fh; ty += p.upy) {
@@ -296,8 +311,10 @@ __global__ __launch_bounds__(256) void upfirdn2d_small_kernel(UpfirdnParams p, i
                         v = fmaf(sp[iy * p.inW + ix], p.f[gy * p.fw + gx], v);
                     }
                 }
-                st<T>(yp + e, v * p.gain);
-                if (p.y_amax) amax_take(am, v * p.gain);
+                v *= p.gain;
+                if (p.y_add) v += ld<T>((const T*)p.y_add + (int64_t)p0 * out_sz + e);
+                st<T>(yp + e, v);
+                if (p.y_amax) amax_take(am, v);
             }
         }
     }
@@ -418,7 +435,7 @@ extern "C" int pasta_upfirdn2d(const void* x, const float* f, void* y, int dtype
                                const int32_t out_size[4], const int64_t out_stride[4],
                                int upx, int upy, int downx, int downy,
                                int padx0, int padx1, int pady0, int pady1,
-                               int flip, float gain, void* stream, float* y_amax) {
+                               int flip, float gain, void* stream, float* y_amax, const void* y_add) {
     using namespace pasta;
     PASTA_CHECK(x && f && y, "upfirdn2d: null pointer");
     PASTA_CHECK(upx >= 1 && upy >= 1, "upfirdn2d: upsampling factor must be at least 1");
@@ -442,7 +459,7 @@ extern "C" int pasta_upfirdn2d(const void* x, const float* f, void* y, int dtype
     p.isn = in_stride[0]; p.isc = in_stride[1]; p.isy = in_stride[2]; p.isx = in_stride[3];
     p.osn = out_stride[0]; p.osc = out_stride[1]; p.osy = out_stride[2]; p.osx = out_stride[3];
     p.upx = upx; p.upy = upy; p.downx = downx; p.downy = downy;
-    p.padx0 = padx0; p.pady0 = pady0; p.flip = flip ? 1 : 0; p.gain = gain; p.y_amax = y_amax;
+    p.padx0 = padx0; p.pady0 = pady0; p.flip = flip ? 1 : 0; p.gain = gain; p.y_amax = y_amax; p.y_add = y_add;
 
     const bool dense_nchw =
         p.isx == 1 && p.isy == p.inW && p.isc == (int64_t)p.inH * p.inW && (p.N == 1 || p.isn == p.isc * p.C) &&

@@ -142,7 +142,7 @@ ABI = {
     'pasta_build_info':   (ctypes.c_char_p, []),
     'pasta_upfirdn2d':    (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, ctypes.c_int,
                                           ctypes.POINTER(_c_i32), ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i32),
-                                          ctypes.POINTER(_c_i32), ctypes.POINTER(_c_i64)] + [ctypes.c_int] * 9 + [_c_f32, _c_ptr, _c_ptr]),
+                                          ctypes.POINTER(_c_i32), ctypes.POINTER(_c_i64)] + [ctypes.c_int] * 9 + [_c_f32, _c_ptr, _c_ptr, _c_ptr]),
     'pasta_bias_act':     (ctypes.c_int, [_c_ptr] * 6 + [ctypes.c_int, _c_i64, ctypes.c_int, _c_i64, ctypes.c_int, ctypes.c_int,
                                                            _c_f32, _c_f32, _c_f32, _c_ptr, _c_ptr]),
     'pasta_bias_grad_workspace': (_c_i64, [_c_i64, ctypes.c_int, _c_i64]),

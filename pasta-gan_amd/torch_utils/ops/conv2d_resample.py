@@ -45,10 +45,12 @@ def conv2d_resample_bias_act(x, w, b=None, f=None, up=1, down=1, padding=0, grou
     again, to be given to the other consumers of ``x`` so that their gradient joins this layer's input gradient in that launch's epilogue
     (``conv2d_gradfix._ConvBiasActHip``; where the convolution does not read ``x`` itself -- resampling layers -- ``x'`` is plainly ``x``)."""
     from . import bias_act
-    if passthrough and (up != 1 or down != 1):
+    fusable = up == 1 and x.dtype in conv2d_gradfix.IO_CODES and x.device.type == 'cuda' and act in conv2d_gradfix.FUSABLE_ACTS
+    if passthrough and (up != 1 or (down != 1 and not fusable)):
         return conv2d_resample_bias_act(x, w, b=b, f=f, up=up, down=down, padding=padding, groups=groups, flip_weight=flip_weight, flip_filter=flip_filter,
                                         act=act, alpha=alpha, gain=gain, clamp=clamp, wgain=wgain, residual=residual), x
-    if up == 1 and x.dtype in conv2d_gradfix.IO_CODES and x.device.type == 'cuda' and act in conv2d_gradfix.FUSABLE_ACTS:
+    again = x
+    if fusable:
         out_channels, in_channels_per_group, kh, kw = _get_weight_shape(w)
         fw, fh = _get_filter_size(f)
         px0, px1, py0, py1 = _parse_padding(padding)
@@ -58,12 +60,19 @@ def conv2d_resample_bias_act(x, w, b=None, f=None, up=1, down=1, padding=0, grou
             py0 += (fh - down + 1) // 2
             py1 += (fh - down) // 2
         wc = w if flip_weight else w.flip([2, 3])
+        # (downsampling layers with ``passthrough``: the FILTER is what reads x, so it hands x on and takes the other consumers' gradient)
         if kw == 1 and kh == 1 and down > 1:          # decimate, then the fused 1x1 convolution
-            x = upfirdn2d.upfirdn2d(x=x, f=f, down=down, padding=[px0, px1, py0, py1], flip_filter=flip_filter)
-            return conv2d_gradfix.conv2d_bias_act(x, wc, b, groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp, wgain=wgain, residual=residual)
+            x = upfirdn2d.upfirdn2d(x=x, f=f, down=down, padding=[px0, px1, py0, py1], flip_filter=flip_filter, passthrough=passthrough)
+            if passthrough:
+                x, again = x
+            y = conv2d_gradfix.conv2d_bias_act(x, wc, b, groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp, wgain=wgain, residual=residual)
+            return (y, again) if passthrough else y
         if down > 1:                                  # low-pass, then the fused strided convolution
-            x = upfirdn2d.upfirdn2d(x=x, f=f, padding=[px0, px1, py0, py1], flip_filter=flip_filter)
-            return conv2d_gradfix.conv2d_bias_act(x, wc, b, stride=down, groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp, wgain=wgain, residual=residual)
+            x = upfirdn2d.upfirdn2d(x=x, f=f, padding=[px0, px1, py0, py1], flip_filter=flip_filter, passthrough=passthrough)
+            if passthrough:
+                x, again = x
+            y = conv2d_gradfix.conv2d_bias_act(x, wc, b, stride=down, groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp, wgain=wgain, residual=residual)
+            return (y, again) if passthrough else y
         if px0 == px1 and py0 == py1 and px0 >= 0 and py0 >= 0:
             return conv2d_gradfix.conv2d_bias_act(x, wc, b, padding=[py0, px0], groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp, wgain=wgain,
                                                   residual=residual, passthrough=passthrough)

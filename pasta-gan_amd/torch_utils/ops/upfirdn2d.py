@@ -77,8 +77,9 @@ def setup_filter(f, device=torch.device('cpu'), normalize=True, flip_filter=Fals
 # launch; ``launch()`` performs it. None = no overhead.
 launch_hook = None
 
-def _launch(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain):
-    """One ``pasta_upfirdn2d`` launch. ``f2d`` is a dense float32 [fh, fw] tensor on x's device."""
+def _launch(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain, add=None):
+    """One ``pasta_upfirdn2d`` launch. ``f2d`` is a dense float32 [fh, fw] tensor on x's device.  ``add``: a tensor of the output's shape
+    added to the result on its way out."""
     _native.require_gpu(x, 'upfirdn2d')
     if x.ndim != 4:
         raise RuntimeError('upfirdn2d: x must be rank 4')
@@ -99,6 +100,12 @@ def _launch(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, ga
                     memory_format=torch.channels_last if channels_last else torch.contiguous_format)
     if y.numel() == 0:
         return y
+    if add is not None:
+        if tuple(add.shape) != tuple(y.shape):
+            raise RuntimeError(f'upfirdn2d: the addend {tuple(add.shape)} does not have the output shape {tuple(y.shape)}')
+        add = add.to(y.dtype)
+        if add.stride() != y.stride():
+            add = add.contiguous(memory_format=torch.channels_last if channels_last else torch.contiguous_format)
     f2d = f2d.contiguous()
     row = _native.amax_slot(y) if y.numel() >= 1 << 16 else None
     def launch():
@@ -107,7 +114,7 @@ def _launch(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, ga
                 _native.ptr(x), _native.ptr(f2d), _native.ptr(y), _native.dtype_code(x, 'upfirdn2d'),
                 _native.i32x(*x.shape), _native.i64x(*x.stride()), _native.i32x(fh, fw),
                 _native.i32x(*y.shape), _native.i64x(*y.stride()),
-                upx, upy, downx, downy, padx0, padx1, pady0, pady1, int(bool(flip)), float(gain), _native.stream(), _native.ptr(row))
+                upx, upy, downx, downy, padx0, padx1, pady0, pady1, int(bool(flip)), float(gain), _native.stream(), _native.ptr(row), _native.ptr(add))
         _native.check(st)
     if launch_hook is None:
         launch()
@@ -120,27 +127,35 @@ class _Upfirdn2dHip(torch.autograd.Function):
     filter mirrored (reference: upfirdn2d.py:246-264), so gradients of any order come for free."""
 
     @staticmethod
-    def forward(ctx, x, f, cfg):
+    def forward(ctx, x, f, cfg, add=None, passthrough=False):
+        """``add`` (shape of the output): ``upfirdn2d(x, f) + add`` in the one launch.  ``passthrough=True`` returns ``(y, x)``: the second
+        output is ``x`` again, for its OTHER consumers, whose gradient then arrives in the backward as ``dxp`` and is the ``add`` operand of
+        the backward launch -- instead of an addition pass of autograd over two tensors (conv2d_gradfix._ConvBiasActHip has the same)."""
         upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain = cfg
         if f is None:
             f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
         assert f.ndim in [1, 2]
         if f.ndim == 2:
-            y = _launch(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain)
+            y = _launch(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain, add=add)
         else:   # separable: a row pass then a column pass, sqrt(gain) each
             g = float(np.sqrt(gain))
             y = _launch(x, f.unsqueeze(0), upx, 1, downx, 1, padx0, padx1, 0, 0, flip, g)
-            y = _launch(y, f.unsqueeze(1), 1, upy, 1, downy, 0, 0, pady0, pady1, flip, g)
+            y = _launch(y, f.unsqueeze(1), 1, upy, 1, downy, 0, 0, pady0, pady1, flip, g, add=add)
         ctx.save_for_backward(f)
         ctx.cfg = cfg
         ctx.in_hw = (x.shape[2], x.shape[3])
+        if passthrough:
+            ctx.set_materialize_grads(False)
+            return y, x
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dxp=None):
         f, = ctx.saved_tensors
         upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain = ctx.cfg
         ih, iw = ctx.in_hw
+        if dy is None:                  # only the pass-through output was differentiated
+            return dxp, None, None, None, None
         oh, ow = dy.shape[2], dy.shape[3]
         fw, fh = _get_filter_size(f)
         dx = None
@@ -149,13 +164,14 @@ class _Upfirdn2dHip(torch.autograd.Function):
                     fw - padx0 - 1, iw * upx - ow * downx + padx0 - upx + 1,
                     fh - pady0 - 1, ih * upy - oh * downy + pady0 - upy + 1,
                     not flip, gain)
-            dx = _Upfirdn2dHip.apply(dy, f, gcfg)
+            dx = _Upfirdn2dHip.apply(dy, f, gcfg, dxp) if dxp is not None else _Upfirdn2dHip.apply(dy, f, gcfg)
         assert not ctx.needs_input_grad[1]
-        return dx, None, None
+        dadd = dy if len(ctx.needs_input_grad) > 3 and ctx.needs_input_grad[3] else None
+        return dx, None, None, dadd, None
 
 #----------------------------------------------------------------------------
 
-def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl='cuda'):
+def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl='cuda', passthrough=False):
     """Pad, upsample, filter and downsample a batch of 2-D images (reference: upfirdn2d.py:120-164).
 
     ``x``: [N, C, H, W] float32/float16/float64 on the GPU. ``f``: float32 [fh, fw], separable
@@ -173,6 +189,14 @@ def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl='cu
     downx, downy = _parse_scaling(down)
     padx0, padx1, pady0, pady1 = _parse_padding(padding)
     cfg = (upx, upy, downx, downy, padx0, padx1, pady0, pady1, bool(flip_filter), gain)
+    if passthrough:             # (y, x'): own extension, see _Upfirdn2dHip.forward
+        if torch.is_grad_enabled() and x.requires_grad:
+            y, again = _Upfirdn2dHip.apply(x, f, cfg, None, True)
+            hit = getattr(x, '_pasta_amax', None)
+            if hit is not None and not again.is_inference():
+                again._pasta_amax = hit
+            return y, again
+        return _Upfirdn2dHip.apply(x, f, cfg), x
     return _Upfirdn2dHip.apply(x, f, cfg)
 
 #----------------------------------------------------------------------------

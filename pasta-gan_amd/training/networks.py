@@ -812,7 +812,12 @@ class StyleEncoderNetworkV16(nn.Module):
     def forward(self, x, const_input):
         pyramid = []
         for layer in self.feat_enc:
-            const_input = layer(const_input)
+            if pyramid and _GRAD_JOIN:
+                # a level feeds the next layer AND the synthesis blocks' merge layers: the next layer hands it on (the level again), and the
+                # merge layers' gradients ride in the backward launch of its filter instead of in addition passes
+                const_input, pyramid[-1] = layer(const_input, passthrough=True)
+            else:
+                const_input = layer(const_input)
             pyramid.append(const_input)
         code = self.fc(self.model(x).flatten(1).float())           # the style code and everything downstream of it: fp32
         return code, pyramid

@@ -114,3 +114,62 @@ def test_spade_blocks_chain_the_feature_map():
     got, want = run(True), run(False)
     for i, (u, v) in enumerate(zip(got, want)):
         assert _rel(u, v) < 5e-6, (i, _rel(u, v))
+
+
+@pytest.mark.parametrize('shape,kw', [
+    ([3, 16, 64, 64], dict(padding=[2, 2, 2, 2])),                      # blur in front of a stride-2 convolution: 64 -> 65 (odd pitch)
+    ([2, 8, 65, 65], dict(padding=[1, 1, 1, 1], gain=4)),               # ... and behind a stride-2 conv_transpose2d
+    ([2, 8, 64, 64], dict(down=2, padding=[1, 1, 1, 1])),               # the skip branch's decimation
+    ([2, 8, 32, 32], dict(up=2, padding=[2, 1, 2, 1], gain=4)),
+    ([4, 512, 8, 8], dict(padding=[2, 2, 2, 2])),                       # small-plane kernel
+])
+def test_upfirdn2d_addend_and_passthrough(shape, kw):
+    """``pasta_upfirdn2d(y_add)``: the filter's result plus a tensor in the one launch; and the pass-through form whose backward uses it."""
+    from torch_utils.ops import upfirdn2d
+    g = torch.Generator().manual_seed(sum(shape))
+    f = upfirdn2d.setup_filter([1, 3, 3, 1], device='cuda')
+    x = torch.randn(shape, generator=g).cuda()
+    y0 = upfirdn2d.upfirdn2d(x, f, **kw)
+    add = torch.randn(y0.shape, generator=g).cuda()
+    up, down = kw.get('up', 1), kw.get('down', 1)
+    px0, px1, py0, py1 = kw['padding']
+    cfg = (up, up, down, down, px0, px1, py0, py1, False, kw.get('gain', 1))
+    y1 = upfirdn2d._Upfirdn2dHip.apply(x, f, cfg, add)
+    assert _rel(y1, y0 + add) < 1e-6
+
+    w2 = torch.randn(shape[1], generator=g).cuda()
+    def run(join):
+        xs = x.clone().requires_grad_(True)
+        h = xs * 1.25
+        if join:
+            y, hp = upfirdn2d.upfirdn2d(h, f, passthrough=True, **kw)
+        else:
+            y, hp = upfirdn2d.upfirdn2d(h, f, **kw), h
+        z = y.square().sum() + (hp * w2[None, :, None, None]).square().sum()
+        first, = torch.autograd.grad(z, [xs], create_graph=True)
+        second, = torch.autograd.grad(first.square().sum(), [xs])
+        return first, second
+    for u, v in zip(run(True), run(False)):
+        assert _rel(u, v) < 2e-6
+
+
+def test_feature_pyramid_levels_are_handed_on():
+    """StyleEncoderNetworkV16: a pyramid level feeds the next stride-2 layer and (later) the synthesis blocks' merge layers."""
+    from training import networks
+    g = torch.Generator().manual_seed(4)
+    enc = networks.StyleEncoderNetworkV16(input_nc=6, output_nc=128, ngf=16, n_downsampling=4, feat_levels=3).cuda()
+    x = torch.randn([2, 6, 64, 64], generator=g).cuda()
+    c = torch.randn([2, 3, 64, 64], generator=g).cuda()
+    params = list(enc.feat_enc.parameters())
+
+    def run(join):
+        old, networks._GRAD_JOIN = networks._GRAD_JOIN, join
+        try:
+            cs = c.clone().requires_grad_(True)
+            code, pyramid = enc(x, cs)
+            loss = sum((lvl * (i + 1.5)).square().sum() for i, lvl in enumerate(pyramid))
+            return tuple(pyramid) + torch.autograd.grad(loss, [cs] + params)
+        finally:
+            networks._GRAD_JOIN = old
+    for i, (u, v) in enumerate(zip(run(True), run(False))):
+        assert _rel(u, v) < 5e-6, (i, _rel(u, v))

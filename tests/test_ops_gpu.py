@@ -131,7 +131,7 @@ def test_upfirdn2d_nonsquare_planes_stay_inside_their_plane(idx):
     rc = lib.pasta_upfirdn2d(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(fc.data_ptr()), ctypes.c_void_p(out.data_ptr()), 0,
                              i32x4(*x.shape), i64x4(*x.stride()), i32x2(*fc.shape), i32x4(*out.shape), i64x4(*out.stride()),
                              up, up, down, down, px0, px1, py0, py1, 0, ctypes.c_float(kw.get('gain', 1)),
-                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.c_void_p(parts.data_ptr()))
+                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.c_void_p(parts.data_ptr()), None)
     assert rc == 0, lib.pasta_last_error()
     torch.cuda.synchronize()
     assert rel_err(out, yr) < TOL
