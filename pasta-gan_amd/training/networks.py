@@ -740,7 +740,9 @@ _GRAD_JOIN = _os.environ.get('PASTA_GRAD_JOIN', '1') != '0'
 def _layer_and_input(layer, x):
     """``(layer(x), x')`` for a tensor with further consumers: give them ``x'`` (= ``x``), and their gradient is added in the epilogue of
     the layer's input-gradient launch instead of by a pass of its own (``Conv2dLayer.forward(passthrough=True)``)."""
-    return layer(x, passthrough=True) if _GRAD_JOIN else (layer(x), x)
+    # fp32 storage only: in 16-bit storage the reference rounds each consumer's gradient to the storage type BEFORE the addition, and the
+    # config-5 fixtures (tests/test_config5_gpu.py) hold the path to that sequence of roundings
+    return layer(x, passthrough=True) if (_GRAD_JOIN and x.dtype == torch.float32) else (layer(x), x)
 
 @persistence.persistent_class
 class ResBlock(torch.nn.Module):
@@ -812,7 +814,7 @@ class StyleEncoderNetworkV16(nn.Module):
     def forward(self, x, const_input):
         pyramid = []
         for layer in self.feat_enc:
-            if pyramid and _GRAD_JOIN:
+            if pyramid and _GRAD_JOIN and const_input.dtype == torch.float32:
                 # a level feeds the next layer AND the synthesis blocks' merge layers: the next layer hands it on (the level again), and the
                 # merge layers' gradients ride in the backward launch of its filter instead of in addition passes
                 const_input, pyramid[-1] = layer(const_input, passthrough=True)
@@ -933,7 +935,7 @@ class Spade_ResBlockV2(torch.nn.Module):
         gb = gb or (None, None, None)
         # x feeds two normalisations: the first hands it on (x again), so that the second one's input gradient is added by the first one's
         # backward kernel on its way out instead of by an addition pass over two 134 MB tensors (and the sum arrives with its maxima)
-        h0, x = self._norm_then_conv(self.spade0, self.conv0, x, denorm_feat, 1, gb=gb[1], passthrough=True) if _GRAD_JOIN else \
+        h0, x = self._norm_then_conv(self.spade0, self.conv0, x, denorm_feat, 1, gb=gb[1], passthrough=True) if (_GRAD_JOIN and x.dtype == torch.float32) else \
             (self._norm_then_conv(self.spade0, self.conv0, x, denorm_feat, 1, gb=gb[1]), x)
         shortcut = self._norm_then_conv(self.spade_skip, self.skip, x, denorm_feat, half, gb=gb[0])
         x = h0
