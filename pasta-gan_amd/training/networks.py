@@ -260,6 +260,8 @@ class _GarmentFeat(torch.autograd.Function):
                     grads.append(dx if ctx.needs_input_grad[4 * k] else None)
         return grads[0], None, None, None, grads[1], None, None, None
 
+_MBA_AMAX = _os.environ.get('PASTA_MBA_AMAX', '1') != '0'         # A/B switch: 0 = the consumer scans the output of mod_bias_act
+
 class _ModBiasAct(torch.autograd.Function):
     """Tail of a modulated-convolution layer in one pass: ``clamp(act(u * d[n,c] + noise * strength + b[c]) * gain)``
     (the demodulation + noise of modulated_conv2d, networks.py:77-82, and SynthesisLayer's bias_act, :313-314).
@@ -276,7 +278,10 @@ class _ModBiasAct(torch.autograd.Function):
             assert noise.numel() in (h * w, n * h * w)
             noise = noise.contiguous()
         y = torch.empty_like(u)
-        row = None          # small workgroups (4096 elements each): the commit costs what a scan of y costs; the consumer scans
+        # producer maxima for the large planes (one commit per 4096-element workgroup, most of them skipped by the look at the slot): the layer's
+        # output is the operand of the next modulated convolution, whose launch would scan it (round 4: 150.35 -> 150.0 ms same box; small
+        # tensors keep the scan: profiles/r4_ab_mba_amax.txt)
+        row = _native.amax_slot(y) if (_MBA_AMAX and y.numel() >= 1 << 22) else None
         with torch.cuda.device(u.device):
             st = _native.lib().pasta_mod_bias_act(_native.ptr(u), _native.ptr(d), _native.ptr(noise), _native.ptr(strength), _native.ptr(b),
                                                   _native.ptr(y), _native.dtype_code(u, 'mod_bias_act'), n, c, h * w, per_sample, act_idx, float(alpha), float(gain), float(clamp),
