@@ -43,7 +43,8 @@ def conv2d_resample_bias_act(x, w, b=None, f=None, up=1, down=1, padding=0, grou
     multiplication kernel of its own.  ``residual`` (extension, shape of the output): added to the convolution before
     the bias -- also in the epilogue when the convolution is fused.  ``passthrough=True`` (extension) returns ``(y, x')``: ``x'`` is ``x``
     again, to be given to the other consumers of ``x`` so that their gradient joins this layer's input gradient in that launch's epilogue
-    (``conv2d_gradfix._ConvBiasActHip``; where the convolution does not read ``x`` itself -- resampling layers -- ``x'`` is plainly ``x``)."""
+    (``conv2d_gradfix._ConvBiasActHip``).  In a downsampling layer the FILTER is what reads ``x``: it hands ``x`` on and takes the gradient
+    as the addend of its backward launch (``upfirdn2d._Upfirdn2dHip``); an upsampling layer returns ``x`` itself (nothing joined)."""
     from . import bias_act
     fusable = up == 1 and x.dtype in conv2d_gradfix.IO_CODES and x.device.type == 'cuda' and act in conv2d_gradfix.FUSABLE_ACTS
     if passthrough and (up != 1 or (down != 1 and not fusable)):
