@@ -92,7 +92,7 @@ class ConvMeter:
                       10: {0: 'conv3x3s2_f16x3_kernel<128>', 1: 'conv3x3s2_f16x3_kernel<64>'}}[kernel.value][tile.value]     # <BM, BN, rows per tile, pieces, storage, input scale, threads>
             if isc and kernel.value != 0:       # the instance with the input scale: same family, another template argument (rocprofv3 names)
                 family = {1: family.replace(',3,3,0,false,false>', ',2,3,0,true,false>').replace(',3,4,0,false,false>', ',2,4,0,true,false>'), 2: family.replace(',false,false>', ',true,false>')}.get(
-                    kernel.value, family.replace(',false,256>', ',true,256>'))
+                    kernel.value, family.replace(',false,256>', ',true,256>').replace(',false,512>', ',true,512>'))      # (round 4: the eight-wave tile has its instance too)
             kernels = launches.value
         else:
             which = ctypes.c_int()
