@@ -341,6 +341,34 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
     const bool has_res = p.res && fused;
     const float* osb = (p.oscale && fused) ? p.oscale + (int64_t)n_img * p.Cout + (int64_t)g * p.Og : nullptr;
     const float* bsb = (p.act && fused && p.bias) ? p.bias + g * p.Og : nullptr;
+    if (!osb && !bsb && !has_res) {
+        // nothing to fetch: the plain launches (every input gradient without a residual, every convolution without an epilogue) keep the
+        // store loop they always had -- the general path below, taken by them too, cost the dominant kernel 3.0 % (286.3 -> 294.8 us on
+        // the micro-benchmark's shapes, same box, profiles/r4_ab_rows2d_epilogue.txt)
+#pragma unroll
+        for (int b = 0; b < WNT; b++) {
+            const int t = (wn * WNT + b) * 32 + jl;
+            const int r = t / SEG, c = t - r * SEG;
+            const int plane_off = (p0 + r) * p.OW + q0 + c;
+            const int64_t yoff = ((int64_t)n_img * p.Cout + (int64_t)g * p.Og) * OHW + plane_off;
+            const float nz = has_noise ? p.noise[(p.noise_ps ? (int64_t)n_img * OHW : 0) + plane_off] * nstr : 0.f;
+            float* pb = p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW + yoff : nullptr;
+#pragma unroll
+            for (int a = 0; a < WMT; a++)
+#pragma unroll
+                for (int r16 = 0; r16 < 16; r16++) {
+                    const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r16, lane);
+                    if (o < p.Og) {
+                        float v = acc[a][b][r16] + nz;
+                        if (p.act && fused) v = conv_epilogue(v, 0.f, p.act, p.alpha, p.gain, p.clamp);
+                        if (pb) pb[(int64_t)o * OHW] = v;
+                        else { io_st<IO>(p.y, yoff + (int64_t)o * OHW, v); if (p.y_amax) amax_take(y_am, v); }
+                    }
+                }
+        }
+        if (p.ksplit == 1) amax_commit(y_am, y_slot);
+        return;
+    }
     float row_b[WMT][16], row_s[WMT][16];
 #pragma unroll
     for (int a = 0; a < WMT; a++)
