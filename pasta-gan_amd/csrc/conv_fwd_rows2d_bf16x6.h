@@ -1,6 +1,7 @@
 // Two-dimensional pixel tiles for the row-reuse forward kernel.  Included by conv_igemm.hip.
 #pragma once
 #include "conv_fwd_bf16x6.h"
+#include <type_traits>
 
 namespace pasta {
 
@@ -345,6 +346,33 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
         // nothing to fetch: the plain launches (every input gradient without a residual, every convolution without an epilogue) keep the
         // store loop they always had -- the general path below, taken by them too, cost the dominant kernel 3.0 % (286.3 -> 294.8 us on
         // the micro-benchmark's shapes, same box, profiles/r4_ab_rows2d_epilogue.txt)
+        if (fused && !p.act && o_blk + BM <= p.Og) {
+            // ... and the commonest of them -- no activation, whole tile of output rows, no K slices -- a loop without a branch per element
+            // (the compiler does not unswitch the wave-uniform tests of the general loops: 454 branches in the epilogue's code)
+            auto lean = [&](auto with_amax) {
+                constexpr bool AM = decltype(with_amax)::value;
+#pragma unroll
+                for (int b = 0; b < WNT; b++) {
+                    const int t = (wn * WNT + b) * 32 + jl;
+                    const int r = t / SEG, c = t - r * SEG;
+                    const int plane_off = (p0 + r) * p.OW + q0 + c;
+                    const int64_t yoff = ((int64_t)n_img * p.Cout + (int64_t)g * p.Og) * OHW + plane_off;
+                    const float nz = has_noise ? p.noise[(p.noise_ps ? (int64_t)n_img * OHW : 0) + plane_off] * nstr : 0.f;
+#pragma unroll
+                    for (int a = 0; a < WMT; a++)
+#pragma unroll
+                        for (int r16 = 0; r16 < 16; r16++) {
+                            const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r16, lane);
+                            const float v = acc[a][b][r16] + nz;
+                            io_st<IO>(p.y, yoff + (int64_t)o * OHW, v);
+                            if constexpr (AM) amax_take(y_am, v);
+                        }
+                }
+            };
+            if (p.y_amax) { lean(std::true_type{}); amax_commit(y_am, y_slot); }
+            else lean(std::false_type{});
+            return;
+        }
 #pragma unroll
         for (int b = 0; b < WNT; b++) {
             const int t = (wn * WNT + b) * 32 + jl;
