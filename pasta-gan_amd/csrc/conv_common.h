@@ -1,5 +1,6 @@
 // Shared declarations of the convolution family (conv_igemm.hip and the kernel headers it includes).
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
@@ -25,6 +26,36 @@ __device__ __forceinline__ float conv_epilogue(float v, float b, int act, float 
     v *= gain;
     if (clamp >= 0.f) v = (v > -clamp && v < clamp) ? v : (v >= 0.f ? clamp : -clamp);
     return v;
+}
+
+// The same with its wave-uniform tests resolved at compile time (the store loops of the kernels are instantiated per case and chosen
+// once per workgroup: the compiler does not unswitch them, and sixty-four stores with three or four scalar branches each cost the
+// dominant kernel 5 % -- profiles/r4_ab_rows2d_epilogue.txt).  slope = conv_act_slope(act, alpha): 1 linear, alpha lrelu.
+// (relu = act == 2 selects an exact 0 for v <= 0 and for NaN, as conv_epilogue does)
+__device__ __forceinline__ float conv_act_slope(int act, float alpha) { return act == 3 ? alpha : 1.f; }
+template <bool ACT, bool CLAMP>
+__device__ __forceinline__ float conv_epilogue_t(float v, float b, float slope, bool relu, float gain, float clamp) {
+    if constexpr (ACT) {
+        v += b;
+        const float neg = relu ? 0.f : v * slope;                // a select on a wave-uniform value, not a branch
+        v = v > 0.f ? v : neg;
+        v *= gain;
+        if constexpr (CLAMP) v = (v > -clamp && v < clamp) ? v : (v >= 0.f ? clamp : -clamp);
+    }
+    return v;
+}
+// calls f(std::bool_constant<ACT>, std::bool_constant<CLAMP>, std::bool_constant<FULL>) for the runtime flags (CLAMP implies ACT)
+template <class F>
+__device__ __forceinline__ void conv_epilogue_dispatch(bool act, bool clamp, bool full, F&& f) {
+    if (full) {
+        if (!act) f(std::false_type{}, std::false_type{}, std::true_type{});
+        else if (!clamp) f(std::true_type{}, std::false_type{}, std::true_type{});
+        else f(std::true_type{}, std::true_type{}, std::true_type{});
+    } else {
+        if (!act) f(std::false_type{}, std::false_type{}, std::false_type{});
+        else if (!clamp) f(std::true_type{}, std::false_type{}, std::false_type{});
+        else f(std::true_type{}, std::true_type{}, std::false_type{});
+    }
 }
 
 //------------------------------------------------------------------------------------

@@ -397,6 +397,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
         if (p.ksplit == 1) amax_commit(y_am, y_slot);
         return;
     }
+    // (here fused holds: an output scale, a bias or a residual exist only without K slices)
     float row_b[WMT][16], row_s[WMT][16];
 #pragma unroll
     for (int a = 0; a < WMT; a++)
@@ -407,38 +408,38 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
             row_b[a][r16] = bsb ? bsb[oc] : 0.f;
             row_s[a][r16] = osb ? osb[oc] : 1.f;
         }
+    const float slope = conv_act_slope(p.act, p.alpha);
+    conv_epilogue_dispatch(p.act != 0, p.act != 0 && p.clamp >= 0.f, o_blk + BM <= p.Og, [&](auto act_c, auto clamp_c, auto full_c) {
+        constexpr bool ACT = decltype(act_c)::value, CLAMP = decltype(clamp_c)::value, FULL = decltype(full_c)::value;
 #pragma unroll
-    for (int b = 0; b < WNT; b++) {
-        const int t = (wn * WNT + b) * 32 + jl;
-        const int r = t / SEG, c = t - r * SEG;
-        const int plane_off = (p0 + r) * p.OW + q0 + c;             // stride-1 lattice: the output plane itself
-        const int64_t yoff = ((int64_t)n_img * p.Cout + (int64_t)g * p.Og) * OHW + plane_off;
-        const float nz = has_noise ? p.noise[(p.noise_ps ? (int64_t)n_img * OHW : 0) + plane_off] * nstr : 0.f;
-        float* pb = p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW + yoff : nullptr;
+        for (int b = 0; b < WNT; b++) {
+            const int t = (wn * WNT + b) * 32 + jl;
+            const int r = t / SEG, c = t - r * SEG;
+            const int plane_off = (p0 + r) * p.OW + q0 + c;             // stride-1 lattice: the output plane itself
+            const int64_t yoff = ((int64_t)n_img * p.Cout + (int64_t)g * p.Og) * OHW + plane_off;
+            const float nz = has_noise ? p.noise[(p.noise_ps ? (int64_t)n_img * OHW : 0) + plane_off] * nstr : 0.f;
 #pragma unroll
-        for (int a = 0; a < WMT; a++) {
-            float rv[16];
-            if (has_res) {
+            for (int a = 0; a < WMT; a++) {
+                float rv[16];
+#pragma unroll
+                for (int r16 = 0; r16 < 16; r16++) rv[r16] = 0.f;
+                if (has_res) {
+#pragma unroll
+                    for (int r16 = 0; r16 < 16; r16++) {
+                        const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r16, lane);
+                        if (FULL || o < p.Og) rv[r16] = io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES);
+                    }
+                }
 #pragma unroll
                 for (int r16 = 0; r16 < 16; r16++) {
                     const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r16, lane);
-                    rv[r16] = o < p.Og ? io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES) : 0.f;
-                }
-            }
-#pragma unroll
-            for (int r16 = 0; r16 < 16; r16++) {
-                const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r16, lane);
-                if (o < p.Og) {
-                    float v = acc[a][b][r16];
-                    v = osb ? fmaf(v, row_s[a][r16], nz) : v + nz;
-                    if (has_res) v += rv[r16];
-                    if (p.act && fused) v = conv_epilogue(v, row_b[a][r16], p.act, p.alpha, p.gain, p.clamp);
-                    if (pb) pb[(int64_t)o * OHW] = v;
-                    else { io_st<IO>(p.y, yoff + (int64_t)o * OHW, v); if (p.y_amax) amax_take(y_am, v); }
+                    float v = fmaf(acc[a][b][r16], row_s[a][r16], nz) + rv[r16];          // row_s = 1, rv = 0 where there is none
+                    v = conv_epilogue_t<ACT, CLAMP>(v, row_b[a][r16], slope, p.act == 2, p.gain, p.clamp);
+                    if (FULL || o < p.Og) { io_st<IO>(p.y, yoff + (int64_t)o * OHW, v); amax_take(y_am, v); }
                 }
             }
         }
-    }
+    });
     if (p.ksplit == 1) amax_commit(y_am, y_slot);
 }
 
