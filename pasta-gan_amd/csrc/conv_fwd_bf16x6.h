@@ -463,6 +463,10 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     }
     const bool has_noise = p.noise && p.ksplit == 1;
     const float nstr = has_noise ? p.noise_strength[0] : 0.f;
+    const float slope = conv_act_slope(p.act, p.alpha);
+    const bool act_on = p.act != 0 && p.ksplit == 1;
+    conv_epilogue_dispatch(act_on, act_on && p.clamp >= 0.f, o_blk + BM <= p.Og, [&](auto act_c, auto clamp_c, auto full_c) {
+    constexpr bool ACT = decltype(act_c)::value, CLAMP = decltype(clamp_c)::value, FULL = decltype(full_c)::value;
 #pragma unroll
     for (int b = 0; b < WNT; b++) {
         const int64_t pix = pix_blk + (wn * WNT + b) * 32 + jl;
@@ -501,20 +505,26 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[a][b][r] += tv[r];
             }
+            if (pb) {                                   // K slices: fp32 partial sums, nothing else (scale, residual, bias, activation ride in the reduction)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
+                    if (o < p.Og) pb[(int64_t)o * OHW] = acc[a][b][r];
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 16; r++) { const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane); tv[r] = has_bias ? p.bias[g * p.Og + (o < p.Og ? o : p.Og - 1)] : 0.f; }
+            // the stores: instantiated per (activation, clamp, whole tile of rows), no wave-uniform branch per element (conv_common.h)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
-                if (o < p.Og) {
-                    float v = acc[a][b][r];
-                    if (p.act && p.ksplit == 1) v = conv_epilogue(v, tv[r], p.act, p.alpha, p.gain, p.clamp);
-                    if (pb) pb[(int64_t)o * OHW] = v;
-                    else { io_st<IO>(p.y, yoff + (int64_t)o * OHW, v); if (p.y_amax) amax_take(y_am, v); }
-                }
+                const float v = conv_epilogue_t<ACT, CLAMP>(acc[a][b][r], tv[r], slope, p.act == 2, p.gain, p.clamp);
+                if (FULL || o < p.Og) { io_st<IO>(p.y, yoff + (int64_t)o * OHW, v); amax_take(y_am, v); }
             }
         }
     }
+    });
     if (p.ksplit == 1) amax_commit(y_am, y_slot);
 }
 
@@ -1107,6 +1117,10 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     }
     const bool has_noise = p.noise && p.ksplit == 1;
     const float nstr = has_noise ? p.noise_strength[0] : 0.f;
+    const float slope = conv_act_slope(p.act, p.alpha);
+    const bool act_on = p.act != 0 && p.ksplit == 1;
+    conv_epilogue_dispatch(act_on, act_on && p.clamp >= 0.f, o_blk + BM <= p.Og, [&](auto act_c, auto clamp_c, auto full_c) {
+    constexpr bool ACT = decltype(act_c)::value, CLAMP = decltype(clamp_c)::value, FULL = decltype(full_c)::value;
 #pragma unroll
     for (int b = 0; b < WNT; b++) {
         const int64_t pix = pix_blk + (wn * WNT + b) * 32 + jl;
@@ -1144,20 +1158,26 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[a][b][r] += tv[r];
             }
+            if (pb) {                                   // K slices: fp32 partial sums, nothing else (scale, residual, bias, activation ride in the reduction)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
+                    if (o < p.Og) pb[(int64_t)o * OHW] = acc[a][b][r];
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 16; r++) { const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane); tv[r] = has_bias ? p.bias[g * p.Og + (o < p.Og ? o : p.Og - 1)] : 0.f; }
+            // the stores: instantiated per (activation, clamp, whole tile of rows), no wave-uniform branch per element (conv_common.h)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
-                if (o < p.Og) {
-                    float v = acc[a][b][r];
-                    if (p.act && p.ksplit == 1) v = conv_epilogue(v, tv[r], p.act, p.alpha, p.gain, p.clamp);
-                    if (pb) pb[(int64_t)o * OHW] = v;
-                    else { io_st<IO>(p.y, yoff + (int64_t)o * OHW, v); if (p.y_amax) amax_take(y_am, v); }
-                }
+                const float v = conv_epilogue_t<ACT, CLAMP>(acc[a][b][r], tv[r], slope, p.act == 2, p.gain, p.clamp);
+                if (FULL || o < p.Og) { io_st<IO>(p.y, yoff + (int64_t)o * OHW, v); amax_take(y_am, v); }
             }
         }
     }
+    });
     if (p.ksplit == 1) amax_commit(y_am, y_slot);
 }
 

@@ -398,16 +398,6 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
         return;
     }
     // (here fused holds: an output scale, a bias or a residual exist only without K slices)
-    float row_b[WMT][16], row_s[WMT][16];
-#pragma unroll
-    for (int a = 0; a < WMT; a++)
-#pragma unroll
-        for (int r16 = 0; r16 < 16; r16++) {
-            const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r16, lane);
-            const int oc = o < p.Og ? o : p.Og - 1;
-            row_b[a][r16] = bsb ? bsb[oc] : 0.f;
-            row_s[a][r16] = osb ? osb[oc] : 1.f;
-        }
     const float slope = conv_act_slope(p.act, p.alpha);
     conv_epilogue_dispatch(p.act != 0, p.act != 0 && p.clamp >= 0.f, o_blk + BM <= p.Og, [&](auto act_c, auto clamp_c, auto full_c) {
         constexpr bool ACT = decltype(act_c)::value, CLAMP = decltype(clamp_c)::value, FULL = decltype(full_c)::value;
@@ -420,21 +410,33 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
             const float nz = has_noise ? p.noise[(p.noise_ps ? (int64_t)n_img * OHW : 0) + plane_off] * nstr : 0.f;
 #pragma unroll
             for (int a = 0; a < WMT; a++) {
-                float rv[16];
+                // one operand kind at a time through the same sixteen registers (output scale, residual, bias side by side in arrays of
+                // their own spill next to the sixty-four accumulators and the store addresses): sixteen loads in a row, then their use
+                float tv[16];
+                if (osb) {
 #pragma unroll
-                for (int r16 = 0; r16 < 16; r16++) rv[r16] = 0.f;
+                    for (int r16 = 0; r16 < 16; r16++) { const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r16, lane); tv[r16] = osb[(FULL || o < p.Og) ? o : p.Og - 1]; }
+#pragma unroll
+                    for (int r16 = 0; r16 < 16; r16++) acc[a][b][r16] = fmaf(acc[a][b][r16], tv[r16], nz);
+                } else if (has_noise) {
+#pragma unroll
+                    for (int r16 = 0; r16 < 16; r16++) acc[a][b][r16] += nz;
+                }
                 if (has_res) {
 #pragma unroll
                     for (int r16 = 0; r16 < 16; r16++) {
                         const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r16, lane);
-                        if (FULL || o < p.Og) rv[r16] = io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES);
+                        tv[r16] = (FULL || o < p.Og) ? io_ld1<IO>((const char*)p.res + (yoff + (int64_t)o * OHW) * ES) : 0.f;
                     }
+#pragma unroll
+                    for (int r16 = 0; r16 < 16; r16++) acc[a][b][r16] += tv[r16];
                 }
+#pragma unroll
+                for (int r16 = 0; r16 < 16; r16++) { const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r16, lane); tv[r16] = (ACT && bsb) ? bsb[(FULL || o < p.Og) ? o : p.Og - 1] : 0.f; }
 #pragma unroll
                 for (int r16 = 0; r16 < 16; r16++) {
                     const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r16, lane);
-                    float v = fmaf(acc[a][b][r16], row_s[a][r16], nz) + rv[r16];          // row_s = 1, rv = 0 where there is none
-                    v = conv_epilogue_t<ACT, CLAMP>(v, row_b[a][r16], slope, p.act == 2, p.gain, p.clamp);
+                    const float v = conv_epilogue_t<ACT, CLAMP>(acc[a][b][r16], tv[r16], slope, p.act == 2, p.gain, p.clamp);
                     if (FULL || o < p.Og) { io_st<IO>(p.y, yoff + (int64_t)o * OHW, v); amax_take(y_am, v); }
                 }
             }
