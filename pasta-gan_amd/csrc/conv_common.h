@@ -30,7 +30,7 @@ __device__ __forceinline__ float conv_epilogue(float v, float b, int act, float 
 
 // The same with its wave-uniform tests resolved at compile time (the store loops of the kernels are instantiated per case and chosen
 // once per workgroup: the compiler does not unswitch them, and sixty-four stores with three or four scalar branches each cost the
-// dominant kernel 5 % -- profiles/r4_ab_rows2d_epilogue.txt).  slope = conv_act_slope(act, alpha): 1 linear, alpha lrelu.
+// dominant kernel 5 % -- profiles/r4_ab_epilogues.txt).  slope = conv_act_slope(act, alpha): 1 linear, alpha lrelu.
 // (relu = act == 2 selects an exact 0 for v <= 0 and for NaN, as conv_epilogue does)
 __device__ __forceinline__ float conv_act_slope(int act, float alpha) { return act == 3 ? alpha : 1.f; }
 template <bool ACT, bool CLAMP>

@@ -168,40 +168,39 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16x3_kernel(ConvFwdParams p) 
     const int64_t ybase = (int64_t)n_img * p.Cout * HW + (pix_blk - (int64_t)n_img * HW);
     // bias per output row and the residual of a 32 x 32 sub-tile are fetched in front of the stores (a load in front of every store serialises on
     // the memory counter: conv_fwd_rows2d_bf16x6.h)
-    float row_b[WMT][16];
+    // the stores: instantiated per (activation, clamp, whole tile of rows) and chosen once per workgroup (conv_common.h)
+    const float slope = conv_act_slope(p.act, p.alpha);
+    conv_epilogue_dispatch(p.act != 0, p.act != 0 && p.clamp >= 0.f, o_blk + BM <= p.Og, [&](auto act_c, auto clamp_c, auto full_c) {
+        constexpr bool ACT = decltype(act_c)::value, CLAMP = decltype(clamp_c)::value, FULL = decltype(full_c)::value;
 #pragma unroll
-    for (int a = 0; a < WMT; a++)
+        for (int b = 0; b < WNT; b++) {
+            const int64_t yoff = ybase + (wn * WNT + b) * 32 + jl;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
-            row_b[a][r] = (p.act && p.bias) ? p.bias[o < p.Og ? o : p.Og - 1] : 0.f;
-        }
+            for (int a = 0; a < WMT; a++) {
+                float tv[16];                           // residual, then bias, through the same registers: sixteen loads in a row, then their use
+                if (p.res) {
 #pragma unroll
-    for (int b = 0; b < WNT; b++) {
-        const int64_t yoff = ybase + (wn * WNT + b) * 32 + jl;
+                    for (int r = 0; r < 16; r++) {
+                        const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
+                        tv[r] = (FULL || o < p.Og) ? p.res[yoff + (int64_t)o * HW] : 0.f;
+                    }
 #pragma unroll
-        for (int a = 0; a < WMT; a++) {
-            float rv[16];
-            if (p.res) {
+                    for (int r = 0; r < 16; r++) acc[a][b][r] += tv[r];
+                }
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
-                    rv[r] = o < p.Og ? p.res[yoff + (int64_t)o * HW] : 0.f;
+                    tv[r] = (ACT && p.bias) ? p.bias[(FULL || o < p.Og) ? o : p.Og - 1] : 0.f;
                 }
-            }
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
-                if (o < p.Og) {
-                    float v = acc[a][b][r];
-                    if (p.res) v += rv[r];
-                    if (p.act) v = conv_epilogue(v, row_b[a][r], p.act, p.alpha, p.gain, p.clamp);
-                    p.y[yoff + (int64_t)o * HW] = v;
-                    if (p.y_amax) amax_take(y_am, v);
+                for (int r = 0; r < 16; r++) {
+                    const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
+                    const float v = conv_epilogue_t<ACT, CLAMP>(acc[a][b][r], tv[r], slope, p.act == 2, p.gain, p.clamp);
+                    if (FULL || o < p.Og) { p.y[yoff + (int64_t)o * HW] = v; amax_take(y_am, v); }
                 }
             }
         }
-    }
+    });
     amax_commit(y_am, y_slot);
 }
 

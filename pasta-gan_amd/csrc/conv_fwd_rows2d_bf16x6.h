@@ -345,7 +345,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
     if (!osb && !bsb && !has_res) {
         // nothing to fetch: the plain launches (every input gradient without a residual, every convolution without an epilogue) keep the
         // store loop they always had -- the general path below, taken by them too, cost the dominant kernel 3.0 % (286.3 -> 294.8 us on
-        // the micro-benchmark's shapes, same box, profiles/r4_ab_rows2d_epilogue.txt)
+        // the micro-benchmark's shapes, same box, profiles/r4_ab_epilogues.txt)
         if (fused && !p.act && o_blk + BM <= p.Og) {
             // ... and the commonest of them -- no activation, whole tile of output rows, no K slices -- a loop without a branch per element
             // (the compiler does not unswitch the wave-uniform tests of the general loops: 454 branches in the epilogue's code)

@@ -200,42 +200,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_f16x3_kernel(ConvFwdParams p
                 for (int r = 0; r < 16; r++) acc[a][b][r] = (acc[a][b][r] * isx) * ws[a][r];
     }
     const int OHW = OH * OW;
-    float row_b[WMT][16];                                // bias per output row, fetched in front of the stores (conv_fwd_rows2d_bf16x6.h)
+    // the stores: instantiated per (activation, clamp, whole tile of rows) and chosen once per workgroup (conv_common.h)
+    const float slope = conv_act_slope(p.act, p.alpha);
+    conv_epilogue_dispatch(p.act != 0, p.act != 0 && p.clamp >= 0.f, o_blk + BM <= p.Og, [&](auto act_c, auto clamp_c, auto full_c) {
+        constexpr bool ACT = decltype(act_c)::value, CLAMP = decltype(clamp_c)::value, FULL = decltype(full_c)::value;
 #pragma unroll
-    for (int a = 0; a < WMT; a++)
+        for (int b = 0; b < WNT_; b++) {
+            const int t = wn * WN_PIX + b * 32 + jl;
+            const int r = t >> seg_log2, c = t & (SEG - 1);
+            const int64_t yoff = (int64_t)n_img * p.Cout * OHW + (p0 + r) * OW + q0 + c;
 #pragma unroll
-        for (int rr = 0; rr < 16; rr++) {
-            const int o = o_blk + (wm * WMT + a) * 32 + acc_row(rr, lane);
-            row_b[a][rr] = (p.act && p.bias) ? p.bias[o < p.Og ? o : p.Og - 1] : 0.f;
-        }
+            for (int a = 0; a < WMT; a++) {
+                float tv[16];                           // residual, then bias, through the same registers
+                if (p.res) {
 #pragma unroll
-    for (int b = 0; b < WNT_; b++) {
-        const int t = wn * WN_PIX + b * 32 + jl;
-        const int r = t >> seg_log2, c = t & (SEG - 1);
-        const int64_t yoff = (int64_t)n_img * p.Cout * OHW + (p0 + r) * OW + q0 + c;
+                    for (int rr = 0; rr < 16; rr++) {
+                        const int o = o_blk + (wm * WMT + a) * 32 + acc_row(rr, lane);
+                        tv[rr] = (FULL || o < p.Og) ? p.res[yoff + (int64_t)o * OHW] : 0.f;
+                    }
 #pragma unroll
-        for (int a = 0; a < WMT; a++) {
-            float rv[16];
-            if (p.res) {
+                    for (int rr = 0; rr < 16; rr++) acc[a][b][rr] += tv[rr];
+                }
 #pragma unroll
                 for (int rr = 0; rr < 16; rr++) {
                     const int o = o_blk + (wm * WMT + a) * 32 + acc_row(rr, lane);
-                    rv[rr] = o < p.Og ? p.res[yoff + (int64_t)o * OHW] : 0.f;
+                    tv[rr] = (ACT && p.bias) ? p.bias[(FULL || o < p.Og) ? o : p.Og - 1] : 0.f;
                 }
-            }
 #pragma unroll
-            for (int rr = 0; rr < 16; rr++) {
-                const int o = o_blk + (wm * WMT + a) * 32 + acc_row(rr, lane);
-                if (o < p.Og) {
-                    float v = acc[a][b][rr];
-                    if (p.res) v += rv[rr];
-                    if (p.act) v = conv_epilogue(v, row_b[a][rr], p.act, p.alpha, p.gain, p.clamp);
-                    p.y[yoff + (int64_t)o * OHW] = v;
-                    if (p.y_amax) amax_take(y_am, v);
+                for (int rr = 0; rr < 16; rr++) {
+                    const int o = o_blk + (wm * WMT + a) * 32 + acc_row(rr, lane);
+                    const float v = conv_epilogue_t<ACT, CLAMP>(acc[a][b][rr], tv[rr], slope, p.act == 2, p.gain, p.clamp);
+                    if (FULL || o < p.Og) { p.y[yoff + (int64_t)o * OHW] = v; amax_take(y_am, v); }
                 }
             }
         }
-    }
+    });
     amax_commit(y_am, y_slot);
 }
 
