@@ -179,6 +179,12 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_kernel(ConvFwdParams p) {
     const int OHW = p.OH * p.OW;
     const bool has_noise = p.noise && p.ksplit == 1;
     const float nstr = has_noise ? p.noise_strength[0] : 0.f;
+    // the stores: instantiated per (activation, clamp, whole tile of rows) and chosen once per workgroup (conv_common.h: a store loop with
+    // three or four wave-uniform branches per element cost the split kernels 5 %)
+    const float slope = conv_act_slope(p.act, p.alpha);
+    const bool act_on = p.act != 0 && p.ksplit == 1;
+    conv_epilogue_dispatch(act_on, act_on && p.clamp >= 0.f, o_blk + BM <= p.Og, [&](auto act_c, auto clamp_c, auto full_c) {
+    constexpr bool ACT = decltype(act_c)::value, CLAMP = decltype(clamp_c)::value, FULL = decltype(full_c)::value;
 #pragma unroll
     for (int b = 0; b < WNT; b++) {
         const int64_t pix = pix_blk + (wn * WNT + b) * 32 + jl;
@@ -192,20 +198,36 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_kernel(ConvFwdParams p) {
         float* yb = (p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW : p.y) + yoff;
         const float* rb = (p.res && p.ksplit == 1) ? p.res + yoff : nullptr;
         const float* osb = (p.oscale && p.ksplit == 1) ? p.oscale + (int64_t)n * p.Cout + (int64_t)g * p.Og : nullptr;
+        const float* bsb = (ACT && p.bias) ? p.bias + g * p.Og : nullptr;
 #pragma unroll
-        for (int a = 0; a < WMT; a++)
+        for (int a = 0; a < WMT; a++) {
+            float tv[16];                               // output scale, residual, bias through the same registers: sixteen loads in a row, then their use
+            if (osb) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) { const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane); tv[r] = osb[(FULL || o < p.Og) ? o : p.Og - 1]; }
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[a][b][r] = fmaf(acc[a][b][r], tv[r], nz);
+            } else if (has_noise) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[a][b][r] += nz;
+            }
+            if (rb) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) { const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane); tv[r] = (FULL || o < p.Og) ? rb[(int64_t)o * OHW] : 0.f; }
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[a][b][r] += tv[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) { const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane); tv[r] = bsb ? bsb[(FULL || o < p.Og) ? o : p.Og - 1] : 0.f; }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
-                if (o < p.Og) {
-                    float v = acc[a][b][r];
-                    v = conv_scale_noise(v, osb, o, nz);
-                    if (rb) v += rb[(int64_t)o * OHW];
-                    if (p.act && p.ksplit == 1) v = conv_epilogue(v, p.bias ? p.bias[g * p.Og + o] : 0.f, p.act, p.alpha, p.gain, p.clamp);
-                    yb[(int64_t)o * OHW] = v;
-                }
+                const float v = conv_epilogue_t<ACT, CLAMP>(acc[a][b][r], tv[r], slope, p.act == 2, p.gain, p.clamp);
+                if (FULL || o < p.Og) yb[(int64_t)o * OHW] = v;
             }
+        }
     }
+    });
 }
 
 template <int BM, int BN, int WMT, int WNT, int KC, int OCC = 1>
