@@ -297,12 +297,20 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
 
     // prologue: the whole B image of the first chunk and the weights of its first two taps
     load_a(0, c_first, 0);
+    {
+        // every unit of the first chunk is fetched before the first one is split: ONE trip to memory in front of the K loop instead of UPT
+        // (the accumulators are not live yet: the register sets are free; a workgroup of the eight-wave tile is alone on its CU, nothing
+        // hides this latency)
+        float fb[UPT][8], fc[UPT][ISC ? 8 : 1];
+        int fnv[UPT];
 #pragma unroll
-    for (int k = 0; k < UPT; k++) {
-        load_unit(k, c_first, nchunks > 0, sb0, sc0, nv0);
+        for (int k = 0; k < UPT; k++) load_unit(k, c_first, nchunks > 0, fb[k], fc[k], fnv[k]);
 #pragma unroll
-        for (int j = 0; j < 4; j++) split_pair(sb0, sc0, nv0, j);
-        store_unit(k, 0);
+        for (int k = 0; k < UPT; k++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) split_pair(fb[k], fc[k], fnv[k], j);
+            store_unit(k, 0);
+        }
     }
     store_a(0, 0);
     load_a(1, c_first, 1);                           // stored by step 0
