@@ -28,33 +28,39 @@ __device__ __forceinline__ float conv_epilogue(float v, float b, int act, float 
     return v;
 }
 
-// The same with its wave-uniform tests resolved at compile time (the store loops of the kernels are instantiated per case and chosen
-// once per workgroup: the compiler does not unswitch them, and sixty-four stores with three or four scalar branches each cost the
-// dominant kernel 5 % -- profiles/r4_ab_epilogues.txt).  slope = conv_act_slope(act, alpha): 1 linear, alpha lrelu.
-// (relu = act == 2 selects an exact 0 for v <= 0 and for NaN, as conv_epilogue does)
-__device__ __forceinline__ float conv_act_slope(int act, float alpha) { return act == 3 ? alpha : 1.f; }
-template <bool ACT, bool CLAMP>
-__device__ __forceinline__ float conv_epilogue_t(float v, float b, float slope, bool relu, float gain, float clamp) {
-    if constexpr (ACT) {
-        v += b;
-        const float neg = relu ? 0.f : v * slope;                // a select on a wave-uniform value, not a branch
-        v = v > 0.f ? v : neg;
-        v *= gain;
-        if constexpr (CLAMP) v = (v > -clamp && v < clamp) ? v : (v >= 0.f ? clamp : -clamp);
-    }
-    return v;
+// The same without a branch: the store loops of the kernels run sixty-four of these per lane, and with three or four wave-uniform
+// scalar branches per element (the compiler does not unswitch them) they cost the dominant kernel 5 % -- profiles/r4_ab_epilogues.txt.
+// "No activation" is expressed by the caller as b = 0, slope = 1, relu = false, gain = 1, clamp_on = false (EpiAct below): the value then
+// passes unchanged (NaN and infinities included).  relu selects an exact 0 for v <= 0 and for NaN, as conv_epilogue does.
+struct EpiAct { float slope, gain, clamp; bool relu, clamp_on, on; };
+__device__ __forceinline__ EpiAct conv_epi_act(int act, float alpha, float gain, float clamp, bool fused) {
+    EpiAct e;
+    e.on = act != 0 && fused;
+    e.slope = (e.on && act == 3) ? alpha : 1.f;
+    e.relu = e.on && act == 2;
+    e.gain = e.on ? gain : 1.f;
+    e.clamp_on = e.on && clamp >= 0.f;
+    e.clamp = clamp;
+    return e;
 }
-// calls f(std::bool_constant<ACT>, std::bool_constant<CLAMP>, std::bool_constant<FULL>) for the runtime flags (CLAMP implies ACT)
-template <class F>
-__device__ __forceinline__ void conv_epilogue_dispatch(bool act, bool clamp, bool full, F&& f) {
-    if (full) {
-        if (!act) f(std::false_type{}, std::false_type{}, std::true_type{});
-        else if (!clamp) f(std::true_type{}, std::false_type{}, std::true_type{});
-        else f(std::true_type{}, std::true_type{}, std::true_type{});
+__device__ __forceinline__ float conv_epilogue_u(float v, float b, const EpiAct& e) {
+    v += b;
+    const float neg = e.relu ? 0.f : v * e.slope;              // selects on wave-uniform values, not branches
+    v = v > 0.f ? v : neg;
+    v *= e.gain;
+    const bool in = (v > -e.clamp && v < e.clamp) || !e.clamp_on;
+    return in ? v : (v >= 0.f ? e.clamp : -e.clamp);
+}
+// The one test that stays a property of the store loop: does the workgroup's tile of output rows lie inside the tensor (then no row test per
+// element)?  SPEC kernels (the default arithmetic and 16-bit storage: what the training and inference steps run) get an instance of their
+// store loop per answer, chosen once per workgroup; the other arithmetics keep one loop with the test per element (compile time:
+// the instances are sixty-four unrolled stores each, in 160 kernels).  f(std::bool_constant<FULL>) or f(bool).
+template <bool SPEC, class F>
+__device__ __forceinline__ void conv_epilogue_dispatch(bool full, F&& f) {
+    if constexpr (SPEC) {
+        if (full) f(std::true_type{}); else f(std::false_type{});
     } else {
-        if (!act) f(std::false_type{}, std::false_type{}, std::false_type{});
-        else if (!clamp) f(std::true_type{}, std::false_type{}, std::false_type{});
-        else f(std::true_type{}, std::true_type{}, std::false_type{});
+        f(full);
     }
 }
 

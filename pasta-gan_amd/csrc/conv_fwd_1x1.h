@@ -169,9 +169,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16x3_kernel(ConvFwdParams p) 
     // bias per output row and the residual of a 32 x 32 sub-tile are fetched in front of the stores (a load in front of every store serialises on
     // the memory counter: conv_fwd_rows2d_bf16x6.h)
     // the stores: instantiated per (activation, clamp, whole tile of rows) and chosen once per workgroup (conv_common.h)
-    const float slope = conv_act_slope(p.act, p.alpha);
-    conv_epilogue_dispatch(p.act != 0, p.act != 0 && p.clamp >= 0.f, o_blk + BM <= p.Og, [&](auto act_c, auto clamp_c, auto full_c) {
-        constexpr bool ACT = decltype(act_c)::value, CLAMP = decltype(clamp_c)::value, FULL = decltype(full_c)::value;
+    const EpiAct ea = conv_epi_act(p.act, p.alpha, p.gain, p.clamp, true);
+    conv_epilogue_dispatch<true>(o_blk + BM <= p.Og, [&](auto full_c) {
+        const bool FULL = full_c;
 #pragma unroll
         for (int b = 0; b < WNT; b++) {
             const int64_t yoff = ybase + (wn * WNT + b) * 32 + jl;
@@ -190,12 +190,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16x3_kernel(ConvFwdParams p) 
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
-                    tv[r] = (ACT && p.bias) ? p.bias[(FULL || o < p.Og) ? o : p.Og - 1] : 0.f;
+                    tv[r] = (ea.on && p.bias) ? p.bias[(FULL || o < p.Og) ? o : p.Og - 1] : 0.f;
                 }
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
-                    const float v = conv_epilogue_t<ACT, CLAMP>(acc[a][b][r], tv[r], slope, p.act == 2, p.gain, p.clamp);
+                    const float v = conv_epilogue_u(acc[a][b][r], tv[r], ea);
                     if (FULL || o < p.Og) { p.y[yoff + (int64_t)o * HW] = v; amax_take(y_am, v); }
                 }
             }

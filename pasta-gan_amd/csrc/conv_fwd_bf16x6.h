@@ -463,10 +463,9 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     }
     const bool has_noise = p.noise && p.ksplit == 1;
     const float nstr = has_noise ? p.noise_strength[0] : 0.f;
-    const float slope = conv_act_slope(p.act, p.alpha);
-    const bool act_on = p.act != 0 && p.ksplit == 1;
-    conv_epilogue_dispatch(act_on, act_on && p.clamp >= 0.f, o_blk + BM <= p.Og, [&](auto act_c, auto clamp_c, auto full_c) {
-    constexpr bool ACT = decltype(act_c)::value, CLAMP = decltype(clamp_c)::value, FULL = decltype(full_c)::value;
+    const EpiAct ea = conv_epi_act(p.act, p.alpha, p.gain, p.clamp, p.ksplit == 1);
+    conv_epilogue_dispatch<(NP == NP_F16X3 || IO != IO_F32)>(o_blk + BM <= p.Og, [&](auto full_c) {
+    const bool FULL = full_c;
 #pragma unroll
     for (int b = 0; b < WNT; b++) {
         const int64_t pix = pix_blk + (wn * WNT + b) * 32 + jl;
@@ -519,7 +518,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
-                const float v = conv_epilogue_t<ACT, CLAMP>(acc[a][b][r], tv[r], slope, p.act == 2, p.gain, p.clamp);
+                const float v = conv_epilogue_u(acc[a][b][r], tv[r], ea);
                 if (FULL || o < p.Og) { io_st<IO>(p.y, yoff + (int64_t)o * OHW, v); amax_take(y_am, v); }
             }
         }
@@ -1117,10 +1116,9 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     }
     const bool has_noise = p.noise && p.ksplit == 1;
     const float nstr = has_noise ? p.noise_strength[0] : 0.f;
-    const float slope = conv_act_slope(p.act, p.alpha);
-    const bool act_on = p.act != 0 && p.ksplit == 1;
-    conv_epilogue_dispatch(act_on, act_on && p.clamp >= 0.f, o_blk + BM <= p.Og, [&](auto act_c, auto clamp_c, auto full_c) {
-    constexpr bool ACT = decltype(act_c)::value, CLAMP = decltype(clamp_c)::value, FULL = decltype(full_c)::value;
+    const EpiAct ea = conv_epi_act(p.act, p.alpha, p.gain, p.clamp, p.ksplit == 1);
+    conv_epilogue_dispatch<(NP == NP_F16X3 || IO != IO_F32)>(o_blk + BM <= p.Og, [&](auto full_c) {
+    const bool FULL = full_c;
 #pragma unroll
     for (int b = 0; b < WNT; b++) {
         const int64_t pix = pix_blk + (wn * WNT + b) * 32 + jl;
@@ -1172,7 +1170,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
-                const float v = conv_epilogue_t<ACT, CLAMP>(acc[a][b][r], tv[r], slope, p.act == 2, p.gain, p.clamp);
+                const float v = conv_epilogue_u(acc[a][b][r], tv[r], ea);
                 if (FULL || o < p.Og) { io_st<IO>(p.y, yoff + (int64_t)o * OHW, v); amax_take(y_am, v); }
             }
         }

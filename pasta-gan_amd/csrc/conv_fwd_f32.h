@@ -181,10 +181,9 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_kernel(ConvFwdParams p) {
     const float nstr = has_noise ? p.noise_strength[0] : 0.f;
     // the stores: instantiated per (activation, clamp, whole tile of rows) and chosen once per workgroup (conv_common.h: a store loop with
     // three or four wave-uniform branches per element cost the split kernels 5 %)
-    const float slope = conv_act_slope(p.act, p.alpha);
-    const bool act_on = p.act != 0 && p.ksplit == 1;
-    conv_epilogue_dispatch(act_on, act_on && p.clamp >= 0.f, o_blk + BM <= p.Og, [&](auto act_c, auto clamp_c, auto full_c) {
-    constexpr bool ACT = decltype(act_c)::value, CLAMP = decltype(clamp_c)::value, FULL = decltype(full_c)::value;
+    const EpiAct ea = conv_epi_act(p.act, p.alpha, p.gain, p.clamp, p.ksplit == 1);
+    conv_epilogue_dispatch<true>(o_blk + BM <= p.Og, [&](auto full_c) {
+    const bool FULL = full_c;
 #pragma unroll
     for (int b = 0; b < WNT; b++) {
         const int64_t pix = pix_blk + (wn * WNT + b) * 32 + jl;
@@ -198,7 +197,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_kernel(ConvFwdParams p) {
         float* yb = (p.ksplit > 1 ? p.partial + (int64_t)ks * p.N * p.Cout * OHW : p.y) + yoff;
         const float* rb = (p.res && p.ksplit == 1) ? p.res + yoff : nullptr;
         const float* osb = (p.oscale && p.ksplit == 1) ? p.oscale + (int64_t)n * p.Cout + (int64_t)g * p.Og : nullptr;
-        const float* bsb = (ACT && p.bias) ? p.bias + g * p.Og : nullptr;
+        const float* bsb = (ea.on && p.bias) ? p.bias + g * p.Og : nullptr;
 #pragma unroll
         for (int a = 0; a < WMT; a++) {
             float tv[16];                               // output scale, residual, bias through the same registers: sixteen loads in a row, then their use
@@ -222,7 +221,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_kernel(ConvFwdParams p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
-                const float v = conv_epilogue_t<ACT, CLAMP>(acc[a][b][r], tv[r], slope, p.act == 2, p.gain, p.clamp);
+                const float v = conv_epilogue_u(acc[a][b][r], tv[r], ea);
                 if (FULL || o < p.Og) yb[(int64_t)o * OHW] = v;
             }
         }

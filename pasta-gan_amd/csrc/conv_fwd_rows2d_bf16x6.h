@@ -377,8 +377,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
                         }
                 }
             };
-            if (p.y_amax) { lean(std::true_type{}); amax_commit(y_am, y_slot); }
-            else lean(std::false_type{});
+            if (p.y_amax) lean(std::true_type{}); else lean(std::false_type{});
+            amax_commit(y_am, y_slot);
             return;
         }
 #pragma unroll
@@ -406,9 +406,9 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
         return;
     }
     // (here fused holds: an output scale, a bias or a residual exist only without K slices)
-    const float slope = conv_act_slope(p.act, p.alpha);
-    conv_epilogue_dispatch(p.act != 0, p.act != 0 && p.clamp >= 0.f, o_blk + BM <= p.Og, [&](auto act_c, auto clamp_c, auto full_c) {
-        constexpr bool ACT = decltype(act_c)::value, CLAMP = decltype(clamp_c)::value, FULL = decltype(full_c)::value;
+    const EpiAct ea = conv_epi_act(p.act, p.alpha, p.gain, p.clamp, true);
+    conv_epilogue_dispatch<(NP == NP_F16X3 || IO != IO_F32)>(o_blk + BM <= p.Og, [&](auto full_c) {
+        const bool FULL = full_c;
 #pragma unroll
         for (int b = 0; b < WNT; b++) {
             const int t = (wn * WNT + b) * 32 + jl;
@@ -440,11 +440,11 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
                     for (int r16 = 0; r16 < 16; r16++) acc[a][b][r16] += tv[r16];
                 }
 #pragma unroll
-                for (int r16 = 0; r16 < 16; r16++) { const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r16, lane); tv[r16] = (ACT && bsb) ? bsb[(FULL || o < p.Og) ? o : p.Og - 1] : 0.f; }
+                for (int r16 = 0; r16 < 16; r16++) { const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r16, lane); tv[r16] = bsb ? bsb[(FULL || o < p.Og) ? o : p.Og - 1] : 0.f; }
 #pragma unroll
                 for (int r16 = 0; r16 < 16; r16++) {
                     const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r16, lane);
-                    const float v = conv_epilogue_t<ACT, CLAMP>(acc[a][b][r16], tv[r16], slope, p.act == 2, p.gain, p.clamp);
+                    const float v = conv_epilogue_u(acc[a][b][r16], tv[r16], ea);
                     if (FULL || o < p.Og) { io_st<IO>(p.y, yoff + (int64_t)o * OHW, v); amax_take(y_am, v); }
                 }
             }
