@@ -420,6 +420,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true', help='--mode infer: also capture the forward as a hipGraph and time its replay (reported as hipgraph_replay)')
     ap.add_argument('--no-meter', action='store_true', help='do not bracket convolution launches with events')
+    ap.add_argument('--replica-check', action='store_true', help='N > 1: after the timed steps compare the replicas (bitwise parameter checksums over all ranks) '
+                    'and report fp64 sums of the parameters and of the last averaged gradients, so that two transports can be compared (tests/test_ddp_gpu.py)')
     ap.add_argument('--by-shape', action='store_true', help='also print a per-shape convolution table to stderr')
     ap.add_argument('--by-shape-top', type=int, default=40, help='rows of that table')
     args = ap.parse_args()
@@ -517,6 +519,22 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     dt = float(t.item())
 
+    replica = None
+    if args.replica_check:
+        # replicas start from rank 0's weights and apply the same averaged gradients: after any number of steps their parameters are
+        # bit-identical (training_loop_wo_flow_fullbody.py:316-324 checks the same with check_ddp_consistency at every snapshot)
+        params = [q for m in (step.G, step.D) for q in m.parameters()]
+        bits = torch.stack([q.detach().view(torch.int32).sum(dtype=torch.int64) for q in params]).sum().reshape(1)
+        every = [torch.zeros_like(bits) for _ in range(world)]
+        if world > 1:
+            torch.distributed.all_gather(every, bits)
+        else:
+            every = [bits]
+        grads = [q.grad for q in params if q.grad is not None]
+        replica = {'bit_identical': all(int(e.item()) == int(bits.item()) for e in every), 'world_size': world,
+                   'param_abs_sum': float(sum(q.detach().double().abs().sum() for q in params).item()),
+                   'grad_abs_sum': float(sum(g_.double().abs().sum() for g_ in grads).item()) if grads else None, 'grads': len(grads)}
+
     if rank == 0:
         images = args.steps * args.batch_gpu * world
         out = {
@@ -533,6 +551,8 @@ def main():
                                    ('vgg_weight=0 (weights unavailable)' if args.vgg_weight <= 0 else f'vgg_weight={args.vgg_weight:g} with random-init VGG-19') + (', no ADA' if args.aug == 'noaug' else f', ADA pipeline bgc ({args.aug}, p0={args.aug_p:g})') + ', random-init weights; timed iterations ' + f'{args.warmup}..{args.warmup + args.steps - 1}',
                        'global_batch': args.batch_gpu * world, 'parallelism': f'dp{world} ({transport})'},
         }
+        if replica is not None:
+            out['replica_check'] = replica
         fam = meter.summary()
         if fam:
             dom = max(fam.items(), key=lambda kv: kv[1]['ms'])

@@ -51,16 +51,37 @@ __device__ __forceinline__ float conv_epilogue_u(float v, float b, const EpiAct&
     const bool in = (v > -e.clamp && v < e.clamp) || !e.clamp_on;
     return in ? v : (v >= 0.f ? e.clamp : -e.clamp);
 }
-// The one test that stays a property of the store loop: does the workgroup's tile of output rows lie inside the tensor (then no row test per
-// element)?  SPEC kernels (the default arithmetic and 16-bit storage: what the training and inference steps run) get an instance of their
-// store loop per answer, chosen once per workgroup; the other arithmetics keep one loop with the test per element (compile time:
-// the instances are sixty-four unrolled stores each, in 160 kernels).  f(std::bool_constant<FULL>) or f(bool).
+// The store loops are instantiated per case and chosen ONCE per workgroup.  SPEC kernels (the default arithmetic, 16-bit storage, the fp32
+// tiles: what the training and inference steps run) get an instance per (whole tile of output rows?, no activation | activation | activation
+// + clamp) -- with the activation's wave-uniform tests resolved at compile time the loop is 1.5 ms per training step faster than the
+// branch-free folded form above (profiles/r4_ab_epilogues.txt) --; the other arithmetics keep ONE loop with the row test per element and
+// the folded form (compile time: an instance is sixty-four unrolled stores, and those arithmetics are side lines).  Round 4 folded every
+// kernel because the family was one translation unit that took 12 minutes with the instances; since round 5 the family is thirteen units
+// compiled in parallel (conv_launch.h).  f(full, EpiCase<MODE>{}): full is std::bool_constant for SPEC kernels, bool otherwise.
+template <int MODE> struct EpiCase {};          // 0: folded, branch-free (conv_epilogue_u); 1: no activation; 2: activation; 3: activation and clamp
+template <int MODE>
+__device__ __forceinline__ float conv_epilogue_c(float v, float b, const EpiAct& e, EpiCase<MODE>) {
+    if constexpr (MODE == 0) return conv_epilogue_u(v, b, e);
+    else if constexpr (MODE == 1) return v;
+    else {
+        v += b;
+        const float neg = e.relu ? 0.f : v * e.slope;          // a select on a wave-uniform value, not a branch (relu: an exact 0 for v <= 0 and for NaN)
+        v = v > 0.f ? v : neg;
+        v *= e.gain;
+        if constexpr (MODE == 3) v = (v > -e.clamp && v < e.clamp) ? v : (v >= 0.f ? e.clamp : -e.clamp);
+        return v;
+    }
+}
 template <bool SPEC, class F>
-__device__ __forceinline__ void conv_epilogue_dispatch(bool full, F&& f) {
+__device__ __forceinline__ void conv_epilogue_dispatch(bool full, const EpiAct& e, F&& f) {
     if constexpr (SPEC) {
-        if (full) f(std::true_type{}); else f(std::false_type{});
+        if (full) {
+            if (!e.on) f(std::true_type{}, EpiCase<1>{}); else if (!e.clamp_on) f(std::true_type{}, EpiCase<2>{}); else f(std::true_type{}, EpiCase<3>{});
+        } else {
+            if (!e.on) f(std::false_type{}, EpiCase<1>{}); else if (!e.clamp_on) f(std::false_type{}, EpiCase<2>{}); else f(std::false_type{}, EpiCase<3>{});
+        }
     } else {
-        f(full);
+        f(full, EpiCase<0>{});
     }
 }
 

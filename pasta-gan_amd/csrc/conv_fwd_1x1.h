@@ -1,5 +1,5 @@
 // Pointwise (1x1, stride 1) convolutions of the three-product fp16 arithmetic, optionally over the channel concatenation of TWO
-// tensors that is never formed.  Included by conv_igemm.hip.
+// tensors that is never formed.  Instantiated by conv_tu_fwd_small.hip (conv_launch.h).
 #pragma once
 #include "conv_fwd_bf16x6.h"
 
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16x3_kernel(ConvFwdParams p) 
     // the memory counter: conv_fwd_rows2d_bf16x6.h)
     // the stores: instantiated per (activation, clamp, whole tile of rows) and chosen once per workgroup (conv_common.h)
     const EpiAct ea = conv_epi_act(p.act, p.alpha, p.gain, p.clamp, true);
-    conv_epilogue_dispatch<true>(o_blk + BM <= p.Og, [&](auto full_c) {
+    conv_epilogue_dispatch<true>(o_blk + BM <= p.Og, ea, [&](auto full_c, auto case_c) {
         const bool FULL = full_c;
 #pragma unroll
         for (int b = 0; b < WNT; b++) {
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16x3_kernel(ConvFwdParams p) 
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
-                    const float v = conv_epilogue_u(acc[a][b][r], tv[r], ea);
+                    const float v = conv_epilogue_c(acc[a][b][r], tv[r], ea, case_c);
                     if (FULL || o < p.Og) { p.y[yoff + (int64_t)o * HW] = v; amax_take(y_am, v); }
                 }
             }
@@ -213,12 +213,6 @@ static bool conv1x1_ok(const ConvFwdParams& p, int kh, int kw, int stride, int p
     if (p.OH != p.H || p.OW != p.W) return false;
     const int bn = p.Og <= 64 ? 256 : 128;
     return ((int64_t)p.H * p.W) % bn == 0;
-}
-
-static void launch_conv1x1(const ConvFwdParams& p, hipStream_t s) {
-    const int64_t pixels = (int64_t)p.N * p.H * p.W;
-    if (p.Og <= 64) hipLaunchKernelGGL((conv1x1_f16x3_kernel<64, 256>), dim3((unsigned)(pixels / 256), (unsigned)((p.Og + 63) / 64)), dim3(256), 0, s, p);
-    else            hipLaunchKernelGGL((conv1x1_f16x3_kernel<128, 128>), dim3((unsigned)(pixels / 128), (unsigned)((p.Og + 127) / 128)), dim3(256), 0, s, p);
 }
 
 }  // namespace pasta

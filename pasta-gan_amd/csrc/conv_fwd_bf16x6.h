@@ -1,4 +1,4 @@
-// Split-bf16 forward-type kernels (v_mfma_f32_32x32x16_bf16, fp32-equivalent products): weight packing, conv_fwd_bf16x6_kernel, conv_fwd_rows_bf16x6_kernel and their launcher.  Included by conv_igemm.hip.
+// Split-bf16 forward-type kernels (v_mfma_f32_32x32x16_bf16, fp32-equivalent products): weight packing, conv_fwd_bf16x6_kernel, conv_fwd_rows_bf16x6_kernel and their launchers.  Instantiated by conv_tu_pack_f32.hip (packing), conv_tu_fwd_base_*.hip, conv_tu_fwd_rows_*.hip.
 #pragma once
 #include "conv_common.h"
 
@@ -26,6 +26,7 @@ __device__ __forceinline__ void split3(float v, __bf16& a, __bf16& b, __bf16& c)
     c = (__bf16)r;
 }
 
+#ifdef PASTA_TU_PACK       // the packing kernels are defined by conv_tu_pack_f32.hip only (conv_launch.h)
 // [g][tap][chunk of 16 channels][piece 3][half 2][O_pad][8]
 __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int G, int Ig,
                                                                 int Og, int Ig_pad, int Og_pad, int kh, int kw, int transposed,
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(256) void pack_weights_f16x3_kernel(const float* __
         *(uint4*)(d + 4 * Og_pad * 8) = make_uint4(sq[0], sq[1], sq[2], sq[3]);
     }
 }
+#endif  // PASTA_TU_PACK
 
 // NP = bf16 pieces kept per operand: 3 = six products (fp32-equivalent, the default), 2 = three products (hi*hi, hi*mid,
 // mid*hi: ~2^-16 relative, PASTA_MATH_BF16X3), 1 = one product (plain bf16 operands, PASTA_MATH_BF16).  The packed
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     const bool has_noise = p.noise && p.ksplit == 1;
     const float nstr = has_noise ? p.noise_strength[0] : 0.f;
     const EpiAct ea = conv_epi_act(p.act, p.alpha, p.gain, p.clamp, p.ksplit == 1);
-    conv_epilogue_dispatch<(NP == NP_F16X3 || IO != IO_F32)>(o_blk + BM <= p.Og, [&](auto full_c) {
+    conv_epilogue_dispatch<(NP == NP_F16X3 || IO != IO_F32)>(o_blk + BM <= p.Og, ea, [&](auto full_c, auto case_c) {
     const bool FULL = full_c;
 #pragma unroll
     for (int b = 0; b < WNT; b++) {
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
-                const float v = conv_epilogue_u(acc[a][b][r], tv[r], ea);
+                const float v = conv_epilogue_c(acc[a][b][r], tv[r], ea, case_c);
                 if (FULL || o < p.Og) { io_st<IO>(p.y, yoff + (int64_t)o * OHW, v); amax_take(y_am, v); }
             }
         }
@@ -1117,7 +1119,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     const bool has_noise = p.noise && p.ksplit == 1;
     const float nstr = has_noise ? p.noise_strength[0] : 0.f;
     const EpiAct ea = conv_epi_act(p.act, p.alpha, p.gain, p.clamp, p.ksplit == 1);
-    conv_epilogue_dispatch<(NP == NP_F16X3 || IO != IO_F32)>(o_blk + BM <= p.Og, [&](auto full_c) {
+    conv_epilogue_dispatch<(NP == NP_F16X3 || IO != IO_F32)>(o_blk + BM <= p.Og, ea, [&](auto full_c, auto case_c) {
     const bool FULL = full_c;
 #pragma unroll
     for (int b = 0; b < WNT; b++) {
@@ -1170,7 +1172,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
-                const float v = conv_epilogue_u(acc[a][b][r], tv[r], ea);
+                const float v = conv_epilogue_c(acc[a][b][r], tv[r], ea, case_c);
                 if (FULL || o < p.Og) { io_st<IO>(p.y, yoff + (int64_t)o * OHW, v); amax_take(y_am, v); }
             }
         }
@@ -1185,73 +1187,79 @@ static bool rows_tile_ok(int P, int Q, int BN) {
     return Q % 32 == 0 && (seg & (seg - 1)) == 0 && BN % seg == 0 && Q % seg == 0 && ((int64_t)P * Q) % BN == 0;
 }
 
+// The row-reuse kernel of one arithmetic / storage type, if the lattice is made of whole row segments (conv_tu_fwd_rows_*.hip).
 template <int BM, int BN, int NP, int IO>
-static void launch_fwd_bf16_np(const ConvFwdParams& q, dim3 grid, hipStream_t s) {
-    if (q.rows && q.ncls == 1 && rows_tile_ok(q.cls[0].P, q.cls[0].Q, BN)) {
-        // row-reuse kernel: full tiles made of whole row segments inside one image
-        constexpr int APT = (2 * Arith<NP>::npa * BM + 255) / 256;
-        constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 2 * Arith<NP>::npb * (BN + 16) * 8) * sizeof(__bf16);
-        static const int pipe = getenv("PASTA_ROWS_PIPE") ? getenv("PASTA_ROWS_PIPE")[0] - '0' : 1;        // read once (thread-safe initialisation), never written again
-        if constexpr (IO == IO_F32 && NP != NP_F16X3)
-            PASTA_SET_LDS((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 0, NP, IO>), lds);
-        if constexpr (IO == IO_F32 && NP == 3)
-            PASTA_SET_LDS((conv_fwd_rows_bf16x6_kernel<BM, BN, 3, 2, NP, IO>), lds);
-        PASTA_SET_LDS((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP, IO>), lds);
-        if constexpr (IO == IO_F32 && NP == 3) {
-            if (pipe == 2) { hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 3, 2, NP, IO>), grid, dim3(256), lds, s, q); return; }
-            if (pipe == 3) {
-                constexpr size_t lds3 = (size_t)(2 * 2 * NP * (BN + 16) * 8) * sizeof(__bf16);       // the B images only
-                PASTA_SET_LDS((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 3, NP, IO>), lds3);
-                hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 3, NP, IO>), grid, dim3(256), lds3, s, q);
-                return;
-            }
+static bool launch_fwd_rows_np(const ConvFwdParams& q, dim3 grid, hipStream_t s) {
+    if (!(q.rows && q.ncls == 1 && rows_tile_ok(q.cls[0].P, q.cls[0].Q, BN))) return false;
+    // full tiles made of whole row segments inside one image
+    constexpr int APT = (2 * Arith<NP>::npa * BM + 255) / 256;
+    constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 2 * Arith<NP>::npb * (BN + 16) * 8) * sizeof(__bf16);
+    static const int pipe = getenv("PASTA_ROWS_PIPE") ? getenv("PASTA_ROWS_PIPE")[0] - '0' : 1;        // read once (thread-safe initialisation), never written again
+    if constexpr (IO == IO_F32 && NP != NP_F16X3)
+        PASTA_SET_LDS((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 0, NP, IO>), lds);
+    if constexpr (IO == IO_F32 && NP == 3)
+        PASTA_SET_LDS((conv_fwd_rows_bf16x6_kernel<BM, BN, 3, 2, NP, IO>), lds);
+    PASTA_SET_LDS((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP, IO>), lds);
+    if constexpr (IO == IO_F32 && NP == 3) {
+        if (pipe == 2) { hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 3, 2, NP, IO>), grid, dim3(256), lds, s, q); return true; }
+        if (pipe == 3) {
+            constexpr size_t lds3 = (size_t)(2 * 2 * NP * (BN + 16) * 8) * sizeof(__bf16);       // the B images only
+            PASTA_SET_LDS((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 3, NP, IO>), lds3);
+            hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 3, NP, IO>), grid, dim3(256), lds3, s, q);
+            return true;
         }
-        if constexpr (IO == IO_F32 && NP != NP_F16X3) {
-            if (pipe == 0) { hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 0, NP, IO>), grid, dim3(256), lds, s, q); return; }
-        }
-        hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP, IO>), grid, dim3(256), lds, s, q);
-        return;
     }
+    if constexpr (IO == IO_F32 && NP != NP_F16X3) {
+        if (pipe == 0) { hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 0, NP, IO>), grid, dim3(256), lds, s, q); return true; }
+    }
+    hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP, IO>), grid, dim3(256), lds, s, q);
+    return true;
+}
+
+// ... and with the input scale in the staging (fp32 storage, fp32-equivalent products: the forward of a modulated convolution;
+// other arithmetics keep the separate scaling pass).
+template <int BM, int BN, int NP>
+static bool launch_fwd_rows_isc(const ConvFwdParams& q, dim3 grid, hipStream_t s) {
+    if (!(q.rows && q.ncls == 1 && rows_tile_ok(q.cls[0].P, q.cls[0].Q, BN))) return false;
+    constexpr int APT = (2 * Arith<NP>::npa * BM + 255) / 256;
+    constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 2 * Arith<NP>::npb * (BN + 16) * 8) * sizeof(__bf16);
+    PASTA_SET_LDS((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP, IO_F32, true>), lds);
+    hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP, IO_F32, true>), grid, dim3(256), lds, s, q);
+    return true;
+}
+
+// q.bf16x6 = pieces per operand (3: six products, 2: three, 1: one, NP_F16X3); q.iscale implies fp32 storage and fp32-equivalent products (the caller checked)
+template <int BM, int BN>
+static bool launch_fwd_rows_any(const ConvFwdParams& q, dim3 grid, hipStream_t s) {
+    if (q.iscale && q.bf16x6 == NP_F16X3) return launch_fwd_rows_isc<BM, BN, NP_F16X3>(q, grid, s);
+    if (q.iscale)                  return launch_fwd_rows_isc<BM, BN, 3>(q, grid, s);
+    if (q.io == IO_BF16)           return launch_fwd_rows_np<BM, BN, 1, IO_BF16>(q, grid, s);       // 16-bit storage: always one product
+    if (q.io == IO_F16)            return launch_fwd_rows_np<BM, BN, 1, IO_F16>(q, grid, s);
+    if (q.bf16x6 == 1)             return launch_fwd_rows_np<BM, BN, 1, IO_F32>(q, grid, s);
+    if (q.bf16x6 == 2)             return launch_fwd_rows_np<BM, BN, 2, IO_F32>(q, grid, s);
+    if (q.bf16x6 == NP_F16X3)      return launch_fwd_rows_np<BM, BN, NP_F16X3, IO_F32>(q, grid, s);
+    return launch_fwd_rows_np<BM, BN, 3, IO_F32>(q, grid, s);
+}
+
+// The base kernel (conv_tu_fwd_base_*.hip): any lattice, the packed-K mode, the input scale.
+template <int BM, int BN, int NP, int IO>
+static void launch_fwd_base_np(const ConvFwdParams& q, dim3 grid, hipStream_t s) {
     if constexpr (IO == IO_F32 && (NP == 3 || NP == NP_F16X3)) {
         if (q.koff) { hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<BM, BN, (BN == 256 ? 2 : 3), NP, IO, false, true>), grid, dim3(256), 0, s, q); return; }
     }
     hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<BM, BN, (BN == 256 ? 2 : 3), NP, IO>), grid, dim3(256), 0, s, q);     // <= 64 KB of LDS: two or three workgroups per CU
 }
 
-// The same two kernels with the input scale in the staging (fp32 storage, six products: the no-grad forward of a modulated
-// convolution; other arithmetics keep the separate scaling pass).
-template <int BM, int BN, int NP = 3>
-static void launch_fwd_bf16_isc(const ConvFwdParams& q, dim3 grid, hipStream_t s) {
-    if (q.rows && q.ncls == 1 && rows_tile_ok(q.cls[0].P, q.cls[0].Q, BN)) {
-        constexpr int APT = (2 * Arith<NP>::npa * BM + 255) / 256;
-        constexpr size_t lds = (size_t)(2 * APT * 256 * 8 + 2 * 2 * Arith<NP>::npb * (BN + 16) * 8) * sizeof(__bf16);
-        PASTA_SET_LDS((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP, IO_F32, true>), lds);
-        hipLaunchKernelGGL((conv_fwd_rows_bf16x6_kernel<BM, BN, 2, 1, NP, IO_F32, true>), grid, dim3(256), lds, s, q);
-        return;
-    }
-    hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<BM, BN, 2, NP, IO_F32, true>), grid, dim3(256), 0, s, q);
-}
-
 template <int BM, int BN>
-static void launch_fwd_bf16x6(const ConvFwdParams& p, hipStream_t s) {
-    ConvFwdParams q = p;
-    q.o_tiles = (p.Og + BM - 1) / BM;
-    int64_t tiles = 0;
-    for (int c = 0; c < p.ncls; c++) {
-        const int64_t t = ceil_div64((int64_t)p.N * p.cls[c].P * p.cls[c].Q, BN);
-        if (t > tiles) tiles = t;
-    }
-    tiles *= p.ncls;
-    dim3 grid((unsigned)tiles, q.o_tiles * q.ksplit, p.G);
-    // p.bf16x6 = number of bf16 pieces per operand (3: six products, 2: three, 1: one)
-    if (p.iscale && p.bf16x6 == NP_F16X3) launch_fwd_bf16_isc<BM, BN, NP_F16X3>(q, grid, s);
-    else if (p.iscale)      launch_fwd_bf16_isc<BM, BN>(q, grid, s);                  // fp32 storage, six products (the caller checked)
-    else if (p.io == IO_BF16)    launch_fwd_bf16_np<BM, BN, 1, IO_BF16>(q, grid, s);       // 16-bit storage: always one product
-    else if (p.io == IO_F16) launch_fwd_bf16_np<BM, BN, 1, IO_F16>(q, grid, s);
-    else if (p.bf16x6 == 1) launch_fwd_bf16_np<BM, BN, 1, IO_F32>(q, grid, s);
-    else if (p.bf16x6 == 2) launch_fwd_bf16_np<BM, BN, 2, IO_F32>(q, grid, s);
-    else if (p.bf16x6 == NP_F16X3) launch_fwd_bf16_np<BM, BN, NP_F16X3, IO_F32>(q, grid, s);
-    else                    launch_fwd_bf16_np<BM, BN, 3, IO_F32>(q, grid, s);
+static void launch_fwd_base_any(const ConvFwdParams& q, dim3 grid, hipStream_t s) {
+    if (q.iscale && q.bf16x6 == NP_F16X3) hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<BM, BN, 2, NP_F16X3, IO_F32, true>), grid, dim3(256), 0, s, q);
+    else if (q.iscale)             hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<BM, BN, 2, 3, IO_F32, true>), grid, dim3(256), 0, s, q);
+    else if (q.io == IO_BF16)      launch_fwd_base_np<BM, BN, 1, IO_BF16>(q, grid, s);
+    else if (q.io == IO_F16)       launch_fwd_base_np<BM, BN, 1, IO_F16>(q, grid, s);
+    else if (q.bf16x6 == 1)        launch_fwd_base_np<BM, BN, 1, IO_F32>(q, grid, s);
+    else if (q.bf16x6 == 2)        launch_fwd_base_np<BM, BN, 2, IO_F32>(q, grid, s);
+    else if (q.bf16x6 == NP_F16X3) launch_fwd_base_np<BM, BN, NP_F16X3, IO_F32>(q, grid, s);
+    else                           launch_fwd_base_np<BM, BN, 3, IO_F32>(q, grid, s);
 }
 
 // Parity-pair launch of the row-reuse kernel (see its PAIR note): p.cls[0..1] are the two vertical parities over the input

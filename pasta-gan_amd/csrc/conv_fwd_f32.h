@@ -1,4 +1,4 @@
-// fp32-MFMA forward-type kernels (v_mfma_f32_32x32x2_f32): weight packing, conv_fwd_kernel and its launcher.  Included by conv_igemm.hip.
+// fp32-MFMA forward-type kernels (v_mfma_f32_32x32x2_f32): weight packing, conv_fwd_kernel and its launcher.  Instantiated by conv_tu_pack_f32.hip.
 #pragma once
 #include "conv_common.h"
 
@@ -8,6 +8,7 @@ namespace pasta {
 // Weight packing: PyTorch layout -> [G][kh*kw][I_pad][O_pad] (O contiguous), zero padded so
 // the GEMM's A-operand staging needs no bounds checks.
 
+#ifdef PASTA_TU_PACK       // defined by conv_tu_pack_f32.hip only (conv_launch.h)
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int G, int Ig,
                                                            int Og, int Ig_pad, int Og_pad, int kh, int kw, int transposed,
                                                            int flip, float wscale, const float* __restrict__ mod_s,
@@ -34,6 +35,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
         wp[idx] = v;
     }
 }
+#endif  // PASTA_TU_PACK
 
 
 template <int BM, int BN, int WMT, int WNT, int KC, int OCC = 1>   // OCC = minimum waves per SIMD asked of the register allocator
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_kernel(ConvFwdParams p) {
     // the stores: instantiated per (activation, clamp, whole tile of rows) and chosen once per workgroup (conv_common.h: a store loop with
     // three or four wave-uniform branches per element cost the split kernels 5 %)
     const EpiAct ea = conv_epi_act(p.act, p.alpha, p.gain, p.clamp, p.ksplit == 1);
-    conv_epilogue_dispatch<true>(o_blk + BM <= p.Og, [&](auto full_c) {
+    conv_epilogue_dispatch<true>(o_blk + BM <= p.Og, ea, [&](auto full_c, auto case_c) {
     const bool FULL = full_c;
 #pragma unroll
     for (int b = 0; b < WNT; b++) {
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_kernel(ConvFwdParams p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r, lane);
-                const float v = conv_epilogue_u(acc[a][b][r], tv[r], ea);
+                const float v = conv_epilogue_c(acc[a][b][r], tv[r], ea, case_c);
                 if (FULL || o < p.Og) yb[(int64_t)o * OHW] = v;
             }
         }

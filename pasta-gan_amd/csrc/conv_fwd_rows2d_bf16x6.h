@@ -1,4 +1,4 @@
-// Two-dimensional pixel tiles for the row-reuse forward kernel.  Included by conv_igemm.hip.
+// Two-dimensional pixel tiles for the row-reuse forward kernel.  Instantiated by conv_tu_rows2d_*.hip (conv_launch.h).
 #pragma once
 #include "conv_fwd_bf16x6.h"
 #include <type_traits>
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
     }
     // (here fused holds: an output scale, a bias or a residual exist only without K slices)
     const EpiAct ea = conv_epi_act(p.act, p.alpha, p.gain, p.clamp, true);
-    conv_epilogue_dispatch<(NP == NP_F16X3 || IO != IO_F32)>(o_blk + BM <= p.Og, [&](auto full_c) {
+    conv_epilogue_dispatch<(NP == NP_F16X3 || IO != IO_F32)>(o_blk + BM <= p.Og, ea, [&](auto full_c, auto case_c) {
         const bool FULL = full_c;
 #pragma unroll
         for (int b = 0; b < WNT; b++) {
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
 #pragma unroll
                 for (int r16 = 0; r16 < 16; r16++) {
                     const int o = o_blk + (wm * WMT + a) * 32 + acc_row(r16, lane);
-                    const float v = conv_epilogue_u(acc[a][b][r16], tv[r16], ea);
+                    const float v = conv_epilogue_c(acc[a][b][r16], tv[r16], ea, case_c);
                     if (FULL || o < p.Og) { io_st<IO>(p.y, yoff + (int64_t)o * OHW, v); amax_take(y_am, v); }
                 }
             }
@@ -507,39 +507,6 @@ static bool rows2d_wide(int P, int Q) {
 static bool rows2d_rows256(int P, int Q) {
     static const int mode = getenv("PASTA_ROWS2D") ? atoi(getenv("PASTA_ROWS2D")) : 8;
     return mode != 0 && mode != 1 && rows2d_tile_ok<256, 8>(P, Q);          // PASTA_ROWS2D=1: 2-D tiles for the 128 x 128 tile only
-}
-
-// The plain six-product fp32 launch of a 3x3 stride-1 lattice on 2-D tiles, if the plane divides into them.
-template <int BM, int BN>
-static bool try_fwd_rows2d(const ConvFwdParams& p, hipStream_t s) {
-    if (!p.rows || p.ncls != 1 || p.cls[0].T != 9 || !p.bf16x6) return false;        // every arithmetic and storage type (an input scale implies fp32 storage, six products)
-    int ymin = p.tap_dy[0], ymax = p.tap_dy[0], xmin = p.tap_dx[0], xmax = p.tap_dx[0];
-    for (int t = 1; t < 9; t++) {
-        ymin = p.tap_dy[t] < ymin ? p.tap_dy[t] : ymin; ymax = p.tap_dy[t] > ymax ? p.tap_dy[t] : ymax;
-        xmin = p.tap_dx[t] < xmin ? p.tap_dx[t] : xmin; xmax = p.tap_dx[t] > xmax ? p.tap_dx[t] : xmax;
-    }
-    if (ymax - ymin != 2 || xmax - xmin != 2 || xmin != p.rows_d0) return false;
-    ConvFwdParams q = p;
-    q.rows_y0 = ymin;
-    if constexpr (BN == 128) {
-        if (rows2d_wide(p.cls[0].P, p.cls[0].Q) && (p.bf16x6 == 3 || p.bf16x6 == NP_F16X3) && p.io == IO_F32 && (!p.iscale || p.bf16x6 == NP_F16X3)) {
-            ConvFwdParams w8 = q;
-            w8.o_tiles = (p.Og + BM - 1) / BM;
-            const int64_t tiles = (int64_t)p.N * (p.cls[0].P / 8) * (p.cls[0].Q / 32);
-            const dim3 grid8((unsigned)tiles, w8.o_tiles * w8.ksplit, p.G);
-            if (p.bf16x6 == NP_F16X3 && p.iscale) launch_fwd_rows2d_np<128, 256, 8, NP_F16X3, IO_F32, true, 512>(w8, grid8, s);      // the training step's modulated layers (round 4)
-            else if (p.bf16x6 == NP_F16X3) launch_fwd_rows2d_np<128, 256, 8, NP_F16X3, IO_F32, false, 512>(w8, grid8, s);
-            else launch_fwd_rows2d_np<128, 256, 8, 3, IO_F32, false, 512>(w8, grid8, s);
-            return true;
-        }
-        const int R = rows2d_rows(p.cls[0].P, p.cls[0].Q);
-        if (R == 4) { launch_fwd_rows2d<BM, BN, 4>(q, s); return true; }
-        if (R == 2) { launch_fwd_rows2d<BM, BN, 2>(q, s); return true; }
-    } else {
-        // 64 x 256 tile: 8 rows x 32 columns (B image 10 x 34 slots, 65 KB double-buffered + 16 KB of weights: two workgroups per CU, just)
-        if (rows2d_rows256(p.cls[0].P, p.cls[0].Q)) { launch_fwd_rows2d<BM, BN, 8>(q, s); return true; }
-    }
-    return false;
 }
 
 }  // namespace pasta

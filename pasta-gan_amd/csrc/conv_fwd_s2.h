@@ -1,6 +1,6 @@
 // 3x3 stride-2 forward convolutions of the three-product fp16 arithmetic (the down path of the discriminator and of the
 // encoders: conv2d_resample.py:119-122 after the blur; 9.9 ms of the training step at 136 TFLOP/s on the one-tap base kernel,
-// profiles/r4_byshape_classes.txt).  Included by conv_igemm.hip.
+// profiles/r4_byshape_classes.txt).  Instantiated by conv_tu_fwd_small.hip (conv_launch.h).
 #pragma once
 #include "conv_fwd_bf16x6.h"
 
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_f16x3_kernel(ConvFwdParams p
     const int OHW = OH * OW;
     // the stores: instantiated per (activation, clamp, whole tile of rows) and chosen once per workgroup (conv_common.h)
     const EpiAct ea = conv_epi_act(p.act, p.alpha, p.gain, p.clamp, true);
-    conv_epilogue_dispatch<true>(o_blk + BM <= p.Og, [&](auto full_c) {
+    conv_epilogue_dispatch<true>(o_blk + BM <= p.Og, ea, [&](auto full_c, auto case_c) {
         const bool FULL = full_c;
 #pragma unroll
         for (int b = 0; b < WNT_; b++) {
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_f16x3_kernel(ConvFwdParams p
 #pragma unroll
                 for (int rr = 0; rr < 16; rr++) {
                     const int o = o_blk + (wm * WMT + a) * 32 + acc_row(rr, lane);
-                    const float v = conv_epilogue_u(acc[a][b][rr], tv[rr], ea);
+                    const float v = conv_epilogue_c(acc[a][b][rr], tv[rr], ea, case_c);
                     if (FULL || o < p.Og) { p.y[yoff + (int64_t)o * OHW] = v; amax_take(y_am, v); }
                 }
             }
@@ -250,12 +250,6 @@ static bool conv3x3s2_ok(const ConvFwdParams& p, int kh, int kw, int stride, int
     if (!enabled || transposed || p.bf16x6 != NP_F16X3 || p.io != IO_F32 || p.G != 1 || kh != 3 || kw != 3 || stride != 2 || pad_h != pad_w || pad_h > 1) return false;
     if (p.iscale || p.oscale || p.noise || p.ksplit != 1 || p.koff || p.x2 || p.Ig < 16 || p.Og <= 32) return false;
     return conv3x3s2_shape_ok(p.OH, p.OW);
-}
-
-static void launch_conv3x3s2(const ConvFwdParams& p, hipStream_t s) {
-    const int64_t tiles = (int64_t)p.N * p.OH * p.OW / 128;
-    if (p.Og <= 64) hipLaunchKernelGGL((conv3x3s2_f16x3_kernel<64>), dim3((unsigned)tiles, (unsigned)((p.Og + 63) / 64)), dim3(256), 0, s, p);
-    else            hipLaunchKernelGGL((conv3x3s2_f16x3_kernel<128>), dim3((unsigned)tiles, (unsigned)((p.Og + 127) / 128)), dim3(256), 0, s, p);
 }
 
 }  // namespace pasta

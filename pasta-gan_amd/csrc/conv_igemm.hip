@@ -1,12 +1,16 @@
 // Dense convolution family for gfx950: conv2d, conv_transpose2d and the weight gradient of either, NCHW fp32, on the
 // matrix cores -- split-bf16 with fp32-equivalent products (v_mfma_f32_32x32x16_bf16, default) or fp32 MFMA
-// (v_mfma_f32_32x32x2_f32).  This file holds the launch plans, the descriptor checks and the C entry points; the kernels
-// live in the headers included below (one translation unit):
-//   conv_common.h         parameter blocks, tile enumeration, epilogue
-//   conv_fwd_f32.h        fp32-MFMA forward-type kernel, weight packing
-//   conv_fwd_bf16x6.h     split-bf16 forward-type kernels (base and row-reuse), weight packing
-//   conv_wgrad_f32.h      fp32-MFMA weight-gradient kernels (tiled and small-Cin), slab reductions
-//   conv_wgrad_bf16x6.h   split-bf16 weight-gradient kernels (3x3, stride 1 and stride 2)
+// (v_mfma_f32_32x32x2_f32).  This file holds the launch plans, the descriptor checks and the C entry points.  The kernels
+// live in the headers included below as templates, which this file never instantiates (it includes them for their host-side
+// shape predicates): every kernel family is compiled in a translation unit of its own, conv_tu_*.hip, and reached through
+// the functions of conv_launch.h -- thirteen units built in parallel (round 5; one unit of 161 kernels took 3 - 12 minutes):
+//   conv_common.h              parameter blocks, tile enumeration, epilogue
+//   conv_fwd_f32.h             fp32-MFMA forward-type kernel, weight packing        -> conv_tu_pack_f32.hip
+//   conv_fwd_bf16x6.h          split forward-type kernels (base and row-reuse)      -> conv_tu_fwd_base_{128,64}.hip, conv_tu_fwd_rows_{128,64}.hip
+//   conv_fwd_rows2d_bf16x6.h   2-D pixel tiles                                      -> conv_tu_rows2d_{wide,128_r4,128_r2,64_r8}.hip
+//   conv_fwd_1x1.h, conv_fwd_s2.h  pointwise and stride-2 kernels                   -> conv_tu_fwd_small.hip
+//   conv_wgrad_f32.h           fp32-MFMA weight gradients, few-channel kernels, slab reductions -> conv_tu_wgrad_f32.hip
+//   conv_wgrad_bf16x6.h        split weight-gradient kernels                        -> conv_tu_wgrad_{3x3,3x3s2,1x1}.hip
 //
 // Stands where the reference hands its convolutions to ATen/cuDNN
 // (torch_utils/ops/conv2d_gradfix.py:38,43 forward; :125-128 input gradient through the
@@ -26,7 +30,7 @@
 //     second kernel that also writes PyTorch's [.., .., kh, kw] layout (bitwise reproducible).
 //
 // C/D fragment map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
-#include "conv_common.h"
+#include "conv_launch.h"
 #include "conv_fwd_f32.h"
 #include "conv_fwd_bf16x6.h"
 #include "conv_fwd_rows2d_bf16x6.h"
@@ -37,24 +41,59 @@
 
 namespace pasta {
 
-constexpr int FWD_KC = 8;
 // Packed input-channel padding: a multiple of the KC of the kernel instance that will run.
 static int fwd_ipad(int Ig, FwdTile t) { return (Ig <= 4 && t == T64x256) ? 4 : Ig <= 8 ? 8 : 16; }
 
-static void dispatch_fwd(FwdTile t, const ConvFwdParams& p, hipStream_t s) {
-    switch (t) {
-        case T128x128:
-            if (p.bf16x6) { if (!try_fwd_rows2d<128, 128>(p, s)) launch_fwd_bf16x6<128, 128>(p, s); break; }
-            launch_fwd<128, 128, 2, 2, FWD_KC, 4>(p, s);        // 4 waves/SIMD: 99-112 TFLOP/s vs 95-104 at 3
-            break;
-        case T64x256:
-            if (p.bf16x6) { if (!try_fwd_rows2d<64, 256>(p, s)) launch_fwd_bf16x6<64, 256>(p, s); break; }
-            if (p.Ig_pad == 4) launch_fwd<64, 256, 2, 2, 4>(p, s);      // RGB stems: 4-channel K chunks
-            else launch_fwd<64, 256, 2, 2, FWD_KC, 4>(p, s);
-            break;
-        case T32x256:  launch_fwd<32, 256, 1, 2, FWD_KC>(p, s); break;
-        case T64x64:   launch_fwd<64, 64, 1, 1, FWD_KC>(p, s); break;
+// The plain six-product fp32 launch of a 3x3 stride-1 lattice on 2-D tiles, if the plane divides into them.
+static bool try_fwd_rows2d(bool tile128, const ConvFwdParams& p, hipStream_t s) {
+    if (!p.rows || p.ncls != 1 || p.cls[0].T != 9 || !p.bf16x6) return false;        // every arithmetic and storage type (an input scale implies fp32 storage, six products)
+    int ymin = p.tap_dy[0], ymax = p.tap_dy[0], xmin = p.tap_dx[0], xmax = p.tap_dx[0];
+    for (int t = 1; t < 9; t++) {
+        ymin = p.tap_dy[t] < ymin ? p.tap_dy[t] : ymin; ymax = p.tap_dy[t] > ymax ? p.tap_dy[t] : ymax;
+        xmin = p.tap_dx[t] < xmin ? p.tap_dx[t] : xmin; xmax = p.tap_dx[t] > xmax ? p.tap_dx[t] : xmax;
     }
+    if (ymax - ymin != 2 || xmax - xmin != 2 || xmin != p.rows_d0) return false;
+    ConvFwdParams q = p;
+    q.rows_y0 = ymin;
+    if (tile128) {
+        // eight waves on 128 x 256 (conv_tu_rows2d_wide.hip): fp32 storage, fp32-equivalent products; an input scale under the three-product arithmetic only
+        if (rows2d_wide(p.cls[0].P, p.cls[0].Q) && (p.bf16x6 == 3 || p.bf16x6 == NP_F16X3) && p.io == IO_F32 && (!p.iscale || p.bf16x6 == NP_F16X3)) {
+            tu_rows2d_wide(q, s);
+            return true;
+        }
+        const int R = rows2d_rows(p.cls[0].P, p.cls[0].Q);
+        if (R == 4) { tu_rows2d_128_r4(q, s); return true; }
+        if (R == 2) { tu_rows2d_128_r2(q, s); return true; }
+    } else {
+        // 64 x 256 tile: 8 rows x 32 columns (B image 10 x 34 slots, 65 KB double-buffered + 16 KB of weights: two workgroups per CU, just)
+        if (rows2d_rows256(p.cls[0].P, p.cls[0].Q)) { tu_rows2d_64_r8(q, s); return true; }
+    }
+    return false;
+}
+
+
+// The split forward-type kernels on a 128 x 128 or 64 x 256 tile: the row-reuse kernel where the lattice is made of whole row segments, else the base kernel.
+static void launch_fwd_bf16x6(bool tile128, const ConvFwdParams& p, hipStream_t s) {
+    const int BM = tile128 ? 128 : 64, BN = tile128 ? 128 : 256;
+    ConvFwdParams q = p;
+    q.o_tiles = (p.Og + BM - 1) / BM;
+    int64_t tiles = 0;
+    for (int c = 0; c < p.ncls; c++) {
+        const int64_t t = ceil_div64((int64_t)p.N * p.cls[c].P * p.cls[c].Q, BN);
+        if (t > tiles) tiles = t;
+    }
+    tiles *= p.ncls;
+    const dim3 grid((unsigned)tiles, q.o_tiles * q.ksplit, p.G);
+    if (tile128) { if (!tu_fwd_rows_128(q, grid, s)) tu_fwd_base_128(q, grid, s); }
+    else         { if (!tu_fwd_rows_64(q, grid, s)) tu_fwd_base_64(q, grid, s); }
+}
+
+static void dispatch_fwd(FwdTile t, const ConvFwdParams& p, hipStream_t s) {
+    if (p.bf16x6 && (t == T128x128 || t == T64x256)) {
+        if (!try_fwd_rows2d(t == T128x128, p, s)) launch_fwd_bf16x6(t == T128x128, p, s);
+        return;
+    }
+    tu_fwd_f32(t, p, s);
 }
 
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
@@ -523,8 +562,7 @@ static void launch_transposed_pairs(const pasta_conv_desc* d, const ConvFwdParam
         }
         p.cls[k] = {H, W, a, 0, nt, 6 * k};
     }
-    if (p.bf16x6 == NP_F16X3) { if (tile == T128x128) launch_fwd_pair<128, 128, NP_F16X3>(p, s); else launch_fwd_pair<64, 256, NP_F16X3>(p, s); }
-    else if (tile == T128x128) launch_fwd_pair<128, 128>(p, s); else launch_fwd_pair<64, 256>(p, s);
+    if (tile == T128x128) tu_fwd_pair_128(p, s); else tu_fwd_pair_64(p, s);
     if (edge_mode == 2) launch_edge();
 }
 
@@ -643,24 +681,19 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
         pk_kh = pk_kw = 1; pk_tr = 0; pk_flip = 0;           // [O][C_in kh kw] as it lies: a 1x1 weight over the K "channels"
     }
     {   // pack weights (times wscale)
-        const int64_t total = (int64_t)p.G * p.KK * p.Ig_pad * p.Og_pad;
-        int64_t blocks = ceil_div64(total, 256);
-        if (blocks > 4096) blocks = 4096;
         if (p.bf16x6 == NP_F16X3 && p.io == IO_F32) {       // two fp16 pieces, one scale per output row found on the way
             static const int pack_xcd = getenv("PASTA_PACK_XCD") ? atoi(getenv("PASTA_PACK_XCD")) : 1;      // A/B switch: 0 = row = workgroup index
-            hipLaunchKernelGGL(pack_weights_f16x3_kernel, dim3((unsigned)p.Og_pad, (unsigned)p.G), dim3(256), 0, s, w, (__bf16*)workspace, ws_rowinv,
-                               p.Ig, p.Og, p.Ig_pad, p.Og_pad, pk_kh, pk_kw, pk_tr, pk_flip, wscale, wmod_s, wmod_d, (p.Og_pad & 63) == 0 ? pack_xcd : 0);
+            tu_pack_weights_f16x3(w, workspace, ws_rowinv, p.G, p.Ig, p.Og, p.Ig_pad, p.Og_pad, pk_kh, pk_kw, pk_tr, pk_flip, wscale, wmod_s, wmod_d,
+                                  (p.Og_pad & 63) == 0 ? pack_xcd : 0, s);
         }
         else if (p.bf16x6)
-            hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, (__bf16*)workspace, p.G, p.Ig, p.Og,
-                               p.Ig_pad, p.Og_pad, pk_kh, pk_kw, pk_tr, pk_flip, wscale, p.io == IO_F16 ? 1 : 0, wmod_s, wmod_d);
+            tu_pack_weights_bf16(w, workspace, p.G, p.Ig, p.Og, p.Ig_pad, p.Og_pad, pk_kh, pk_kw, pk_tr, pk_flip, wscale, p.io == IO_F16 ? 1 : 0, wmod_s, wmod_d, s);
         else
-            hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, (float*)workspace, p.G, p.Ig, p.Og,
-                               p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip, wscale, wmod_s, wmod_d);
+            tu_pack_weights_f32(w, (float*)workspace, p.G, p.Ig, p.Og, p.Ig_pad, p.Og_pad, d->kh, d->kw, d->transposed, d->flip, wscale, wmod_s, wmod_d, s);
     }
 
     if (conv1x1_ok(p, d->kh, d->kw, d->stride, d->pad_h, d->pad_w)) {
-        launch_conv1x1(p, s);           // conv2d and conv_transpose2d coincide for 1x1 / stride 1 (the packing kernel reads either weight layout)
+        tu_conv1x1(p, s);           // conv2d and conv_transpose2d coincide for 1x1 / stride 1 (the packing kernel reads either weight layout)
         return launch_status("conv2d");
     }
     PASTA_CHECK(!p.x2, "conv2d: a second input tensor is served by the pointwise kernel only (1x1, stride 1, fp32 tensors, PASTA_MATH_F16X3, "
@@ -669,7 +702,7 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
         p.P = d->OH; p.Q = d->OW; p.oy0 = 0; p.ox0 = 0; p.osy = 1; p.osx = 1; p.isy = d->stride; p.isx = d->stride;
         p.T = 1; p.tap_dy[0] = 0; p.tap_dx[0] = 0; p.tap_slab[0] = 0;      // the window's corner in the padded plane; the taps are in koff
         p.ncls = 1; p.cls[0] = {p.P, p.Q, 0, 0, 1, 0};
-        if (tile == T128x128) launch_fwd_bf16x6<128, 128>(p, s); else launch_fwd_bf16x6<64, 256>(p, s);
+        launch_fwd_bf16x6(tile == T128x128, p, s);
     } else if (!d->transposed) {
         p.P = d->OH; p.Q = d->OW; p.oy0 = 0; p.ox0 = 0; p.osy = 1; p.osx = 1; p.isy = d->stride; p.isx = d->stride;
         p.T = p.KK;
@@ -680,7 +713,7 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
             }
         p.ncls = 1; p.cls[0] = {p.P, p.Q, 0, 0, p.T, 0};
         if (conv3x3s2_ok(p, d->kh, d->kw, d->stride, d->pad_h, d->pad_w, d->transposed)) {
-            launch_conv3x3s2(p, s);
+            tu_conv3x3s2(p, s);
             return launch_status("conv2d");
         }
         detect_tap_rows(p, p.T);
@@ -865,12 +898,8 @@ int pasta::wgrad_run(const void* xv, const void* dyv, float* dw, const pasta_con
         const int64_t per = (total + fks - 1) / fks;
         const int a_pad = ws.a_tiles * 64, bpad = ws.nb * 32;
         const dim3 grid((unsigned)fks, (unsigned)((d->C_out + 7) / 8));
-#define PASTA_FEW(CI_) case CI_: hipLaunchKernelGGL((wgrad1x1_fewcin_kernel<CI_>), grid, dim3(256), 0, s, dy, x, (float*)workspace, d->N, d->C_out, d->H * d->W, per, a_pad, bpad); break;
-        switch (d->C_in) { PASTA_FEW(1) PASTA_FEW(2) PASTA_FEW(3) PASTA_FEW(4) PASTA_FEW(5) PASTA_FEW(6) PASTA_FEW(7) PASTA_FEW(8) }
-#undef PASTA_FEW
-        const int totw = d->C_out * ws.bprime;
-        hipLaunchKernelGGL(wgrad_smallcin_reduce_kernel, dim3((unsigned)((totw + 255) / 256)), dim3(256), 0, s, (const float*)workspace, dw,
-                           fks, d->C_out, ws.bprime, a_pad, bpad, d->wscale == 0.f ? 1.f : d->wscale);
+        tu_wgrad1x1_fewcin(d->C_in, grid, dy, x, (float*)workspace, d->N, d->C_out, d->H * d->W, per, a_pad, bpad, s);
+        tu_wgrad_smallcin_reduce((const float*)workspace, dw, fks, d->C_out, ws.bprime, a_pad, bpad, d->wscale == 0.f ? 1.f : d->wscale, s);
         return launch_status("conv2d_wgrad(few-channel 1x1)");
     }
     if (ws.use) {
@@ -881,10 +910,8 @@ int pasta::wgrad_run(const void* xv, const void* dyv, float* dw, const pasta_con
         q.bprime = ws.bprime; q.nb = ws.nb; q.cw_log2 = ws.cw_log2; q.rows_total = ws.rows_total; q.qblocks = ws.qblocks;
         q.chunks_total = ws.chunks_total; q.ksplit = ws.ksplit; q.a_tiles = ws.a_tiles;
         PASTA_CHECK(ws.lds_bytes <= 64 * 1024, "conv2d_wgrad: small-cin LDS footprint %zu too large", ws.lds_bytes);
-        hipLaunchKernelGGL(conv_wgrad_smallcin_kernel, dim3((unsigned)(ws.a_tiles * ws.ksplit)), dim3(256), ws.lds_bytes, s, q);
-        const int total = d->C_out * ws.bprime;
-        hipLaunchKernelGGL(wgrad_smallcin_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)workspace, dw,
-                           ws.ksplit, d->C_out, ws.bprime, ws.a_tiles * 64, ws.nb * 32, d->wscale == 0.f ? 1.f : d->wscale);
+        tu_wgrad_smallcin(q, ws.a_tiles * ws.ksplit, ws.lds_bytes, s);
+        tu_wgrad_smallcin_reduce((const float*)workspace, dw, ws.ksplit, d->C_out, ws.bprime, ws.a_tiles * 64, ws.nb * 32, d->wscale == 0.f ? 1.f : d->wscale, s);
         return launch_status("conv2d_wgrad(small-cin)");
     }
 
@@ -912,19 +939,7 @@ int pasta::wgrad_run(const void* xv, const void* dyv, float* dw, const pasta_con
 
     const int64_t blocks = (int64_t)p.G * w.a_tiles * w.b_tiles * w.tgr * w.tgs * w.ksplit;
     PASTA_CHECK(blocks <= INT32_MAX, "conv2d_wgrad: grid too large");
-#define PASTA_WGRAD1(TR_, TS_, WA_, WB_, PIPE_, KP_)                                                                      \
-    do {                                                                                                                  \
-        if (w.lds_bytes > 64 * 1024)                                                                                      \
-            PASTA_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_kernel<TR_, TS_, WA_, WB_, PIPE_, KP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds_bytes)); \
-        hipLaunchKernelGGL((conv_wgrad_kernel<TR_, TS_, WA_, WB_, PIPE_, KP_>), dim3((unsigned)blocks), dim3(256), w.lds_bytes, s, p); \
-    } while (0)
-#define PASTA_WGRAD(TR_, TS_, WA_, WB_)                                                                                   \
-    do {                                                                                                                  \
-        if (w.kp == 16) { if (w.pipe) PASTA_WGRAD1(TR_, TS_, WA_, WB_, 1, 16); else PASTA_WGRAD1(TR_, TS_, WA_, WB_, 0, 16); } \
-        else            { if (w.pipe) PASTA_WGRAD1(TR_, TS_, WA_, WB_, 1, 32); else PASTA_WGRAD1(TR_, TS_, WA_, WB_, 0, 32); } \
-    } while (0)
     const int np = p.io != IO_F32 ? 1 : math_pieces(d->math);          // bf16 pieces per operand of the split-bf16 kernels (NP_F16X3: fp16 pieces)
-    const int npw = np == NP_F16X3 ? 2 : np;                           // pieces per operand in LDS
     p.s_amax = p.l_amax = nullptr;
     if (np == NP_F16X3 && (wgrad_bf16x6(d, w) || wgrad_s2_bf16x6(d, w) || (wgrad_1x1_bf16x6(d, w) && !(w.TR == 3 && w.TS == 3) && w.TS != 7 && w.TS != 4))) {
         const float* xa = d->x_amax; const float* ya = d->dy_amax;
@@ -935,39 +950,11 @@ int pasta::wgrad_run(const void* xv, const void* dyv, float* dw, const pasta_con
     }
     PASTA_CHECK(p.io == IO_F32 || wgrad_bf16x6(d, w) || wgrad_s2_bf16x6(d, w) || (wgrad_1x1_bf16x6(d, w) && !(w.TR == 3 && w.TS == 3) && w.TS != 7 && w.TS != 4),
                 "conv2d_wgrad: no 16-bit-storage kernel for this shape (pasta_conv2d_wgrad_plan tells beforehand)");
-#define PASTA_NP(LAUNCH_)   /* LAUNCH_(NP, IO) for the runtime np and storage type */                                        \
-    do { if (p.io == IO_BF16) { LAUNCH_(1, IO_BF16); } else if (p.io == IO_F16) { LAUNCH_(1, IO_F16); }                      \
-         else if (np == 1) { LAUNCH_(1, IO_F32); } else if (np == 2) { LAUNCH_(2, IO_F32); } else if (np == NP_F16X3) { LAUNCH_(NP_F16X3, IO_F32); } else { LAUNCH_(3, IO_F32); } } while (0)
-    if (wgrad_bf16x6(d, w)) {
-        const size_t lds = (size_t)(npw * 64 * 40 + npw * 64 * 3 * 40) * 2;
-#define PASTA_L(NP_, IO_) hipLaunchKernelGGL((conv_wgrad3x3_bf16x6_kernel<NP_, IO_>), dim3((unsigned)blocks), dim3(256), lds, s, p)
-        PASTA_NP(PASTA_L);
-#undef PASTA_L
-    }
-    else if (wgrad_s2_bf16x6(d, w)) {
-        const size_t lds = (size_t)(npw * 64 * 16 + npw * 64 * 3 * 40) * 2;
-#define PASTA_L(NP_, IO_)                                                                                                     \
-        if (d->pad_w == 1) hipLaunchKernelGGL((conv_wgrad3x3s2_bf16x6_kernel<1, NP_, IO_>), dim3((unsigned)blocks), dim3(256), lds, s, p); \
-        else               hipLaunchKernelGGL((conv_wgrad3x3s2_bf16x6_kernel<0, NP_, IO_>), dim3((unsigned)blocks), dim3(256), lds, s, p)
-        PASTA_NP(PASTA_L);
-#undef PASTA_L
-    }
-    else if (w.TR == 3 && w.TS == 3) PASTA_WGRAD(3, 3, 1, 1);
-    else if (w.TS == 7) PASTA_WGRAD(1, 7, 1, 1);
-    else if (w.TS == 4) PASTA_WGRAD(1, 4, 1, 1);
-    else if (wgrad_1x1_bf16x6(d, w)) {
-        const size_t lds = (size_t)(npw * 64 * 40) * 2 * 2 * w.WA;        // S and L images of 64 WA (= 64 WB) channels
-#define PASTA_L(NP_, IO_)                                                                                                     \
-        if (w.WA == 2) hipLaunchKernelGGL((conv_wgrad1x1_bf16x6_kernel<2, 2, NP_, IO_>), dim3((unsigned)blocks), dim3(256), lds, s, p); \
-        else           hipLaunchKernelGGL((conv_wgrad1x1_bf16x6_kernel<1, 1, NP_, IO_>), dim3((unsigned)blocks), dim3(256), lds, s, p)
-        PASTA_NP(PASTA_L);
-#undef PASTA_L
-    }
-    else if (w.WA == 2) PASTA_WGRAD(1, 1, 2, 2);
-    else PASTA_WGRAD(1, 1, 1, 1);
-#undef PASTA_WGRAD
-#undef PASTA_WGRAD1
-#undef PASTA_NP
+    const bool split1x1 = wgrad_1x1_bf16x6(d, w) && !(w.TR == 3 && w.TS == 3) && w.TS != 7 && w.TS != 4;
+    if (wgrad_bf16x6(d, w)) tu_wgrad3x3(np, p, blocks, s);
+    else if (wgrad_s2_bf16x6(d, w)) tu_wgrad3x3s2(np, p, blocks, s);
+    else if (split1x1) tu_wgrad1x1(np, w.WA, p, blocks, s);
+    else if (int e = tu_wgrad_f32(w.TR, w.TS, w.WA, w.pipe, w.kp, p, blocks, w.lds_bytes, s)) return e;
     if (mod_s) {
         // slices [n m, (n + 1) m) hold sample n's gradient with respect to the modulated weight: dw = sum_n s[n, i] (.), ds[n, i] = sum_{o, taps} w (.)
         const int Ap = w.a_tiles * 64 * w.WA, Bp = w.b_tiles * 64 * w.WB;
@@ -975,21 +962,13 @@ int pasta::wgrad_run(const void* xv, const void* dyv, float* dw, const pasta_con
         const float wsc = d->wscale == 0.f ? 1.f : d->wscale;
         const int wg_rows = wgrad_mod_rows(Ap, Bp, p.kh * p.kw);
         const dim3 grid((unsigned)(Bp / 64), (unsigned)(Ap / wg_rows), (unsigned)(p.kh * p.kw));
-        if (d->transposed) hipLaunchKernelGGL((wgrad_reduce_modulated_kernel<true>), grid, dim3(256), 0, s, (const float*)workspace, mod_s, mod_w, dw, dsp, w.ksplit, d->N,
-                                              p.Ag, p.Bg, Ap, Bp, p.kh, p.kw, d->flip, wsc, wg_rows);
-        else               hipLaunchKernelGGL((wgrad_reduce_modulated_kernel<false>), grid, dim3(256), 0, s, (const float*)workspace, mod_s, mod_w, dw, dsp, w.ksplit, d->N,
-                                              p.Ag, p.Bg, Ap, Bp, p.kh, p.kw, d->flip, wsc, wg_rows);
+        tu_wgrad_reduce_modulated(d->transposed != 0, grid, (const float*)workspace, mod_s, mod_w, dw, dsp, w.ksplit, d->N, p.Ag, p.Bg, Ap, Bp, p.kh, p.kw, d->flip, wsc, wg_rows, s);
         const int tiles = wgrad_modulated_blocks(d, w);
         const int nc = d->N * d->C_in;
-        hipLaunchKernelGGL(sum_blocks_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, (const float*)dsp, ds, tiles, nc);
+        tu_sum_blocks((const float*)dsp, ds, tiles, nc, s);
         return launch_status("conv2d_wgrad_modulated");
     }
-    {
-        const int64_t total = (int64_t)p.G * p.kh * p.kw * p.Ag * p.Bg;
-        int64_t rb = ceil_div64(total, 256);
-        if (rb > 8192) rb = 8192;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, s, (const float*)workspace, dw, w.ksplit, p.G,
-                           p.Ag, p.Bg, w.a_tiles * 64 * w.WA, w.b_tiles * 64 * w.WB, p.kh, p.kw, d->flip, d->wscale == 0.f ? 1.f : d->wscale);
-    }
+    tu_wgrad_reduce((const float*)workspace, dw, w.ksplit, p.G, p.Ag, p.Bg, w.a_tiles * 64 * w.WA, w.b_tiles * 64 * w.WB, p.kh, p.kw, d->flip,
+                    d->wscale == 0.f ? 1.f : d->wscale, s);
     return launch_status("conv2d_wgrad");
 }

@@ -1,4 +1,4 @@
-// Split-bf16 weight-gradient kernels for 3x3 convolutions: stride 1 (conv_wgrad3x3_bf16x6_kernel) and stride 2 (conv_wgrad3x3s2_bf16x6_kernel).  Included by conv_igemm.hip.
+// Split-bf16 weight-gradient kernels for 3x3 convolutions: stride 1 (conv_wgrad3x3_bf16x6_kernel) and stride 2 (conv_wgrad3x3s2_bf16x6_kernel).  Instantiated by conv_tu_wgrad_{3x3,3x3s2,1x1}.hip (conv_launch.h).
 #pragma once
 #include "conv_common.h"
 

@@ -1,4 +1,4 @@
-// fp32-MFMA weight-gradient kernels: conv_wgrad_kernel, the small-Cin variant, their slab reductions and the small-Cin plan.  Included by conv_igemm.hip.
+// fp32-MFMA weight-gradient kernels: conv_wgrad_kernel, the small-Cin variant, their slab reductions and the small-Cin plan.  Instantiated by conv_tu_wgrad_f32.hip (conv_launch.h).
 #pragma once
 #include "conv_common.h"
 
@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 1) void conv_wgrad_kernel(WgradPara
 }
 
 // dW[(g*Ag + a)][b][ty][tx] = sum_ks slab[ks][g][t][a][b]   (tap index optionally mirrored)
+#ifdef PASTA_TU_WGRAD_F32  // defined by conv_tu_wgrad_f32.hip only (conv_launch.h)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int ksplit,
                                                            int G, int Ag, int Bg, int Ag_pad, int Bg_pad, int kh, int kw,
                                                            int flip, float wscale) {
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         dw[(((int64_t)(g * Ag + a) * Bg + b) * kh + ty) * kw + tx] = v;
     }
 }
+#endif  // PASTA_TU_WGRAD_F32
 
 //------------------------------------------------------------------------------------
 // Weight gradient AND style gradient of a modulated convolution y = conv(x * s[n, i], w) (networks.py:72-76) from the weight-gradient kernels run on
@@ -325,6 +327,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_modulated_kernel(const float
 }
 
 // out[i] = sum_k blocks[k][i] in the order of k (bitwise reproducible)
+#ifdef PASTA_TU_WGRAD_F32  // defined by conv_tu_wgrad_f32.hip only (conv_launch.h)
 __global__ __launch_bounds__(256) void sum_blocks_kernel(const float* __restrict__ blocks, float* __restrict__ out, int nblocks, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -336,6 +339,7 @@ __global__ __launch_bounds__(256) void sum_blocks_kernel(const float* __restrict
     for (; k < nblocks; k++) v0 += blocks[(int64_t)k * n + i];
     out[i] = (v0 + v1) + (v2 + v3);
 }
+#endif  // PASTA_TU_WGRAD_F32
 
 //------------------------------------------------------------------------------------
 // Weight gradient when the input has very few channels (RGB / pose stems: 3 or 6 channels, up to 7x7):
@@ -352,6 +356,7 @@ struct WgradSmallParams {
     int cw_log2, rows_total, qblocks, chunks_total, ksplit, a_tiles;
 };
 
+#ifdef PASTA_TU_WGRAD_F32  // defined by conv_tu_wgrad_f32.hip only (conv_launch.h)
 __global__ __launch_bounds__(256) void conv_wgrad_smallcin_kernel(WgradSmallParams p) {
     constexpr int KP = 32, SPITCH = KP + 1, MAXT = 3;     // each wave owns column tiles wb, wb+2, wb+4
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -471,8 +476,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_smallcin_kernel(WgradSmallPara
         }
     }
 }
+#endif  // PASTA_TU_WGRAD_F32
 
 // dw[o][b'] = sum_ks slab[ks][o][b']   (b' already in PyTorch's [i][r][s] order)
+#ifdef PASTA_TU_WGRAD_F32  // defined by conv_tu_wgrad_f32.hip only (conv_launch.h)
 __global__ __launch_bounds__(256) void wgrad_smallcin_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int ksplit,
                                                                     int Ag, int bprime, int a_pad, int bpad, float wscale) {
     const int total = Ag * bprime;
@@ -493,6 +500,7 @@ __global__ __launch_bounds__(256) void wgrad_smallcin_reduce_kernel(const float*
         dw[idx] = ((v0 + v1) + (v2 + v3)) * wscale;
     }
 }
+#endif  // PASTA_TU_WGRAD_F32
 
 struct WgradSmallPlan { bool use; int nb, bprime, cw_log2, qblocks, chunks_total, ksplit, a_tiles, rows_total; int64_t slab_floats; size_t lds_bytes; };
 

@@ -15,6 +15,8 @@ import os
 import shutil
 import subprocess
 import threading
+import time
+import warnings
 
 # PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so) and puts it in the process-global symbol scope.
 # Importing torch BEFORE loading libpasta_hip.so makes the library's HIP calls bind to that same runtime, so its
@@ -28,6 +30,7 @@ _LIBDIR = os.path.join(_ROOT, 'lib')
 _OBJDIR = os.path.join(_ROOT, 'build')
 _INCLUDE = os.path.join(os.path.dirname(_ROOT), 'include')
 LIB_NAME = 'libpasta_hip.so'
+EXPECTED_ABI = 18                   # PASTA_ABI_VERSION of include/pasta_hip.h = pasta_abi_version() of csrc/common.hip
 ARCH = 'gfx950'
 
 _lock = threading.Lock()
@@ -85,20 +88,40 @@ def build(force=False, verbose=False, extra_flags=()):
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
+def _unit_weight(src):
+    """Rough compile cost of a translation unit, for the build order: the kernel instances are in the conv_tu_* units and in bias_act."""
+    name = os.path.basename(src)
+    return (4 if name.startswith(('conv_tu_fwd_rows', 'conv_tu_rows2d', 'conv_tu_fwd_base', 'bias_act')) else 2 if name.startswith(('conv_tu_', 'upfirdn2d')) else 1)
+
 def _compile_and_link(hipcc, sources, lib_path, stamp, digest, verbose, extra_flags):
     flags = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast', '-I', _INCLUDE] + list(extra_flags)
-    objs, procs = [], []
-    for src in sources:
-        obj = os.path.join(_OBJDIR, os.path.basename(src)[:-4] + '.o')
-        objs.append(obj)
-        cmd = [hipcc] + flags + ['-c', src, '-o', obj]
-        if verbose:
-            print(' '.join(cmd))
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for src, proc in procs:
-        out, _ = proc.communicate()
-        if proc.returncode != 0:
-            raise RuntimeError('hipcc failed on %s:\n%s' % (src, out.decode(errors='replace')))
+    # one hipcc per translation unit, at most one per core at a time, the large units first (the convolution family is thirteen
+    # units, csrc/conv_launch.h: a forced build takes about a minute on eight cores)
+    objs = [os.path.join(_OBJDIR, os.path.basename(src)[:-4] + '.o') for src in sources]
+    queue = sorted(zip(sources, objs), key=lambda so: -_unit_weight(so[0]))
+    jobs = max(1, min(len(queue), int(os.environ.get('PASTA_BUILD_JOBS', 0)) or os.cpu_count() or 1))
+    running, failed = [], None
+    while (queue and failed is None) or running:
+        while queue and failed is None and len(running) < jobs:
+            src, obj = queue.pop(0)
+            cmd = [hipcc] + flags + ['-c', src, '-o', obj]
+            if verbose:
+                print(' '.join(cmd))
+            log = open(obj[:-2] + '.log', 'wb')      # a file, not a pipe: a unit that prints many warnings must not block on a full pipe
+            running.append((src, log, subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT)))
+        for item in list(running):
+            src, log, proc = item
+            if proc.poll() is None:
+                continue
+            running.remove(item)
+            log.close()
+            if proc.returncode != 0 and failed is None:
+                with open(log.name, 'rb') as f:
+                    failed = 'hipcc failed on %s:\n%s' % (src, f.read().decode(errors='replace'))
+        if running:
+            time.sleep(0.05)
+    if failed is not None:
+        raise RuntimeError(failed)
     tmp = lib_path + '.tmp%d' % os.getpid()
     cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', tmp] + objs
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
@@ -196,12 +219,22 @@ def get_plugin(module_name='pasta_hip', sources=None, **build_kwargs):
             return _cached_plugins[module_name]
         lib_path = build(**build_kwargs)
         # same-box A/B of two builds (tools/ab_lib.sh): PASTA_LIB_AB names another library built from THIS tree with other compile flags
-        lib_path = os.environ.get('PASTA_LIB_AB') or lib_path
+        ab = os.environ.get('PASTA_LIB_AB')
+        if ab:
+            if not os.path.isfile(ab):
+                raise RuntimeError('PASTA_LIB_AB names %r, which does not exist' % ab)
+            warnings.warn('PASTA_LIB_AB: loading %s instead of %s (same-box A/B measurement)' % (ab, lib_path))
+            lib_path = ab
         lib = ctypes.CDLL(lib_path)
         for name, (restype, argtypes) in ABI.items():
             fn = getattr(lib, name)       # AttributeError here = header/library mismatch
             fn.restype = restype
             fn.argtypes = argtypes
+        # the structure layouts above (ConvDesc, ConvEpilogue, ...) are those of ONE ABI revision: a library of another one -- a stale A/B
+        # build, a copy from another checkout -- would read pointer fields at the wrong offsets
+        if lib.pasta_abi_version() != EXPECTED_ABI:
+            raise RuntimeError('%s reports ABI %d, this tree expects %d (include/pasta_hip.h): rebuild it from this tree'
+                               % (lib_path, lib.pasta_abi_version(), EXPECTED_ABI))
         _cached_plugins[module_name] = lib
         return lib
 

@@ -74,7 +74,7 @@ def amax_attach(t, row):
     (``torch.inference_mode()``) track no version, so nothing is attached and their consumers scan."""
     if row is not None and not t.is_inference():
         try:
-            t._pasta_amax = (t._version, t.data_ptr(), row)
+            t._pasta_amax = (t._version, t.data_ptr(), row, 'producer')      # a fourth field marks a producer's row (conv2d_gradfix.tensor_amax)
         except AttributeError:
             pass
     return t

@@ -33,6 +33,44 @@ activation_funcs = {
 }
 
 #----------------------------------------------------------------------------
+# Slope tape: a TEST instrument (tests/test_training_step_gpu.py; None = off, one ``is not None`` per activation otherwise).
+# Two evaluations of the same network in different launch plans differ by fp32 rounding, and a leaky-ReLU / ReLU pre-activation within
+# rounding of zero then takes the other slope in one of them: one unit's share of ONE sample's gradient moves by percent while everything else
+# agrees to 1e-6 -- which makes "equal gradients" untestable at fp32 accuracy, and which unit flips changes with every rounding anywhere
+# upstream.  The tape removes the flips from such a comparison: in ``record`` mode it notes the sign mask of every piecewise-linear
+# activation output in call order (the fused convolution epilogues included: conv2d_gradfix._ConvBiasActHip); in ``replay`` mode the
+# outputs whose sign differs from the recorded one are moved across zero (to 1e-30 where the recorded pass took the positive slope, to 0
+# where it took the other: the backward kernels read the slope off the sign of the saved output), so both passes differentiate the SAME
+# piecewise-linear function.  ``moved`` counts the elements and ``worst`` keeps the largest magnitude moved, relative to the tensor's
+# maximum -- the test asserts it is rounding-sized.
+
+class SlopeTape:
+    def __init__(self, replay=None, select=None):
+        self.masks = [] if replay is None else None
+        self.replay, self.select, self.pos, self.moved, self.worst = replay, select, 0, 0, 0.0
+
+    def visit(self, y, act):
+        if act not in ('lrelu', 'relu') or y.numel() == 0:
+            return y
+        if self.masks is not None:
+            self.masks.append(y > 0)
+            return y
+        want = self.replay[self.pos]
+        self.pos += 1
+        if self.select is not None:
+            want = self.select(want)
+        assert want.shape == y.shape, (self.pos - 1, tuple(want.shape), tuple(y.shape))
+        flip = (y > 0) != want
+        n = int(flip.sum())
+        if n:
+            self.moved += n
+            self.worst = max(self.worst, float(y[flip].abs().max() / y.abs().max()))
+            y.masked_fill_(flip & want, 1e-30).masked_fill_(flip & ~want, 0.0)
+        return y
+
+slope_tape = None
+
+#----------------------------------------------------------------------------
 
 def _dense_format(t):
     """Memory format the kernel will run in (the tensor must be dense in that order)."""
@@ -135,6 +173,8 @@ class _BiasActHip(torch.autograd.Function):
         y = x
         if act != 'linear' or gain != 1 or clamp >= 0 or b is not None:
             y = _launch(x, b, None, None, None, 0, dim, spec.cuda_idx, alpha, gain, clamp)
+            if slope_tape is not None:
+                y = slope_tape.visit(y, act)
         keep_x = 'x' in spec.ref or spec.has_2nd_grad
         # The clamp mask of the gradient is taken from y. The reference's CUDA wrapper drops y for
         # 'linear' (bias_act.py:160) and so lets gradients through a clamped ToRGB output; its CPU

@@ -110,7 +110,8 @@ def _native16(kind, desc, has_iscale=False):
 #   * tensors with a ``grad_fn`` (results of recorded operations: only autograd-visible code writes them), and
 #   * tensors met inside a backward pass (gradients, saved activations being differentiated),
 # and a leaf met outside a backward pass -- an input batch, a parameter used as an activation, a no-grad intermediate of a
-# torch operator -- is scanned at every use (its maxima are never read from the object).  Producer rows are written by the
+# torch operator -- is scanned at every use (its maxima are never read from the object: ``tensor_amax`` applies the same predicate
+# when it READS a scan result, so a result attached to a leaf inside a backward pass is not found by a later forward).  Producer rows are written by the
 # kernel that wrote the tensor and are trusted for that version.  Inference tensors (``torch.inference_mode()``) track no
 # version: nothing is cached on them or read back from them.
 AMAX_PARTS = 256
@@ -143,7 +144,10 @@ def _amax_cacheable(t):
 def tensor_amax(t):
     """[256] partial |max| of a contiguous fp32 GPU tensor; cached on the tensor only where no write can bypass the key."""
     hit = None if t.is_inference() else getattr(t, '_pasta_amax', None)
-    if hit is not None and hit[0] == t._version and hit[1] == t.data_ptr():
+    # the read side applies the rule of the write side (ADVICE r4): a SCAN result found on a leaf outside a backward pass is not trusted --
+    # it may have been attached while the leaf was met inside one (an image batch whose forward ran a kernel that takes no maxima, scanned by
+    # the weight gradient), and a `.data` write since then is invisible to the key.  Producer rows (hit[3]) stand for their version.
+    if hit is not None and hit[0] == t._version and hit[1] == t.data_ptr() and (len(hit) > 3 or _amax_cacheable(t)):
         return hit[2]
     if _SCAN_TRACE is not None:                        # diagnostic (PASTA_AMAX_TRACE=1): which tensors still cost a scan
         import sys as _sys
@@ -397,6 +401,8 @@ class _ConvBiasActHip(torch.autograd.Function):
         from . import bias_act as ba
         used = {}
         y = _launch_conv(x, w, cfg, epilogue=(b, ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, res), used=used)
+        if ba.slope_tape is not None:               # test instrument (bias_act.SlopeTape)
+            y = ba.slope_tape.visit(y, act)
         # y is needed by the backward only as the activation / clamp mask; a linear, unclamped layer (the residual
         # skips, whose output the blocks then update in place) must not pin it
         keep_y = act != 'linear' or clamp >= 0

@@ -183,10 +183,15 @@ class _SplitGroups(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        h, ctx.holder = ctx.holder, None
-        if h.buf is not None and all(g is not None and g.data_ptr() == h.view(i).data_ptr() and g.shape == h.view(i).shape and g.stride() == h.view(i).stride()
-                                     for i, g in enumerate(grads)):
-            return _native.amax_attach(h.buf, h.row), None
+        # the holder stays with the node (a second backward pass over a retained graph finds it again); the BUFFER is handed out once and the
+        # holder forgets it, so the next pass writes a fresh one instead of a tensor someone already holds as a gradient
+        h = ctx.holder
+        buf, row = h.buf, h.row
+        if buf is not None and all(g is not None and g.data_ptr() == h.view(i).data_ptr() and g.shape == h.view(i).shape and g.stride() == h.view(i).stride()
+                                   for i, g in enumerate(grads)):
+            h.buf = h.row = None
+            return _native.amax_attach(buf, row), None
+        h.buf = h.row = None
         c = h.shape[1] // h.groups
         parts = [g if g is not None else torch.zeros([h.shape[0], c, *h.shape[2:]], dtype=h.dtype, device=h.device) for g in grads]
         return torch.cat(parts, dim=1), None
@@ -572,7 +577,10 @@ class Conv2dLayer(_FilteredConv):
                 args = self._resample_args(x)
                 args['wgain'] = args['wgain'] * float(gain)
                 return conv2d_resample.conv2d_resample_bias_act(x=x, b=None, act='linear', gain=1, clamp=None, residual=add, **args)
-            return self.forward(x, gain=gain, passthrough=passthrough).add_(add)
+            y = self.forward(x, gain=gain, passthrough=passthrough)
+            if passthrough:                             # (y, x'): the sum belongs to the first element
+                return y[0].add_(add), y[1]
+            return y.add_(add)
         act_gain, act_clamp = _scaled_act(self.activation, gain, self.conv_clamp)
         return conv2d_resample.conv2d_resample_bias_act(x=x, b=(None if self.bias is None else self.bias.to(x.dtype)), act=self.activation,
                                                         gain=act_gain, clamp=act_clamp, passthrough=passthrough, **self._resample_args(x))

@@ -34,7 +34,7 @@ def test_two_ranks_on_one_gpu_over_gloo(ddp_mode):
     """Two ranks share the one card of the test box (gloo transport): the launcher, the process group, the gradient
     exchange and the max-over-ranks timing all run; the line says which transport carried the gradients."""
     res = _run({'PASTA_DIST_BACKEND': 'gloo'}, '--gpus', '2', '--steps', '1', '--warmup', '1', '--batch-gpu', '4',
-               '--no-cpu-baseline', '--ddp-mode', ddp_mode)
+               '--no-cpu-baseline', '--ddp-mode', ddp_mode, '--replica-check')
     assert res.returncode == 0, res.stderr[-4000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, res.stdout
@@ -44,6 +44,8 @@ def test_two_ranks_on_one_gpu_over_gloo(ddp_mode):
     par = out['config']['parallelism']
     assert par.startswith('dp2') and 'gloo' in par and 'world_size 2' in par and 'RCCL' not in par and ddp_mode in par
     assert out['roofline']['frac'] > 0
+    rc = out['replica_check']       # the same check the two-GPU RCCL test makes (tests/test_ddp_gpu.py), here over the rehearsal transport
+    assert rc['world_size'] == 2 and rc['bit_identical'] and rc['grads'] > 0 and rc['grad_abs_sum'] > 0
 
 
 @pytest.mark.gpu

@@ -137,3 +137,38 @@ def test_rccl_initialises_and_carries_the_flat_reducer_single_rank():
     res = out.get(timeout=500)
     p.join(timeout=60)
     assert res == 'ok', res
+
+
+def _bench_line(extra_env, *args):
+    import json, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, **extra_env)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *args], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1100)
+    assert res.returncode == 0, res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, res.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(2400)
+def test_two_gpus_over_rccl_match_the_gloo_run():
+    """BASELINE config 3 on the smallest node that can carry it: where the box shows two GPUs, ``bench.py --gpus 2``
+    runs two ranks over RCCL -- (a) the line names the transport, (b) the replicas' parameters are bit-identical after the steps,
+    (c) parameters and the last averaged gradients equal those of the same two ranks exchanging over gloo (a sum of two addends has one
+    rounding whatever the transport; every kernel of the step is bitwise reproducible).  Skipped on the one-GPU boxes of this pool, where
+    only the refusal (tests/test_bench_launch.py) and world size 1 (above) can run; the driver's 8-GPU node runs the curve itself."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs on one node')
+    common = ('--gpus', '2', '--steps', '2', '--warmup', '1', '--batch-gpu', '4', '--no-cpu-baseline', '--no-variants', '--replica-check')
+    rccl = _bench_line({'PASTA_DIST_BACKEND': 'nccl'}, *common)
+    par = rccl['config']['parallelism']
+    assert rccl['n_gpus'] == 2 and par.startswith('dp2') and 'backend nccl' in par and 'RCCL' in par and 'world_size 2' in par and 'REHEARSAL' not in par
+    assert rccl['config']['global_batch'] == 8 and rccl['scaling'] == 'weak' and rccl['value'] > 0
+    rc = rccl['replica_check']
+    assert rc['world_size'] == 2 and rc['bit_identical'] and rc['grads'] > 0
+    gloo = _bench_line({'PASTA_DIST_BACKEND': 'gloo'}, *common)
+    gc = gloo['replica_check']
+    assert gc['bit_identical'] and gc['grads'] == rc['grads']
+    assert abs(rc['param_abs_sum'] / gc['param_abs_sum'] - 1) < 1e-6 and abs(rc['grad_abs_sum'] / gc['grad_abs_sum'] - 1) < 1e-6, (rc, gc)

@@ -99,6 +99,39 @@ def test_scan_results_are_cached_only_where_no_write_can_bypass_the_key():
     assert q2 is not q1 and float(q2.max()) == float(u.abs().max())
 
 
+def test_scan_attached_inside_a_backward_pass_is_not_read_by_a_later_forward():
+    """a leaf image batch whose forward ran a kernel that takes no maxima (3 input channels: the fp32 tile) is scanned by the
+    weight gradient INSIDE the backward pass, where scan results are attached to the object.  A ``.data`` write afterwards is invisible to the
+    (version, pointer) key: a forward that read the attribute back would scale the operand by stale maxima (inf under fp16 pieces)."""
+    from torch_utils.ops import conv2d_gradfix as cg
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn([4, 32, 32, 32], generator=g).cuda()     # a leaf batch (no grad_fn, requires no gradient)
+    w = (torch.randn([64, 32, 3, 3], generator=g) / 17).cuda().requires_grad_(True)
+
+    class Probe(torch.autograd.Function):                    # meets the leaf inside a backward pass, as _launch_wgrad does with a saved input
+        @staticmethod
+        def forward(ctx, w_):
+            return w_.sum()
+        @staticmethod
+        def backward(ctx, gy):
+            ctx_parts.append(cg.tensor_amax(x))
+            return gy * torch.ones_like(w)
+    ctx_parts = []
+    Probe.apply(w).backward()
+    hit = getattr(x, '_pasta_amax', None)
+    assert hit is not None and hit[2] is ctx_parts[0] and len(hit) == 3      # attached there, as a scan result
+    x.data.mul_(1000.0)                                      # behind the version counter
+    p2 = cg.tensor_amax(x)
+    assert p2 is not ctx_parts[0] and float(p2.max()) == float(x.abs().max())   # the forward side scans the leaf again
+    y = cg.conv2d(x, w.detach(), padding=1)
+    assert torch.isfinite(y).all() and _rel(y, _conv64(x, w.detach(), padding=1)) < 1e-5
+    # a producer's row (fourth field) stands for its version whoever reads it
+    z = cg.conv2d_bias_act(x, w.detach(), None, padding=1, act='lrelu')
+    zh = getattr(z, '_pasta_amax', None)
+    if zh is not None:
+        assert len(zh) == 4 and cg.tensor_amax(z) is zh[2]
+
+
 def test_check_finite_debug_flag_names_the_launch():
     from torch_utils.ops import conv2d_gradfix as cg
     g = torch.Generator().manual_seed(6)

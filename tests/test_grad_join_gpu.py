@@ -116,6 +116,41 @@ def test_spade_blocks_chain_the_feature_map():
         assert _rel(u, v) < 5e-6, (i, _rel(u, v))
 
 
+def test_spade_block_backward_twice_over_a_retained_graph():
+    """the three normalisations of a block write dgamma | dbeta into ONE shared buffer that the split node hands out as the
+    gradient; a second backward pass over the same graph (retain_graph=True, or autograd.grad followed by backward) must find the node's
+    holder again and must get a FRESH buffer -- not overwrite the tensor the first pass returned."""
+    from training import networks
+    g = torch.Generator().manual_seed(4)
+    blk = networks.Spade_ResBlockV2(32, 32, resolution=16, feat_channels=24).cuda()
+    x = torch.randn([2, 32, 16, 16], generator=g).cuda().requires_grad_(True)
+    feat = torch.randn([2, 24, 16, 16], generator=g).cuda().requires_grad_(True)
+    params = list(blk.parameters())
+    y = blk(x * 1.0, feat * 1.0)
+    first = torch.autograd.grad(y.square().sum(), [x, feat] + params, retain_graph=True)
+    kept = [t.clone() for t in first]
+    second = torch.autograd.grad((2 * y).square().sum(), [x, feat] + params)             # another loss over the SAME graph: 4 x the gradients
+    for i, (a, k, b) in enumerate(zip(first, kept, second)):
+        assert torch.equal(a, k), i                                                   # what the first pass returned was not written again
+        assert _rel(b, 4 * k) < 5e-6, (i, _rel(b, 4 * k))
+
+
+def test_layer_sum_with_passthrough():
+    """``Conv2dLayer.forward(add=..., passthrough=True)`` returns ``(layer(x) + add, x')``, fused or not."""
+    from training import networks
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn([2, 16, 16, 16], generator=g).cuda().requires_grad_(True)
+    for kwargs in (dict(bias=False), dict(bias=True, activation='lrelu')):
+        layer = networks.Conv2dLayer(16, 32, kernel_size=1, **kwargs).cuda()
+        add = torch.randn([2, 32, 16, 16], generator=g).cuda()
+        want = layer(x) + add
+        y, again = layer(x, passthrough=True, add=add.clone())
+        assert _rel(y, want) < 1e-6 and again.shape == x.shape
+        gx, = torch.autograd.grad(y.sum() + again.sum(), [x])
+        rx, = torch.autograd.grad(want.sum() + x.sum(), [x])
+        assert _rel(gx, rx) < 5e-6
+
+
 @pytest.mark.parametrize('shape,kw', [
     ([3, 16, 64, 64], dict(padding=[2, 2, 2, 2])),                      # blur in front of a stride-2 convolution: 64 -> 65 (odd pitch)
     ([2, 8, 65, 65], dict(padding=[1, 1, 1, 1], gain=4)),               # ... and behind a stride-2 conv_transpose2d
