@@ -54,6 +54,27 @@ int pasta_upfirdn2d(const void* x, const float* f, void* y, int dtype,
                                                gradient of upfirdn2d is upfirdn2d (upfirdn2d.py:246-264): when x has further consumers their gradient
                                                rides here instead of in an addition pass over two tensors */
 
+/* -------------------------------------------------------------------------
+ * Producer-written operand pieces (ABI 19).  Replaces, for the low-pass in front of a stride-2 convolution
+ * (torch_utils/ops/conv2d_resample.py:119-122: `x = upfirdn2d(x, f, padding)` then `conv2d(x, w, stride=2)`), the fp32 NCHW
+ * intermediate of the reference by the matrix-core operand itself: y = upfirdn2d(x, f, up = down = 1, padding, flip, gain) for a
+ * 4x4 filter f (fp32 [4][4] on the device) is written ONCE as PASTA_LAYOUT_PIECES16 -- units [N][C / 8][OH][OW] of 32 bytes holding
+ * fp16 h[8] = fp16(v S) and l'[8] = fp16(2^11 (v S - h)) of eight consecutive channels -- and the consumers (pasta_conv2d_ex /
+ * pasta_conv2d_wgrad with pasta_conv_desc.x_layout = PASTA_LAYOUT_PIECES16) copy sixteen-byte pieces into LDS instead of gathering
+ * channel-strided fp32 and splitting it at every launch.  OH = H + pady0 + pady1 - 3, OW likewise; the fp32 value in front of the split
+ * is bit-identical to pasta_upfirdn2d's.
+ *   x_amax  (in)  PASTA_AMAX_PARTS partial |max| of x (its producer's row, or pasta_tensor_amax).
+ *   y_amax  (out) PASTA_AMAX_PARTS floats: x_amax times gain * sum |f| -- a bound of |y| known BEFORE the blur runs.  The power of two S
+ *                 comes from this row on both sides (pass it as pasta_conv_desc.x_amax); being a power of two, the consumers' results do
+ *                 not depend on which admissible S was used (tests/test_pieces_gpu.py scales the row by 2 and by 1/2).
+ * pasta_pieces_bytes: size of the piece tensor (-1: C is not a multiple of 8).  pasta_pieces_unpack: (h + 2^-11 l') / S back to fp32
+ * NCHW (tests and diagnostics: 22 of the 24 bits).
+ * ------------------------------------------------------------------------- */
+int64_t pasta_pieces_bytes(int N, int C, int H, int W);
+int pasta_blur_pieces(const float* x, const float* f, void* pieces, const float* x_amax, float* y_amax,
+                      int N, int C, int H, int W, int padx0, int padx1, int pady0, int pady1, int flip, float gain, void* stream);
+int pasta_pieces_unpack(const void* pieces, const float* y_amax, float* y, int N, int C, int H, int W, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * bias_act -- fused bias + activation + gain + clamp, and its 1st/2nd grads.
  * Replaces: bias_act_plugin.bias_act(x, b, xref, yref, dy, grad, dim, act,
@@ -132,7 +153,16 @@ typedef struct pasta_conv_desc {
     const float* dy_amax;         /* the same for dy (pasta_conv2d_wgrad only).  The WEIGHTS need nothing of the kind (ABI 17): their
                                      packing kernel finds one scale per output row itself at every launch, so no |max| of w is
                                      passed, cached or trusted across launches                                            */
+    int32_t      x_layout;        /* ABI 19.  0 = x is a contiguous NCHW tensor of io_dtype (everything above).  PASTA_LAYOUT_PIECES16 = x is the
+                                     producer-written operand of the three-product arithmetic (pasta_blur_pieces below): [N][C_in / 8][H][W] units of
+                                     32 bytes, fp16 h[8] | l'[8] of v S, and x_amax (REQUIRED then) is the 256-float row the producer wrote -- the bound
+                                     both sides take the power-of-two scale S from.  Served by the 3x3 stride-2 forward kernel and its weight gradient
+                                     (pasta_conv2d_plan kernel 10, pasta_conv2d_wgrad_plan kernel 6: fp32 y / dy, PASTA_MATH_F16X3, one group, C_in a
+                                     multiple of 8, pad 0); the planners return an error for every other launch and the caller keeps the fp32 tensor. */
 } pasta_conv_desc;
+
+#define PASTA_LAYOUT_NCHW      0
+#define PASTA_LAYOUT_PIECES16  1
 
 /* Arithmetic of the convolution products.  Accumulation is fp32 in every mode.
  *   PASTA_MATH_F32    v_mfma_f32_32x32x2_f32: every product and sum is an fp32 FMA (bit-exact fp32 chains).
@@ -200,7 +230,8 @@ int pasta_conv2d_tile(const pasta_conv_desc* d);
  * >= 16 input and > 32 output channels, planes of a multiple of 128 / 256 pixels: 16-byte loads along the pixels, 32 channels per barrier pair,
  * optionally over two input tensors -- pasta_conv_desc.x2), 10 conv3x3s2_f16x3_kernel (round 4: 3x3 stride-2 conv2d with pads 0 / 1 under PASTA_MATH_F16X3,
  * fp32 tensors, >= 16 input and > 32 output channels, output widths 16 .. 128 .. that are powers of two: a round stages the input ROW segments of a kernel
- * row once, de-interleaved by pixel parity, for its three taps).  Any out pointer may be NULL. */
+ * row once, de-interleaved by pixel parity, for its three taps; round 5: with pasta_conv_desc.x_layout = PASTA_LAYOUT_PIECES16 its staging is a copy of
+ * the producer's sixteen-byte pieces, no split).  Any out pointer may be NULL. */
 #define PASTA_PLAN_ISCALE   1
 #define PASTA_PLAN_OSCALE   2
 #define PASTA_PLAN_EPILOGUE 4
@@ -212,7 +243,9 @@ int pasta_conv2d_plan(const pasta_conv_desc* d, int launch_flags, int* tile, int
  * conv_wgrad3x3_bf16x6_kernel (split-bf16; 3x3, stride 1, pad 1, row length a multiple of 32), 3
  * conv_wgrad3x3s2_bf16x6_kernel (split-bf16; 3x3, stride 2, pad 0 or 1, row length a multiple of 16), 4
  * conv_wgrad1x1_bf16x6_kernel (split-bf16; 1x1, stride 1, planes of a multiple of 32 pixels, >= 16 channels), 5
- * wgrad1x1_fewcin_kernel (round 4: 1x1, <= 8 input channels, planes of a multiple of 4 pixels: one bandwidth-bound fp32 pass over dy). */
+ * wgrad1x1_fewcin_kernel (round 4: 1x1, <= 8 input channels, planes of a multiple of 4 pixels: one bandwidth-bound fp32 pass over dy), 6
+ * conv_wgrad3x3s2_pieces_kernel (round 5: kernel 3's shapes with pad 0 and x given as PASTA_LAYOUT_PIECES16: the x halo is copied into a
+ * [pixel][channel] LDS image and the stride-2 tap operands are gathered by ds_read_b64_tr_b16, no split and no permutes). */
 int pasta_conv2d_wgrad_plan(const pasta_conv_desc* d, int* kernel);
 
 /* y = conv(x, w).  w is the PyTorch-layout weight ([C_out, C_in/g, kh, kw], or

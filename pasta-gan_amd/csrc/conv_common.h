@@ -8,6 +8,7 @@
 namespace pasta {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));      // sixteen bytes in registers (HIP's uint4 is a struct: arrays of it handed to a lambda end up in scratch)
 
 // An empty asm that makes a VGPR value opaque to the SLP vectoriser (no instruction is emitted).
 #define PASTA_KEEP_SCALAR(x) asm("" : "+v"(x))
@@ -72,9 +73,14 @@ __device__ __forceinline__ float conv_epilogue_c(float v, float b, const EpiAct&
         return v;
     }
 }
+#ifndef PASTA_EPI_CASES
+#define PASTA_EPI_CASES 1       // build switch for same-box A/B (tools/ab_lib.sh): 0 = round 4's final form, an instance per whole-tile answer with the folded activation
+#endif
 template <bool SPEC, class F>
 __device__ __forceinline__ void conv_epilogue_dispatch(bool full, const EpiAct& e, F&& f) {
-    if constexpr (SPEC) {
+    if constexpr (SPEC && !PASTA_EPI_CASES) {
+        if (full) f(std::true_type{}, EpiCase<0>{}); else f(std::false_type{}, EpiCase<0>{});
+    } else if constexpr (SPEC) {
         if (full) {
             if (!e.on) f(std::true_type{}, EpiCase<1>{}); else if (!e.clamp_on) f(std::true_type{}, EpiCase<2>{}); else f(std::true_type{}, EpiCase<3>{});
         } else {
@@ -292,6 +298,7 @@ struct ConvFwdParams {
     // koff[k] bytes behind the pixel's base address in a zero-padded copy of the input; null = off
     const unsigned* koff;
     int xcd_order;                        // conv_fwd_rows2d_bf16x6_kernel, eight-wave tile: consecutive pixel tiles on ONE XCD (PASTA_XCD_ORDER=0: off)
+    int x_pieces;                         // conv3x3s2_f16x3_kernel: x is PASTA_LAYOUT_PIECES16 (pieces.hip), p.x_amax the producer's bound row
 };
 
 // Tile choice.  O_pad multiple returned so that the caller can pack weights accordingly.
@@ -317,6 +324,7 @@ struct WgradParams {
     int ksplit;             // K slices
     int a_tiles, b_tiles, tap_groups_r, tap_groups_s;
     int xcd_order;          // split weight-gradient kernels: workgroup order (0: K slice fastest; 1: see wgrad_decode)
+    int l_pieces;           // conv_wgrad3x3s2_pieces_kernel: L is PASTA_LAYOUT_PIECES16 (pieces.hip), l_amax the producer's bound row
 };
 
 }  // namespace pasta

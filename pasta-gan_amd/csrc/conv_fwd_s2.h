@@ -20,7 +20,10 @@ namespace pasta {
 //     MFMAs, two workgroups per CU: while one stages the other multiplies (the scheme of conv1x1_f16x3_kernel);
 //   * tile = BM output channels x 128 output pixels = R = 128 / SEG rows of SEG = min(OW, 128) columns.
 // Weights: the standard packed layout, one scale per output row (p.w_rowinv).  Planes: OW a power of two >= 16 (the live shapes: 128, 64, 32, 16).
-template <int BM>
+// XP (round 5): x is the producer-written operand (PASTA_LAYOUT_PIECES16, pieces.hip: [N][C / 8][H][W] units of 32 bytes, fp16 h[8] | l'[8] of v S with
+// S from p.x_amax, the producer's bound row) -- a staging task is then two sixteen-byte loads and two LDS stores: no channel-strided dword gathers,
+// no split (the eight loads and ~25 VALU instructions of a task were a third of this kernel's issue slots: profiles/r4_pmc_summary.txt, issue 0.35).
+template <int BM, bool XP = false>
 __global__ __launch_bounds__(256, 2) void conv3x3s2_f16x3_kernel(ConvFwdParams p) {
     constexpr int NP = NP_F16X3, BN = 128;
     constexpr int WMT = 2, WNT = 2;
@@ -70,7 +73,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_f16x3_kernel(ConvFwdParams p
     }
     const float* const xb = p.x + (int64_t)n_img * p.Cin * p.H * p.W;
     const int HW = p.H * p.W;
-    float xv[3][8];
+    constexpr int XV = XP ? 1 : 8;
+    float xv[3][XV];
+    u32x4 xq[3][XP ? 2 : 1];                            // XP: the unit's h and l' pieces as they lie
     int xvalid[3];                                      // channels of the task that exist and lie inside the plane (0: a zero pixel)
     auto load_x = [&](int rnd) {
         const int dy = rnd / NC, cc = rnd - dy * NC;    // scalar
@@ -82,8 +87,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_f16x3_kernel(ConvFwdParams p
             const int off = in ? iy * p.W + t_ix[k] : 0;
             const int c0 = cc * 16 + t_half[k] * 8;
             xvalid[k] = in ? p.Ig - c0 : 0;
+            if constexpr (XP) {
+                const int c8 = c0 < p.Ig ? (c0 >> 3) : 0;                   // Ig is a multiple of 8: an octet exists whole or not at all
+                const u32x4* const src = (const u32x4*)((const char*)p.x + ((((int64_t)n_img * (p.Cin >> 3) + c8) * HW) + off) * 32);
+                xq[k][0] = src[0]; xq[k][1] = src[1];
+                continue;
+            }
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
+            for (int j = 0; j < XV; j++) {
                 const int c = c0 + j < p.Ig ? c0 + j : p.Ig - 1;
                 xv[k][j] = xb[(int64_t)c * HW + off];
             }
@@ -93,10 +104,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_f16x3_kernel(ConvFwdParams p
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             if (k == 2 && !t_on[2]) continue;
+            if constexpr (XP) {
+                const bool on = xvalid[k] > 0;
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                __bf16* const d = &Bs[t_lds[k]];
+                *(u32x4*)d = on ? xq[k][0] : z;
+                *(u32x4*)(d + 2 * SLOTS * 8) = on ? xq[k][1] : z;
+                continue;
+            }
             uint32_t h[4], l[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                float v0 = xv[k][2 * q], v1 = xv[k][2 * q + 1];
+                float v0 = xv[k][(2 * q) % XV], v1 = xv[k][(2 * q + 1) % XV];
                 if (xvalid[k] < 8) { v0 = 2 * q < xvalid[k] ? v0 : 0.f; v1 = 2 * q + 1 < xvalid[k] ? v1 : 0.f; }
                 f16_split2(v0 * sx, v1 * sx, h[q], l[q]);
             }
@@ -249,6 +268,7 @@ static bool conv3x3s2_ok(const ConvFwdParams& p, int kh, int kw, int stride, int
     static const bool enabled = !(getenv("PASTA_CONV_S2") && getenv("PASTA_CONV_S2")[0] == '0');         // A/B switch
     if (!enabled || transposed || p.bf16x6 != NP_F16X3 || p.io != IO_F32 || p.G != 1 || kh != 3 || kw != 3 || stride != 2 || pad_h != pad_w || pad_h > 1) return false;
     if (p.iscale || p.oscale || p.noise || p.ksplit != 1 || p.koff || p.x2 || p.Ig < 16 || p.Og <= 32) return false;
+    if (p.x_pieces && ((p.Ig & 7) || pad_h != 0)) return false;         // the producer's units hold eight channels; the blur absorbs the padding
     return conv3x3s2_shape_ok(p.OH, p.OW);
 }
 

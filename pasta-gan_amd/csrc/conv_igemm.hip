@@ -269,6 +269,7 @@ static int check_desc(const pasta_conv_desc* d, const char* who) {
     PASTA_CHECK(d->math >= PASTA_MATH_DEFAULT && d->math <= PASTA_MATH_F16X3, "%s: unknown math mode %d", who, d->math);
     PASTA_CHECK(d->io_dtype == PASTA_F32 || d->io_dtype == PASTA_F16 || d->io_dtype == PASTA_BF16, "%s: io_dtype %d is not PASTA_F32 / PASTA_F16 / PASTA_BF16", who, d->io_dtype);
     PASTA_CHECK(d->groups >= 1 && d->C_in % d->groups == 0 && d->C_out % d->groups == 0, "%s: channels not divisible by groups=%d", who, d->groups);
+    PASTA_CHECK(d->x_layout == PASTA_LAYOUT_NCHW || d->x_layout == PASTA_LAYOUT_PIECES16, "%s: unknown x_layout %d", who, d->x_layout);
     if (!d->transposed) {
         const int oh = (d->H + 2 * d->pad_h - d->kh) / d->stride + 1, ow = (d->W + 2 * d->pad_w - d->kw) / d->stride + 1;
         PASTA_CHECK(d->H + 2 * d->pad_h >= d->kh && d->W + 2 * d->pad_w >= d->kw && oh == d->OH && ow == d->OW,
@@ -324,6 +325,15 @@ extern "C" int pasta_conv2d_tile(const pasta_conv_desc* d) {
 }
 
 namespace pasta {
+// Does conv3x3s2_f16x3_kernel take this launch with x as the producer wrote it (PASTA_LAYOUT_PIECES16)?  The conditions of conv3x3s2_ok (conv_fwd_s2.h)
+// on the descriptor, plus whole channel octets and the blur's pad 0.
+static bool pieces_fwd_ok(const pasta_conv_desc* d, int launch_flags) {
+    const FwdPlan f = plan_fwd(d);
+    return !d->transposed && f.bf16x6 && !f.packed && math_pieces(d->math) == NP_F16X3 && d->io_dtype == PASTA_F32 && d->groups == 1 && d->kh == 3 && d->kw == 3 &&
+           d->stride == 2 && d->pad_h == 0 && d->pad_w == 0 && !(launch_flags & (PASTA_PLAN_ISCALE | PASTA_PLAN_OSCALE | PASTA_PLAN_MODULATED)) && f.ksplit == 1 &&
+           d->C_in >= 16 && (d->C_in & 7) == 0 && d->C_out > 32 && !d->x2 && conv3x3s2_shape_ok(d->OH, d->OW) &&
+           !(getenv("PASTA_CONV_S2") && getenv("PASTA_CONV_S2")[0] == '0');
+}
 static bool pair_launch_ok(const pasta_conv_desc* d, int pieces, int ksplit, FwdTile tile, bool plain);
 // The parity-pair kernel carries no scales and no epilogue: ONE predicate for the planner and the launch.
 static inline bool pair_plain(int launch_flags) { return launch_flags == 0; }
@@ -366,6 +376,9 @@ extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int launch_flags, int
                          d->C_in >= 16 && d->C_out > 32 && conv3x3s2_shape_ok(d->OH, d->OW);
         *kernel = !sb ? 0 : c1x1 ? 9 : s2k ? 10 : packed ? 8 : pair ? 3 : wide ? 7 : rows2d ? (rows2d_rows(d->OH, d->OW) == 4 ? 4 : 5) : rows2d_256 ? 6 : rows ? 2 : 1;
     }
+    if (d->x_layout == PASTA_LAYOUT_PIECES16 && !pieces_fwd_ok(d, launch_flags))
+        return fail("conv2d: x_layout = PASTA_LAYOUT_PIECES16 is served by the 3x3 stride-2 forward kernel only (conv2d, pad 0, fp32 y, PASTA_MATH_F16X3, one group, "
+                    "C_in a multiple of 8 and >= 16, C_out > 32, output width a power of two >= 16, more than 8192 output pixels, no scale vectors)");
     return 0;
 }
 
@@ -606,6 +619,12 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
     ConvFwdParams p;
     p.x = (const float*)x; p.y = (float*)y; p.wp = (const float*)workspace; p.iscale = iscale; p.oscale = oscale;
     p.x_amax = nullptr; p.w_rowinv = nullptr;
+    p.x_pieces = d->x_layout == PASTA_LAYOUT_PIECES16;
+    if (p.x_pieces) {
+        PASTA_CHECK(d->x_amax, "conv2d: x_layout = PASTA_LAYOUT_PIECES16 needs x_amax, the row pasta_blur_pieces wrote (the operand's scale)");
+        PASTA_CHECK(pieces_fwd_ok(d, launch_flags_of(iscale, oscale, nullptr) | (wmod_s ? PASTA_PLAN_MODULATED : 0)) && !(ep && ep->noise),
+                    "conv2d: no kernel takes x_layout = PASTA_LAYOUT_PIECES16 for this launch (pasta_conv2d_plan tells beforehand)");
+    }
     p.x2 = (const float*)d->x2; p.x2_amax = nullptr; p.C1 = d->C1;
     PASTA_CHECK(!d->x2 || (d->C1 > 0 && d->C1 < d->C_in && d->groups == 1 && !wmod_s), "conv2d: a second input tensor needs 0 < C1 < C_in, one group and plain weights");
     p.N = d->N; p.Cin = d->C_in; p.H = d->H; p.W = d->W;
@@ -636,7 +655,7 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
         // operand scale of x: partial |max| (the caller's, or one pass here), times max |iscale| when the styles ride in the staging.
         // The weights carry one scale per output row, found by their packing kernel (no |max| of w is passed or cached).
         const float* xa = d->x_amax;
-        if (!xa) {
+        if (!xa) {          // (never with the pieces layout: checked above)
             if (int e = tensor_amax(x, (int64_t)d->N * d->C_in * d->H * d->W, PASTA_F32, ws_amax, s)) return e;
             xa = ws_amax;
         }
@@ -789,6 +808,11 @@ static bool wgrad_s2_bf16x6(const pasta_conv_desc* d, const WgradPlan& w) {
     return (d->math != PASTA_MATH_F32 || d->io_dtype != PASTA_F32) && d->kh == 3 && d->kw == 3 && d->stride == 2 && d->pad_h == d->pad_w && d->pad_h <= 1 &&
            Q % 16 == 0 && w.kp == 16 && w.cw_log2 == 4;
 }
+// ... with x as the producer wrote it (PASTA_LAYOUT_PIECES16): conv_wgrad3x3s2_pieces_kernel
+static bool wgrad_pieces_ok(const pasta_conv_desc* d, const WgradPlan& w) {
+    return d->x_layout == PASTA_LAYOUT_PIECES16 && wgrad_s2_bf16x6(d, w) && !d->transposed && d->pad_h == 0 && d->groups == 1 && d->io_dtype == PASTA_F32 &&
+           math_pieces(d->math) == NP_F16X3 && (d->C_in & 7) == 0;
+}
 // ... and the pointwise one: 1x1, stride 1, no padding, planes of a multiple of 32 pixels (ToRGB heads included: the shape is
 // bandwidth-bound, so a mostly empty 64-channel tile costs nothing).
 static bool wgrad_1x1_bf16x6(const pasta_conv_desc* d, const WgradPlan& w) {
@@ -811,10 +835,13 @@ extern "C" int pasta_conv2d_wgrad_plan(const pasta_conv_desc* d, int* kernel) {
         const WgradPlan w = d->transposed ? plan_wgrad(d->N, d->H, d->W, d->groups, Ig, Og, d->kh, d->kw, d->stride)
                                           : plan_wgrad(d->N, d->OH, d->OW, d->groups, Og, Ig, d->kh, d->kw, d->stride);
         if (wgrad_bf16x6(d, w)) k = 2;
-        else if (wgrad_s2_bf16x6(d, w)) k = 3;
+        else if (wgrad_s2_bf16x6(d, w)) k = wgrad_pieces_ok(d, w) ? 6 : 3;
         else if (wgrad_1x1_bf16x6(d, w)) k = 4;
     }
     if (kernel) *kernel = k;
+    if (d->x_layout == PASTA_LAYOUT_PIECES16 && k != 6)
+        return fail("conv2d_wgrad: x_layout = PASTA_LAYOUT_PIECES16 is served by the 3x3 stride-2 weight gradient only (conv2d, pad 0, fp32 dy, PASTA_MATH_F16X3, "
+                    "one group, C_in a multiple of 8, output rows of a multiple of 16 pixels)");
     if (d->io_dtype != PASTA_F32 && k < 2)
         return fail("conv2d_wgrad: no 16-bit-storage kernel for this shape: convert the tensors to fp32 for this launch");
     return 0;
@@ -891,6 +918,11 @@ int pasta::wgrad_run(const void* xv, const void* dyv, float* dw, const pasta_con
     workspace = (float*)workspace + WS_AMAX_FLOATS;                  // the partial slabs follow
 
     const WgradSmallPlan ws = mod_s ? WgradSmallPlan{} : plan_wgrad_small(d);
+    if (d->x_layout == PASTA_LAYOUT_PIECES16) {
+        int k = 0;
+        if (int e = pasta_conv2d_wgrad_plan(d, &k)) return e;
+        PASTA_CHECK(!mod_s && d->x_amax, "conv2d_wgrad: x_layout = PASTA_LAYOUT_PIECES16 needs x_amax (the row pasta_blur_pieces wrote) and plain weights");
+    }
     PASTA_CHECK(d->io_dtype == PASTA_F32 || !ws.use, "conv2d_wgrad: no 16-bit-storage kernel for this shape (pasta_conv2d_wgrad_plan tells beforehand)");
     if (const int fks = plan_wgrad1x1_fewcin(d, ws)) {
         // few input channels, 1x1: one bandwidth-bound pass over dy with plain FMAs (conv_wgrad_f32.h)
@@ -934,6 +966,7 @@ int pasta::wgrad_run(const void* xv, const void* dyv, float* dw, const pasta_con
     // every other shape within 0.5 %
     static const int wgrad_xcd = getenv("PASTA_WGRAD_XCD") ? atoi(getenv("PASTA_WGRAD_XCD")) : 1;
     p.xcd_order = wgrad_xcd;
+    p.l_pieces = d->x_layout == PASTA_LAYOUT_PIECES16;
     PASTA_CHECK(w.lds_bytes <= 160 * 1024, "conv2d_wgrad: LDS footprint %zu too large", w.lds_bytes);
     PASTA_CHECK(w.npos <= 256, "conv2d_wgrad: halo of %d positions per chunk is not supported", w.npos);
 
@@ -943,7 +976,7 @@ int pasta::wgrad_run(const void* xv, const void* dyv, float* dw, const pasta_con
     p.s_amax = p.l_amax = nullptr;
     if (np == NP_F16X3 && (wgrad_bf16x6(d, w) || wgrad_s2_bf16x6(d, w) || (wgrad_1x1_bf16x6(d, w) && !(w.TR == 3 && w.TS == 3) && w.TS != 7 && w.TS != 4))) {
         const float* xa = d->x_amax; const float* ya = d->dy_amax;
-        if (!xa) { if (int e = tensor_amax(x, (int64_t)d->N * d->C_in * d->H * d->W, PASTA_F32, ws_amax, s)) return e; xa = ws_amax; }
+        if (!xa) { if (int e = tensor_amax(x, (int64_t)d->N * d->C_in * d->H * d->W, PASTA_F32, ws_amax, s)) return e; xa = ws_amax; }      // (pieces layout: given, checked above)
         if (!ya) { if (int e = tensor_amax(dy, (int64_t)d->N * d->C_out * d->OH * d->OW, PASTA_F32, ws_amax + AMAX_PARTS, s)) return e; ya = ws_amax + AMAX_PARTS; }
         p.s_amax = d->transposed ? xa : ya;
         p.l_amax = d->transposed ? ya : xa;

@@ -457,6 +457,191 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
 }
 
 //------------------------------------------------------------------------------------
+// Round 5: the stride-2 weight gradient with L given as the producer-written operand (PASTA_LAYOUT_PIECES16, pieces.hip: [N][LC / 8][LH][LW] units of
+// 32 bytes, fp16 h[8] | l'[8] of v S) -- the blurred tensor in front of every stride-2 convolution of the discriminator and the encoders
+// (conv2d_resample.py:119-122), pad 0, PASTA_MATH_F16X3.  conv_wgrad3x3s2_bf16x6_kernel spends 41 % of its wave cycles issuing instructions
+// (profiles/r4_pmc_summary.txt): 24 dword loads and three splits per thread and chunk for the halo, and in the product loop four v_perm per
+// operand to gather every second halo column.  Here
+//   * the halo rows are COPIED: a staging unit is (pixel, channel octet) = two sixteen-byte loads (h, l') and two sixteen-byte LDS stores into a
+//     [piece][ring slot][column][64 channels] image -- the layout of the tensor itself, channels contiguous;
+//   * the operand of tap (r, s) -- K = 16 S pixels x 32 channels b, K-contiguous per lane -- is gathered by the transposed LDS read of gfx950,
+//     ds_read_b64_tr_b16: per group of 16 lanes a block of 4 rows (K: halo columns 2 k + s, i.e. every second column: the stride is just the
+//     rows' addresses) x 16 columns (channels) arrives column-major.  The column pitch is 160 bytes (64 channels + 32 bytes of padding), so the
+//     four rows of a block -- two columns = 320 bytes = 80 dwords apart -- fall on the four quarters of the 64 banks: conflict-free;
+//   * l' is the pre-scaled low piece (2^11 r); the weight gradient's products (S h)(L h) + (S l)(L h) + (S h)(L l) become
+//     (S h)(L h) + (S l)(L h) + (S h'')(L l') with h'' = 2^-11 h formed when S is split (exact down to 2^-3 in the operand's units, i.e. for
+//     elements within 2^-17 of their tensor's largest: the range the arithmetic states for weight-gradient operands, conv_common.h).
+// S (dy, fp32 NCHW) is staged and split as in the kernel above.  Same chunk order, ring of three halo rows, slab layout and reduction.
+// LDS: S [3 pieces][64][16] + L [2][3][34][80] fp16 = 38.8 KB.
+template <int PW>        // the convolution's pad: 0 (the blur in front of it absorbs the padding); a template so that only the unit that launches it holds the kernel
+__global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_pieces_kernel(WgradParams p) {
+    static_assert(PW == 0, "the producer-written operand feeds pad-0 convolutions");
+    constexpr int SP = 16, S_PIECE = 64 * SP;
+    constexpr int LCOLS = 34, LPX = 80, L_ROW = LCOLS * LPX, L_PIECE = 3 * L_ROW;      // halo columns 2 q0 .. 2 q0 + 33 (taps reach 2 q0 + 32)
+    __shared__ __attribute__((aligned(16))) _Float16 Ss[3 * S_PIECE];
+    __shared__ __attribute__((aligned(16))) _Float16 Ls[2 * L_PIECE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave >> 1, wb = wave & 1;
+    const int hl = lane >> 5, jl = lane & 31;
+    float s_scale, l_scale, is_, il_;
+    scale_from_amax(amax_of_parts(p.s_amax), s_scale, is_);
+    scale_from_amax(amax_of_parts(p.l_amax), l_scale, il_);           // the producer's bound row: the S the pieces were written with
+    const float out_scale = is_ * il_;
+
+    int ks, bt, at, g;
+    wgrad_decode(p, ks, bt, at, g);                  // g = 0: one group
+    const int a_blk = at * 64, b_blk = bt * 64;
+    const int PQ = p.P * p.Q;
+    const float* const Sg = p.S + (int64_t)a_blk * PQ;
+    const int LC8 = p.LC >> 3;
+    const char* const Lg = (const char*)p.L + (int64_t)(b_blk >> 3) * p.LH * p.LW * 32;
+
+    auto decode = [&](int ch, int& n, int& qb, int& pp) {
+        const int per_img = p.P * p.qblocks;
+        n = ch / per_img;
+        const int rem = ch - n * per_img;
+        qb = rem / p.P; pp = rem - qb * p.P;
+    };
+    // staging roles: S unit = (channel a, eight pixels), threads 0..127; L units = (column, octet) of one halo row: 34 x 8 = 272 per row,
+    // unit v = tid + 256 j < 544 belongs to new row 1 + v / 272 (the ring holds row 0); octet fastest: eight lanes fill one column's 128 bytes
+    const int s_a = tid >> 1, s_grp = tid & 1;
+    const bool s_on = tid < 128 && a_blk + s_a < p.Ag;
+    int l_k[3], l_col[3], l_oct[3];
+    bool l_on[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int v = tid + 256 * j;
+        l_k[j] = v >= 272 ? 2 : 1;
+        const int u = v - (l_k[j] - 1) * 272;
+        l_col[j] = u >> 3; l_oct[j] = u & 7;
+        l_on[j] = v < 544 && b_blk + 8 * l_oct[j] < p.Bg;
+    }
+    float4 sreg[2];
+    u32x4 lreg[3][2];
+    bool lok[3];
+    // one unit of halo row ly: column lx, octet oct -> (h, l'); false = outside the plane (a zero unit)
+    auto fetch_unit = [&](int n, int ly, int lx, int oct, bool on, u32x4 (&r)[2]) -> bool {
+        const bool ok = on && (unsigned)ly < (unsigned)p.LH && (unsigned)lx < (unsigned)p.LW;
+        const u32x4* src = (const u32x4*)(Lg + ((((int64_t)n * LC8 + oct) * p.LH + (ok ? ly : 0)) * p.LW + (ok ? lx : 0)) * 32);
+        if (!on) src = (const u32x4*)Lg;             // an octet beyond the tensor: any valid address
+        r[0] = src[0]; r[1] = src[1];
+        return ok;
+    };
+    auto stash_unit = [&](const u32x4 (&r)[2], bool ok, int slot, int col, int oct) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        _Float16* const d = Ls + slot * L_ROW + col * LPX + oct * 8;
+        *(u32x4*)d = ok ? r[0] : z;
+        *(u32x4*)(d + L_PIECE) = ok ? r[1] : z;
+    };
+    auto fetch = [&](int ch) {
+        int n, qb, pp;
+        decode(ch, n, qb, pp);
+        const int q0 = qb * 16;
+        if (s_on) {
+            const float* sp = Sg + (int64_t)n * p.SC * PQ + (int64_t)s_a * PQ + pp * p.Q + q0 + 8 * s_grp;
+            sreg[0] = *(const float4*)sp; sreg[1] = *(const float4*)(sp + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            lok[j] = fetch_unit(n, 2 * pp + l_k[j], 2 * q0 + l_col[j], l_oct[j], l_on[j], lreg[j]);
+    };
+    auto slot_of = [](int y) { return y % 3; };          // y >= 0 (pad 0)
+    typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+    auto stash_s = [&]() {
+        if (tid >= 128) return;
+        const float sv[8] = {s_on ? sreg[0].x : 0.f, s_on ? sreg[0].y : 0.f, s_on ? sreg[0].z : 0.f, s_on ? sreg[0].w : 0.f,
+                             s_on ? sreg[1].x : 0.f, s_on ? sreg[1].y : 0.f, s_on ? sreg[1].z : 0.f, s_on ? sreg[1].w : 0.f};
+        uint32_t qh[4], ql[4], qs[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            f16_split2_direct(sv[2 * j] * s_scale, sv[2 * j + 1] * s_scale, qh[j], ql[j]);
+            const f16x2v h2 = __builtin_bit_cast(f16x2v, qh[j]);
+            const f16x2v k2 = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};       // 2^-11: an exponent shift
+            qs[j] = __builtin_bit_cast(uint32_t, h2 * k2);
+        }
+        _Float16* const d = Ss + s_a * SP + 8 * s_grp;
+        *(uint4*)d = make_uint4(qh[0], qh[1], qh[2], qh[3]);
+        *(uint4*)(d + S_PIECE) = make_uint4(ql[0], ql[1], ql[2], ql[3]);
+        *(uint4*)(d + 2 * S_PIECE) = make_uint4(qs[0], qs[1], qs[2], qs[3]);
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+
+    // transposed reads: lane 4 q + c of a 16-lane group supplies the address of block row q (K), columns 4 c .. 4 c + 3 (channels); the group's
+    // lane i receives column i, row q in element q.  Group (lane >> 4): channels 16 (grp & 1) .. + 15 of this wave's 32, K block 8 (grp >> 1) (= 8 hl)
+    const int tq = (lane >> 2) & 3, tc = lane & 3, tgrp = lane >> 4;
+    const _Float16* const lbase = Ls + (2 * (8 * (tgrp >> 1) + tq)) * LPX + wb * 32 + 16 * (tgrp & 1) + 4 * tc;
+    typedef __fp16 v4h __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4h* lds_v4h;
+
+    const int c_begin = (int)((int64_t)p.chunks_total * ks / p.ksplit);
+    const int c_end = (int)((int64_t)p.chunks_total * (ks + 1) / p.ksplit);
+    if (c_begin < c_end) fetch(c_begin);
+    for (int ch = c_begin; ch < c_end; ch++) {
+        int n_c, qb_c, pp_c;
+        decode(ch, n_c, qb_c, pp_c);
+        const int y0 = 2 * pp_c;
+        __syncthreads();                  // the previous chunk's fragment reads are done
+        if (pp_c == 0 || ch == c_begin) { // a column block or this K slice begins: the first halo row is not in the ring yet (272 units: tid, and 256 + tid for 16 threads)
+            u32x4 t[2];
+            bool ok = fetch_unit(n_c, y0, 2 * qb_c * 16 + (tid >> 3), tid & 7, b_blk + 8 * (tid & 7) < p.Bg, t);
+            stash_unit(t, ok, slot_of(y0), tid >> 3, tid & 7);
+            if (tid < 16) {
+                ok = fetch_unit(n_c, y0, 2 * qb_c * 16 + 32 + (tid >> 3), tid & 7, b_blk + 8 * (tid & 7) < p.Bg, t);
+                stash_unit(t, ok, slot_of(y0), 32 + (tid >> 3), tid & 7);
+            }
+        }
+        stash_s();
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            if (tid + 256 * j < 544) stash_unit(lreg[j], lok[j], slot_of(y0 + l_k[j]), l_col[j], l_oct[j]);
+        __syncthreads();
+        if (ch + 1 < c_end) fetch(ch + 1);
+        const int slot0 = slot_of(y0);
+        bf16x8 af[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; pc++) af[pc] = *(const bf16x8*)&Ss[pc * S_PIECE + (wa * 32 + jl) * SP + 8 * hl];
+#pragma unroll
+        for (int row = 0; row < 3; row++) {
+            const int slot = slot0 + row >= 3 ? slot0 + row - 3 : slot0 + row;
+            const _Float16* const lrow = lbase + slot * L_ROW;
+#pragma unroll
+            for (int ts = 0; ts < 3; ts++) {
+                // K rows 8 hl + q and 8 hl + 4 + q of tap column ts: halo columns 2 k + ts
+                const v4h h0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_v4h)(lrow + ts * LPX));
+                const v4h h1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_v4h)(lrow + (8 + ts) * LPX));
+                const v4h l0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_v4h)(lrow + L_PIECE + ts * LPX));
+                const v4h l1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_v4h)(lrow + L_PIECE + (8 + ts) * LPX));
+                typedef __fp16 v8h __attribute__((ext_vector_type(8)));
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+                const int tap = row * 3 + ts;
+                acc[tap] = mfma16<IO_F32, NP_F16X3>(af[2], bl, acc[tap]);       // (S h'')(L l'): the smallest term first
+                acc[tap] = mfma16<IO_F32, NP_F16X3>(af[1], bh, acc[tap]);       // (S l)(L h)
+                acc[tap] = mfma16<IO_F32, NP_F16X3>(af[0], bh, acc[tap]);       // (S h)(L h)
+            }
+        }
+    }
+
+    const int Ag_pad = p.a_tiles * 64, Bg_pad = p.b_tiles * 64;
+    float* out = p.slab + (int64_t)ks * 9 * Ag_pad * Bg_pad;
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        float* ot = out + (int64_t)t * Ag_pad * Bg_pad;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int a = a_blk + wa * 32 + acc_row(r, lane), b = b_blk + wb * 32 + jl;
+            ot[(int64_t)a * Bg_pad + b] = acc[t][r] * out_scale;
+        }
+    }
+}
+
+//------------------------------------------------------------------------------------
 // 1x1, stride 1, no padding (the residual skips, ToRGB-side merges and the discriminator's fromrgb/skip convolutions):
 // a plain GEMM dW[a][b] = sum_pix S[a][pix] * L[b][pix] over K = all pixels, both operands pixel-contiguous.  Same
 // split-bf16 arithmetic; workgroup tile (64 WA) x (64 WB) channels, every wave WA x WB tiles of 32 x 32; K chunk = 32

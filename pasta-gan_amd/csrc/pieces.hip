@@ -1,0 +1,165 @@
+// Producer-written operand pieces (round 5): the 4x4 low-pass in front of a stride-2 convolution (conv2d_resample.py:119-122) writes its
+// output ONCE, as the matrix-core operand of the three-product fp16 arithmetic (conv_common.h, PASTA_MATH_F16X3), instead of as an fp32 NCHW
+// tensor that each consumer launch -- the stride-2 forward convolution and its weight gradient -- fetches with eight channel-strided dword
+// loads per staging unit and splits with ~20 VALU instructions per unit, launch after launch.
+//
+// Layout PASTA_LAYOUT_PIECES16 of a logical [N, C, H, W] tensor (C a multiple of 8):
+//     unit (n, c / 8, y, x) = 32 bytes:  h[8] = fp16(v S)  |  l'[8] = fp16(2^11 (v S - h))      for the eight channels 8 (c / 8) .. + 7
+//     units in the order [N][C / 8][H][W]: a row of W units is 32 W contiguous bytes, every unit 32-byte aligned whatever W is (the
+//     fp32 planes of 257 columns are not even 16-byte aligned from row to row, and their odd pitch is what holds the fp32 blur at 0.32 of
+//     the HBM rate: profiles/r4_hbm_microbench.txt)
+// 4 bytes per logical element, like fp32.  S is the power of two that scale_from_amax() takes from a BOUND of the output's magnitude that
+// is known before the blur starts: the 256 partial maxima of the blur's INPUT (the producer row its writer left, or one scan) times
+// gain * sum |f| (1 for the normalised low-pass of the networks).  The kernel leaves that bound as a 256-float row of its own (y_amax), and
+// the consumer, handed the row, derives the same S (a maximum commutes with the multiplication by a positive constant, bit for bit).
+// Because S is a power of two, v S, h and l' scale exactly with it: the consumer's result does not depend on WHICH admissible S was used
+// (tests/test_pieces_gpu.py halves and doubles it), as long as nothing overflows (S too large) or leaves fp16's normal range (S too small).
+//
+// Kernel: one workgroup = 8 channels x (8 rows x 64 columns) of outputs.  The 8 x 11 x 67 input footprint is staged in LDS with row-coalesced
+// loads, a thread computes two rows of one column for the eight channels (sixteen 16-tap sums, the taps in the order of upfirdn2d_tile_kernel:
+// the fp32 value in front of the split is bit-identical to pasta_upfirdn2d's) and stores two 32-byte units: a wave writes 2 KB contiguous.
+// Planes of 64 k + 1 columns (257, 129, 65: every live shape) are covered by k tile columns whose last thread column computes the extra one.
+#include "conv_common.h"
+
+namespace pasta {
+
+struct BlurPiecesParams {
+    const float* x; const float* f; void* pieces; const float* parts; float* bound;
+    int N, C, H, W, OH, OW, padx0, pady0, flip;
+    float gain;
+};
+
+template <int TOW, int TOH>
+__global__ __launch_bounds__(256) void blur_pieces_kernel(BlurPiecesParams p, int tiles_x, int tiles_y, int rem_x) {
+    static_assert(TOW == 64 && TOH == 8, "thread map: 64 columns x 4 row pairs");
+    constexpr int TIW = TOW + 4, TIH = TOH + 3, LDW = TIW | 1;         // one more column for the remainder column of the last tile
+    __shared__ float sx[8][TIH][LDW];
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    int b = blockIdx.x;
+    const int tile_x = b % tiles_x; b /= tiles_x;
+    const int tile_y = b % tiles_y; b /= tiles_y;
+    const int C8 = p.C >> 3;
+    const int c8 = b % C8, n = b / C8;
+
+    float g[4][4];
+    float fsum = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) { g[a][c] = p.f[(p.flip ? a : 3 - a) * 4 + (p.flip ? c : 3 - c)]; fsum += fabsf(p.f[a * 4 + c]); }
+    const float bmul = fsum * fabsf(p.gain);          // |y| <= bmul max |x|
+    float sc, isc;
+    scale_from_amax(amax_of_parts(p.parts) * bmul, sc, isc);
+    if (blockIdx.x == 0) p.bound[tid] = p.parts[tid] * bmul;         // the row the consumers take the same S from
+
+    const int ix0 = tile_x * TOW - p.padx0, iy0 = tile_y * TOH - p.pady0;
+    const float* const xp = p.x + ((int64_t)n * p.C + (int64_t)c8 * 8) * p.H * p.W;
+    constexpr int NEL = 8 * TIH * TIW, NLOAD = (NEL + 255) / 256;
+    float stage[NLOAD];
+#pragma unroll
+    for (int j = 0; j < NLOAD; j++) {                  // every load of the thread in flight before the first LDS store
+        const int e = tid + 256 * j;
+        const int ch = e / (TIH * TIW), r = e - ch * (TIH * TIW);
+        const int row = r / TIW, col = r - row * TIW;
+        const int iy = iy0 + row, ix = ix0 + col;
+        float v = 0.f;
+        if (e < NEL && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v = xp[((int64_t)ch * p.H + iy) * p.W + ix];
+        stage[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NLOAD; j++) {
+        const int e = tid + 256 * j;
+        const int ch = e / (TIH * TIW), r = e - ch * (TIH * TIW);
+        const int row = r / TIW, col = r - row * TIW;
+        if (e < NEL) sx[ch][row][col] = stage[j];
+    }
+    __syncthreads();
+
+    char* const out = (char*)p.pieces + (((int64_t)n * C8 + c8) * p.OH) * (int64_t)p.OW * 32;
+    auto one = [&](int yy, int xx) {                    // output (yy, xx) relative to the tile origin, eight channels -> one 32-byte unit
+        const int oy = tile_y * TOH + yy, ox = tile_x * TOW + xx;
+        if (oy >= p.OH || ox >= p.OW) return;
+        uint32_t h[4], l[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float v[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                float a = 0.f;
+#pragma unroll
+                for (int jy = 0; jy < 4; jy++)
+#pragma unroll
+                    for (int jx = 0; jx < 4; jx++) a = fmaf(g[jy][jx], sx[2 * q + k][yy + jy][xx + jx], a);
+                v[k] = a * p.gain;
+            }
+            f16_split2(v[0] * sc, v[1] * sc, h[q], l[q]);
+        }
+        uint4* const d = (uint4*)(out + ((int64_t)oy * p.OW + ox) * 32);
+        d[0] = make_uint4(h[0], h[1], h[2], h[3]);
+        d[1] = make_uint4(l[0], l[1], l[2], l[3]);
+    };
+    one(2 * ty, tx);
+    one(2 * ty + 1, tx);
+    if (rem_x && tile_x == tiles_x - 1 && tx == TOW - 1) {
+        one(2 * ty, TOW);
+        one(2 * ty + 1, TOW);
+    }
+}
+
+// v = (h + 2^-11 l') / S per element, back to fp32 NCHW (tests, diagnostics; the operand's 22 bits, not the blur's 24)
+__global__ __launch_bounds__(256) void pieces_unpack_kernel(const void* pieces, const float* parts, float* y, int N, int C, int H, int W) {
+    float sc, isc;
+    scale_from_amax(amax_of_parts(parts), sc, isc);
+    const int64_t units = (int64_t)N * (C >> 3) * H * W;
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (int64_t)gridDim.x * 256) {
+        const uint4 hq = ((const uint4*)pieces)[2 * u], lq = ((const uint4*)pieces)[2 * u + 1];
+        const f16x8 h = __builtin_bit_cast(f16x8, hq), l = __builtin_bit_cast(f16x8, lq);
+        const int64_t x = u % W, r = u / W;
+        const int64_t yy = r % H, r2 = r / H;
+        const int64_t c8 = r2 % (C >> 3), n = r2 / (C >> 3);
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            y[((n * C + c8 * 8 + j) * H + yy) * W + x] = ((float)h[j] + (float)l[j] * (1.f / 2048.f)) * isc;
+    }
+}
+
+}  // namespace pasta
+
+extern "C" int64_t pasta_pieces_bytes(int N, int C, int H, int W) {
+    if (N < 1 || C < 8 || (C & 7) || H < 1 || W < 1) return -1;
+    return (int64_t)N * (C >> 3) * H * W * 32;
+}
+
+extern "C" int pasta_blur_pieces(const float* x, const float* f, void* pieces, const float* x_amax, float* y_amax, int N, int C, int H, int W,
+                                 int padx0, int padx1, int pady0, int pady1, int flip, float gain, void* stream) {
+    using namespace pasta;
+    PASTA_CHECK(x && f && pieces && x_amax && y_amax, "blur_pieces: null pointer (the partial maxima of x are required: they fix the operand scale)");
+    PASTA_CHECK(N >= 1 && C >= 8 && (C & 7) == 0 && H >= 1 && W >= 1, "blur_pieces: [%d, %d, %d, %d]: the channel count must be a multiple of 8", N, C, H, W);
+    BlurPiecesParams p;
+    p.x = x; p.f = f; p.pieces = pieces; p.parts = x_amax; p.bound = y_amax;
+    p.N = N; p.C = C; p.H = H; p.W = W;
+    p.OW = W + padx0 + padx1 - 3; p.OH = H + pady0 + pady1 - 3;
+    PASTA_CHECK(p.OW >= 1 && p.OH >= 1, "blur_pieces: output must be at least 1x1");
+    PASTA_CHECK((int64_t)N * C * H * W <= INT32_MAX && (int64_t)N * C * p.OH * p.OW <= INT32_MAX, "blur_pieces: tensor too large");
+    p.padx0 = padx0; p.pady0 = pady0; p.flip = flip ? 1 : 0; p.gain = gain;
+    constexpr int TOW = 64, TOH = 8;
+    int tiles_x = (p.OW + TOW - 1) / TOW;
+    const int rem_x = (p.OW > TOW && p.OW % TOW == 1) ? 1 : 0;
+    tiles_x -= rem_x;
+    const int tiles_y = (p.OH + TOH - 1) / TOH;
+    const int64_t blocks = (int64_t)tiles_x * tiles_y * (C >> 3) * N;
+    PASTA_CHECK(blocks <= INT32_MAX, "blur_pieces: grid too large");
+    hipLaunchKernelGGL((blur_pieces_kernel<TOW, TOH>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, tiles_x, tiles_y, rem_x);
+    return launch_status("blur_pieces");
+}
+
+extern "C" int pasta_pieces_unpack(const void* pieces, const float* x_amax, float* y, int N, int C, int H, int W, void* stream) {
+    using namespace pasta;
+    PASTA_CHECK(pieces && x_amax && y, "pieces_unpack: null pointer");
+    PASTA_CHECK(N >= 1 && C >= 8 && (C & 7) == 0 && H >= 1 && W >= 1, "pieces_unpack: [%d, %d, %d, %d]: the channel count must be a multiple of 8", N, C, H, W);
+    const int64_t units = (int64_t)N * (C >> 3) * H * W;
+    int64_t blocks = ceil_div64(units, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pieces_unpack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pieces, x_amax, y, N, C, H, W);
+    return launch_status("pieces_unpack");
+}

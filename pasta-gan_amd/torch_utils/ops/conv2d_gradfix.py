@@ -195,7 +195,7 @@ launch_hook = None
 def _f32(t):
     return t if t.dtype == torch.float32 else t.float()
 
-def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, noise=None, x2=None, used=None):
+def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, noise=None, x2=None, used=None, pieces=None):
     """y = conv(x * iscale[n,c]) * oscale[n,c'] through ``pasta_conv2d_ex``; fp32 accumulation.  fp32 tensors run the
     split-bf16 (fp32-equivalent) or fp32 matrix-core kernels; fp16 / bf16 tensors stay 16-bit in HBM where a kernel exists
     (``_native16``) and are converted for the launch otherwise.
@@ -208,8 +208,13 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, 
     ``cat([x, x2], 1)`` without forming it (``pasta_conv_desc.x2``).
     ``used`` (dict, optional): receives ``'x_amax'`` / ``'x2_amax'`` = the partial maxima the launch took for its activations, so that the
     autograd node can hand them to the weight gradient of the SAME saved tensor (a saved non-leaf tensor comes back from autograd as a new
-    Python object without the attribute the maxima travel on: it would be scanned a second time)."""
+    Python object without the attribute the maxima travel on: it would be scanned a second time).
+    ``pieces`` = (bound row [256], logical shape (N, C, H, W)): ``x`` is not an NCHW tensor but the producer-written operand of the three-product
+    arithmetic (``blur_pieces``: PASTA_LAYOUT_PIECES16, include/pasta_hip.h) -- the launch copies its sixteen-byte pieces instead of splitting."""
     _native.require_gpu(x, 'conv2d')
+    if pieces is not None:
+        assert iscale is None and oscale is None and wmod is None and noise is None and x2 is None
+        return _launch_conv_pieces(x, w, cfg, epilogue, pieces)
     if x.ndim != 4 or w.ndim != 4:
         raise RuntimeError('conv2d: x and w must be rank 4')
     out_dtype = x.dtype
@@ -313,6 +318,145 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, 
     if y_row is not None and y.dtype == out_dtype:
         _native.amax_attach(y, y_row)
     return y.to(out_dtype)
+
+# ---- producer-written operand pieces (round 5; csrc/pieces.hip, include/pasta_hip.h "Producer-written operand pieces") --------------------
+# The low-pass in front of a stride-2 convolution (reference conv2d_resample.py:119-122) has ONE reader besides that convolution's weight
+# gradient, and its magnitude is bounded by its input's: it can write its output once as the fp16 pieces h | l' of the three-product
+# arithmetic (32-byte units of eight channels, [N][C / 8][H][W]), and both consumers copy pieces instead of fetching fp32 with eight
+# channel-strided loads per unit and splitting it -- in every launch that touches the tensor.
+_PIECES = _os.environ.get('PASTA_PIECES', '1') != '0'       # A/B switch: 0 = fp32 blurred tensor, as before
+_pieces_cache = {}
+
+def pieces_available(x, f, weight, pad4, groups=1):
+    """Can ``conv2d(upfirdn2d(x, f, padding=pad4), weight, stride=2)`` run on the blurred tensor as producer-written pieces (forward kernel 10 and
+    weight-gradient kernel 6 of the planners)?  fp32 tensors, the default arithmetic, a 4 x 4 filter, whole channel octets."""
+    if not (_PIECES and x.device.type == 'cuda' and x.dtype == torch.float32 and weight.dtype == torch.float32 and conv_math in ('default', 'f16x3')
+            and groups == 1 and f is not None and f.ndim == 2 and tuple(f.shape) == (4, 4) and x.ndim == 4 and x.shape[1] % 8 == 0
+            and tuple(weight.shape[2:]) == (3, 3) and weight.shape[1] == x.shape[1] and x.numel() > 0 and _SCOPE == 'all'):
+        return False
+    px0, px1, py0, py1 = pad4
+    n, c, h, wd = (int(v) for v in x.shape)
+    bh, bw = h + py0 + py1 - 3, wd + px0 + px1 - 3
+    key = (n, c, bh, bw, int(weight.shape[0]))
+    hit = _pieces_cache.get(key)
+    if hit is None:
+        hit = False
+        if bh >= 3 and bw >= 3:
+            cfg = _Cfg((False, 2, 0, 0, 0, 0, 1, 1.0))
+            oh, ow = _out_hw(cfg, bh, bw, 3, 3)
+            desc = _desc(cfg, (n, c, bh, bw), int(weight.shape[0]), oh, ow, 3, 3)
+            desc.x_layout = 1
+            lib, k = _native.lib(), ctypes.c_int()
+            hit = lib.pasta_conv2d_plan(ctypes.byref(desc), 4, None, None, None, None, ctypes.byref(k)) == 0 and k.value == 10
+            hit = hit and lib.pasta_conv2d_wgrad_plan(ctypes.byref(desc), ctypes.byref(k)) == 0 and k.value == 6
+        _pieces_cache[key] = hit
+    return hit
+
+def blur_pieces(x, f, pad4, flip_filter=False, gain=1.0, x_amax=None):
+    """``upfirdn2d(x, f, padding=pad4, flip_filter, gain)`` for a 4 x 4 filter, written as PASTA_LAYOUT_PIECES16.  Returns (pieces -- a uint8
+    tensor of N * C / 8 * OH * OW * 32 bytes --, bound row [256] fp32, logical shape (N, C, OH, OW)); the bound row is ``x_amax`` (the partial
+    maxima of x: its producer's row, or one scan) times gain * sum |f| and fixes the operand's power-of-two scale on both sides."""
+    _native.require_gpu(x, 'blur_pieces')
+    x = x.contiguous()
+    n, c, h, wd = (int(v) for v in x.shape)
+    px0, px1, py0, py1 = pad4
+    oh, ow = h + py0 + py1 - 3, wd + px0 + px1 - 3
+    lib = _native.lib()
+    nbytes = lib.pasta_pieces_bytes(n, c, oh, ow)
+    if nbytes < 0 or oh < 1 or ow < 1:
+        raise RuntimeError(f'blur_pieces: {tuple(x.shape)} -> {oh} x {ow}: the channel count must be a multiple of 8 and the output at least 1 x 1')
+    parts = tensor_amax(x) if x_amax is None else x_amax
+    pieces = torch.empty([nbytes], dtype=torch.uint8, device=x.device)
+    bound = torch.empty([AMAX_PARTS], dtype=torch.float32, device=x.device)
+    f = f.contiguous()
+    def launch():
+        with torch.cuda.device(x.device):
+            _native.check(lib.pasta_blur_pieces(_native.ptr(x), _native.ptr(f), _native.ptr(pieces), _native.ptr(parts), _native.ptr(bound), n, c, h, wd,
+                                                int(px0), int(px1), int(py0), int(py1), int(bool(flip_filter)), float(gain), _native.stream()))
+    from . import upfirdn2d as _up
+    if _up.launch_hook is None:
+        launch()
+    else:       # algorithmic bytes: fp32 in, 4 bytes per element out (two fp16 pieces)
+        _up.launch_hook((x.numel() + n * c * oh * ow) * 4, (tuple(x.shape), 1, 1, 4, 'pieces'), launch)
+    return pieces, bound, (n, c, oh, ow)
+
+def pieces_unpack(pieces, bound, shape):
+    """(h + 2^-11 l') / S as an fp32 NCHW tensor (tests, diagnostics): the 22 bits the consumers multiply."""
+    n, c, h, wd = shape
+    y = torch.empty([n, c, h, wd], dtype=torch.float32, device=pieces.device)
+    with torch.cuda.device(pieces.device):
+        _native.check(_native.lib().pasta_pieces_unpack(_native.ptr(pieces), _native.ptr(bound), _native.ptr(y), n, c, h, wd, _native.stream()))
+    return y
+
+def _launch_conv_pieces(x, w, cfg, epilogue, pieces):
+    """The stride-2 forward convolution on a producer-written operand (``_launch_conv`` with ``pieces``)."""
+    bound, (n, c_in, h, wd) = pieces
+    w = _f32(w).contiguous()
+    kh, kw = w.shape[2], w.shape[3]
+    assert not cfg.transposed and cfg.groups == 1 and w.shape[1] == c_in
+    c_out = w.shape[0]
+    oh, ow = _out_hw(cfg, h, wd, kh, kw)
+    y = torch.empty([n, c_out, oh, ow], dtype=torch.float32, device=x.device)
+    desc = _desc(cfg, (n, c_in, h, wd), c_out, oh, ow, kh, kw)
+    desc.x_layout, desc.x_amax = 1, bound.data_ptr()
+    lib = _native.lib()
+    nbytes = lib.pasta_conv2d_workspace(ctypes.byref(desc))
+    if nbytes < 0:
+        _native.check(1)
+    work = torch.empty([max(nbytes // 4, 4)], dtype=torch.float32, device=x.device)
+    ep = y_row = None
+    if epilogue is not None:
+        bias, act_code, alpha, gain, clamp = epilogue[:5]
+        res = epilogue[5] if len(epilogue) > 5 else None
+        bias = _f32(bias).contiguous() if bias is not None else None
+        if res is not None:
+            res = res.float().contiguous()
+            if res.shape != y.shape:
+                raise RuntimeError(f'conv2d: residual {tuple(res.shape)} does not match the output {tuple(y.shape)}')
+        ep = custom_ops.ConvEpilogue(bias=bias.data_ptr() if bias is not None else None, act=int(act_code), alpha=float(alpha), gain=float(gain),
+                                     clamp=float(clamp), res=res.data_ptr() if res is not None else None, noise=None, noise_strength=None, noise_per_sample=0)
+        y_row = _native.amax_slot(y)
+        if y_row is not None:
+            ep.y_amax = y_row.data_ptr()
+    def launch():
+        with torch.cuda.device(x.device):
+            st = lib.pasta_conv2d_ex(_native.ptr(x), _native.ptr(w), _native.ptr(y), None, None, ctypes.byref(ep) if ep is not None else None,
+                                     ctypes.byref(desc), _native.ptr(work), work.numel() * 4, _native.stream())
+        _native.check(st)
+    if launch_hook is None:
+        launch()
+    else:
+        launch_hook('conv', desc, launch, 4 if ep is not None else 0)
+    _check_finite(y, 'conv2d')
+    if y_row is not None:
+        _native.amax_attach(y, y_row)
+    return y
+
+def _launch_wgrad_pieces(pieces_x, dy, cfg, w_shape, pieces, out_dtype=None):
+    """dw of the stride-2 convolution whose input is a producer-written operand (pasta_conv2d_wgrad_plan kernel 6)."""
+    bound, (n, c_in, h, wd) = pieces
+    out_dtype = dy.dtype if out_dtype is None else out_dtype
+    dy = _f32(dy).contiguous()
+    dw = torch.empty(list(w_shape), dtype=torch.float32, device=dy.device)
+    desc = _desc(cfg, (n, c_in, h, wd), dy.shape[1], dy.shape[2], dy.shape[3], w_shape[2], w_shape[3], kind='wgrad')
+    desc.x_layout, desc.x_amax = 1, bound.data_ptr()
+    amax_dy = tensor_amax(dy)
+    desc.dy_amax = amax_dy.data_ptr()
+    lib = _native.lib()
+    nbytes = lib.pasta_conv2d_wgrad_workspace(ctypes.byref(desc))
+    if nbytes < 0:
+        _native.check(1)
+    work = torch.empty([max(nbytes // 4, 4)], dtype=torch.float32, device=dy.device)
+    def launch():
+        with torch.cuda.device(dy.device):
+            st = lib.pasta_conv2d_wgrad(_native.ptr(pieces_x), _native.ptr(dy), _native.ptr(dw), ctypes.byref(desc), _native.ptr(work), work.numel() * 4, _native.stream())
+        _native.check(st)
+    if launch_hook is None:
+        launch()
+    else:
+        launch_hook('wgrad', desc, launch, 0)
+    _check_finite(dw, 'conv2d_wgrad')
+    return dw.to(out_dtype)
 
 def _launch_wgrad(x, dy, cfg, w_shape, out_dtype=None, x_amax=None):
     """dw of ``conv(x, w)`` given dy through ``pasta_conv2d_wgrad``; the gradient comes out fp32 (weights are fp32 masters)
@@ -444,6 +588,91 @@ class _ConvBiasActHip(torch.autograd.Function):
             db = ba._BiasSum.apply(dz, 1)
         dres = dz if ctx.needs_input_grad[5] else None     # the residual enters before the activation
         return dx, dw, db, None, None, dres, None
+
+class _BlurConvS2Hip(torch.autograd.Function):
+    """``bias_act(conv2d(upfirdn2d(x, f, padding), w, stride=2) [+ res], b)`` -- the down path of conv2d_resample (reference :119-122 followed by the
+    layer's bias_act) -- with the blurred tensor written once as the operand pieces of the default arithmetic (``blur_pieces``) instead of as an
+    fp32 tensor: the forward convolution and, in the backward, the weight gradient copy pieces.  The backward is assembled from the stand-alone
+    differentiable operators (conv_transpose2d for the input gradient, the mirrored filter behind it), so gradients of any order keep working;
+    where a gradient OF the weight gradient may be asked for (a backward pass that records a graph: R1), the weight gradient is formed from the
+    fp32 blurred tensor recomputed from ``x`` by the differentiable operators instead.  ``passthrough`` as in ``_ConvBiasActHip``: the filter is
+    what reads ``x``, and the other consumers' gradient is the addend of its backward launch."""
+    @staticmethod
+    def forward(ctx, x, f, w, b, ucfg, cfg, act_cfg, res=None, passthrough=False):
+        act, alpha, gain, clamp = act_cfg
+        from . import bias_act as ba
+        px0, px1, py0, py1, flip, ugain = ucfg
+        pieces, bound, shape = blur_pieces(x, f, (px0, px1, py0, py1), flip, ugain)
+        y = _launch_conv(pieces, w, cfg, epilogue=(b, ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, res), pieces=(bound, shape))
+        if ba.slope_tape is not None:               # test instrument (bias_act.SlopeTape)
+            y = ba.slope_tape.visit(y, act)
+        keep_y = act != 'linear' or clamp >= 0
+        ctx.save_for_backward(x, f, w, b, y if keep_y else None, pieces, bound)
+        ctx.ucfg, ctx.cfg, ctx.act_cfg, ctx.shape = ucfg, cfg, act_cfg, shape
+        if passthrough:
+            ctx.set_materialize_grads(False)
+            return y, x
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, dxp=None):
+        from . import bias_act as ba
+        from . import upfirdn2d as up
+        x, f, w, b, y, pieces, bound = ctx.saved_tensors
+        if dy is None:
+            return dxp, None, None, None, None, None, None, None, None
+        act, alpha, gain, clamp = ctx.act_cfg
+        cfg, shape = ctx.cfg, ctx.shape
+        px0, px1, py0, py1, flip, ugain = ctx.ucfg
+        dz = dy
+        dx = dw = db = None
+        want_db = b is not None and ctx.needs_input_grad[3]
+        if act != 'linear' or gain != 1 or clamp >= 0:
+            if want_db:
+                dz, db = ba.grad_with_bias_grad(dy.contiguous(), y, (1, act, alpha, gain, clamp))
+            else:
+                dz = ba._BiasActHipGrad.apply(dy.contiguous(), None, None, y, (1, act, alpha, gain, clamp))
+        if ctx.needs_input_grad[0]:
+            gcfg = _grad_cfg(cfg, shape[2:], dz.shape[2:], w.shape[2], w.shape[3])
+            dxb = _ConvHip.apply(dz, w, gcfg)                   # gradient of the blurred tensor
+            assert tuple(dxb.shape) == tuple(shape)
+            ih, iw = x.shape[2], x.shape[3]
+            ucfg_t = (1, 1, 1, 1, 3 - px0, iw - shape[3] + px0, 3 - py0, ih - shape[2] + py0, not flip, ugain)      # upfirdn2d._Upfirdn2dHip.backward, up = down = 1, 4 taps
+            dx = up._Upfirdn2dHip.apply(dxb, f, ucfg_t, dxp) if dxp is not None else up._Upfirdn2dHip.apply(dxb, f, ucfg_t)
+            assert dx.shape == x.shape
+        elif dxp is not None:
+            dx = dxp
+        if ctx.needs_input_grad[2] and not weight_gradients_disabled:
+            if torch.is_grad_enabled():             # a graph of this backward pass is being recorded: keep everything differentiable
+                xb = up._Upfirdn2dHip.apply(x, f, (1, 1, 1, 1, px0, px1, py0, py1, flip, ugain))
+                dw = _ConvWgradHip.apply(dz, xb, cfg, tuple(w.shape), w.dtype, None)
+            else:
+                dw = _launch_wgrad_pieces(pieces, dz, cfg, tuple(w.shape), (bound, shape), w.dtype)
+        if want_db and db is None:
+            db = ba._BiasSum.apply(dz, 1)
+        dres = dz if ctx.needs_input_grad[7] else None
+        return dx, None, dw, db, None, None, None, dres, None
+
+def blur_conv2d_s2_bias_act(x, f, weight, pad4, flip_filter=False, bias=None, act='linear', alpha=None, gain=None, clamp=None, wgain=1.0,
+                            residual=None, passthrough=False):
+    """``bias_act(conv2d(upfirdn2d(x, f, padding=pad4, flip_filter=flip_filter), weight, stride=2) [+ residual], bias, ...)`` with the blurred
+    tensor as producer-written operand pieces (``pieces_available`` says whether the kernels exist for these shapes)."""
+    from . import bias_act as ba
+    spec = ba.activation_funcs[act]
+    alpha = float(alpha if alpha is not None else spec.def_alpha)
+    gain = float(gain if gain is not None else spec.def_gain)
+    clampf = float(clamp if clamp is not None else -1)
+    assert act in FUSABLE_ACTS
+    cfg = _Cfg((False, 2, 0, 0, 0, 0, 1, float(wgain)))
+    ucfg = (int(pad4[0]), int(pad4[1]), int(pad4[2]), int(pad4[3]), bool(flip_filter), 1.0)
+    if passthrough and torch.is_grad_enabled() and x.requires_grad:
+        y, again = _BlurConvS2Hip.apply(x, f, weight, bias, ucfg, cfg, (act, alpha, gain, clampf), residual, True)
+        hit = getattr(x, '_pasta_amax', None)
+        if hit is not None and not again.is_inference():
+            again._pasta_amax = hit
+        return y, again
+    y = _BlurConvS2Hip.apply(x, f, weight, bias, ucfg, cfg, (act, alpha, gain, clampf), residual)
+    return (y, x) if passthrough else y
 
 _LINEAR_EPILOGUE = ('linear', 0.0, 1.0, -1.0)      # (act, alpha, gain, clamp) of an epilogue that only adds the residual
 

@@ -68,6 +68,11 @@ def conv2d_resample_bias_act(x, w, b=None, f=None, up=1, down=1, padding=0, grou
                 x, again = x
             y = conv2d_gradfix.conv2d_bias_act(x, wc, b, groups=groups, act=act, alpha=alpha, gain=gain, clamp=clamp, wgain=wgain, residual=residual)
             return (y, again) if passthrough else y
+        if down == 2 and conv2d_gradfix.pieces_available(x, f, wc, (px0, px1, py0, py1), groups):
+            # round 5: the low-pass writes the operand pieces of the default arithmetic instead of an fp32 tensor; the strided convolution and
+            # its weight gradient copy them (conv2d_gradfix._BlurConvS2Hip)
+            return conv2d_gradfix.blur_conv2d_s2_bias_act(x, f, wc, (px0, px1, py0, py1), flip_filter=flip_filter, bias=b, act=act, alpha=alpha, gain=gain,
+                                                          clamp=clamp, wgain=wgain, residual=residual, passthrough=passthrough)
         if down > 1:                                  # low-pass, then the fused strided convolution
             x = upfirdn2d.upfirdn2d(x=x, f=f, padding=[px0, px1, py0, py1], flip_filter=flip_filter, passthrough=passthrough)
             if passthrough:

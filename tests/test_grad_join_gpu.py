@@ -140,7 +140,7 @@ def test_layer_sum_with_passthrough():
     from training import networks
     g = torch.Generator().manual_seed(6)
     x = torch.randn([2, 16, 16, 16], generator=g).cuda().requires_grad_(True)
-    for kwargs in (dict(bias=False), dict(bias=True, activation='lrelu')):
+    for kwargs in (dict(bias=False), dict(bias=True)):      # (fused in the epilogue; `add_` on the layer's output, as the reference writes it: linear layers only -- an activation's saved output must not be written)
         layer = networks.Conv2dLayer(16, 32, kernel_size=1, **kwargs).cuda()
         add = torch.randn([2, 32, 16, 16], generator=g).cuda()
         want = layer(x) + add
