@@ -49,7 +49,7 @@ def bf16x6_pair_names():    # stride-2 conv_transpose2d on the row-reuse kernel'
 
 TILE_NAMES = {0: 'conv_fwd_kernel<128,128,2,2,8,4>', 1: 'conv_fwd_kernel<64,256,2,2,8,4>',
               2: 'conv_fwd_kernel<32,256,1,2,8>', 3: 'conv_fwd_kernel<64,64,1,1,8>'}
-WGRAD_NAMES = {0: 'conv_wgrad_kernel', 1: 'conv_wgrad_smallcin_kernel', 2: 'conv_wgrad3x3_bf16x6_kernel', 3: 'conv_wgrad3x3s2_bf16x6_kernel', 4: 'conv_wgrad1x1_bf16x6_kernel', 5: 'wgrad1x1_fewcin_kernel'}
+WGRAD_NAMES = {0: 'conv_wgrad_kernel', 1: 'conv_wgrad_smallcin_kernel', 2: 'conv_wgrad3x3_bf16x6_kernel', 3: 'conv_wgrad3x3s2_bf16x6_kernel', 4: 'conv_wgrad1x1_bf16x6_kernel', 5: 'wgrad1x1_fewcin_kernel', 6: 'conv_wgrad3x3s2_pieces_kernel'}
 
 
 class ConvMeter:
@@ -69,7 +69,7 @@ class ConvMeter:
     def __call__(self, kind, desc, launch, flags=0):
         import ctypes
         key = (kind, flags, desc.N, desc.C_in, desc.H, desc.W, desc.C_out, desc.OH, desc.OW, desc.kh, desc.kw, desc.stride, desc.pad_h, desc.pad_w,
-               desc.groups, desc.transposed, desc.math, desc.io_dtype)
+               desc.groups, desc.transposed, desc.math, desc.io_dtype, desc.x_layout)
         hit = self._family.get(key)
         if hit is not None:
             c = self.counts.setdefault(self.iteration, {})
@@ -90,6 +90,8 @@ class ConvMeter:
                       7: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,256,8,{_np()},0,false,512>'},
                       9: {0: 'conv1x1_f16x3_kernel<128,128>', 1: 'conv1x1_f16x3_kernel<64,256>'},
                       10: {0: 'conv3x3s2_f16x3_kernel<128>', 1: 'conv3x3s2_f16x3_kernel<64>'}}[kernel.value][tile.value]     # <BM, BN, rows per tile, pieces, storage, input scale, threads>
+            if kernel.value == 10 and desc.x_layout:     # round 5: x as the producer wrote it (the blur's operand pieces): another instance
+                family = family.replace('>', ',true>')
             if isc and kernel.value != 0:       # the instance with the input scale: same family, another template argument (rocprofv3 names)
                 family = {1: family.replace(',3,3,0,false,false>', ',2,3,0,true,false>').replace(',3,4,0,false,false>', ',2,4,0,true,false>'), 2: family.replace(',false,false>', ',true,false>')}.get(
                     kernel.value, family.replace(',false,256>', ',true,256>').replace(',false,512>', ',true,512>'))      # (round 4: the eight-wave tile has its instance too)

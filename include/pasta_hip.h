@@ -58,8 +58,8 @@ int pasta_upfirdn2d(const void* x, const float* f, void* y, int dtype,
  * Producer-written operand pieces (ABI 19).  Replaces, for the low-pass in front of a stride-2 convolution
  * (torch_utils/ops/conv2d_resample.py:119-122: `x = upfirdn2d(x, f, padding)` then `conv2d(x, w, stride=2)`), the fp32 NCHW
  * intermediate of the reference by the matrix-core operand itself: y = upfirdn2d(x, f, up = down = 1, padding, flip, gain) for a
- * 4x4 filter f (fp32 [4][4] on the device) is written ONCE as PASTA_LAYOUT_PIECES16 -- units [N][C / 8][OH][OW] of 32 bytes holding
- * fp16 h[8] = fp16(v S) and l'[8] = fp16(2^11 (v S - h)) of eight consecutive channels -- and the consumers (pasta_conv2d_ex /
+ * 4x4 filter f (fp32 [4][4] on the device) is written ONCE as PASTA_LAYOUT_PIECES16 -- units [N][C / 8][OH][2][OW] of 16 bytes: eight fp16
+ * values of eight consecutive channels, piece 0 = h = fp16(v S), piece 1 = l' = fp16(2^11 (v S - h)) -- and the consumers (pasta_conv2d_ex /
  * pasta_conv2d_wgrad with pasta_conv_desc.x_layout = PASTA_LAYOUT_PIECES16) copy sixteen-byte pieces into LDS instead of gathering
  * channel-strided fp32 and splitting it at every launch.  OH = H + pady0 + pady1 - 3, OW likewise; the fp32 value in front of the split
  * is bit-identical to pasta_upfirdn2d's.
@@ -154,8 +154,8 @@ typedef struct pasta_conv_desc {
                                      packing kernel finds one scale per output row itself at every launch, so no |max| of w is
                                      passed, cached or trusted across launches                                            */
     int32_t      x_layout;        /* ABI 19.  0 = x is a contiguous NCHW tensor of io_dtype (everything above).  PASTA_LAYOUT_PIECES16 = x is the
-                                     producer-written operand of the three-product arithmetic (pasta_blur_pieces below): [N][C_in / 8][H][W] units of
-                                     32 bytes, fp16 h[8] | l'[8] of v S, and x_amax (REQUIRED then) is the 256-float row the producer wrote -- the bound
+                                     producer-written operand of the three-product arithmetic (pasta_blur_pieces below): [N][C_in / 8][H][2][W] units of
+                                     16 bytes, fp16 h[8] / l'[8] of v S, and x_amax (REQUIRED then) is the 256-float row the producer wrote -- the bound
                                      both sides take the power-of-two scale S from.  Served by the 3x3 stride-2 forward kernel and its weight gradient
                                      (pasta_conv2d_plan kernel 10, pasta_conv2d_wgrad_plan kernel 6: fp32 y / dy, PASTA_MATH_F16X3, one group, C_in a
                                      multiple of 8, pad 0); the planners return an error for every other launch and the caller keeps the fp32 tensor. */

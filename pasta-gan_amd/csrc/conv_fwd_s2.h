@@ -20,7 +20,7 @@ namespace pasta {
 //     MFMAs, two workgroups per CU: while one stages the other multiplies (the scheme of conv1x1_f16x3_kernel);
 //   * tile = BM output channels x 128 output pixels = R = 128 / SEG rows of SEG = min(OW, 128) columns.
 // Weights: the standard packed layout, one scale per output row (p.w_rowinv).  Planes: OW a power of two >= 16 (the live shapes: 128, 64, 32, 16).
-// XP (round 5): x is the producer-written operand (PASTA_LAYOUT_PIECES16, pieces.hip: [N][C / 8][H][W] units of 32 bytes, fp16 h[8] | l'[8] of v S with
+// XP (round 5): x is the producer-written operand (PASTA_LAYOUT_PIECES16, pieces.hip: [N][C / 8][H][2][W] units of 16 bytes, fp16 h[8] / l'[8] of v S with
 // S from p.x_amax, the producer's bound row) -- a staging task is then two sixteen-byte loads and two LDS stores: no channel-strided dword gathers,
 // no split (the eight loads and ~25 VALU instructions of a task were a third of this kernel's issue slots: profiles/r4_pmc_summary.txt, issue 0.35).
 template <int BM, bool XP = false>
@@ -89,8 +89,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_f16x3_kernel(ConvFwdParams p
             xvalid[k] = in ? p.Ig - c0 : 0;
             if constexpr (XP) {
                 const int c8 = c0 < p.Ig ? (c0 >> 3) : 0;                   // Ig is a multiple of 8: an octet exists whole or not at all
-                const u32x4* const src = (const u32x4*)((const char*)p.x + ((((int64_t)n_img * (p.Cin >> 3) + c8) * HW) + off) * 32);
-                xq[k][0] = src[0]; xq[k][1] = src[1];
+                // [N][C / 8][H][2 pieces][W] units of sixteen bytes: consecutive lanes (pixels of a row) fetch consecutive units
+                const int offp = in ? 2 * iy * p.W + t_ix[k] : 0;
+                const u32x4* const src = (const u32x4*)((const char*)p.x + ((int64_t)n_img * (p.Cin >> 3) + c8) * HW * 32) + offp;
+                xq[k][0] = src[0]; xq[k][1] = src[p.W];
                 continue;
             }
 #pragma unroll

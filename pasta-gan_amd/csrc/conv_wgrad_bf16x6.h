@@ -457,8 +457,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
 }
 
 //------------------------------------------------------------------------------------
-// Round 5: the stride-2 weight gradient with L given as the producer-written operand (PASTA_LAYOUT_PIECES16, pieces.hip: [N][LC / 8][LH][LW] units of
-// 32 bytes, fp16 h[8] | l'[8] of v S) -- the blurred tensor in front of every stride-2 convolution of the discriminator and the encoders
+// Round 5: the stride-2 weight gradient with L given as the producer-written operand (PASTA_LAYOUT_PIECES16, pieces.hip: [N][LC / 8][LH][2][LW] units of
+// 16 bytes, fp16 h[8] / l'[8] of v S) -- the blurred tensor in front of every stride-2 convolution of the discriminator and the encoders
 // (conv2d_resample.py:119-122), pad 0, PASTA_MATH_F16X3.  conv_wgrad3x3s2_bf16x6_kernel spends 41 % of its wave cycles issuing instructions
 // (profiles/r4_pmc_summary.txt): 24 dword loads and three splits per thread and chunk for the halo, and in the product loop four v_perm per
 // operand to gather every second halo column.  Here
@@ -523,9 +523,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_pieces_kernel(WgradPar
     // one unit of halo row ly: column lx, octet oct -> (h, l'); false = outside the plane (a zero unit)
     auto fetch_unit = [&](int n, int ly, int lx, int oct, bool on, u32x4 (&r)[2]) -> bool {
         const bool ok = on && (unsigned)ly < (unsigned)p.LH && (unsigned)lx < (unsigned)p.LW;
-        const u32x4* src = (const u32x4*)(Lg + ((((int64_t)n * LC8 + oct) * p.LH + (ok ? ly : 0)) * p.LW + (ok ? lx : 0)) * 32);
+        const u32x4* src = (const u32x4*)(Lg + ((int64_t)n * LC8 + oct) * p.LH * p.LW * 32) + (ok ? 2 * ly * p.LW + lx : 0);      // [..][LH][2 pieces][LW] units
         if (!on) src = (const u32x4*)Lg;             // an octet beyond the tensor: any valid address
-        r[0] = src[0]; r[1] = src[1];
+        r[0] = src[0]; r[1] = src[p.LW];
         return ok;
     };
     auto stash_unit = [&](const u32x4 (&r)[2], bool ok, int slot, int col, int oct) {

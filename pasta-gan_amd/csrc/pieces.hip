@@ -4,10 +4,11 @@
 // loads per staging unit and splits with ~20 VALU instructions per unit, launch after launch.
 //
 // Layout PASTA_LAYOUT_PIECES16 of a logical [N, C, H, W] tensor (C a multiple of 8):
-//     unit (n, c / 8, y, x) = 32 bytes:  h[8] = fp16(v S)  |  l'[8] = fp16(2^11 (v S - h))      for the eight channels 8 (c / 8) .. + 7
-//     units in the order [N][C / 8][H][W]: a row of W units is 32 W contiguous bytes, every unit 32-byte aligned whatever W is (the
-//     fp32 planes of 257 columns are not even 16-byte aligned from row to row, and their odd pitch is what holds the fp32 blur at 0.32 of
-//     the HBM rate: profiles/r4_hbm_microbench.txt)
+//     unit (n, c / 8, y, piece, x) = 16 bytes: eight fp16 values, one per channel 8 (c / 8) .. + 7:  piece 0: h = fp16(v S),  piece 1: l' = fp16(2^11 (v S - h))
+//     units in the order [N][C / 8][H][2][W]: a row of one piece is 16 W contiguous bytes -- what a wave stores (producer) or fetches (consumers)
+//     with one sixteen-byte access per lane is one contiguous run -- and every unit is 16-byte aligned whatever W is (the fp32 planes of 257
+//     columns are not even 16-byte aligned from row to row).  (First version: h | l' interleaved per pixel, 32-byte units -- every store
+//     instruction of a wave then filled half of each 32-byte sector it touched, and the blur ran no faster than the fp32 one.)
 // 4 bytes per logical element, like fp32.  S is the power of two that scale_from_amax() takes from a BOUND of the output's magnitude that
 // is known before the blur starts: the 256 partial maxima of the blur's INPUT (the producer row its writer left, or one scan) times
 // gain * sum |f| (1 for the normalised low-pass of the networks).  The kernel leaves that bound as a 256-float row of its own (y_amax), and
@@ -17,7 +18,7 @@
 //
 // Kernel: one workgroup = 8 channels x (8 rows x 64 columns) of outputs.  The 8 x 11 x 67 input footprint is staged in LDS with row-coalesced
 // loads, a thread computes two rows of one column for the eight channels (sixteen 16-tap sums, the taps in the order of upfirdn2d_tile_kernel:
-// the fp32 value in front of the split is bit-identical to pasta_upfirdn2d's) and stores two 32-byte units: a wave writes 2 KB contiguous.
+// the fp32 value in front of the split is bit-identical to pasta_upfirdn2d's) and stores four 16-byte units (two rows x two pieces): a wave writes 1 KB runs.
 // Planes of 64 k + 1 columns (257, 129, 65: every live shape) are covered by k tile columns whose last thread column computes the extra one.
 #include "conv_common.h"
 
@@ -33,7 +34,7 @@ template <int TOW, int TOH>
 __global__ __launch_bounds__(256) void blur_pieces_kernel(BlurPiecesParams p, int tiles_x, int tiles_y, int rem_x) {
     static_assert(TOW == 64 && TOH == 8, "thread map: 64 columns x 4 row pairs");
     constexpr int TIW = TOW + 4, TIH = TOH + 3, LDW = TIW | 1;         // one more column for the remainder column of the last tile
-    __shared__ float sx[8][TIH][LDW];
+    __shared__ f32x2_t sx[4][TIH][LDW];                // [channel pair][row][column]: the pair (2 q, 2 q + 1) is one 8-byte read and one packed operand
     const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
     int b = blockIdx.x;
     const int tile_x = b % tiles_x; b /= tiles_x;
@@ -54,49 +55,49 @@ __global__ __launch_bounds__(256) void blur_pieces_kernel(BlurPiecesParams p, in
 
     const int ix0 = tile_x * TOW - p.padx0, iy0 = tile_y * TOH - p.pady0;
     const float* const xp = p.x + ((int64_t)n * p.C + (int64_t)c8 * 8) * p.H * p.W;
-    constexpr int NEL = 8 * TIH * TIW, NLOAD = (NEL + 255) / 256;
-    float stage[NLOAD];
+    // Staging: wave w fetches channels 2 w and 2 w + 1 -- row and channel of every load are wave-uniform (scalar address arithmetic, no division
+    // per slot: the first version decoded 24 flat slots per thread with two divisions each and spent more instructions there than on the taps),
+    // lane = column; the four columns beyond the 64th by the first four lanes.  Every load of the thread in flight before the first LDS store.
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    f32x2_t stage[TIH], extra[TIH];
 #pragma unroll
-    for (int j = 0; j < NLOAD; j++) {                  // every load of the thread in flight before the first LDS store
-        const int e = tid + 256 * j;
-        const int ch = e / (TIH * TIW), r = e - ch * (TIH * TIW);
-        const int row = r / TIW, col = r - row * TIW;
-        const int iy = iy0 + row, ix = ix0 + col;
-        float v = 0.f;
-        if (e < NEL && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v = xp[((int64_t)ch * p.H + iy) * p.W + ix];
-        stage[j] = v;
+    for (int row = 0; row < TIH; row++) {
+        const int iy = iy0 + row, ix = ix0 + lane;
+        const bool rok = (unsigned)iy < (unsigned)p.H;
+        const bool in = rok && (unsigned)ix < (unsigned)p.W, in2 = rok && lane < TIW - 64 && (unsigned)(ix + 64) < (unsigned)p.W;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; c2++) {
+            const float* const rp = xp + ((int64_t)(2 * wave + c2) * p.H + (rok ? iy : 0)) * p.W;
+            const float v = rp[ix < 0 ? 0 : ix < p.W ? ix : p.W - 1];      // always a valid address, no branch around the load; zeroed below
+            stage[row][c2] = in ? v : 0.f;
+            extra[row][c2] = in2 ? rp[ix + 64] : 0.f;
+        }
     }
 #pragma unroll
-    for (int j = 0; j < NLOAD; j++) {
-        const int e = tid + 256 * j;
-        const int ch = e / (TIH * TIW), r = e - ch * (TIH * TIW);
-        const int row = r / TIW, col = r - row * TIW;
-        if (e < NEL) sx[ch][row][col] = stage[j];
+    for (int row = 0; row < TIH; row++) {
+        sx[wave][row][lane] = stage[row];
+        if (lane < TIW - 64) sx[wave][row][64 + lane] = extra[row];
     }
     __syncthreads();
 
-    char* const out = (char*)p.pieces + (((int64_t)n * C8 + c8) * p.OH) * (int64_t)p.OW * 32;
-    auto one = [&](int yy, int xx) {                    // output (yy, xx) relative to the tile origin, eight channels -> one 32-byte unit
+    char* const out = (char*)p.pieces + (((int64_t)n * C8 + c8) * p.OH) * (int64_t)p.OW * 32;        // rows of this octet: [OH][2 pieces][OW] units of 16 bytes
+    auto one = [&](int yy, int xx) {                    // output (yy, xx) relative to the tile origin, eight channels -> the h unit and the l' unit
         const int oy = tile_y * TOH + yy, ox = tile_x * TOW + xx;
         if (oy >= p.OH || ox >= p.OW) return;
         uint32_t h[4], l[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            float v[2];
+            f32x2_t a = {0.f, 0.f};                     // channels 2 q, 2 q + 1: sixteen packed FMAs, the taps in pasta_upfirdn2d's order
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
-                float a = 0.f;
+            for (int jy = 0; jy < 4; jy++)
 #pragma unroll
-                for (int jy = 0; jy < 4; jy++)
-#pragma unroll
-                    for (int jx = 0; jx < 4; jx++) a = fmaf(g[jy][jx], sx[2 * q + k][yy + jy][xx + jx], a);
-                v[k] = a * p.gain;
-            }
-            f16_split2(v[0] * sc, v[1] * sc, h[q], l[q]);
+                for (int jx = 0; jx < 4; jx++) a = __builtin_elementwise_fma(f32x2_t{g[jy][jx], g[jy][jx]}, sx[q][yy + jy][xx + jx], a);
+            a *= p.gain;
+            f16_split2(a[0] * sc, a[1] * sc, h[q], l[q]);
         }
-        uint4* const d = (uint4*)(out + ((int64_t)oy * p.OW + ox) * 32);
-        d[0] = make_uint4(h[0], h[1], h[2], h[3]);
-        d[1] = make_uint4(l[0], l[1], l[2], l[3]);
+        u32x4* const d = (u32x4*)(out + ((int64_t)oy * 2 * p.OW + ox) * 16);
+        d[0] = u32x4{h[0], h[1], h[2], h[3]};
+        d[p.OW] = u32x4{l[0], l[1], l[2], l[3]};
     };
     one(2 * ty, tx);
     one(2 * ty + 1, tx);
@@ -112,9 +113,9 @@ __global__ __launch_bounds__(256) void pieces_unpack_kernel(const void* pieces, 
     scale_from_amax(amax_of_parts(parts), sc, isc);
     const int64_t units = (int64_t)N * (C >> 3) * H * W;
     for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (int64_t)gridDim.x * 256) {
-        const uint4 hq = ((const uint4*)pieces)[2 * u], lq = ((const uint4*)pieces)[2 * u + 1];
-        const f16x8 h = __builtin_bit_cast(f16x8, hq), l = __builtin_bit_cast(f16x8, lq);
         const int64_t x = u % W, r = u / W;
+        const u32x4 hq = ((const u32x4*)pieces)[2 * r * W + x], lq = ((const u32x4*)pieces)[(2 * r + 1) * W + x];      // r = (n, octet, row)
+        const f16x8 h = __builtin_bit_cast(f16x8, hq), l = __builtin_bit_cast(f16x8, lq);
         const int64_t yy = r % H, r2 = r / H;
         const int64_t c8 = r2 % (C >> 3), n = r2 / (C >> 3);
 #pragma unroll

@@ -322,7 +322,7 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, 
 # ---- producer-written operand pieces (round 5; csrc/pieces.hip, include/pasta_hip.h "Producer-written operand pieces") --------------------
 # The low-pass in front of a stride-2 convolution (reference conv2d_resample.py:119-122) has ONE reader besides that convolution's weight
 # gradient, and its magnitude is bounded by its input's: it can write its output once as the fp16 pieces h | l' of the three-product
-# arithmetic (32-byte units of eight channels, [N][C / 8][H][W]), and both consumers copy pieces instead of fetching fp32 with eight
+# arithmetic (16-byte units of eight channels, [N][C / 8][H][piece][W]), and both consumers copy pieces instead of fetching fp32 with eight
 # channel-strided loads per unit and splitting it -- in every launch that touches the tensor.
 _PIECES = _os.environ.get('PASTA_PIECES', '1') != '0'       # A/B switch: 0 = fp32 blurred tensor, as before
 _pieces_cache = {}

@@ -53,9 +53,9 @@ def test_pieces_are_the_split_of_the_fp32_blur(shape, pad):
     S = 2.0 ** (13 - torch.floor(torch.log2(bound.max())).item())
     assert 2 ** 13 <= amax * S < 2 ** 14
     n, c, oh, ow = lshape
-    units = pieces.view(torch.float16).reshape(n, c // 8, oh, ow, 2, 8)
-    h = units[..., 0, :].permute(0, 1, 4, 2, 3).reshape(n, c, oh, ow)
-    lp = units[..., 1, :].permute(0, 1, 4, 2, 3).reshape(n, c, oh, ow)
+    units = pieces.view(torch.float16).reshape(n, c // 8, oh, 2, ow, 8)            # [N][C / 8][H][piece][W] units of eight channels
+    h = units[:, :, :, 0].permute(0, 1, 4, 2, 3).reshape(n, c, oh, ow)
+    lp = units[:, :, :, 1].permute(0, 1, 4, 2, 3).reshape(n, c, oh, ow)
     vs = ref * S
     assert torch.equal(h, vs.half())
     assert torch.equal(lp, ((vs - vs.half().float()) * 2048.0).half())

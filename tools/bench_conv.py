@@ -1,6 +1,6 @@
 """Per-shape timing of the native convolution family (forward, input gradient, weight gradient) on the layer
 shapes of the 256x256 'fashion' model at batch 16; optionally next to MIOpen (torch.nn.functional.conv2d) as a
-same-hardware reference.  Usage: python tools/bench_conv.py [--miopen] [--reps 10] [--only fwd,dgrad,wgrad]"""
+same-hardware reference.  Usage: python tools/bench_conv.py [--miopen] [--reps 10] [--only fwd,dgrad,wgrad | down] [--match text]"""
 
 import argparse
 import os
@@ -66,7 +66,7 @@ def main():
     dev = torch.device('cuda')
     print(f"{'shape':28s} {'pass':6s} {'ms':>8s} {'TFLOP/s':>8s}" + (f" {'miopen ms':>10s} {'TF/s':>7s}" if args.miopen else ''))
     for name, n, ci, h, co, k, st, tr, *rest in SHAPES:
-        if args.match and args.match not in name:
+        if (args.match and args.match not in name) or only == ['down']:
             continue
         pad = rest[0] if rest else (k // 2 if not tr else 0)
         x = torch.randn([n, ci, h, h], device=dev)
@@ -97,6 +97,43 @@ def main():
                 except Exception as ex:  # noqa: BLE001
                     line += f'  miopen failed: {type(ex).__name__}'
             print(line, flush=True)
+
+    if 'down' in only or args.only == 'fwd,dgrad,wgrad':
+        down_path(args)
+
+
+DOWN = [  # the down path of conv2d_resample (blur to 2 k + 1, then 3x3 stride 2 without padding): name, N, Cin, H (input), Cout
+    ('down 64->128 @256', 16, 64, 256, 128), ('down 64->128 @256 x48', 48, 64, 256, 128), ('down 128->256 @128', 16, 128, 128, 256),
+    ('down 128->256 @128 x48', 48, 128, 128, 256), ('down 256->512 @64', 16, 256, 64, 512), ('down 256->512 @64 x48', 48, 256, 64, 512)]
+
+
+def down_path(args):
+    """blur / forward convolution / weight gradient of a down layer, with the blurred tensor as fp32 (PASTA_PIECES=0's path) and as the
+    producer-written operand pieces (round 5): per-stage times from events, TFLOP/s of the convolutions, GB/s of the blur on the bytes it moves."""
+    from torch_utils.ops import upfirdn2d
+    dev = torch.device('cuda')
+    f = upfirdn2d.setup_filter([1, 3, 3, 1]).to(dev)
+    cfg = cg._Cfg((False, 2, 0, 0, 0, 0, 1))
+    print(f"{'down path':28s} {'stage':14s} {'ms':>8s} {'TFLOP/s | GB/s':>14s}")
+    for name, n, ci, h, co in DOWN:
+        if args.match and args.match not in name:
+            continue
+        x = torch.randn([n, ci, h, h], device=dev)
+        w = torch.randn([co, ci, 3, 3], device=dev) * 0.05
+        parts = cg.tensor_amax(x)
+        xb = upfirdn2d.upfirdn2d(x, f, padding=[2, 2, 2, 2])
+        pieces, bound, shape = cg.blur_pieces(x, f, (2, 2, 2, 2), x_amax=parts)
+        y = cg._launch_conv(xb, w, cfg)
+        dy = torch.randn_like(y)
+        flops = 2.0 * n * ci * co * 9 * y.shape[2] * y.shape[3]
+        nbytes = (x.numel() + xb.numel()) * 4
+        stages = [('blur fp32', lambda: upfirdn2d.upfirdn2d(x, f, padding=[2, 2, 2, 2]), None), ('blur pieces', lambda: cg.blur_pieces(x, f, (2, 2, 2, 2), x_amax=parts), None),
+                  ('fwd fp32', lambda: cg._launch_conv(xb, w, cfg), flops), ('fwd pieces', lambda: cg._launch_conv(pieces, w, cfg, pieces=(bound, shape)), flops),
+                  ('wgrad fp32', lambda: cg._launch_wgrad(xb, dy, cfg, tuple(w.shape)), flops),
+                  ('wgrad pieces', lambda: cg._launch_wgrad_pieces(pieces, dy, cfg, tuple(w.shape), (bound, shape)), flops)]
+        for tag, fn, fl in stages:
+            ms = timeit(fn, args.reps)
+            print(f'{name:28s} {tag:14s} {ms:8.3f} {(fl / ms / 1e9) if fl else (nbytes / ms / 1e6):14.1f}', flush=True)
 
 
 if __name__ == '__main__':
