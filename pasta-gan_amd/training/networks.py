@@ -480,13 +480,54 @@ class FullyConnectedLayer(torch.nn.Module):
         self.bias_gain = lr_multiplier
 
     def forward(self, x):
-        # both gains ride in the GEMM's alpha / beta: no scaling kernels
+        # both gains ride in the GEMM's alpha / beta: no scaling kernels, forwards (addmm) or backwards (_ScaledLinear)
         w = self.weight.to(x.dtype)
-        if self.bias is None:
+        b = None if self.bias is None else self.bias.to(x.dtype)
+        if _FC_FUSED_GRADS and x.ndim == 2 and x.device.type == 'cuda' and x.dtype == torch.float32 and x.shape[0] > 0:
+            y = _ScaledLinear.apply(x, w, b, float(self.weight_gain), float(self.bias_gain))
+        elif b is None:
             y = torch.mm(x, w.t()) * self.weight_gain
         else:
-            y = torch.addmm(self.bias.to(x.dtype)[None], x, w.t(), beta=float(self.bias_gain), alpha=float(self.weight_gain))
+            y = torch.addmm(b[None], x, w.t(), beta=float(self.bias_gain), alpha=float(self.weight_gain))
         return y if self.activation == 'linear' else bias_act.bias_act(y, None, act=self.activation)
+
+# A/B switch: 0 = autograd's own backward of addmm (a GEMM and a scaling kernel per gradient, a sum and a scaling kernel for the bias)
+_FC_FUSED_GRADS = _os.environ.get('PASTA_FC_FUSED_GRADS', '1') != '0'
+
+class _ScaledLinear(torch.autograd.Function):
+    """``y = alpha x w^T + beta b`` (FullyConnectedLayer: reference networks.py:117-128 with the gains folded into the GEMM) whose backward is three
+    launches -- ``dx = alpha dy w``, ``dw = alpha dy^T x``, ``db = beta dy^T 1`` as GEMM / GEMV calls that carry their factor -- where autograd's
+    backward of ``addmm`` with ``alpha`` / ``beta`` runs six (a product and a scaling kernel each, a sum and a scaling kernel for the bias):
+    about 80 dense layers per training step (the affine layer of every synthesis layer, the mapping networks).  The backward is written with
+    differentiable operators, so gradients of any order follow (R1 passes through the discriminator's dense layers)."""
+    @staticmethod
+    def forward(ctx, x, w, b, alpha, beta):
+        ctx.save_for_backward(x, w)
+        ctx.alpha, ctx.beta, ctx.has_b = alpha, beta, b is not None
+        if b is None:
+            return torch.addmm(x[:1, :1], x, w.t(), beta=0.0, alpha=alpha)       # beta = 0: the addend is ignored (a view: no kernel to make one)
+        return torch.addmm(b[None], x, w.t(), beta=beta, alpha=alpha)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        ignored = dy[:1, :1]                        # the addend of a product with beta = 0 (never read; NaN / inf in it do not propagate)
+        dx = torch.addmm(ignored, dy, w, beta=0.0, alpha=ctx.alpha) if ctx.needs_input_grad[0] else None
+        dw = torch.addmm(ignored, dy.t(), x, beta=0.0, alpha=ctx.alpha) if ctx.needs_input_grad[1] else None
+        db = None
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = torch.addmv(ignored[0], dy.t(), _ones_vector(dy), beta=0.0, alpha=ctx.beta)
+        return dx, dw, db, None, None
+
+_ones_cache = {}
+
+def _ones_vector(like):
+    """[N] ones on ``like``'s device and of its dtype, one per (device, dtype, N) for the life of the process (the summing vector of the bias gradient)."""
+    key = (like.device, like.dtype, int(like.shape[0]))
+    v = _ones_cache.get(key)
+    if v is None:
+        v = _ones_cache[key] = torch.ones([like.shape[0]], dtype=like.dtype, device=like.device)
+    return v
 
 @persistence.persistent_class
 class MappingNetwork(torch.nn.Module):

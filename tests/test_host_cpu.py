@@ -178,3 +178,34 @@ def test_infinite_sampler_reproduces_the_reference_index_streams():
     import torch.utils.data as tud
     it = iter(tud.DataLoader(list(range(10)), sampler=misc.InfiniteSampler(list(range(10)), seed=5), batch_size=4))
     assert next(it).shape == (4,)
+
+
+def test_scaled_linear_gradients_of_first_and_second_order():
+    """FullyConnectedLayer's three-launch backward (training/networks._ScaledLinear) against autograd's own backward of the same expression
+    (reference networks.py:117-128: ``addmm(b * bias_gain, x, (w * weight_gain).t())``): values, first and second derivatives."""
+    import torch
+    from training import networks
+    g = torch.Generator().manual_seed(0)
+    for has_b in (True, False):
+        x = torch.randn([6, 40], generator=g, dtype=torch.float64, requires_grad=True)
+        w = torch.randn([24, 40], generator=g, dtype=torch.float64, requires_grad=True)
+        b = torch.randn([24], generator=g, dtype=torch.float64, requires_grad=True) if has_b else None
+        alpha, beta = 0.37, 1.5
+        def ref(x, w, b):
+            y = x @ (w * alpha).t()
+            return y + b * beta if b is not None else y
+        ins = [x, w] + ([b] if has_b else [])
+        y0, y1 = ref(x, w, b), networks._ScaledLinear.apply(x, w, b, alpha, beta)
+        assert torch.allclose(y0, y1, rtol=1e-12, atol=1e-12)
+        dy = torch.randn(y0.shape, generator=g, dtype=torch.float64)
+        g0 = torch.autograd.grad(y0, ins, dy, create_graph=True)
+        g1 = torch.autograd.grad(y1, ins, dy, create_graph=True)
+        for a, r in zip(g1, g0):
+            assert torch.allclose(a, r, rtol=1e-12, atol=1e-12)
+        # R1's shape: a function of the input gradient, differentiated with respect to the weights
+        h0 = torch.autograd.grad(g0[0].square().sum(), [w, x], allow_unused=True)
+        h1 = torch.autograd.grad(g1[0].square().sum(), [w, x], allow_unused=True)
+        for a, r in zip(h1, h0):
+            assert (a is None) == (r is None)
+            if a is not None:
+                assert torch.allclose(a, r, rtol=1e-11, atol=1e-11)
