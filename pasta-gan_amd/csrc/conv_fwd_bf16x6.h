@@ -223,8 +223,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_bf16x6_kernel(ConvFwdParams
     const int HW = p.H * p.W;
     const int NC = p.Ig_pad / KC;
     const int chunks_all = T * NC;
-    const int c_first = (int)((int64_t)chunks_all * ks / p.ksplit);
-    const int nchunks = (int)((int64_t)chunks_all * (ks + 1) / p.ksplit) - c_first;
+    const int c_first = (int)(((unsigned)chunks_all * (unsigned)ks) / (unsigned)p.ksplit);
+    const int nchunks = (int)(((unsigned)chunks_all * (unsigned)(ks + 1)) / (unsigned)p.ksplit) - c_first;
 
     // B staging: this thread's pixel column (fixed for the whole K loop) and its k-halves:
     //   BN 128: one half, tid >> 7 (uniform per wave);  BN 256: both halves of pixel tid.
@@ -604,8 +604,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_rows_bf16x6_kernel(ConvFwdP
     const int HW = p.H * p.W;
     const int NC = p.Ig_pad / KC;
     const int stages_all = KH * NC;
-    const int s_first = (int)((int64_t)stages_all * ks / p.ksplit);
-    const int nstages = (int)((int64_t)stages_all * (ks + 1) / p.ksplit) - s_first;
+    const int s_first = (int)(((unsigned)stages_all * (unsigned)ks) / (unsigned)p.ksplit);
+    const int nstages = (int)(((unsigned)stages_all * (unsigned)(ks + 1)) / (unsigned)p.ksplit) - s_first;
     const int seg_log2 = 31 - __builtin_clz(Q < BN ? Q : BN);
     const int SEG = 1 << seg_log2, R = BN >> seg_log2;
     const int d0 = p.rows_d0;

@@ -61,8 +61,8 @@ __global__ __launch_bounds__(256, OCC) void conv_fwd_kernel(ConvFwdParams p) {
     const int HW = p.H * p.W;
     const int NC = p.Ig_pad / KC;
     const int chunks_all = p.T * NC;
-    const int c_first = (int)((int64_t)chunks_all * ks / p.ksplit);
-    const int nchunks = (int)((int64_t)chunks_all * (ks + 1) / p.ksplit) - c_first;
+    const int c_first = (int)(((unsigned)chunks_all * (unsigned)ks) / (unsigned)p.ksplit);
+    const int nchunks = (int)(((unsigned)chunks_all * (unsigned)(ks + 1)) / (unsigned)p.ksplit) - c_first;
 
     // ---- B staging: this thread's pixel column is fixed for the whole K loop.
     const int bcol = tid % BN, brow0 = tid / BN;

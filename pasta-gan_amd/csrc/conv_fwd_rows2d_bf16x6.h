@@ -73,8 +73,10 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
     const int P = p.cls[0].P, Q = p.cls[0].Q;
     const int HW = p.H * p.W;
     const int NC = p.Ig_pad / KC;
-    const int c_first = (int)((int64_t)NC * ks / p.ksplit);
-    const int nchunks = (int)((int64_t)NC * (ks + 1) / p.ksplit) - c_first;
+    // (32-bit: NC <= a few hundred chunks, ksplit <= 32; the 64-bit quotients this was written with are ~150 scalar instructions each, in front of
+    // the first load of a workgroup that is alone on its CU)
+    const int c_first = (int)(((unsigned)NC * (unsigned)ks) / (unsigned)p.ksplit);
+    const int nchunks = (int)(((unsigned)NC * (unsigned)(ks + 1)) / (unsigned)p.ksplit) - c_first;
     // tile -> (image, row block, column block)
     const int cblocks = Q / SEG, tpi = (P / R) * cblocks;
     // Workgroups go round-robin to the eight XCDs (one L2 each).  On the eight-wave tile an XCD receives CONSECUTIVE pixel tiles -- the
@@ -114,13 +116,6 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
         u_lds[k] = real ? (half * SLOTS + slot) * 8 : -1;           // element offset inside a piece of the B image; -1: no unit
     }
 
-    // PASTA_MATH_F16X3: power-of-two scales of the two operands (every wave reduces the partial maxima itself)
-    float x_scale = 1.f, out_scale = 1.f;
-    if constexpr (HX) {
-        float sx, isx;
-        scale_from_amax(amax_of_parts(p.x_amax), sx, isx);
-        x_scale = sx; out_scale = isx;                 // the weight rows carry their own scales: p.w_rowinv, applied per output row in the epilogue
-    }
     float sb0[8], sb1[8];                               // the two staging register sets
     float sc0[ISC ? 8 : 1], sc1[ISC ? 8 : 1];           // ISC: the input scales of their channels
     const float* const isb = ISC ? p.iscale + (int64_t)n_img * p.Cin + (int64_t)g * p.Ig : nullptr;
@@ -136,6 +131,40 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
         }
         nv = (u_ok[k] && real_chunk) ? p.Ig - c0 : 0;
     };
+    // ---- weights: tap slabs and the fetch position (two steps ahead of the multiplication)
+    const __bf16* wtap[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) wtap[t] = wb + (int64_t)p.tap_slab[t] * NC * a_chunk;
+    float4 areg0, areg1, areg2, breg0, breg1, breg2;
+    auto load_a = [&](int tap, int cc, int set) {              // tap and set are literals at every call
+        const int ccl = cc < NC ? cc : NC - 1;          // past the end of the K range (or of an empty slice): a valid address, unused data
+        const __bf16* wt = wtap[tap] + (int64_t)ccl * a_chunk;
+        auto unit = [&](int j) {
+            int e = tid + NT * j;
+            if (NT * (j + 1) > AUNITS) e = e < AUNITS ? e : AUNITS - 1;
+            const int seg = e / BM, within = e - seg * BM;
+            return *(const float4*)(wt + ((int64_t)seg * p.Og_pad + o_blk + within) * 8);
+        };
+        if (set == 0) { areg0 = unit(0); if (APT > 1) areg1 = unit(1); if (APT > 2) areg2 = unit(2); }
+        else          { breg0 = unit(0); if (APT > 1) breg1 = unit(1); if (APT > 2) breg2 = unit(2); }
+    };
+    // The first trip to memory is issued HERE, in front of the rest of the set-up (operand scale, accumulators, fragment slots, tap offsets:
+    // several hundred mostly scalar instructions that the compiler otherwise places in front of the first load -- 680 instructions on the
+    // eight-wave tile, whose workgroup is alone on its CU: nothing hides them): the weights of the first tap and every unit of the first
+    // chunk (ONE trip to memory in front of the K loop instead of UPT; the accumulators are not live yet: the register sets are free).
+    load_a(0, c_first, 0);
+    float fb[UPT][8], fc[UPT][ISC ? 8 : 1];
+    int fnv[UPT];
+#pragma unroll
+    for (int k = 0; k < UPT; k++) load_unit(k, c_first, nchunks > 0, fb[k], fc[k], fnv[k]);
+
+    // PASTA_MATH_F16X3: power-of-two scales of the two operands (every wave reduces the partial maxima itself)
+    float x_scale = 1.f, out_scale = 1.f;
+    if constexpr (HX) {
+        float sx, isx;
+        scale_from_amax(amax_of_parts(p.x_amax), sx, isx);
+        x_scale = sx; out_scale = isx;                 // the weight rows carry their own scales: p.w_rowinv, applied per output row in the epilogue
+    }
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     uint32_t q1[4], q2[4], q3[4];
@@ -178,23 +207,6 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
         }
     };
 
-    // ---- weights: tap slabs and the fetch position (two steps ahead of the multiplication)
-    const __bf16* wtap[9];
-#pragma unroll
-    for (int t = 0; t < 9; t++) wtap[t] = wb + (int64_t)p.tap_slab[t] * NC * a_chunk;
-    float4 areg0, areg1, areg2, breg0, breg1, breg2;
-    auto load_a = [&](int tap, int cc, int set) {              // tap and set are literals at every call
-        const int ccl = cc < NC ? cc : NC - 1;          // past the end of the K range (or of an empty slice): a valid address, unused data
-        const __bf16* wt = wtap[tap] + (int64_t)ccl * a_chunk;
-        auto unit = [&](int j) {
-            int e = tid + NT * j;
-            if (NT * (j + 1) > AUNITS) e = e < AUNITS ? e : AUNITS - 1;
-            const int seg = e / BM, within = e - seg * BM;
-            return *(const float4*)(wt + ((int64_t)seg * p.Og_pad + o_blk + within) * 8);
-        };
-        if (set == 0) { areg0 = unit(0); if (APT > 1) areg1 = unit(1); if (APT > 2) areg2 = unit(2); }
-        else          { breg0 = unit(0); if (APT > 1) breg1 = unit(1); if (APT > 2) breg2 = unit(2); }
-    };
     auto store_a = [&](int buf, int set) {
         __bf16* d = As + buf * ABUF;
         *(float4*)&d[tid * 8] = set ? breg0 : areg0;
@@ -295,22 +307,12 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
         __syncthreads();
     };
 
-    // prologue: the whole B image of the first chunk and the weights of its first two taps
-    load_a(0, c_first, 0);
-    {
-        // every unit of the first chunk is fetched before the first one is split: ONE trip to memory in front of the K loop instead of UPT
-        // (the accumulators are not live yet: the register sets are free; a workgroup of the eight-wave tile is alone on its CU, nothing
-        // hides this latency)
-        float fb[UPT][8], fc[UPT][ISC ? 8 : 1];
-        int fnv[UPT];
+    // prologue, second half: split and store the first chunk (fetched above), the weights of its first two taps
 #pragma unroll
-        for (int k = 0; k < UPT; k++) load_unit(k, c_first, nchunks > 0, fb[k], fc[k], fnv[k]);
+    for (int k = 0; k < UPT; k++) {
 #pragma unroll
-        for (int k = 0; k < UPT; k++) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) split_pair(fb[k], fc[k], fnv[k], j);
-            store_unit(k, 0);
-        }
+        for (int j = 0; j < 4; j++) split_pair(fb[k], fc[k], fnv[k], j);
+        store_unit(k, 0);
     }
     store_a(0, 0);
     load_a(1, c_first, 1);                           // stored by step 0

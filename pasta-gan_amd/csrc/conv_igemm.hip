@@ -967,6 +967,7 @@ int pasta::wgrad_run(const void* xv, const void* dyv, float* dw, const pasta_con
     static const int wgrad_xcd = getenv("PASTA_WGRAD_XCD") ? atoi(getenv("PASTA_WGRAD_XCD")) : 1;
     p.xcd_order = wgrad_xcd;
     p.l_pieces = d->x_layout == PASTA_LAYOUT_PIECES16;
+    PASTA_CHECK((int64_t)w.chunks_total * (w.ksplit + 1) < (1ll << 32), "conv2d_wgrad: %d chunks x %d K slices overflow the kernels' 32-bit slice bounds", w.chunks_total, w.ksplit);
     PASTA_CHECK(w.lds_bytes <= 160 * 1024, "conv2d_wgrad: LDS footprint %zu too large", w.lds_bytes);
     PASTA_CHECK(w.npos <= 256, "conv2d_wgrad: halo of %d positions per chunk is not supported", w.npos);
 

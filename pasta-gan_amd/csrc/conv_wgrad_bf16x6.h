@@ -105,9 +105,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
         return m;
     };
     // prefetch of chunk ch: its S pixels and the ONE L row the ring does not hold yet (pp + 1)
-    auto fetch = [&](int ch) {
-        int n, qb, pp;
-        decode(ch, n, qb, pp);
+    auto fetch = [&](int n, int qb, int pp) {
         const int q0 = qb * 32;
         vmask = 0;
         const char* sp = Sg + ((int64_t)n * p.SC * PQ + (int64_t)s_a * PQ + pp * p.Q + q0 + 8 * s_grp) * ES;
@@ -162,12 +160,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
 
-    const int c_begin = (int)((int64_t)p.chunks_total * ks / p.ksplit);
-    const int c_end = (int)((int64_t)p.chunks_total * (ks + 1) / p.ksplit);
-    if (c_begin < c_end) fetch(c_begin);
+    const int c_begin = (int)(((unsigned)p.chunks_total * (unsigned)ks) / (unsigned)p.ksplit);
+    const int c_end = (int)(((unsigned)p.chunks_total * (unsigned)(ks + 1)) / (unsigned)p.ksplit);
+    // position of the current chunk and of the next one: decoded ONCE (two divisions by run-time values), then advanced -- the chunks walk down a
+    // column block, then the column blocks of an image, then the images (a decode per chunk and per prefetch was ~200 scalar instructions per
+    // chunk in front of this wave's matrix instructions)
+    int n_c = 0, qb_c = 0, pp_c = 0, n_n = 0, qb_n = 0, pp_n = 0;
+    auto advance = [&](int n, int qb, int pp, int& n2, int& qb2, int& pp2) {
+        pp2 = pp + 1; qb2 = qb; n2 = n;
+        if (pp2 == p.P) { pp2 = 0; qb2 = qb + 1; if (qb2 == p.qblocks) { qb2 = 0; n2 = n + 1; } }
+    };
+    if (c_begin < c_end) { decode(c_begin, n_c, qb_c, pp_c); fetch(n_c, qb_c, pp_c); advance(n_c, qb_c, pp_c, n_n, qb_n, pp_n); }
     for (int ch = c_begin; ch < c_end; ch++) {
-        int n_c, qb_c, pp_c;
-        decode(ch, n_c, qb_c, pp_c);
         __syncthreads();                  // the previous chunk's fragment reads are done
         if (pp_c == 0 || ch == c_begin) { // a column block or this K slice begins: rows pp-1 and pp are not in the ring yet
             float4 t[2][2];
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
         split_store(sreg[0], sreg[1], vmask & 1u, vmask & 2u, Ss + s_a * SP + 8 * s_grp, S_PIECE, s_scale);
         stash_row(lreg, vmask >> 2, slot_of(pp_c + 1));
         __syncthreads();
-        if (ch + 1 < c_end) fetch(ch + 1);
+        if (ch + 1 < c_end) fetch(n_n, qb_n, pp_n);
         const int slot0 = slot_of(pp_c - 1);          // ring slot of halo row 0; rows 1, 2 follow cyclically
 #pragma unroll
         for (int s = 0; s < 2; s++) {
@@ -220,6 +224,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
                 }
             }
         }
+        n_c = n_n; qb_c = qb_n; pp_c = pp_n;
+        advance(n_c, qb_c, pp_c, n_n, qb_n, pp_n);
     }
 
     // partial slab: [ksplit][G][9][Ag_pad][Bg_pad], b contiguous (same layout as conv_wgrad_kernel)
@@ -325,9 +331,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
         }
         return m;
     };
-    auto fetch = [&](int ch) {
-        int n, qb, pp;
-        decode(ch, n, qb, pp);
+    auto fetch = [&](int n, int qb, int pp) {
         const int q0 = qb * 16;
         s_ok = s_on;
         if (s_on) {
@@ -390,12 +394,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
 
-    const int c_begin = (int)((int64_t)p.chunks_total * ks / p.ksplit);
-    const int c_end = (int)((int64_t)p.chunks_total * (ks + 1) / p.ksplit);
-    if (c_begin < c_end) fetch(c_begin);
+    const int c_begin = (int)(((unsigned)p.chunks_total * (unsigned)ks) / (unsigned)p.ksplit);
+    const int c_end = (int)(((unsigned)p.chunks_total * (unsigned)(ks + 1)) / (unsigned)p.ksplit);
+    // position of the current chunk and of the next one: decoded ONCE (two divisions by run-time values), then advanced -- the chunks walk down a
+    // column block, then the column blocks of an image, then the images (a decode per chunk and per prefetch was ~200 scalar instructions per
+    // chunk in front of this wave's matrix instructions)
+    int n_c = 0, qb_c = 0, pp_c = 0, n_n = 0, qb_n = 0, pp_n = 0;
+    auto advance = [&](int n, int qb, int pp, int& n2, int& qb2, int& pp2) {
+        pp2 = pp + 1; qb2 = qb; n2 = n;
+        if (pp2 == p.P) { pp2 = 0; qb2 = qb + 1; if (qb2 == p.qblocks) { qb2 = 0; n2 = n + 1; } }
+    };
+    if (c_begin < c_end) { decode(c_begin, n_c, qb_c, pp_c); fetch(n_c, qb_c, pp_c); advance(n_c, qb_c, pp_c, n_n, qb_n, pp_n); }
     for (int ch = c_begin; ch < c_end; ch++) {
-        int n_c, qb_c, pp_c;
-        decode(ch, n_c, qb_c, pp_c);
         const int y0 = 2 * pp_c - p.pad_h;
         __syncthreads();                  // the previous chunk's fragment reads are done
         if (pp_c == 0 || ch == c_begin) { // a column block or this K slice begins: the first halo row is not in the ring yet
@@ -412,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
         for (int j = 0; j < 3; j++)
             if (tid + 256 * j < 640) stash_unit(lreg[j], (lmask >> (8 * j)) & 0xffu, l_b[j], l_grp[j], slot_of(y0 + l_k[j]));
         __syncthreads();
-        if (ch + 1 < c_end) fetch(ch + 1);
+        if (ch + 1 < c_end) fetch(n_n, qb_n, pp_n);
         const int slot0 = slot_of(y0);
         bf16x8 af[3];
 #pragma unroll
@@ -441,6 +451,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
                 }
             }
         }
+        n_c = n_n; qb_c = qb_n; pp_c = pp_n;
+        advance(n_c, qb_c, pp_c, n_n, qb_n, pp_n);
     }
 
     const int Ag_pad = p.a_tiles * 64, Bg_pad = p.b_tiles * 64;
@@ -534,9 +546,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_pieces_kernel(WgradPar
         *(u32x4*)d = ok ? r[0] : z;
         *(u32x4*)(d + L_PIECE) = ok ? r[1] : z;
     };
-    auto fetch = [&](int ch) {
-        int n, qb, pp;
-        decode(ch, n, qb, pp);
+    auto fetch = [&](int n, int qb, int pp) {
         const int q0 = qb * 16;
         if (s_on) {
             const float* sp = Sg + (int64_t)n * p.SC * PQ + (int64_t)s_a * PQ + pp * p.Q + q0 + 8 * s_grp;
@@ -579,12 +589,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_pieces_kernel(WgradPar
     typedef __fp16 v4h __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) v4h* lds_v4h;
 
-    const int c_begin = (int)((int64_t)p.chunks_total * ks / p.ksplit);
-    const int c_end = (int)((int64_t)p.chunks_total * (ks + 1) / p.ksplit);
-    if (c_begin < c_end) fetch(c_begin);
+    const int c_begin = (int)(((unsigned)p.chunks_total * (unsigned)ks) / (unsigned)p.ksplit);
+    const int c_end = (int)(((unsigned)p.chunks_total * (unsigned)(ks + 1)) / (unsigned)p.ksplit);
+    // position of the current chunk and of the next one: decoded ONCE (two divisions by run-time values), then advanced -- the chunks walk down a
+    // column block, then the column blocks of an image, then the images (a decode per chunk and per prefetch was ~200 scalar instructions per
+    // chunk in front of this wave's matrix instructions)
+    int n_c = 0, qb_c = 0, pp_c = 0, n_n = 0, qb_n = 0, pp_n = 0;
+    auto advance = [&](int n, int qb, int pp, int& n2, int& qb2, int& pp2) {
+        pp2 = pp + 1; qb2 = qb; n2 = n;
+        if (pp2 == p.P) { pp2 = 0; qb2 = qb + 1; if (qb2 == p.qblocks) { qb2 = 0; n2 = n + 1; } }
+    };
+    if (c_begin < c_end) { decode(c_begin, n_c, qb_c, pp_c); fetch(n_c, qb_c, pp_c); advance(n_c, qb_c, pp_c, n_n, qb_n, pp_n); }
     for (int ch = c_begin; ch < c_end; ch++) {
-        int n_c, qb_c, pp_c;
-        decode(ch, n_c, qb_c, pp_c);
         const int y0 = 2 * pp_c;
         __syncthreads();                  // the previous chunk's fragment reads are done
         if (pp_c == 0 || ch == c_begin) { // a column block or this K slice begins: the first halo row is not in the ring yet (272 units: tid, and 256 + tid for 16 threads)
@@ -601,7 +617,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_pieces_kernel(WgradPar
         for (int j = 0; j < 3; j++)
             if (tid + 256 * j < 544) stash_unit(lreg[j], lok[j], slot_of(y0 + l_k[j]), l_col[j], l_oct[j]);
         __syncthreads();
-        if (ch + 1 < c_end) fetch(ch + 1);
+        if (ch + 1 < c_end) fetch(n_n, qb_n, pp_n);
         const int slot0 = slot_of(y0);
         bf16x8 af[3];
 #pragma unroll
@@ -626,6 +642,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_pieces_kernel(WgradPar
                 acc[tap] = mfma16<IO_F32, NP_F16X3>(af[0], bh, acc[tap]);       // (S h)(L h)
             }
         }
+        n_c = n_n; qb_c = qb_n; pp_c = pp_n;
+        advance(n_c, qb_c, pp_c, n_n, qb_n, pp_n);
     }
 
     const int Ag_pad = p.a_tiles * 64, Bg_pad = p.b_tiles * 64;
@@ -752,8 +770,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1x1_bf16x6_kernel(WgradParam
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
-    const int c_begin = (int)((int64_t)p.chunks_total * ks / p.ksplit);
-    const int c_end = (int)((int64_t)p.chunks_total * (ks + 1) / p.ksplit);
+    const int c_begin = (int)(((unsigned)p.chunks_total * (unsigned)ks) / (unsigned)p.ksplit);
+    const int c_end = (int)(((unsigned)p.chunks_total * (unsigned)(ks + 1)) / (unsigned)p.ksplit);
     if (c_begin < c_end) fetch(c_begin);
     for (int ch = c_begin; ch < c_end; ch++) {
         __syncthreads();                  // the previous chunk's fragment reads are done

@@ -71,8 +71,8 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 1) void conv_wgrad_kernel(WgradPara
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[t][i][j][r] = 0.f;
 
-    const int c_begin = (int)((int64_t)p.chunks_total * ks / p.ksplit);
-    const int c_end = (int)((int64_t)p.chunks_total * (ks + 1) / p.ksplit);
+    const int c_begin = (int)(((unsigned)p.chunks_total * (unsigned)ks) / (unsigned)p.ksplit);
+    const int c_end = (int)(((unsigned)p.chunks_total * (unsigned)(ks + 1)) / (unsigned)p.ksplit);
     const int kl = lane >> 5, jl = lane & 31;
     const float* const Sg = p.S + ((int64_t)g * p.Ag + a_blk) * PQ;
     const float* const Lg = p.L + ((int64_t)g * p.Bg + b_blk) * LHW;
@@ -394,8 +394,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_smallcin_kernel(WgradSmallPara
 
     const int s_k = tid & 31, s_a0 = tid >> 5;
     const int s_dr = s_k >> p.cw_log2, s_dq = s_k & (CW - 1);
-    const int c_begin = (int)((int64_t)p.chunks_total * ks / p.ksplit);
-    const int c_end = (int)((int64_t)p.chunks_total * (ks + 1) / p.ksplit);
+    const int c_begin = (int)(((unsigned)p.chunks_total * (unsigned)ks) / (unsigned)p.ksplit);
+    const int c_end = (int)(((unsigned)p.chunks_total * (unsigned)(ks + 1)) / (unsigned)p.ksplit);
 
     // Register prefetch: chunk ch+1 is fetched while chunk ch is multiplied out of LDS.  Every thread owns the same 8 S
     // elements (channel s_a0 + 8j, pixel s_k) and up to 4 halo slots of every chunk; the slot -> (channel, kernel row,

@@ -123,7 +123,7 @@ if _SCAN_TRACE is not None:
         import sys
         rows = sorted(_SCAN_TRACE.items(), key=lambda kv: -kv[1] * max(1, int(torch.Size(kv[0][0]).numel())))
         for (shape, src), n in rows[:60]:
-            print(f'amax scan x{n:5d}  {str(shape):28s} {src}', file=sys.stderr)
+            print(f'amax scan x{n:5d}  {str(shape):22s} {src}', file=sys.stderr)
     _atexit.register(_dump_scans)
 
 # PASTA_CHECK_FINITE=1 (debug; synchronises): every convolution under the three-product arithmetic checks its output for
@@ -151,9 +151,13 @@ def tensor_amax(t):
         return hit[2]
     if _SCAN_TRACE is not None:                        # diagnostic (PASTA_AMAX_TRACE=1): which tensors still cost a scan
         import sys as _sys
-        fr = _sys._getframe(1)
+        fr, chain = _sys._getframe(1), []
+        while fr is not None and len(chain) < 8:           # the callers inside this package, innermost first
+            if 'pasta-gan_amd' in fr.f_code.co_filename and fr.f_code.co_name not in ('apply', '_call_impl', '_wrapped_call_impl'):
+                chain.append(f'{fr.f_code.co_name}:{fr.f_lineno}')
+            fr = fr.f_back
         key = (tuple(t.shape), (type(t.grad_fn).__name__ if t.grad_fn is not None else ('param' if t.requires_grad else 'plain'))
-               + f' <- {fr.f_code.co_name}:{fr.f_lineno}' + (' [stale attr]' if hit is not None else ''))
+               + ' <- ' + ' <- '.join(chain) + (' [stale attr]' if hit is not None else ''))
         _SCAN_TRACE[key] = _SCAN_TRACE.get(key, 0) + 1
     parts = torch.empty([AMAX_PARTS], dtype=torch.float32, device=t.device)
     with torch.cuda.device(t.device):
