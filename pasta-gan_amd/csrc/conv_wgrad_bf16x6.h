@@ -87,20 +87,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
         qb = rem / p.P; pp = rem - qb * p.P;
     };
     // one L row (image row ly of sample n, columns q0 - 4 .. q0 + 36) into r[0..1]; returns the validity bits of its four halves
+    // (no control flow around the loads: every load is issued, from the tensor's first element where its four-pack lies outside the plane or the
+    // channel does not exist, and the validity bits zero it at the split -- the branches this was written with, one per four-pack, made the
+    // compiler wait for ALL outstanding loads at each of them: round 5's census of the staging code)
     auto fetch_row = [&](int n, int q0, int ly, float4 (&r)[2][2]) -> unsigned {
         unsigned m = 0;
         const bool rowok = (unsigned)ly < (unsigned)p.P;
         {
             const int lx = q0 - 4 + 8 * l_g0;
             const char* lp = Lg + ((int64_t)n * p.LC * PQ + (int64_t)l_b0 * PQ + ly * p.Q + lx) * ES;
-            if (rowok && l_ok0 && lx >= 0 && lx + 4 <= p.Q) { r[0][0] = io_ld4<IO>(lp); m |= 1u; }
-            if (rowok && l_ok0 && lx + 4 >= 0 && lx + 8 <= p.Q) { r[0][1] = io_ld4<IO>(lp + 4 * ES); m |= 2u; }
+            const bool v0 = rowok && l_ok0 && lx >= 0 && lx + 4 <= p.Q, v1 = rowok && l_ok0 && lx + 4 >= 0 && lx + 8 <= p.Q;
+            r[0][0] = io_ld4<IO>(v0 ? lp : Lg); r[0][1] = io_ld4<IO>(v1 ? lp + 4 * ES : Lg);
+            m |= (v0 ? 1u : 0u) | (v1 ? 2u : 0u);
         }
-        {
+        if (tid < 64) {                              // the second unit exists for the first wave only (wave-uniform)
             const int lx = q0 - 4 + 8 * l_g1;
             const char* lp = Lg + ((int64_t)n * p.LC * PQ + (int64_t)l_b1 * PQ + ly * p.Q + lx) * ES;
-            if (rowok && l_ok1 && lx >= 0 && lx + 4 <= p.Q) { r[1][0] = io_ld4<IO>(lp); m |= 4u; }
-            if (rowok && l_ok1 && lx + 4 >= 0 && lx + 8 <= p.Q) { r[1][1] = io_ld4<IO>(lp + 4 * ES); m |= 8u; }
+            const bool v0 = rowok && l_ok1 && lx >= 0 && lx + 4 <= p.Q, v1 = rowok && l_ok1 && lx + 4 >= 0 && lx + 8 <= p.Q;
+            r[1][0] = io_ld4<IO>(v0 ? lp : Lg); r[1][1] = io_ld4<IO>(v1 ? lp + 4 * ES : Lg);
+            m |= (v0 ? 4u : 0u) | (v1 ? 8u : 0u);
         }
         return m;
     };
@@ -108,11 +113,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
     auto fetch = [&](int n, int qb, int pp) {
         const int q0 = qb * 32;
         vmask = 0;
-        const char* sp = Sg + ((int64_t)n * p.SC * PQ + (int64_t)s_a * PQ + pp * p.Q + q0 + 8 * s_grp) * ES;
-        if (s_ch_ok) {
-            sreg[0] = io_ld4<IO>(sp); sreg[1] = io_ld4<IO>(sp + 4 * ES);
-            vmask |= 3u;
-        }
+        const char* sp = s_ch_ok ? Sg + ((int64_t)n * p.SC * PQ + (int64_t)s_a * PQ + pp * p.Q + q0 + 8 * s_grp) * ES : Sg;
+        sreg[0] = io_ld4<IO>(sp); sreg[1] = io_ld4<IO>(sp + 4 * ES);
+        vmask |= s_ch_ok ? 3u : 0u;
         vmask |= fetch_row(n, q0, pp + 1, lreg) << 2;
     };
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -329,13 +332,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_bf16x6_kernel(WgradPar
             for (int e = 0; e < 8; e++)
                 if ((m >> e) & 1u) r[e] = io_ld1<IO>(lp + e * ES);
         }
+        // (round 5, measured and dropped: every element fetched unconditionally from a selected address, as the stride-1 kernel now does with its
+        // four-packs -- two address selects per ELEMENT here: 123 -> 98 TFLOP/s on 64 -> 128 at 257 x 257, profiles/r5_ab_wgrad_branchfree.txt)
         return m;
     };
     auto fetch = [&](int n, int qb, int pp) {
         const int q0 = qb * 16;
         s_ok = s_on;
-        if (s_on) {
-            const char* sp = Sg + ((int64_t)n * p.SC * PQ + (int64_t)s_a * PQ + pp * p.Q + q0 + 8 * s_grp) * ES;
+        if (tid < 128) {                              // (wave-uniform: the S units belong to the first two waves)
+            const char* sp = s_on ? Sg + ((int64_t)n * p.SC * PQ + (int64_t)s_a * PQ + pp * p.Q + q0 + 8 * s_grp) * ES : Sg;
             sreg[0] = io_ld4<IO>(sp); sreg[1] = io_ld4<IO>(sp + 4 * ES);
         }
         lmask = 0;
@@ -548,8 +553,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3s2_pieces_kernel(WgradPar
     };
     auto fetch = [&](int n, int qb, int pp) {
         const int q0 = qb * 16;
-        if (s_on) {
-            const float* sp = Sg + (int64_t)n * p.SC * PQ + (int64_t)s_a * PQ + pp * p.Q + q0 + 8 * s_grp;
+        if (tid < 128) {                              // (wave-uniform; a channel beyond the tensor re-reads its first element and is zeroed at the split)
+            const float* sp = s_on ? Sg + (int64_t)n * p.SC * PQ + (int64_t)s_a * PQ + pp * p.Q + q0 + 8 * s_grp : Sg;
             sreg[0] = *(const float4*)sp; sreg[1] = *(const float4*)(sp + 4);
         }
 #pragma unroll
