@@ -28,6 +28,8 @@
 // 148 / 209 for the tile kernel on the same box -- the address arithmetic per element and two barriers per 4112 outputs cost more than
 // the partial cache lines.
 #include "common.h"
+#include <type_traits>
+#include <stdlib.h>
 
 namespace pasta {
 
@@ -109,19 +111,33 @@ __host__ __device__ constexpr int c_ntaps(int a, int D, int U, int PH, int F) { 
 // REM = 1 (1:1 kernels only): an output plane of k * TOW + 1 columns (k * TOH + 1 rows) is covered by k tiles per row
 // (column); the last tile's last thread column (row) computes the one extra output column (row).  Every blur behind a
 // pad-2 convolution has such planes (257, 129, 65, 33): without this a fifth 64-column tile runs 1/64 used.
+// PL (round 5) = planes per work item: 2 (fp32, an even number of planes) = two consecutive planes at once, interleaved in LDS as float2, so that
+// a tap is ONE 8-byte read feeding ONE v_pk_fma_f32 for the two planes.  The round's ablation of the blur in front of the stride-2 convolutions
+// (pieces.hip; profiles/r5_down_path_microbench.txt) showed these kernels bound by instruction issue, not by memory: with one plane per item the
+// compiler packs pairs of OUTPUTS into v_pk_fma_f32 and spends two v_mov per packed operand (85 v_mov for 32 packed FMAs in the 1:1 4 x 4 instance).
+typedef float up_f32x2 __attribute__((ext_vector_type(2)));
+template <int PL> struct UpVec { typedef float type; };
+template <> struct UpVec<2> { typedef up_f32x2 type; };
+__device__ __forceinline__ float up_fma(float g, float x, float v) { return fmaf(g, x, v); }
+__device__ __forceinline__ up_f32x2 up_fma(float g, up_f32x2 x, up_f32x2 v) { return __builtin_elementwise_fma(up_f32x2{g, g}, x, v); }
+__device__ __forceinline__ float up_lane(float v, int) { return v; }
+__device__ __forceinline__ float up_lane(up_f32x2 v, int k) { return v[k]; }
+
 template <class T, int UX, int UY, int DX, int DY, int FW, int FH, int PHX, int PHY,
-          int MX, int MY, int BX, int BY, int REM>
+          int MX, int MY, int BX, int BY, int REM, int PL = 1>
 __global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p, int tiles_x, int tiles_y, int nitems, int rem_x, int rem_y) {
     static_assert(MX % UX == 0 && MY % UY == 0, "micro-tile must cover whole phases");
     static_assert((BX * BY) % 64 == 0, "whole wavefronts");
     static_assert(REM == 0 || (UX == 1 && UY == 1 && DX == 1 && DY == 1), "remainder strips exist for the 1:1 kernels only");
+    static_assert(PL == 1 || PL == 2, "one plane, or a pair of planes, per work item");
+    typedef typename UpVec<PL>::type V;
     constexpr int NT = BX * BY;
     constexpr int TOW = BX * MX, TOH = BY * MY;
     constexpr int TIW = ((TOW + REM - 1) * DX + FW - 1) / UX + 2;
     constexpr int TIH = ((TOH + REM - 1) * DY + FH - 1) / UY + 2;
     constexpr int LDW = TIW | 1;   // odd row pitch keeps strided column reads off one bank
     constexpr int NLOAD = (TIH * TIW + NT - 1) / NT;
-    __shared__ float sx[TIH * LDW];
+    __shared__ V sx[TIH * LDW];
 
     const int tid = threadIdx.x;
     const int tx = tid % BX, ty = tid / BX;
@@ -144,19 +160,26 @@ __global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p,
 
     // A work item is one output tile of one plane; the workgroup walks items blockIdx.x, +gridDim.x, ... and
     // fetches the next item's input tile into registers while it computes the current one from LDS.
-    float stage[NLOAD];
+    V stage[NLOAD];
     auto fetch = [&](int item) {
         const int tile_x = item % tiles_x, r = item / tiles_x;
-        const int tile_y = r % tiles_y, plane = r / tiles_y;
+        const int tile_y = r % tiles_y, plane = (r / tiles_y) * PL;       // the item's first plane
         const int ix0 = (tile_x * TOW * DX - p.padx0 + PHX) / UX;      // exact divisions by construction
         const int iy0 = (tile_y * TOH * DY - p.pady0 + PHY) / UY;
         const T* xp = (const T*)p.x + (int64_t)plane * p.inH * p.inW;
 #pragma unroll
         for (int j = 0; j < NLOAD; j++) {
             const int iy = iy0 + slot_row[j], ix = ix0 + slot_col[j];
-            float v = 0.f;
-            if (slot_row[j] < TIH && iy >= 0 && iy < p.inH && ix >= 0 && ix < p.inW) v = ld<T>(xp + (int64_t)iy * p.inW + ix);
-            stage[j] = v;
+            const bool in = slot_row[j] < TIH && iy >= 0 && iy < p.inH && ix >= 0 && ix < p.inW;
+            if constexpr (PL == 2) {
+                up_f32x2 v = {0.f, 0.f};
+                if (in) { v[0] = ld<T>(xp + (int64_t)iy * p.inW + ix); v[1] = ld<T>(xp + (int64_t)(p.inH + iy) * p.inW + ix); }
+                stage[j] = v;
+            } else {
+                float v = 0.f;
+                if (in) v = ld<T>(xp + (int64_t)iy * p.inW + ix);
+                stage[j] = v;
+            }
         }
     };
 
@@ -174,38 +197,49 @@ __global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p,
         if (next < nitems) fetch(next);
 
         const int tile_x = item % tiles_x, r_ = item / tiles_x;
-        const int tile_y = r_ % tiles_y, plane = r_ / tiles_y;
-        T* yp = (T*)p.y + (int64_t)plane * p.outH * p.outW;
+        const int tile_y = r_ % tiles_y, plane = (r_ / tiles_y) * PL;
+        const int64_t OHW = (int64_t)p.outH * p.outW;
+        T* yp = (T*)p.y + (int64_t)plane * OHW;
         const int rx = tx * (MX * DX / UX), ry = ty * (MY * DY / UY);
-        float acc[MY][MX];
+        V acc[MY][MX];
 #pragma unroll
         for (int b = 0; b < MY; b++)
 #pragma unroll
             for (int a = 0; a < MX; a++) {
-                float v = 0.f;
+                V v = V(0.f);
 #pragma unroll
                 for (int jy = 0; jy < c_ntaps(b, DY, UY, PHY, FH); jy++)
 #pragma unroll
                     for (int jx = 0; jx < c_ntaps(a, DX, UX, PHX, FW); jx++)
-                        v = fmaf(g[c_tap0(b, DY, UY, PHY) + jy * UY][c_tap0(a, DX, UX, PHX) + jx * UX],
-                                 sx[(ry + c_in0(b, DY, UY, PHY) + jy) * LDW + rx + c_in0(a, DX, UX, PHX) + jx], v);
+                        v = up_fma(g[c_tap0(b, DY, UY, PHY) + jy * UY][c_tap0(a, DX, UX, PHX) + jx * UX],
+                                   sx[(ry + c_in0(b, DY, UY, PHY) + jy) * LDW + rx + c_in0(a, DX, UX, PHX) + jx], v);
                 acc[b][a] = v * p.gain;
             }
         const int ox = tile_x * TOW + tx * MX, oy = tile_y * TOH + ty * MY;
-        const T* ap = p.y_add ? (const T*)p.y_add + (int64_t)plane * p.outH * p.outW : nullptr;
+        const T* ap = p.y_add ? (const T*)p.y_add + (int64_t)plane * OHW : nullptr;
         if (ap) {                                       // the addend of this thread's outputs, fetched in one go in front of the stores
 #pragma unroll
             for (int b = 0; b < MY; b++)
 #pragma unroll
                 for (int a = 0; a < MX; a++)
-                    if (oy + b < p.outH && ox + a < p.outW) acc[b][a] += ld<T>(ap + (int64_t)(oy + b) * p.outW + ox + a);
+                    if (oy + b < p.outH && ox + a < p.outW) {
+                        if constexpr (PL == 2) { acc[b][a][0] += ld<T>(ap + (int64_t)(oy + b) * p.outW + ox + a); acc[b][a][1] += ld<T>(ap + OHW + (int64_t)(oy + b) * p.outW + ox + a); }
+                        else acc[b][a] += ld<T>(ap + (int64_t)(oy + b) * p.outW + ox + a);
+                    }
         }
 #pragma unroll
         for (int b = 0; b < MY; b++) {
             if (oy + b >= p.outH) break;
 #pragma unroll
             for (int a = 0; a < MX; a++)
-                if (ox + a < p.outW) { st<T>(yp + (int64_t)(oy + b) * p.outW + ox + a, acc[b][a]); if (p.y_amax) amax_take(am, acc[b][a]); }
+                if (ox + a < p.outW) {
+#pragma unroll
+                    for (int k = 0; k < PL; k++) {
+                        const float v = up_lane(acc[b][a], k);
+                        st<T>(yp + k * OHW + (int64_t)(oy + b) * p.outW + ox + a, v);
+                        if (p.y_amax) amax_take(am, v);
+                    }
+                }
         }
         if constexpr (REM == 1) {
             // one extra output column / row / corner of the plane, by the last thread column / row of the last tile
@@ -214,15 +248,19 @@ __global__ __launch_bounds__(BX* BY) void upfirdn2d_tile_kernel(UpfirdnParams p,
             auto one = [&](int yy, int xx) {          // output (yy, xx) relative to the tile origin
                 // the OTHER dimension may end inside this tile (non-square planes: 20 x 33 on 32 x 32 tiles)
                 if (tile_y * TOH + yy >= p.outH || tile_x * TOW + xx >= p.outW) return;
-                float v = 0.f;
+                V v = V(0.f);
 #pragma unroll
                 for (int jy = 0; jy < FH; jy++)
 #pragma unroll
-                    for (int jx = 0; jx < FW; jx++) v = fmaf(g[jy][jx], sx[(yy + jy) * LDW + xx + jx], v);
+                    for (int jx = 0; jx < FW; jx++) v = up_fma(g[jy][jx], sx[(yy + jy) * LDW + xx + jx], v);
                 v *= p.gain;
-                if (ap) v += ld<T>(ap + (int64_t)(tile_y * TOH + yy) * p.outW + tile_x * TOW + xx);
-                st<T>(yp + (int64_t)(tile_y * TOH + yy) * p.outW + tile_x * TOW + xx, v);
-                if (p.y_amax) amax_take(am, v);
+#pragma unroll
+                for (int k = 0; k < PL; k++) {
+                    float w = up_lane(v, k);
+                    if (ap) w += ld<T>(ap + k * OHW + (int64_t)(tile_y * TOH + yy) * p.outW + tile_x * TOW + xx);
+                    st<T>(yp + k * OHW + (int64_t)(tile_y * TOH + yy) * p.outW + tile_x * TOW + xx, w);
+                    if (p.y_amax) amax_take(am, w);
+                }
             };
             if (ex) {
 #pragma unroll
@@ -357,17 +395,24 @@ static void launch_tile(const UpfirdnParams& p, hipStream_t s) {
         rem_y = (p.outH > TOH && p.outH % TOH == 1) ? 1 : 0;
         tiles_x -= rem_x; tiles_y -= rem_y;
     }
-    const int64_t nitems = (int64_t)tiles_x * tiles_y * p.N * p.C;
+    const int64_t planes = (int64_t)p.N * p.C;
+    static const bool pairs_on = !(getenv("PASTA_UPFIRDN_PAIRS") && getenv("PASTA_UPFIRDN_PAIRS")[0] == '0');       // A/B switch
+    // fp32, an even number of planes: two planes per work item (packed FMAs on plane pairs), as long as the items still fill the chip
+    const bool pair = std::is_same<T, float>::value && pairs_on && (planes & 1) == 0 && (int64_t)tiles_x * tiles_y * (planes / 2) >= 2048;      // (the RGB up-sampling, 768 pair items, ran 2x slower on pairs: measured)
+    const int64_t nitems = (int64_t)tiles_x * tiles_y * (pair ? planes / 2 : planes);
     const int64_t grid = nitems < 256 * 16 ? nitems : 256 * 16;     // up to 16 resident-or-queued workgroups per CU
+#define PASTA_TILE(REM_, PL_, RX_, RY_) hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, UX, UY, DX, DY, FW, FH, PHX, PHY, MX, MY, BX, BY, REM_, PL_>), \
+                                                          dim3((unsigned)grid), dim3(BX * BY), 0, s, p, tiles_x, tiles_y, (int)nitems, RX_, RY_)
     if constexpr (UX == 1 && UY == 1 && DX == 1 && DY == 1) {
         if (rem_x || rem_y) {
-            hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, UX, UY, DX, DY, FW, FH, PHX, PHY, MX, MY, BX, BY, 1>), dim3((unsigned)grid), dim3(BX * BY), 0, s,
-                               p, tiles_x, tiles_y, (int)nitems, rem_x, rem_y);
+            if constexpr (std::is_same<T, float>::value) { if (pair) { PASTA_TILE(1, 2, rem_x, rem_y); return; } }
+            PASTA_TILE(1, 1, rem_x, rem_y);
             return;
         }
     }
-    hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, UX, UY, DX, DY, FW, FH, PHX, PHY, MX, MY, BX, BY, 0>), dim3((unsigned)grid), dim3(BX * BY), 0, s,
-                       p, tiles_x, tiles_y, (int)nitems, 0, 0);
+    if constexpr (std::is_same<T, float>::value) { if (pair) { PASTA_TILE(0, 2, 0, 0); return; } }
+    PASTA_TILE(0, 1, 0, 0);
+#undef PASTA_TILE
 }
 
 // Phase dispatch (runtime pad0 mod U -> template constant).
