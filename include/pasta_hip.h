@@ -231,7 +231,10 @@ int pasta_conv2d_tile(const pasta_conv_desc* d);
  * optionally over two input tensors -- pasta_conv_desc.x2), 10 conv3x3s2_f16x3_kernel (round 4: 3x3 stride-2 conv2d with pads 0 / 1 under PASTA_MATH_F16X3,
  * fp32 tensors, >= 16 input and > 32 output channels, output widths 16 .. 128 .. that are powers of two: a round stages the input ROW segments of a kernel
  * row once, de-interleaved by pixel parity, for its three taps; round 5: with pasta_conv_desc.x_layout = PASTA_LAYOUT_PIECES16 its staging is a copy of
- * the producer's sixteen-byte pieces, no split).  Any out pointer may be NULL. */
+ * the producer's sixteen-byte pieces, no split), 11 / 12 conv1x1_fewcin_kernel / conv1x1_fewcout_kernel (round 5: 1x1 stride-1 launches with <= 16 input
+ * or <= 16 output channels over more than 8192 pixels, fp32 tensors, one group, planes of a multiple of four pixels -- the RGB / pose stems, the ToRGB and
+ * parsing heads and their input gradients: streaming kernels of plain fp32 FMAs on the raw weights, no packing launch, *math = PASTA_MATH_F32).
+ * Any out pointer may be NULL. */
 #define PASTA_PLAN_ISCALE   1
 #define PASTA_PLAN_OSCALE   2
 #define PASTA_PLAN_EPILOGUE 4

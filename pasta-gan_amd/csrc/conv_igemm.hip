@@ -36,6 +36,7 @@
 #include "conv_fwd_rows2d_bf16x6.h"
 #include "conv_fwd_1x1.h"
 #include "conv_fwd_s2.h"
+#include "conv_fwd_fewch.h"
 #include "conv_wgrad_f32.h"
 #include "conv_wgrad_bf16x6.h"
 
@@ -351,6 +352,15 @@ extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int launch_flags, int
     const bool sb = f.bf16x6 && (!has_iscale || isc_in_staging(d)) && (!f.packed || packed);
     if (d->io_dtype != PASTA_F32 && !sb) return fail("conv2d: no 16-bit-storage kernel for this shape (fewer than 16 input channels per group, at most 32 "
                                                       "output channels, or an input scale): convert the tensors to fp32 for this launch");
+    if (const int few = conv1x1_fewch_kind(d, has_iscale, (launch_flags & PASTA_PLAN_OSCALE) != 0, false, (launch_flags & PASTA_PLAN_MODULATED) != 0)) {
+        // a streaming fp32 kernel on the raw weights (conv_fwd_fewch.h): no packing, no operand scale
+        if (tile) *tile = (int)f.tile;
+        if (ksplit) *ksplit = 1;
+        if (math) *math = PASTA_MATH_F32;
+        if (launches) *launches = 1;
+        if (kernel) *kernel = 10 + few;
+        return 0;
+    }
     if (tile) *tile = (int)f.tile;
     if (ksplit) *ksplit = f.ksplit;
     if (math) *math = !sb ? PASTA_MATH_F32 : d->io_dtype != PASTA_F32 ? PASTA_MATH_BF16 : d->math == PASTA_MATH_BF16X3 ? PASTA_MATH_BF16X3 : d->math == PASTA_MATH_BF16 ? PASTA_MATH_BF16 :
@@ -609,6 +619,17 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
     PASTA_CHECK(workspace && workspace_bytes >= need, "conv2d: workspace of %lld bytes needed, %lld given", (long long)need, (long long)workspace_bytes);
     PASTA_CHECK(((uintptr_t)workspace & 15) == 0, "conv2d: workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    if (const int few = conv1x1_fewch_kind(d, iscale != nullptr, oscale != nullptr, ep && ep->noise, wmod_s != nullptr)) {
+        FewChParams q;
+        q.x = (const float*)x; q.w = w; q.y = (float*)y; q.iscale = iscale;
+        q.bias = ep ? ep->bias : nullptr; q.res = ep ? (const float*)ep->res : nullptr; q.y_amax = ep ? ep->y_amax : nullptr;
+        q.N = d->N; q.Cin = d->C_in; q.Cout = d->C_out; q.HW = d->H * d->W;
+        q.w_io = d->transposed ? 1 : 0;
+        q.wscale = d->wscale == 0.f ? 1.f : d->wscale;
+        q.act = ep ? ep->act : 0; q.alpha = ep ? ep->alpha : 0.f; q.gain = ep ? ep->gain : 1.f; q.clamp = ep ? ep->clamp : -1.f;
+        tu_conv1x1_fewch(few, q, s);
+        return launch_status("conv2d");
+    }
 
     float* const ws_amax = (float*)workspace;                         // [2][AMAX_PARTS]: partial |max| of x (second row: spare)
     float* const ws_rowinv = ws_amax + WS_AMAX_FLOATS;                // [G][Og_pad]: 1 / S_w per packed weight row (PASTA_MATH_F16X3)

@@ -37,6 +37,10 @@ void tu_rows2d_64_r8(const ConvFwdParams& q, hipStream_t s);
 void tu_conv1x1(const ConvFwdParams& p, hipStream_t s);
 void tu_conv3x3s2(const ConvFwdParams& p, hipStream_t s);
 
+// conv_tu_fwd_fewch.hip: pointwise convolutions with <= 16 channels on one side (kind 1: few input channels, 2: few output channels)
+struct FewChParams;
+void tu_conv1x1_fewch(int kind, const FewChParams& p, hipStream_t s);
+
 // conv_tu_wgrad_f32.hip: fp32-MFMA weight gradients, few-channel kernels, slab reductions
 int  tu_wgrad_f32(int TR, int TS, int WA, int pipe, int kp, const WgradParams& p, int64_t blocks, size_t lds_bytes, hipStream_t s);
 void tu_wgrad_reduce(const float* slab, float* dw, int ksplit, int G, int Ag, int Bg, int Ag_pad, int Bg_pad, int kh, int kw, int flip, float wscale,
