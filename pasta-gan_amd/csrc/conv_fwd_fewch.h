@@ -21,15 +21,27 @@
 namespace pasta {
 
 struct FewChParams {
-    const float* x; const float* w; float* y;
+    const void* x; const float* w; void* y;      // x, y, res: elements of the storage type IO (fp32, or 16-bit storage: BASELINE config 5)
     const float* iscale;            // [N][Cin] or null (fewcout only)
-    const float* bias; const float* res;
+    const float* bias; const void* res;
     float* y_amax;
+    int io;                         // IO_F32 / IO_F16 / IO_BF16
     int N, Cin, Cout, HW;
     int w_io;                       // the weight tensor is [Cin][Cout] (conv_transpose2d), else [Cout][Cin]
     float wscale;
     int act; float alpha, gain, clamp;
 };
+
+// four consecutive elements at element index `idx` of `base` (a multiple of four: naturally aligned), as fp32 / from fp32
+template <int IO> __device__ __forceinline__ float4 fewch_ld4(const void* base, int64_t idx) { return io_ld4<IO>((const char*)base + idx * io_size<IO>::value); }
+template <int IO> __device__ __forceinline__ void fewch_st4(void* base, int64_t idx, float4 v) {
+    if constexpr (IO == IO_F32) *(float4*)((float*)base + idx) = v;
+    else {
+        uint2 q;
+        q.x = io_pack2<IO>(v.x, v.y); q.y = io_pack2<IO>(v.z, v.w);
+        *(uint2*)((char*)base + idx * 2) = q;
+    }
+}
 
 __device__ __forceinline__ float4 fewch_epilogue(float4 v, float b, const FewChParams& p) {
     if (p.act) {
@@ -41,7 +53,7 @@ __device__ __forceinline__ float4 fewch_epilogue(float4 v, float b, const FewChP
 
 // grid.x = N * HW / 4 / 256 quads of pixels (HW % 4 == 0; a workgroup may straddle samples: the sample is per thread).  The weights of the
 // launch (Cout x CI values times wscale, <= 32 KB) sit in LDS as [Cout][CI] and are read as broadcasts.
-template <int CI>
+template <int CI, int IO>
 __global__ __launch_bounds__(256) void conv1x1_fewcin_kernel(FewChParams p) {
     constexpr int CIP = (CI + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) float fewch_w[];      // [Cout][CIP]
@@ -60,9 +72,8 @@ __global__ __launch_bounds__(256) void conv1x1_fewcin_kernel(FewChParams p) {
         const int off = (int)(quad - (int64_t)n * hwq) * 4;
         float4 xv[CI];
 #pragma unroll
-        for (int i = 0; i < CI; i++) xv[i] = *(const float4*)(p.x + ((int64_t)n * CI + i) * p.HW + off);
-        float* const yb = p.y + (int64_t)n * p.Cout * p.HW + off;
-        const float* const rb = p.res ? p.res + (int64_t)n * p.Cout * p.HW + off : nullptr;
+        for (int i = 0; i < CI; i++) xv[i] = fewch_ld4<IO>(p.x, ((int64_t)n * CI + i) * p.HW + off);
+        const int64_t ybase = (int64_t)n * p.Cout * p.HW + off;
         for (int o = 0; o < p.Cout; o++) {              // wave-uniform trip count; the weight row: one LDS address for the wave
             float wv[CIP];
 #pragma unroll
@@ -72,9 +83,9 @@ __global__ __launch_bounds__(256) void conv1x1_fewcin_kernel(FewChParams p) {
             for (int i = 0; i < CI; i++) {
                 a.x = fmaf(wv[i], xv[i].x, a.x); a.y = fmaf(wv[i], xv[i].y, a.y); a.z = fmaf(wv[i], xv[i].z, a.z); a.w = fmaf(wv[i], xv[i].w, a.w);
             }
-            if (rb) { const float4 r = *(const float4*)(rb + (int64_t)o * p.HW); a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w; }
+            if (p.res) { const float4 r = fewch_ld4<IO>(p.res, ybase + (int64_t)o * p.HW); a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w; }
             a = fewch_epilogue(a, (p.act && p.bias) ? p.bias[o] : 0.f, p);
-            *(float4*)(yb + (int64_t)o * p.HW) = a;
+            fewch_st4<IO>(p.y, ybase + (int64_t)o * p.HW, a);
             if (p.y_amax) { amax_take(am, a.x); amax_take(am, a.y); amax_take(am, a.z); amax_take(am, a.w); }
         }
     }
@@ -82,7 +93,7 @@ __global__ __launch_bounds__(256) void conv1x1_fewcin_kernel(FewChParams p) {
 }
 
 // grid = (HW / 4 / 256 rounded up, N): a workgroup lies inside one sample (its styles ride in the LDS copy of the weights)
-template <int CO>
+template <int CO, int IO>
 __global__ __launch_bounds__(256) void conv1x1_fewcout_kernel(FewChParams p) {
     constexpr int COP = (CO + 3) & ~3;                  // outputs padded to whole 16-byte LDS reads
     extern __shared__ __attribute__((aligned(16))) float fewch_w[];      // [Cin][COP]: w[o][i] * wscale (* iscale[n][i])
@@ -103,7 +114,7 @@ __global__ __launch_bounds__(256) void conv1x1_fewcout_kernel(FewChParams p) {
     const AmaxSlot aslot = amax_begin(p.y_amax);
     if (q < hwq) {
         const int off = q * 4;
-        const float* const xb = p.x + (int64_t)n * p.Cin * p.HW + off;
+        const int64_t xbase = (int64_t)n * p.Cin * p.HW + off;
         float4 acc[CO];
 #pragma unroll
         for (int o = 0; o < CO; o++) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -111,7 +122,7 @@ __global__ __launch_bounds__(256) void conv1x1_fewcout_kernel(FewChParams p) {
         for (; i + 8 <= p.Cin; i += 8) {                // eight channel quads in flight
             float4 xv[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) xv[k] = *(const float4*)(xb + (int64_t)(i + k) * p.HW);
+            for (int k = 0; k < 8; k++) xv[k] = fewch_ld4<IO>(p.x, xbase + (int64_t)(i + k) * p.HW);
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 float wv[COP];
@@ -125,31 +136,31 @@ __global__ __launch_bounds__(256) void conv1x1_fewcout_kernel(FewChParams p) {
             }
         }
         for (; i < p.Cin; i++) {
-            const float4 xv = *(const float4*)(xb + (int64_t)i * p.HW);
+            const float4 xv = fewch_ld4<IO>(p.x, xbase + (int64_t)i * p.HW);
 #pragma unroll
             for (int o = 0; o < CO; o++) {
                 const float wv = fewch_w[i * COP + o];
                 acc[o].x = fmaf(wv, xv.x, acc[o].x); acc[o].y = fmaf(wv, xv.y, acc[o].y); acc[o].z = fmaf(wv, xv.z, acc[o].z); acc[o].w = fmaf(wv, xv.w, acc[o].w);
             }
         }
-        float* const yb = p.y + (int64_t)n * CO * p.HW + off;
+        const int64_t ybase = (int64_t)n * CO * p.HW + off;
 #pragma unroll
         for (int o = 0; o < CO; o++) {
             float4 a = acc[o];
-            if (p.res) { const float4 r = *(const float4*)(p.res + (int64_t)n * CO * p.HW + (int64_t)o * p.HW + off); a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w; }
+            if (p.res) { const float4 r = fewch_ld4<IO>(p.res, ybase + (int64_t)o * p.HW); a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w; }
             a = fewch_epilogue(a, (p.act && p.bias) ? p.bias[o] : 0.f, p);
-            *(float4*)(yb + (int64_t)o * p.HW) = a;
+            fewch_st4<IO>(p.y, ybase + (int64_t)o * p.HW, a);
             if (p.y_amax) { amax_take(am, a.x); amax_take(am, a.y); amax_take(am, a.z); amax_take(am, a.w); }
         }
     }
     amax_commit(am, aslot);
 }
 
-// Which of the two takes a launch (0: neither): fp32 tensors, 1x1, stride 1, no padding, one group, plain weights, no output scale / noise,
+// Which of the two takes a launch (0: neither): fp32 or 16-bit tensors (the stored element is converted on the way in and out: fp32 FMAs), 1x1, stride 1, no padding, one group, plain weights, no output scale / noise,
 // planes of a multiple of four pixels, more than 8192 pixels (the K-sliced small-plane path keeps the rest); an input scale on the few-output side only.
 static int conv1x1_fewch_kind(const pasta_conv_desc* d, bool has_iscale, bool has_oscale, bool has_noise, bool modulated) {
     static const bool enabled = !(getenv("PASTA_CONV_FEWCH") && getenv("PASTA_CONV_FEWCH")[0] == '0');       // A/B switch
-    if (!enabled || d->io_dtype != PASTA_F32 || d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad_h || d->pad_w || d->groups != 1) return 0;
+    if (!enabled || d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad_h || d->pad_w || d->groups != 1) return 0;
     if (has_oscale || has_noise || modulated || d->x2 || d->x_layout || d->OH != d->H || d->OW != d->W) return 0;
     const int64_t hw = (int64_t)d->H * d->W;
     if (hw % 4 || (int64_t)d->N * hw <= 8192) return 0;

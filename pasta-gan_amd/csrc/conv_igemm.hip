@@ -350,8 +350,10 @@ extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int launch_flags, int
     const FwdPlan f = plan_fwd(d);
     const bool packed = f.packed && !has_iscale && !(launch_flags & PASTA_PLAN_MODULATED);
     const bool sb = f.bf16x6 && (!has_iscale || isc_in_staging(d)) && (!f.packed || packed);
-    if (d->io_dtype != PASTA_F32 && !sb) return fail("conv2d: no 16-bit-storage kernel for this shape (fewer than 16 input channels per group, at most 32 "
-                                                      "output channels, or an input scale): convert the tensors to fp32 for this launch");
+    const int few_kind = conv1x1_fewch_kind(d, has_iscale, (launch_flags & PASTA_PLAN_OSCALE) != 0, false, (launch_flags & PASTA_PLAN_MODULATED) != 0);
+    if (d->io_dtype != PASTA_F32 && !sb && !few_kind)
+        return fail("conv2d: no 16-bit-storage kernel for this shape (fewer than 16 input channels per group, at most 32 "
+                    "output channels, or an input scale -- pointwise layers over more than 8192 pixels excepted): convert the tensors to fp32 for this launch");
     if (const int few = conv1x1_fewch_kind(d, has_iscale, (launch_flags & PASTA_PLAN_OSCALE) != 0, false, (launch_flags & PASTA_PLAN_MODULATED) != 0)) {
         // a streaming fp32 kernel on the raw weights (conv_fwd_fewch.h): no packing, no operand scale
         if (tile) *tile = (int)f.tile;
@@ -621,8 +623,8 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
     hipStream_t s = (hipStream_t)stream;
     if (const int few = conv1x1_fewch_kind(d, iscale != nullptr, oscale != nullptr, ep && ep->noise, wmod_s != nullptr)) {
         FewChParams q;
-        q.x = (const float*)x; q.w = w; q.y = (float*)y; q.iscale = iscale;
-        q.bias = ep ? ep->bias : nullptr; q.res = ep ? (const float*)ep->res : nullptr; q.y_amax = ep ? ep->y_amax : nullptr;
+        q.x = x; q.w = w; q.y = y; q.iscale = iscale; q.io = d->io_dtype;
+        q.bias = ep ? ep->bias : nullptr; q.res = ep ? ep->res : nullptr; q.y_amax = ep ? ep->y_amax : nullptr;
         q.N = d->N; q.Cin = d->C_in; q.Cout = d->C_out; q.HW = d->H * d->W;
         q.w_io = d->transposed ? 1 : 0;
         q.wscale = d->wscale == 0.f ? 1.f : d->wscale;

@@ -90,3 +90,27 @@ def test_modulated_head_takes_its_styles_in_the_weights():
     if hit is not None:
         torch.cuda.synchronize()
         assert abs(float(hit[2].max()) - float(z.abs().max())) <= 1e-6 * float(z.abs().max())
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('n,ci,co,h', [(6, 3, 64, 64), (4, 64, 3, 64), (3, 512, 9, 64)])
+def test_few_channel_layers_stay_in_16_bit_storage(n, ci, co, h, dtype):
+    """BASELINE config 5: with 16-bit activation storage the few-channel pointwise layers used to be converted to fp32 for the launch and back
+    (no 16-bit tile kernel for them); the streaming kernels read and write the stored type (fp32 FMAs in between, one rounding on the way out)."""
+    from torch_utils import custom_ops
+    from torch_utils.ops import conv2d_gradfix as cg, _native
+    io = cg.IO_CODES[dtype]
+    d = custom_ops.ConvDesc(N=n, C_in=ci, H=h, W=h, C_out=co, OH=h, OW=h, kh=1, kw=1, stride=1, pad_h=0, pad_w=0, groups=1, transposed=0, flip=0, math=0, io_dtype=io)
+    k = ctypes.c_int(-1)
+    assert _native.lib().pasta_conv2d_plan(ctypes.byref(d), 4, None, None, None, None, ctypes.byref(k)) == 0 and k.value in (11, 12)
+    g = torch.Generator().manual_seed(ci + co)
+    x = torch.randn([n, ci, h, h], generator=g).cuda().to(dtype)
+    w = (torch.randn([co, ci, 1, 1], generator=g) / ci ** 0.5).cuda()
+    b = torch.randn([co], generator=g).cuda()
+    y = cg.conv2d_bias_act(x, w, b, act='lrelu', gain=2 ** 0.5, clamp=256)
+    assert y.dtype == dtype
+    pre = torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu()) + b.double().cpu().reshape(1, -1, 1, 1)
+    ref = (torch.where(pre > 0, pre, pre * 0.2) * 2 ** 0.5).clamp(-256, 256)
+    tol = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -10         # one rounding of the result to the stored type
+    err = (y.double().cpu() - ref).abs()
+    assert float((err / (ref.abs() + 1e-2 * ref.abs().max())).max()) < tol
