@@ -946,14 +946,14 @@ int pasta::wgrad_run(const void* xv, const void* dyv, float* dw, const pasta_con
         if (int e = pasta_conv2d_wgrad_plan(d, &k)) return e;
         PASTA_CHECK(!mod_s && d->x_amax, "conv2d_wgrad: x_layout = PASTA_LAYOUT_PIECES16 needs x_amax (the row pasta_blur_pieces wrote) and plain weights");
     }
-    PASTA_CHECK(d->io_dtype == PASTA_F32 || !ws.use, "conv2d_wgrad: no 16-bit-storage kernel for this shape (pasta_conv2d_wgrad_plan tells beforehand)");
+    PASTA_CHECK(d->io_dtype == PASTA_F32 || !ws.use || plan_wgrad1x1_fewcin(d, ws), "conv2d_wgrad: no 16-bit-storage kernel for this shape (pasta_conv2d_wgrad_plan tells beforehand)");
     if (const int fks = plan_wgrad1x1_fewcin(d, ws)) {
         // few input channels, 1x1: one bandwidth-bound pass over dy with plain FMAs (conv_wgrad_f32.h)
         const int64_t total = (int64_t)d->N * ((int64_t)d->H * d->W / 4);
         const int64_t per = (total + fks - 1) / fks;
         const int a_pad = ws.a_tiles * 64, bpad = ws.nb * 32;
         const dim3 grid((unsigned)fks, (unsigned)((d->C_out + 7) / 8));
-        tu_wgrad1x1_fewcin(d->C_in, grid, dy, x, (float*)workspace, d->N, d->C_out, d->H * d->W, per, a_pad, bpad, s);
+        tu_wgrad1x1_fewcin(d->C_in, d->io_dtype, grid, dy, x, (float*)workspace, d->N, d->C_out, d->H * d->W, per, a_pad, bpad, s);
         tu_wgrad_smallcin_reduce((const float*)workspace, dw, fks, d->C_out, ws.bprime, a_pad, bpad, d->wscale == 0.f ? 1.f : d->wscale, s);
         return launch_status("conv2d_wgrad(few-channel 1x1)");
     }

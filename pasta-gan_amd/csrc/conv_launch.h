@@ -51,7 +51,7 @@ void tu_sum_blocks(const float* blocks, float* out, int nblocks, int n, hipStrea
 struct WgradSmallParams;
 void tu_wgrad_smallcin(const WgradSmallParams& q, int blocks, size_t lds_bytes, hipStream_t s);
 void tu_wgrad_smallcin_reduce(const float* slab, float* dw, int ksplit, int Ag, int bprime, int a_pad, int bpad, float wscale, hipStream_t s);
-void tu_wgrad1x1_fewcin(int CI, dim3 grid, const float* dy, const float* x, float* slab, int N, int Co, int HW, int64_t quads_per_slice, int a_pad,
+void tu_wgrad1x1_fewcin(int CI, int io, dim3 grid, const void* dy, const void* x, float* slab, int N, int Co, int HW, int64_t quads_per_slice, int a_pad,
                         int bpad, hipStream_t s);
 
 // conv_tu_wgrad_{3x3,3x3s2,1x1}.hip: the split weight-gradient kernels (np: pieces per operand, NP_F16X3 included; p.io: storage type)

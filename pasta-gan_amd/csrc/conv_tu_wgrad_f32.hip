@@ -54,9 +54,11 @@ void tu_wgrad_smallcin_reduce(const float* slab, float* dw, int ksplit, int Ag, 
     hipLaunchKernelGGL(wgrad_smallcin_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, slab, dw, ksplit, Ag, bprime, a_pad, bpad, wscale);
 }
 
-void tu_wgrad1x1_fewcin(int CI, dim3 grid, const float* dy, const float* x, float* slab, int N, int Co, int HW, int64_t quads_per_slice, int a_pad,
+void tu_wgrad1x1_fewcin(int CI, int io, dim3 grid, const void* dy, const void* x, float* slab, int N, int Co, int HW, int64_t quads_per_slice, int a_pad,
                         int bpad, hipStream_t s) {
-#define PASTA_FEW(CI_) case CI_: hipLaunchKernelGGL((wgrad1x1_fewcin_kernel<CI_>), grid, dim3(256), 0, s, dy, x, slab, N, Co, HW, quads_per_slice, a_pad, bpad); break;
+#define PASTA_FEW(CI_) case CI_: if (io == IO_BF16) hipLaunchKernelGGL((wgrad1x1_fewcin_kernel<CI_, IO_BF16>), grid, dim3(256), 0, s, dy, x, slab, N, Co, HW, quads_per_slice, a_pad, bpad); \
+                                else if (io == IO_F16) hipLaunchKernelGGL((wgrad1x1_fewcin_kernel<CI_, IO_F16>), grid, dim3(256), 0, s, dy, x, slab, N, Co, HW, quads_per_slice, a_pad, bpad); \
+                                else hipLaunchKernelGGL((wgrad1x1_fewcin_kernel<CI_, IO_F32>), grid, dim3(256), 0, s, dy, x, slab, N, Co, HW, quads_per_slice, a_pad, bpad); break;
     switch (CI) { PASTA_FEW(1) PASTA_FEW(2) PASTA_FEW(3) PASTA_FEW(4) PASTA_FEW(5) PASTA_FEW(6) PASTA_FEW(7) PASTA_FEW(8) }
 #undef PASTA_FEW
 }

@@ -536,9 +536,11 @@ static WgradSmallPlan plan_wgrad_small(const pasta_conv_desc* d) {
 // 8 x CI sums; a workgroup walks one K slice (pixel quads of the whole batch) for one group of eight output channels; sums are combined by
 // wave shuffles and a fixed-order pass over the four waves (bitwise reproducible) and land in the slab layout of the kernel above, whose
 // reduction kernel finishes the job.
-template <int CI>
-__global__ __launch_bounds__(256) void wgrad1x1_fewcin_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ slab,
+template <int CI, int IO = IO_F32>      // IO (round 5): storage type of dy and x (16-bit storage: converted on the way in; fp32 sums)
+__global__ __launch_bounds__(256) void wgrad1x1_fewcin_kernel(const void* __restrict__ dyv, const void* __restrict__ xv_, float* __restrict__ slab,
                                                               int N, int Co, int HW, int64_t quads_per_slice, int a_pad, int bpad) {
+    constexpr int ES = io_size<IO>::value;
+    const char* const dy = (const char*)dyv; const char* const x = (const char*)xv_;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int og = blockIdx.y * 8;
     const int hwq = HW >> 2;
@@ -555,11 +557,11 @@ __global__ __launch_bounds__(256) void wgrad1x1_fewcin_kernel(const float* __res
         const int off = (int)(q - (int64_t)n * hwq) * 4;
         float4 xv[CI], dv[8];
 #pragma unroll
-        for (int i = 0; i < CI; i++) xv[i] = *(const float4*)(x + ((int64_t)n * CI + i) * HW + off);
+        for (int i = 0; i < CI; i++) xv[i] = io_ld4<IO>(x + (((int64_t)n * CI + i) * HW + off) * ES);
 #pragma unroll
         for (int o = 0; o < 8; o++) {
             const int oc = og + o < Co ? og + o : Co - 1;          // rows beyond C_out re-read the last one; their sums are not stored
-            dv[o] = *(const float4*)(dy + ((int64_t)n * Co + oc) * HW + off);
+            dv[o] = io_ld4<IO>(dy + (((int64_t)n * Co + oc) * HW + off) * ES);
         }
 #pragma unroll
         for (int o = 0; o < 8; o++)
@@ -591,7 +593,7 @@ __global__ __launch_bounds__(256) void wgrad1x1_fewcin_kernel(const float* __res
 // Does the few-channel pointwise kernel take this weight gradient, and with how many K slices (<= the slab the small-cin plan reserved)?
 static int plan_wgrad1x1_fewcin(const pasta_conv_desc* d, const WgradSmallPlan& ws) {
     static const bool enabled = !(getenv("PASTA_WGRAD_FEWCIN") && getenv("PASTA_WGRAD_FEWCIN")[0] == '0');         // A/B switch
-    if (!enabled || !ws.use || d->kh != 1 || d->kw != 1 || d->pad_h || d->pad_w || d->io_dtype != PASTA_F32 || d->C_in > 8) return 0;
+    if (!enabled || !ws.use || d->kh != 1 || d->kw != 1 || d->pad_h || d->pad_w || d->C_in > 8) return 0;      // (any storage type: round 5)
     const int64_t hw = (int64_t)d->H * d->W;
     if (hw % 4 || d->OH != d->H || d->OW != d->W) return 0;
     int64_t ks = (int64_t)d->N * (hw / 4) / (256 * 8);          // at least eight trips per thread
