@@ -398,19 +398,20 @@ static void launch_tile(const UpfirdnParams& p, hipStream_t s) {
     const int64_t planes = (int64_t)p.N * p.C;
     static const bool pairs_on = !(getenv("PASTA_UPFIRDN_PAIRS") && getenv("PASTA_UPFIRDN_PAIRS")[0] == '0');       // A/B switch
     // fp32, an even number of planes: two planes per work item (packed FMAs on plane pairs), as long as the items still fill the chip
-    const bool pair = std::is_same<T, float>::value && pairs_on && (planes & 1) == 0 && (int64_t)tiles_x * tiles_y * (planes / 2) >= 2048;      // (the RGB up-sampling, 768 pair items, ran 2x slower on pairs: measured)
+    constexpr bool PAIRS_T = !std::is_same<T, double>::value;        // fp32 and the 16-bit storage types (fp32 arithmetic inside); fp64 keeps one plane
+    const bool pair = PAIRS_T && pairs_on && (planes & 1) == 0 && (int64_t)tiles_x * tiles_y * (planes / 2) >= 2048;      // (the RGB up-sampling, 768 pair items, ran 2x slower on pairs: measured)
     const int64_t nitems = (int64_t)tiles_x * tiles_y * (pair ? planes / 2 : planes);
     const int64_t grid = nitems < 256 * 16 ? nitems : 256 * 16;     // up to 16 resident-or-queued workgroups per CU
 #define PASTA_TILE(REM_, PL_, RX_, RY_) hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, UX, UY, DX, DY, FW, FH, PHX, PHY, MX, MY, BX, BY, REM_, PL_>), \
                                                           dim3((unsigned)grid), dim3(BX * BY), 0, s, p, tiles_x, tiles_y, (int)nitems, RX_, RY_)
     if constexpr (UX == 1 && UY == 1 && DX == 1 && DY == 1) {
         if (rem_x || rem_y) {
-            if constexpr (std::is_same<T, float>::value) { if (pair) { PASTA_TILE(1, 2, rem_x, rem_y); return; } }
+            if constexpr (PAIRS_T) { if (pair) { PASTA_TILE(1, 2, rem_x, rem_y); return; } }
             PASTA_TILE(1, 1, rem_x, rem_y);
             return;
         }
     }
-    if constexpr (std::is_same<T, float>::value) { if (pair) { PASTA_TILE(0, 2, 0, 0); return; } }
+    if constexpr (PAIRS_T) { if (pair) { PASTA_TILE(0, 2, 0, 0); return; } }
     PASTA_TILE(0, 1, 0, 0);
 #undef PASTA_TILE
 }
