@@ -68,12 +68,13 @@ def test_flipped_weight_and_gradients():
         assert float((dw.cpu().double() - rdw).abs().max() / rdw.abs().max()) < 1e-5
 
 
-def test_small_tap_counts_stay_on_the_fp32_kernel():
-    """3x3 over three channels (27 pairs) and 1x1: the launch is its output store, and the fp32 kernel's is the faster one."""
+def test_small_tap_counts_stay_off_the_packed_k_mode():
+    """3x3 over three channels (27 pairs): the launch is its output store, and the fp32 tile kernel's is the faster one (kernel 0); 1x1 over three
+    channels: since round 5 the streaming few-channel kernel (kernel 11, tests/test_conv_fewch_gpu.py) -- never the packed-K mode (8)."""
     from torch_utils.ops import conv2d_gradfix as cg, _native
-    for k in (3, 1):
+    for k, want in ((3, 0), (1, 11)):
         cfg = cg._Cfg((False, 1, k // 2, k // 2, 0, 0, 1, 1.0))
         desc = cg._desc(cfg, (4, 3, 128, 128), 64, 128, 128, k, k)
         kernel = ctypes.c_int()
         assert _native.lib().pasta_conv2d_plan(ctypes.byref(desc), 0, None, None, None, None, ctypes.byref(kernel)) == 0
-        assert kernel.value == 0, (k, kernel.value)
+        assert kernel.value == want, (k, kernel.value)
