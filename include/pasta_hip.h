@@ -74,6 +74,9 @@ int64_t pasta_pieces_bytes(int N, int C, int H, int W);
 int pasta_blur_pieces(const float* x, const float* f, void* pieces, const float* x_amax, float* y_amax,
                       int N, int C, int H, int W, int padx0, int padx1, int pady0, int pady1, int flip, float gain, void* stream);
 int pasta_pieces_unpack(const void* pieces, const float* y_amax, float* y, int N, int C, int H, int W, void* stream);
+/* (ABI 20) an fp32 NCHW tensor whose partial maxima are known, split as the consuming kernels split it in their staging (bit for bit): for a
+ * caller whose producer is not one of this library's kernels, and for the tests of the pieces-reading kernels. */
+int pasta_pieces_pack(const float* x, const float* x_amax, void* pieces, int N, int C, int H, int W, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * bias_act -- fused bias + activation + gain + clamp, and its 1st/2nd grads.

@@ -43,9 +43,21 @@ namespace pasta {
 // sched_group_barrier).  Its timing-only instances on the 512 -> 512 layer at 32 x 32: MFMAs + barriers alone 509 TFLOP/s, + fragment
 // reads 421, + staging (everything) 339: the chip is at its power cap (1.9 GHz), and every LDS byte and fetch next to the MFMAs costs
 // clock, however well it is hidden in the schedule.
-template <int BM, int BN, int R, int NP = 3, int IO = IO_F32, bool ISC = false, int NT = 256>
+// XP (round 5): x is PASTA_LAYOUT_PIECES16 (pieces.hip) -- the producer wrote the operand's fp16 pieces h | l' as 16-byte units of eight channels,
+// [N][C/8][H][piece][W] -- so a staging unit is TWO 16-byte loads (lanes along a row: 1 KB runs) straight into the B image: eight dword loads,
+// the scale and the split (some forty vector instructions per unit) are the producer's, done once per tensor instead of once per consuming tile.
+// GA (round 5): the WEIGHTS of a step go from L2 straight into their LDS buffer (global_load_lds_dwordx4: the packed tensor already has the
+// image's layout, one 16-byte unit per lane, a wave's units contiguous) one step ahead, instead of two steps ahead into one of two register
+// sets and from there to LDS: no ds_write_b128 pass in front of the barrier, 24 registers fewer.  The waits are counted by hand (the DMA is a
+// vector-memory operation the compiler does not see as a write to LDS): at the end of a step `s_waitcnt vmcnt(K)`, K = the activation loads
+// issued BEHIND the DMA in that step (a compiler barrier pins that order), so that those stay in flight across the barrier and the DMA has
+// landed; in the steps that split and store a unit the DMA is issued behind the split (hipcc waits vmcnt(0) at the first use of an ordinary
+// load while a DMA is in flight: nothing else is outstanding there).
+template <int BM, int BN, int R, int NP = 3, int IO = IO_F32, bool ISC = false, int NT = 256, bool XP = false, bool GA = false>
 __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_kernel(ConvFwdParams p) {
+    static_assert(!GA || (!ISC && IO == IO_F32), "weights by LDS-DMA: the counted waits are written for the plain fp32-storage launches");
     static_assert(IO == IO_F32 || NP == 1, "16-bit storage: the element is the operand, one product");
+    static_assert(!XP || (NP == NP_F16X3 && IO == IO_F32 && !ISC), "operand pieces: the three-product arithmetic's, plain launches");
     static_assert(!ISC || ((NP == 3 || NP == NP_F16X3) && IO == IO_F32), "the input scale rides in the fp32-equivalent staging");
     constexpr bool HX = Arith<NP>::f16x3;               // PASTA_MATH_F16X3: fp16 pieces, three products (conv_common.h)
     constexpr int NPA = Arith<NP>::npa, NPB = Arith<NP>::npb;
@@ -111,7 +123,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
         const int i = slot / SW, j = slot - i * SW;
         const int y = p0 + ymin + i, x = q0 + d0 + j;
         u_ok[k] = real && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-        u_pix[k] = u_ok[k] ? xb_off + (unsigned)(y * p.W + x) * ES : xb_off;
+        if constexpr (XP) u_pix[k] = (unsigned)((n_img * (p.Cin >> 3)) * HW) * 32u + (u_ok[k] ? (unsigned)(2 * y * p.W + x) * 16u : 0u);      // octet 0, piece h
+        else u_pix[k] = u_ok[k] ? xb_off + (unsigned)(y * p.W + x) * ES : xb_off;
         u_half[k] = half;
         u_lds[k] = real ? (half * SLOTS + slot) * 8 : -1;           // element offset inside a piece of the B image; -1: no unit
     }
@@ -123,6 +136,15 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
     auto load_unit = [&](int k, int cc, bool real_chunk, float (&sb)[8], float (&sc)[ISC ? 8 : 1], int& nv) {
         const int c0 = cc * KC + u_half[k] * 8;
         const int last = p.Ig - 1;
+        if constexpr (XP) {
+            const int c8 = c0 < p.Ig ? c0 >> 3 : 0;             // past the last octet: a valid address, unused data
+            const char* src = xbytes + u_pix[k] + (unsigned)c8 * (unsigned)HW * 32u;
+            const u32x4 hq = *(const u32x4*)src, lq = *(const u32x4*)(src + (unsigned)p.W * 16u);
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const uint32_t hj = hq[j], lj = lq[j]; sb[j] = __builtin_bit_cast(float, hj); sb[4 + j] = __builtin_bit_cast(float, lj); }      // (a bit_cast of the vector ELEMENT itself reads element 0: hipcc 7.2)
+            nv = (u_ok[k] && real_chunk && c0 < p.Ig) ? 8 : 0;
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int c = c0 + j < last ? c0 + j : last;
@@ -148,11 +170,24 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
         if (set == 0) { areg0 = unit(0); if (APT > 1) areg1 = unit(1); if (APT > 2) areg2 = unit(2); }
         else          { breg0 = unit(0); if (APT > 1) breg1 = unit(1); if (APT > 2) breg2 = unit(2); }
     };
+    auto glds_a = [&](int tap, int cc, int buf) {              // GA: the weights of (tap, chunk cc) into A buffer `buf`
+        const int ccl = cc < NC ? cc : NC - 1;
+        const __bf16* wt = wtap[tap] + (int64_t)ccl * a_chunk;
+#pragma unroll
+        for (int j = 0; j < APT; j++) {
+            int e = tid + NT * j;
+            if (NT * (j + 1) > AUNITS) e = e < AUNITS ? e : AUNITS - 1;       // past the image: a valid address into the buffer's padding
+            const int seg = e / BM, within = e - seg * BM;
+            const __bf16* src = wt + ((int64_t)seg * p.Og_pad + o_blk + within) * 8;
+            __bf16* dst = As + buf * ABUF + (wave * 64 + NT * j) * 8;        // the wave's base: the hardware adds lane * 16 bytes
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
     // The first trip to memory is issued HERE, in front of the rest of the set-up (operand scale, accumulators, fragment slots, tap offsets:
     // several hundred mostly scalar instructions that the compiler otherwise places in front of the first load -- 680 instructions on the
     // eight-wave tile, whose workgroup is alone on its CU: nothing hides them): the weights of the first tap and every unit of the first
     // chunk (ONE trip to memory in front of the K loop instead of UPT; the accumulators are not live yet: the register sets are free).
-    load_a(0, c_first, 0);
+    if constexpr (GA) glds_a(0, c_first, 0); else load_a(0, c_first, 0);
     float fb[UPT][8], fc[UPT][ISC ? 8 : 1];
     int fnv[UPT];
 #pragma unroll
@@ -169,6 +204,11 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     uint32_t q1[4], q2[4], q3[4];
     auto split_pair = [&](const float (&sb)[8], const float (&sc)[ISC ? 8 : 1], int nv, int j) {
+        if constexpr (XP) {
+            q1[j] = nv ? __builtin_bit_cast(uint32_t, sb[j]) : 0u;
+            q2[j] = nv ? __builtin_bit_cast(uint32_t, sb[4 + j]) : 0u;
+            return;
+        }
         float v0 = sb[2 * j], v1 = sb[2 * j + 1];
         if constexpr (ISC) { v0 *= sc[2 * j]; v1 *= sc[2 * j + 1]; }
         if (nv < 8) {
@@ -260,20 +300,30 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
     auto step = [&](const int S, const int PAR, int cc) {
         const int gpar = (PAR * 9 + S) & 1;              // parity of the global step index within the trip (18 steps: even)
         const bool next_real = cc + 1 < c_first + nchunks;
-        // fetches first: they are the oldest outstanding loads when the split of a later step waits for them
-        if (S + 2 < 9) load_a(S + 2, cc, gpar); else load_a(S + 2 - 9, cc + 1, gpar);
-#pragma unroll
-        for (int k = 0; k < UPT; k++)
-            if (S == USTRIDE * k) {
-                if ((k & 1) == 0) load_unit(k, cc + 1 < c_first + nchunks ? cc + 1 : cc, next_real, sb0, sc0, nv0);
-                else              load_unit(k, cc + 1 < c_first + nchunks ? cc + 1 : cc, next_real, sb1, sc1, nv1);
-            }
         // which unit is split and stored in this step (literal): k with 3k + 3 == S, or the last unit at S == 8
         constexpr int NOUNIT = -1;
         int ku = NOUNIT;
 #pragma unroll
         for (int k = 0; k < UPT; k++)
             if (S == (USTRIDE * (k + 1) < 8 ? USTRIDE * (k + 1) : 8)) ku = k;
+        int behind = 0;                                  // GA: vector-memory loads issued behind the DMA in this step
+        auto fetches = [&]() {
+            // fetches first: they are the oldest outstanding loads when the split of a later step waits for them
+            if constexpr (GA) {
+                if (S + 1 < 9) glds_a(S + 1, cc, gpar ^ 1); else glds_a(0, cc + 1, gpar ^ 1);
+                asm volatile("" ::: "memory");           // the activation loads below stay behind the DMA (they are counted)
+            } else {
+                if (S + 2 < 9) load_a(S + 2, cc, gpar); else load_a(S + 2 - 9, cc + 1, gpar);
+            }
+#pragma unroll
+            for (int k = 0; k < UPT; k++)
+                if (S == USTRIDE * k) {
+                    if ((k & 1) == 0) load_unit(k, cc + 1 < c_first + nchunks ? cc + 1 : cc, next_real, sb0, sc0, nv0);
+                    else              load_unit(k, cc + 1 < c_first + nchunks ? cc + 1 : cc, next_real, sb1, sc1, nv1);
+                    behind += XP ? 2 : 8;
+                }
+        };
+        if (!GA || ku == NOUNIT) fetches();
         Frag f;
         read_frag(f, gpar, PAR, toff[S]);
 #define PASTA_MM(PA, PB)                                                                                       \
@@ -281,7 +331,15 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
         _Pragma("unroll") for (int a = 0; a < WMT; a++) _Pragma("unroll") for (int b = 0; b < WNT; b++)          \
             acc[a][b] = mfma16<IO, NP>(f.a[a][PA], f.b[b][PB], acc[a][b]); }
 #define PASTA_SPLIT(J) if (ku != NOUNIT) { if ((ku & 1) == 0) split_pair(sb0, sc0, nv0, J); else split_pair(sb1, sc1, nv1, J); }
-        if constexpr (HX) {                 // three product groups: h'' l', l h, h h -- smallest terms first
+        if constexpr (HX && GA) {           // the whole split behind the first group, then the DMA: it has two groups to land
+            PASTA_MM(2, 1)
+            PASTA_SPLIT(0)
+            PASTA_SPLIT(1)
+            PASTA_SPLIT(2)
+            PASTA_SPLIT(3)
+            if (ku != NOUNIT) { store_unit(ku, PAR ^ 1); fetches(); }
+            PASTA_MM(1, 0)
+        } else if constexpr (HX) {          // three product groups: h'' l', l h, h h -- smallest terms first
             PASTA_MM(2, 1)
             PASTA_SPLIT(0)
             PASTA_SPLIT(1)
@@ -299,12 +357,25 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
         PASTA_SPLIT(3)
         PASTA_MM(0, 1)
         }
-        if (ku != NOUNIT) store_unit(ku, PAR ^ 1);
-        store_a(gpar ^ 1, gpar ^ 1);
+        if constexpr (HX && GA) {
+        } else if constexpr (GA) {
+            if (ku != NOUNIT) { store_unit(ku, PAR ^ 1); fetches(); }                 // behind the split (see the note at the head of the kernel)
+        } else {
+            if (ku != NOUNIT) store_unit(ku, PAR ^ 1);
+            store_a(gpar ^ 1, gpar ^ 1);
+        }
         PASTA_MM(0, 0)
 #undef PASTA_MM
 #undef PASTA_SPLIT
-        __syncthreads();
+        if constexpr (GA) {
+            if (behind == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (behind == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (behind == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else __syncthreads();
     };
 
     // prologue, second half: split and store the first chunk (fetched above), the weights of its first two taps
@@ -314,9 +385,11 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void conv_fwd_rows2d_bf16x6_
         for (int j = 0; j < 4; j++) split_pair(fb[k], fc[k], fnv[k], j);
         store_unit(k, 0);
     }
-    store_a(0, 0);
-    load_a(1, c_first, 1);                           // stored by step 0
-    __syncthreads();
+    if constexpr (!GA) {
+        store_a(0, 0);
+        load_a(1, c_first, 1);                       // stored by step 0
+    }
+    __syncthreads();                                 // (GA: its fence waits for the DMA of the first tap's weights)
     for (int c = 0; c < nchunks; c += 2) {           // an odd count runs one all-zero chunk (its fetches re-read valid addresses)
         const int cc = c_first + c;
         step(0, 0, cc); step(1, 0, cc); step(2, 0, cc); step(3, 0, cc); step(4, 0, cc); step(5, 0, cc); step(6, 0, cc); step(7, 0, cc); step(8, 0, cc);
@@ -462,13 +535,13 @@ static bool rows2d_tile_ok(int P, int Q) {
     return P % R == 0 && Q % SEG == 0;
 }
 
-template <int BM, int BN, int R, int NP, int IO, bool ISC = false, int NT = 256>
+template <int BM, int BN, int R, int NP, int IO, bool ISC = false, int NT = 256, bool XP = false, bool GA = false>
 static void launch_fwd_rows2d_np(const ConvFwdParams& q, dim3 grid, hipStream_t s) {
     constexpr int SEG = BN / R, SLOTS = (R + 2) * (SEG + 2);
     constexpr int APT = (2 * Arith<NP>::npa * BM + NT - 1) / NT;
     constexpr size_t lds = (size_t)(2 * APT * NT * 8 + 2 * 2 * Arith<NP>::npb * SLOTS * 8) * sizeof(__bf16);
-    PASTA_SET_LDS((conv_fwd_rows2d_bf16x6_kernel<BM, BN, R, NP, IO, ISC, NT>), lds);
-    hipLaunchKernelGGL((conv_fwd_rows2d_bf16x6_kernel<BM, BN, R, NP, IO, ISC, NT>), grid, dim3(NT), lds, s, q);
+    PASTA_SET_LDS((conv_fwd_rows2d_bf16x6_kernel<BM, BN, R, NP, IO, ISC, NT, XP, GA>), lds);
+    hipLaunchKernelGGL((conv_fwd_rows2d_bf16x6_kernel<BM, BN, R, NP, IO, ISC, NT, XP, GA>), grid, dim3(NT), lds, s, q);
 }
 
 template <int BM, int BN, int R>

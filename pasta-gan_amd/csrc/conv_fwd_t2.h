@@ -1,0 +1,298 @@
+// 3x3 stride-2 conv_transpose2d of the three-product fp16 arithmetic as ONE pass over the input lattice (round 5): every upsampling layer of
+// the generator (conv2d_resample.py:104-115, the transposed convolution in front of the blur) and the input gradient of every stride-2
+// convolution.  Instantiated by conv_tu_fwd_t2.hip (conv_launch.h).
+#pragma once
+#include "conv_fwd_bf16x6.h"
+
+namespace pasta {
+
+//------------------------------------------------------------------------------------
+// With pad 0 (OH = 2 H + 1: every live shape) input pixel (i, j) and kernel tap (r, c) meet in output (2 i + r, 2 j + c); seen from the
+// output, y[2 i + a, 2 j + b] sums the taps of parity (r & 1, c & 1) = (a, b) over the input pixels (i - (r >> 1), j - (c >> 1)): four
+// parity classes with 4, 2, 2 and 1 taps, all of them reading the 2 x 2 window x[i - 1 .. i, j - 1 .. j].  The parity-pair mode of the row
+// kernel (conv_fwd_bf16x6.h: one vertical parity per workgroup, one input ROW per stage, 143 - 220 TFLOP/s on the live shapes and nothing at
+// all for planes below 128 x 128 with a remainder row, which ran as four per-class launches) stages every input row twice and a tap's
+// weights once per 128 pixels.  Here a workgroup owns a tile of R x SEG = 8 x 32 lattice pixels and 64 output channels, ALL FOUR classes:
+//   * B image of a 16-channel chunk: the (R + 1) x (SEG + 1) input pixels of the tile's windows, fetched and split once (1.16 staging units
+//     per thread); the four window positions are four fragment offsets into it, read once per chunk and wave (16 ds_read_b128);
+//   * A image of a chunk: the nine taps' weights, 9 x 6 x 64 sixteen-byte units = 54 KB, by LDS-DMA (global_load_lds_dwordx4: the packed
+//     weight tensor has the image's layout; seven instructions per thread and chunk, no registers, no ds_write) one chunk ahead;
+//   * a wave = 32 output channels x 64 pixels x 4 classes: eight accumulator tiles, 9 taps x 2 pixel blocks x 3 products = 54 MFMAs per
+//     chunk on 27 + 16 fragment reads, ONE barrier per chunk (the dominant kernel: 12 MFMAs on 10 reads per barrier);
+//   * eight waves (2 x 4), one workgroup per CU: 112 KB of weights + 37 KB of activations double-buffered in LDS;
+//   * an output row leaves as 8-byte pairs (2 j, 2 j + 1), 256 contiguous bytes per 32 lanes, the two rows 2 i and 2 i + 1 by the same lane.
+// Output row 2 H and column 2 W (OH = 2 H + 1: lattice row i = H, lattice column j = W) are EDGE TILES of the same launch -- as a launch of
+// their own (conv_t2_edge_kernel: a few dozen workgroups with K loops as long as anyone's) they took 52 - 149 us in front of a main kernel
+// of 123 - 190 us.  An edge tile keeps the tile's shape and changes what a tile row / column means:
+//   * row edge:    tile row r = image n0 + r, tile columns = lattice columns j0 .. j0 + 31 of lattice row H: only the windows one row up
+//                  exist (taps 6, 7, 8: classes (0, 0) and (0, 1)), B image slot (ir, ic) = x[n0 + ir, H - 1, j0 - 1 + ic];
+//   * column edge: tile column c = image n0 + c, tile rows = lattice rows i0 .. i0 + 7 (up to H: the corner) of lattice column W: only the
+//                  windows one column to the left exist (taps 2, 5, 8: classes (0, 0) and (1, 0)), slot (ir, ic) = x[n0 + ic, i0 - 1 + ir, W - 1].
+// The K loop, the weights and the fragment offsets are the regular tile's; the kind is uniform per workgroup.
+// ISC: p.iscale[n, channel] (the styles of a modulated layer: pasta_conv2d_modulated's x * s) multiplied onto the activations between
+// fetch and split, as in the other forward-type kernels.
+// The DMA is a vector-memory operation whose LDS write the compiler does not see: the waits are written by hand -- `s_waitcnt vmcnt(0)`
+// in front of the barrier that ends a chunk (the activation loads of the chunk have been consumed by then: nothing else is in flight).
+// KIND is a template parameter of the body: with the kind as a (uniform) run-time value the branches around the window groups cut the K loop into
+// basic blocks and the regular tiles ran 30 - 60 % slower (0.152 -> 0.199 ms on 256 -> 128 at 64 x 64, 0.136 -> 0.223 ms on 512 -> 256 at 32 x 32).
+template <bool ISC, int KIND>
+__device__ __forceinline__ void conv_t2_body(const ConvFwdParams& p, const int n0, const int i0, const int j0) {
+    constexpr int kind = KIND;
+    constexpr int NP = NP_F16X3, BM = 64, R = 8, SEG = 32, NT = 512;
+    constexpr int IW = SEG + 1, SLOTS = (R + 1) * IW;           // B image: rows i0 - 1 .. i0 + R - 1, columns j0 - 1 .. j0 + SEG - 1
+    constexpr int AUNITS = 9 * 6 * BM, APT = (AUNITS + NT - 1) / NT;
+    constexpr int ABUF = APT * NT * 8;                          // 16-bit elements of an A buffer (padded to whole DMA instructions)
+    constexpr int BSEG = SLOTS * 8, BBUF = 2 * 2 * BSEG;        // [piece][k-half][slot][8]
+    constexpr int BUNITS = 2 * SLOTS;                           // (slot, k-half) staging units: every thread one, the first BUNITS - NT a second one
+    static_assert(BUNITS > NT && BUNITS <= 2 * NT, "one or two staging units per thread");
+    extern __shared__ __attribute__((aligned(16))) __bf16 t2_smem[];
+    __bf16* const As = t2_smem;                         // [2][ABUF]
+    __bf16* const Bs = t2_smem + 2 * ABUF;              // [2][BBUF]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int hl = lane >> 5, jl = lane & 31;
+    const int g = blockIdx.z;
+    const int o_blk = blockIdx.y * BM;
+    const int HW = p.H * p.W;
+    const int NC = p.Ig_pad / 16;
+
+    // ---- weights: sixteen-byte unit u = tid + NT j of a chunk's image -> (tap, piece * 2 + k-half, output row)
+    const int64_t a_chunk = (int64_t)6 * p.Og_pad * 8;             // elements of one packed 16-channel chunk of one tap
+    const __bf16* const wb = (const __bf16*)p.wp + (int64_t)g * 9 * NC * a_chunk + (int64_t)o_blk * 8;
+    unsigned a_off[APT];                                // byte offsets from the chunk's (uniform) base: scalar base + 32-bit lane offset addressing
+    unsigned a_need = 0;                                // edge tiles: the units of the three taps they multiply (bit j)
+#pragma unroll
+    for (int j = 0; j < APT; j++) {
+        int u = tid + NT * j;
+        u = u < AUNITS ? u : AUNITS - 1;                // past the image: a valid address, the unit lands in the buffer's padding
+        const int tap = u / (6 * BM), rem = u - tap * (6 * BM);
+        const int seg = rem / BM, within = rem - seg * BM;
+        a_off[j] = ((unsigned)tap * (unsigned)NC * (unsigned)a_chunk + (unsigned)(seg * p.Og_pad + within) * 8u) * 2u;
+        const bool need = tap == 8 || (kind == 1 ? tap >= 6 : (tap == 2 || tap == 5));
+        a_need |= need ? 1u << j : 0u;
+    }
+    auto glds_a = [&](int cc, int buf) {
+        const char* const wc = (const char*)(wb + (int64_t)cc * a_chunk);
+#pragma unroll
+        for (int j = 0; j < APT; j++) {
+            __bf16* dst = As + buf * ABUF + (wave * 64 + NT * j) * 8;        // the wave's base: the hardware adds lane * 16 bytes
+            if (kind == 0 || (a_need >> j & 1u))         // (a lane that is switched off leaves its sixteen bytes of the buffer alone)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wc + a_off[j]), (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+    glds_a(0, 0);
+
+    // ---- activations: staging unit k of this thread -> (slot, k-half); pixel offset and validity
+    const char* const xb = (const char*)p.x;            // (uniform; the planner keeps the tensor below 2^30 elements: 32-bit byte offsets)
+    unsigned u_pix[2];
+    int u_half[2], u_lds[2], u_isc[2];
+    bool u_ok[2];
+    const bool second = tid < BUNITS - NT;              // wave-uniform for all but one wave (82 threads)
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int u = (k == 0 || second) ? tid + NT * k : 0;
+        const int half = u >= SLOTS ? 1 : 0, slot = u - half * SLOTS;
+        const int ir = slot / IW, ic = slot - ir * IW;
+        int img = n0, y = i0 - 1 + ir, x = j0 - 1 + ic;
+        bool in_tile = true;
+        if (kind == 1) { img = n0 + ir; y = p.H - 1; in_tile = ir < R; }
+        if (kind == 2) { img = n0 + ic; x = p.W - 1; in_tile = ic < SEG; }
+        u_ok[k] = (k == 0 || second) && in_tile && img < p.N && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        u_isc[k] = u_ok[k] ? img * p.Cin + g * p.Ig : 0;
+        u_pix[k] = u_ok[k] ? ((unsigned)u_isc[k] * (unsigned)HW + (unsigned)(y * p.W + x)) * 4u : 0u;
+        u_half[k] = half;
+        u_lds[k] = (half * SLOTS + slot) * 8;
+    }
+    float sb[2][8], sc[2][ISC ? 8 : 1];
+    int nv[2];
+    auto load_units = [&](int cc) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (k == 1 && !second) continue;
+            const int c0 = cc * 16 + u_half[k] * 8;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int c = c0 + j < p.Ig ? c0 + j : p.Ig - 1;
+                sb[k][j] = io_ld<IO_F32>(xb, u_pix[k] + (unsigned)c * (unsigned)HW * 4u);
+                if constexpr (ISC) sc[k][j] = p.iscale[u_isc[k] + c];
+            }
+            nv[k] = u_ok[k] ? p.Ig - c0 : 0;
+        }
+    };
+    load_units(0);
+
+    float x_scale, out_scale;
+    scale_from_amax(amax_of_parts(p.x_amax), x_scale, out_scale);
+    auto store_units = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (k == 1 && !second) continue;
+            uint32_t q1[4], q2[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float v0 = sb[k][2 * j], v1 = sb[k][2 * j + 1];
+                if constexpr (ISC) { v0 *= sc[k][2 * j]; v1 *= sc[k][2 * j + 1]; }
+                v0 = 2 * j < nv[k] ? v0 : 0.f;
+                v1 = 2 * j + 1 < nv[k] ? v1 : 0.f;
+                f16_split2(v0 * x_scale, v1 * x_scale, q1[j], q2[j]);
+            }
+            __bf16* const bd = Bs + buf * BBUF + u_lds[k];
+            *(uint4*)bd = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+            *(uint4*)(bd + 2 * BSEG) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+        }
+    };
+
+    f32x16 acc[4][2];                                   // [class 2 a + b][pixel block]
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[c][b][r] = 0.f;
+
+    // Fragment addresses: everything that depends on the lane in ONE base per operand (A: the lane's output row and k-half; B: the slot of
+    // the lane's pixel of block b at window position (0, 0) -- tile row wn * 2 + b, column jl -- and its k-half), everything else -- buffer,
+    // tap, piece, window position -- literal byte offsets (ds_read's immediate field; loop-invariant address registers are what spills here)
+    const char* const a_lane = (const char*)(As + ((hl * BM) + wm * 32 + jl) * 8);
+    const char* b_lane[2];
+#pragma unroll
+    for (int b = 0; b < 2; b++) b_lane[b] = (const char*)(Bs + (hl * SLOTS + (wn * 2 + b + 1) * IW + jl + 1) * 8);
+
+    auto compute = [&](int buf, bool stage) {
+        bf16x8 bh[2], bl[2];
+        auto window = [&](int off) {
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                bl[b] = *(const bf16x8*)(b_lane[b] + (buf * BBUF + 2 * BSEG + off * 8) * 2);
+                bh[b] = *(const bf16x8*)(b_lane[b] + (buf * BBUF + off * 8) * 2);
+            }
+        };
+        auto tap = [&](int t, int cls) {                // both literals: three products, smallest terms first (h'' l', l h, h h)
+            const char* const at = a_lane + (buf * ABUF + t * (6 * BM * 8)) * 2;
+            const bf16x8 a2 = *(const bf16x8*)(at + (4 * BM * 8) * 2);
+            const bf16x8 a1 = *(const bf16x8*)(at + (2 * BM * 8) * 2);
+            const bf16x8 a0 = *(const bf16x8*)(at);
+#pragma unroll
+            for (int b = 0; b < 2; b++) acc[cls][b] = mfma16<IO_F32, NP>(a2, bl[b], acc[cls][b]);
+#pragma unroll
+            for (int b = 0; b < 2; b++) acc[cls][b] = mfma16<IO_F32, NP>(a1, bh[b], acc[cls][b]);
+#pragma unroll
+            for (int b = 0; b < 2; b++) acc[cls][b] = mfma16<IO_F32, NP>(a0, bh[b], acc[cls][b]);
+        };
+        // tap (r, c) = 3 r + c: class (r & 1, c & 1), window position (-(r >> 1), -(c >> 1)); an edge tile has one row / column of windows
+        window(-IW - 1); tap(8, 0);
+        if (kind != 2) { window(-IW); tap(6, 0); tap(7, 1); }
+        if (kind != 1) { window(-1);  tap(2, 0); tap(5, 2); }
+        // the next chunk's activations: split and stored HERE, between the MFMA groups (their loads were issued at the head of the chunk, five
+        // taps ago), so that this wave's vector instructions run beside the other wave's MFMAs instead of behind everybody's
+        if (stage) store_units(buf ^ 1);
+        if (kind == 0) { window(0);   tap(0, 0); tap(1, 1); tap(3, 2); tap(4, 3); }
+    };
+
+    // prologue: the first chunk's activations; the barrier's fence waits for the DMA of its weights
+    store_units(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c = 0; c < NC; c += 2) {
+#pragma unroll
+        for (int par = 0; par < 2; par++) {
+            const int cc = c + par;
+            if (cc < NC) {                               // (uniform)
+                const bool more = cc + 1 < NC;
+                if (more) {
+                    // (the ordinary loads FIRST: behind a DMA hipcc puts `s_waitcnt vmcnt(0)` in front of the first write to a register that an
+                    // earlier load returned into -- the DMA just issued would be waited for at the head of every chunk: 44 us of 196 on 256 -> 128 at 64 x 64)
+                    load_units(cc + 1);
+                    asm volatile("" ::: "memory");
+                    glds_a(cc + 1, par ^ 1);
+                }
+                compute(par, more);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+        }
+    }
+
+    // back to the operands' units: 1 / S_x for the tile, 1 / S_w per weight row (p.w_rowinv, written by the packing kernel)
+    const float* const wri = p.w_rowinv + (int64_t)g * p.Og_pad + o_blk + wm * 32;
+    float ws[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) ws[r] = wri[acc_row(r, lane)] * out_scale;
+    struct __attribute__((packed, aligned(4))) Pair { float even, odd; };
+    const int64_t OHW = (int64_t)p.OH * p.OW;
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        const int tr = wn * 2 + b;                      // tile row / column of this lane's pixel
+        const int img = kind == 1 ? n0 + tr : kind == 2 ? n0 + jl : n0;
+        const int i = kind == 1 ? p.H : i0 + tr, j = kind == 2 ? p.W : j0 + jl;
+        if (img >= p.N || 2 * i >= p.OH) continue;      // (edge tiles: images / rows past the end)
+        float* const yb = (float*)p.y + ((int64_t)img * p.Cout + (int64_t)g * p.Og) * OHW + (int64_t)(2 * i) * p.OW + 2 * j;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int o = o_blk + wm * 32 + acc_row(r, lane);
+            if (o < p.Og) {
+                float* const yo = yb + (int64_t)o * OHW;
+                if (kind == 2) {                        // column 2 W: classes (0, 0) and (1, 0)
+                    yo[0] = acc[0][b][r] * ws[r];
+                    if (i < p.H) yo[p.OW] = acc[2][b][r] * ws[r];
+                } else {
+                    Pair v0;
+                    v0.even = acc[0][b][r] * ws[r]; v0.odd = acc[1][b][r] * ws[r];
+                    *(Pair*)yo = v0;
+                    if (kind == 0) {
+                        Pair v1;
+                        v1.even = acc[2][b][r] * ws[r]; v1.odd = acc[3][b][r] * ws[r];
+                        *(Pair*)(yo + p.OW) = v1;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <bool ISC>
+__global__ __launch_bounds__(512, 1) void conv_t2_f16x3_kernel(ConvFwdParams p) {
+    constexpr int R = 8, SEG = 32;
+    const int cblocks = p.W / SEG, tpi = (p.H / R) * cblocks;
+    // tile kind (uniform): 0 regular, 1 row edge (lattice row H), 2 column edge (lattice column W).  The edge tiles come FIRST: they are a third
+    // of a regular tile's work, and the CUs that start with one pick up regular tiles behind it -- at the end of the grid they would be a wave
+    // of workgroups of their own behind a grid that fills the chip exactly.
+    int bx = blockIdx.x;
+    const int rb = p.H / R + 1;                         // row blocks of the column edge: rows 0 .. H
+    const int row_tiles = p.OH > 2 * p.H ? ((p.N + R - 1) / R) * cblocks : 0;
+    const int col_tiles = p.OW > 2 * p.W ? ((p.N + SEG - 1) / SEG) * rb : 0;
+    if (bx < row_tiles) {
+        conv_t2_body<ISC, 1>(p, (bx / cblocks) * R, p.H, (bx % cblocks) * SEG);
+    } else if (bx < row_tiles + col_tiles) {
+        bx -= row_tiles;
+        conv_t2_body<ISC, 2>(p, (bx / rb) * SEG, (bx % rb) * R, p.W);
+    } else {
+        bx -= row_tiles + col_tiles;
+        const int n0 = bx / tpi, t_in = bx - n0 * tpi;
+        conv_t2_body<ISC, 0>(p, n0, (t_in / cblocks) * R, (t_in % cblocks) * SEG);
+    }
+}
+
+// Does the kernel take the MAIN lattice of this launch (pad 0, OH in {2 H, 2 H + 1}: rows / columns 2 H, 2 W are the remainder's)?
+static bool conv_t2_shape_ok(int H, int W) { return H % 8 == 0 && W % 32 == 0; }
+
+static void launch_conv_t2(const ConvFwdParams& p, hipStream_t s) {
+    constexpr int NT = 512, APT = (9 * 6 * 64 + NT - 1) / NT, SLOTS = 9 * 33;
+    constexpr size_t lds = (size_t)(2 * APT * NT * 8 + 2 * 2 * 2 * SLOTS * 8) * sizeof(__bf16);
+    // regular tiles, then the edge tiles of lattice row H (eight images x 32 columns each) and of lattice column W (32 images x 8 rows, rows 0 .. H)
+    const int64_t tiles = (int64_t)p.N * (p.H / 8) * (p.W / 32) + (p.OH > 2 * p.H ? (int64_t)((p.N + 7) / 8) * (p.W / 32) : 0) +
+                          (p.OW > 2 * p.W ? (int64_t)((p.N + 31) / 32) * (p.H / 8 + 1) : 0);
+    const dim3 grid((unsigned)tiles, (unsigned)((p.Og + 63) / 64), (unsigned)p.G);
+    if (p.iscale) {
+        PASTA_SET_LDS(conv_t2_f16x3_kernel<true>, lds);
+        hipLaunchKernelGGL(conv_t2_f16x3_kernel<true>, grid, dim3(NT), lds, s, p);
+    } else {
+        PASTA_SET_LDS(conv_t2_f16x3_kernel<false>, lds);
+        hipLaunchKernelGGL(conv_t2_f16x3_kernel<false>, grid, dim3(NT), lds, s, p);
+    }
+}
+
+}  // namespace pasta

@@ -59,7 +59,7 @@ static bool try_fwd_rows2d(bool tile128, const ConvFwdParams& p, hipStream_t s) 
     if (tile128) {
         // eight waves on 128 x 256 (conv_tu_rows2d_wide.hip): fp32 storage, fp32-equivalent products; an input scale under the three-product arithmetic only
         if (rows2d_wide(p.cls[0].P, p.cls[0].Q) && (p.bf16x6 == 3 || p.bf16x6 == NP_F16X3) && p.io == IO_F32 && (!p.iscale || p.bf16x6 == NP_F16X3)) {
-            tu_rows2d_wide(q, s);
+            if (q.x_pieces) tu_rows2d_wide_pieces(q, s); else tu_rows2d_wide(q, s);
             return true;
         }
         const int R = rows2d_rows(p.cls[0].P, p.cls[0].Q);
@@ -330,12 +330,19 @@ namespace pasta {
 // on the descriptor, plus whole channel octets and the blur's pad 0.
 static bool pieces_fwd_ok(const pasta_conv_desc* d, int launch_flags) {
     const FwdPlan f = plan_fwd(d);
+    // (round 5) ... or the eight-wave 2-D tile kernel (plan kernel 7: 3x3 stride-1 convolution or input gradient, >= 128 output channels, planes of
+    // 8 rows x 32 columns), plain launches of the three-product arithmetic
+    if (d->stride == 1 && d->kh == 3 && d->kw == 3 && f.bf16x6 && !f.packed && f.tile == T128x128 && math_pieces(d->math) == NP_F16X3 && d->io_dtype == PASTA_F32 &&
+        d->groups == 1 && !(launch_flags & (PASTA_PLAN_ISCALE | PASTA_PLAN_MODULATED)) && d->C_in >= 16 && (d->C_in & 7) == 0 && !d->x2 &&
+        rows2d_rows(d->OH, d->OW) > 0 && rows2d_wide(d->OH, d->OW))
+        return true;
     return !d->transposed && f.bf16x6 && !f.packed && math_pieces(d->math) == NP_F16X3 && d->io_dtype == PASTA_F32 && d->groups == 1 && d->kh == 3 && d->kw == 3 &&
            d->stride == 2 && d->pad_h == 0 && d->pad_w == 0 && !(launch_flags & (PASTA_PLAN_ISCALE | PASTA_PLAN_OSCALE | PASTA_PLAN_MODULATED)) && f.ksplit == 1 &&
            d->C_in >= 16 && (d->C_in & 7) == 0 && d->C_out > 32 && !d->x2 && conv3x3s2_shape_ok(d->OH, d->OW) &&
            !(getenv("PASTA_CONV_S2") && getenv("PASTA_CONV_S2")[0] == '0');
 }
 static bool pair_launch_ok(const pasta_conv_desc* d, int pieces, int ksplit, FwdTile tile, bool plain);
+static bool t2_launch_ok(const pasta_conv_desc* d, int pieces, int ksplit, int launch_flags);
 // The parity-pair kernel carries no scales and no epilogue: ONE predicate for the planner and the launch.
 static inline bool pair_plain(int launch_flags) { return launch_flags == 0; }
 static inline int launch_flags_of(const float* iscale, const float* oscale, const pasta_conv_epilogue* ep) {
@@ -367,8 +374,9 @@ extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int launch_flags, int
     if (ksplit) *ksplit = f.ksplit;
     if (math) *math = !sb ? PASTA_MATH_F32 : d->io_dtype != PASTA_F32 ? PASTA_MATH_BF16 : d->math == PASTA_MATH_BF16X3 ? PASTA_MATH_BF16X3 : d->math == PASTA_MATH_BF16 ? PASTA_MATH_BF16 :
                        d->math == PASTA_MATH_BF16X6 ? PASTA_MATH_BF16X6 : PASTA_MATH_F16X3;
-    const bool pair = sb && pair_launch_ok(d, math_pieces(d->math), f.ksplit, f.tile, pair_plain(launch_flags));
-    if (launches) *launches = !d->transposed ? 1 : pair ? 1 + (d->OH > 2 * d->H || d->OW > 2 * d->W ? 1 : 0) : merged_classes(d, sb) ? 1 :
+    const bool t2 = sb && t2_launch_ok(d, math_pieces(d->math), f.ksplit, launch_flags);
+    const bool pair = t2 || (sb && pair_launch_ok(d, math_pieces(d->math), f.ksplit, f.tile, pair_plain(launch_flags)));
+    if (launches) *launches = !d->transposed ? 1 : t2 ? 1 : pair ? 1 + (d->OH > 2 * d->H || d->OW > 2 * d->W ? 1 : 0) : merged_classes(d, sb) ? 1 :
                               (d->stride < d->OH ? d->stride : d->OH) * (d->stride < d->OW ? d->stride : d->OW);
     if (kernel) {
         // the lattice of a stride-1 launch is the output plane itself, its taps kh rows of kw adjacent offsets
@@ -386,11 +394,12 @@ extern "C" int pasta_conv2d_plan(const pasta_conv_desc* d, int launch_flags, int
         const bool s2k = s2_on && sb && !d->transposed && math_pieces(d->math) == NP_F16X3 && d->io_dtype == PASTA_F32 && d->groups == 1 && d->kh == 3 && d->kw == 3 &&
                          d->stride == 2 && d->pad_h == d->pad_w && d->pad_h <= 1 && !(launch_flags & (PASTA_PLAN_ISCALE | PASTA_PLAN_OSCALE)) && f.ksplit == 1 && !packed &&
                          d->C_in >= 16 && d->C_out > 32 && conv3x3s2_shape_ok(d->OH, d->OW);
-        *kernel = !sb ? 0 : c1x1 ? 9 : s2k ? 10 : packed ? 8 : pair ? 3 : wide ? 7 : rows2d ? (rows2d_rows(d->OH, d->OW) == 4 ? 4 : 5) : rows2d_256 ? 6 : rows ? 2 : 1;
+        *kernel = !sb ? 0 : c1x1 ? 9 : s2k ? 10 : packed ? 8 : t2 ? 13 : pair ? 3 : wide ? 7 : rows2d ? (rows2d_rows(d->OH, d->OW) == 4 ? 4 : 5) : rows2d_256 ? 6 : rows ? 2 : 1;
     }
     if (d->x_layout == PASTA_LAYOUT_PIECES16 && !pieces_fwd_ok(d, launch_flags))
-        return fail("conv2d: x_layout = PASTA_LAYOUT_PIECES16 is served by the 3x3 stride-2 forward kernel only (conv2d, pad 0, fp32 y, PASTA_MATH_F16X3, one group, "
-                    "C_in a multiple of 8 and >= 16, C_out > 32, output width a power of two >= 16, more than 8192 output pixels, no scale vectors)");
+        return fail("conv2d: x_layout = PASTA_LAYOUT_PIECES16 is served by the 3x3 stride-2 forward kernel (conv2d, pad 0, fp32 y, PASTA_MATH_F16X3, one group, "
+                    "C_in a multiple of 8 and >= 16, C_out > 32, output width a power of two >= 16, more than 8192 output pixels, no scale vectors) and by the "
+                    "eight-wave 3x3 stride-1 tile kernel (plan kernel 7, no input scale, C_in a multiple of 8) only");
     return 0;
 }
 
@@ -414,6 +423,19 @@ static bool pair_launch_ok(const pasta_conv_desc* d, int pieces, int ksplit, Fwd
     const bool remainder = d->OH > 2 * d->H || d->OW > 2 * d->W;
     if (remainder && (int64_t)d->H * d->W < 128 * 128 && !(getenv("PASTA_T2_PAIR") && getenv("PASTA_T2_PAIR")[0] == '2')) return false;
     return rows_tile_ok(d->H, d->W, tile == T128x128 ? 128 : 256);
+}
+
+// ... or the one-pass kernel over the input lattice (conv_fwd_t2.h, round 5; plan kernel 13): pad 0, the three-product arithmetic, planes of
+// 8 x 32 tiles, an input scale allowed (the modulated layers of the training step), nothing behind the sum.  Takes precedence over the pair mode.
+static bool t2_launch_ok(const pasta_conv_desc* d, int pieces, int ksplit, int launch_flags) {
+    static const bool enabled = !(getenv("PASTA_CONV_T2") && getenv("PASTA_CONV_T2")[0] == '0');
+    if (!enabled || !d->transposed || d->stride != 2 || d->kh != 3 || d->kw != 3 || d->pad_h != 0 || d->pad_w != 0) return false;
+    if (pieces != NP_F16X3 || d->io_dtype != PASTA_F32 || (launch_flags & ~(PASTA_PLAN_ISCALE | PASTA_PLAN_MODULATED)) || ksplit != 1 || d->x2 || d->x_layout) return false;
+    if (d->OH < 2 * d->H || d->OH > 2 * d->H + 1 || d->OW < 2 * d->W || d->OW > 2 * d->W + 1) return false;
+    // planes of 64 x 64 and larger: at 32 x 32 the regular tiles of a batch of 16 fill the chip exactly once and the edge tiles in front of them
+    // cost more than the four per-class launches did (0.204 -> 0.214 ms on 512 -> 256; PASTA_CONV_T2=2 takes them too)
+    static const bool small_too = getenv("PASTA_CONV_T2") && getenv("PASTA_CONV_T2")[0] == '2';
+    return d->C_in / d->groups >= 16 && d->H % 8 == 0 && d->W % 32 == 0 && ((int64_t)d->H * d->W >= 4096 || small_too);
 }
 
 // The remainder of the parity-pair launch: output row 2H and / or column 2W of a stride-2 conv_transpose2d onto an odd plane --
@@ -765,6 +787,10 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
         // input row = pp + (a + pad - r)/u.
         const int u = d->stride;
         p.osy = u; p.osx = u; p.isy = 1; p.isx = 1;
+        if (t2_launch_ok(d, p.bf16x6, p.ksplit, launch_flags_of(iscale, oscale, ep))) {
+            tu_conv_t2(p, s);                             // the whole lattice, remainder row and column included, in one launch
+            return launch_status("conv2d");
+        }
         if (pair_launch_ok(d, p.bf16x6, p.ksplit, tile, pair_plain(launch_flags_of(iscale, oscale, ep)))) {
             launch_transposed_pairs(d, p, tile, s, EdgeWeights{w, wmod_s, wmod_d, wscale, d->flip});
             return launch_status("conv2d");

@@ -29,6 +29,8 @@ void tu_fwd_pair_64(const ConvFwdParams& p, hipStream_t s);
 
 // conv_tu_rows2d_*.hip: conv_fwd_rows2d_bf16x6_kernel, one unit per tile shape (q.rows_y0 set by the caller)
 void tu_rows2d_wide(const ConvFwdParams& q, hipStream_t s);       // <128, 256, 8, ., IO_F32, ., 512>: the dominant kernel
+void tu_rows2d_wide_glds(const ConvFwdParams& w8, dim3 grid8, hipStream_t s);     // conv_tu_rows2d_wide_glds.hip: the same with the weights by LDS-DMA
+void tu_rows2d_wide_pieces(const ConvFwdParams& q, hipStream_t s);       // conv_tu_rows2d_wide_xp.hip: x as PASTA_LAYOUT_PIECES16
 void tu_rows2d_128_r4(const ConvFwdParams& q, hipStream_t s);
 void tu_rows2d_128_r2(const ConvFwdParams& q, hipStream_t s);
 void tu_rows2d_64_r8(const ConvFwdParams& q, hipStream_t s);
@@ -36,6 +38,9 @@ void tu_rows2d_64_r8(const ConvFwdParams& q, hipStream_t s);
 // conv_tu_fwd_small.hip: the pointwise and the stride-2 kernels
 void tu_conv1x1(const ConvFwdParams& p, hipStream_t s);
 void tu_conv3x3s2(const ConvFwdParams& p, hipStream_t s);
+
+// conv_tu_fwd_t2.hip: 3x3 stride-2 conv_transpose2d in one pass over the input lattice (p.iscale: the modulated layers)
+void tu_conv_t2(const ConvFwdParams& p, hipStream_t s);
 
 // conv_tu_fwd_fewch.hip: pointwise convolutions with <= 16 channels on one side (kind 1: few input channels, 2: few output channels)
 struct FewChParams;

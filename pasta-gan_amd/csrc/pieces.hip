@@ -124,6 +124,30 @@ __global__ __launch_bounds__(256) void pieces_unpack_kernel(const void* pieces, 
     }
 }
 
+// The reverse: an fp32 NCHW tensor whose partial maxima are known, split as the consuming kernels split it (f16_split2 under the same power-of-two
+// scale: the pieces a kernel would have formed in its staging, bit for bit).  For tests and measurements of the pieces-reading kernels, and for a
+// caller whose producer is not one of this library's kernels.
+__global__ __launch_bounds__(256) void pieces_pack_kernel(const float* x, const float* parts, void* pieces, int N, int C, int H, int W) {
+    float sc, isc;
+    scale_from_amax(amax_of_parts(parts), sc, isc);
+    const int64_t units = (int64_t)N * (C >> 3) * H * W;
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (int64_t)gridDim.x * 256) {
+        const int64_t xx = u % W, r = u / W;
+        const int64_t yy = r % H, r2 = r / H;
+        const int64_t c8 = r2 % (C >> 3), n = r2 / (C >> 3);
+        u32x4 hq, lq;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float v0 = x[((n * C + c8 * 8 + 2 * j) * H + yy) * W + xx], v1 = x[((n * C + c8 * 8 + 2 * j + 1) * H + yy) * W + xx];
+            uint32_t a, b;
+            f16_split2(v0 * sc, v1 * sc, a, b);
+            hq[j] = a; lq[j] = b;
+        }
+        ((u32x4*)pieces)[2 * r * W + xx] = hq;
+        ((u32x4*)pieces)[(2 * r + 1) * W + xx] = lq;
+    }
+}
+
 }  // namespace pasta
 
 extern "C" int64_t pasta_pieces_bytes(int N, int C, int H, int W) {
@@ -163,4 +187,15 @@ extern "C" int pasta_pieces_unpack(const void* pieces, const float* x_amax, floa
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(pieces_unpack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pieces, x_amax, y, N, C, H, W);
     return launch_status("pieces_unpack");
+}
+
+extern "C" int pasta_pieces_pack(const float* x, const float* x_amax, void* pieces, int N, int C, int H, int W, void* stream) {
+    using namespace pasta;
+    PASTA_CHECK(x && x_amax && pieces, "pieces_pack: null pointer (the partial maxima of x fix the operand scale)");
+    PASTA_CHECK(N >= 1 && C >= 8 && (C & 7) == 0 && H >= 1 && W >= 1, "pieces_pack: [%d, %d, %d, %d]: the channel count must be a multiple of 8", N, C, H, W);
+    const int64_t units = (int64_t)N * (C >> 3) * H * W;
+    int64_t blocks = ceil_div64(units, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pieces_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, x_amax, pieces, N, C, H, W);
+    return launch_status("pieces_pack");
 }

@@ -30,7 +30,7 @@ _LIBDIR = os.path.join(_ROOT, 'lib')
 _OBJDIR = os.path.join(_ROOT, 'build')
 _INCLUDE = os.path.join(os.path.dirname(_ROOT), 'include')
 LIB_NAME = 'libpasta_hip.so'
-EXPECTED_ABI = 19                   # PASTA_ABI_VERSION of include/pasta_hip.h = pasta_abi_version() of csrc/common.hip
+EXPECTED_ABI = 20                   # PASTA_ABI_VERSION of include/pasta_hip.h = pasta_abi_version() of csrc/common.hip
 ARCH = 'gfx950'
 
 _lock = threading.Lock()
@@ -176,6 +176,7 @@ ABI = {
     'pasta_pieces_bytes':  (_c_i64, [ctypes.c_int] * 4),
     'pasta_blur_pieces':   (ctypes.c_int, [_c_ptr] * 5 + [ctypes.c_int] * 9 + [_c_f32, _c_ptr]),
     'pasta_pieces_unpack': (ctypes.c_int, [_c_ptr] * 3 + [ctypes.c_int] * 4 + [_c_ptr]),
+    'pasta_pieces_pack': (ctypes.c_int, [_c_ptr] * 3 + [ctypes.c_int] * 4 + [_c_ptr]),
     'pasta_conv2d_workspace':       (_c_i64, [ctypes.POINTER(ConvDesc)]),
     'pasta_conv2d_wgrad_workspace': (_c_i64, [ctypes.POINTER(ConvDesc)]),
     'pasta_conv2d_tile':  (ctypes.c_int, [ctypes.POINTER(ConvDesc)]),

@@ -384,6 +384,22 @@ def blur_pieces(x, f, pad4, flip_filter=False, gain=1.0, x_amax=None):
         _up.launch_hook((x.numel() + n * c * oh * ow) * 4, (tuple(x.shape), 1, 1, 4, 'pieces'), launch)
     return pieces, bound, (n, c, oh, ow)
 
+def pieces_pack(x, x_amax=None):
+    """An fp32 NCHW tensor as PASTA_LAYOUT_PIECES16, split exactly as the consuming kernels split it in their staging (``pasta_pieces_pack``).
+    Returns (pieces, bound row, shape) like ``blur_pieces``; the bound row is x's own partial maxima."""
+    _native.require_gpu(x, 'pieces_pack')
+    x = x.float().contiguous()
+    n, c, h, wd = (int(v) for v in x.shape)
+    lib = _native.lib()
+    nbytes = lib.pasta_pieces_bytes(n, c, h, wd)
+    if nbytes < 0:
+        raise RuntimeError(f'pieces_pack: {tuple(x.shape)}: the channel count must be a multiple of 8')
+    parts = tensor_amax(x) if x_amax is None else x_amax
+    pieces = torch.empty([nbytes], dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _native.check(lib.pasta_pieces_pack(_native.ptr(x), _native.ptr(parts), _native.ptr(pieces), n, c, h, wd, _native.stream()))
+    return pieces, parts, (n, c, h, wd)
+
 def pieces_unpack(pieces, bound, shape):
     """(h + 2^-11 l') / S as an fp32 NCHW tensor (tests, diagnostics): the 22 bits the consumers multiply."""
     n, c, h, wd = shape
@@ -397,8 +413,8 @@ def _launch_conv_pieces(x, w, cfg, epilogue, pieces):
     bound, (n, c_in, h, wd) = pieces
     w = _f32(w).contiguous()
     kh, kw = w.shape[2], w.shape[3]
-    assert not cfg.transposed and cfg.groups == 1 and w.shape[1] == c_in
-    c_out = w.shape[0]
+    assert cfg.groups == 1 and w.shape[0 if cfg.transposed else 1] == c_in
+    c_out = w.shape[1 if cfg.transposed else 0]
     oh, ow = _out_hw(cfg, h, wd, kh, kw)
     y = torch.empty([n, c_out, oh, ow], dtype=torch.float32, device=x.device)
     desc = _desc(cfg, (n, c_in, h, wd), c_out, oh, ow, kh, kw)

@@ -66,7 +66,7 @@ def main():
     dev = torch.device('cuda')
     print(f"{'shape':28s} {'pass':6s} {'ms':>8s} {'TFLOP/s':>8s}" + (f" {'miopen ms':>10s} {'TF/s':>7s}" if args.miopen else ''))
     for name, n, ci, h, co, k, st, tr, *rest in SHAPES:
-        if (args.match and args.match not in name) or only == ['down']:
+        if (args.match and args.match not in name) or only == ['down'] or only == ['s1pieces']:
             continue
         pad = rest[0] if rest else (k // 2 if not tr else 0)
         x = torch.randn([n, ci, h, h], device=dev)
@@ -100,6 +100,8 @@ def main():
 
     if 'down' in only or args.only == 'fwd,dgrad,wgrad':
         down_path(args)
+    if 's1pieces' in only:
+        s1_pieces(args)
 
 
 DOWN = [  # the down path of conv2d_resample (blur to 2 k + 1, then 3x3 stride 2 without padding): name, N, Cin, H (input), Cout
@@ -134,6 +136,31 @@ def down_path(args):
         for tag, fn, fl in stages:
             ms = timeit(fn, args.reps)
             print(f'{name:28s} {tag:14s} {ms:8.3f} {(fl / ms / 1e9) if fl else (nbytes / ms / 1e6):14.1f}', flush=True)
+
+
+def s1_pieces(args):
+    """The eight-wave 3x3 stride-1 tile kernel on fp32 x (its maxima attached: no scan in either line) and on the same operand as
+    PASTA_LAYOUT_PIECES16 (pasta_pieces_pack: the same pieces, bit for bit): forward and input gradient."""
+    from torch_utils.ops import _native
+    dev = torch.device('cuda')
+    print(f"{'3x3 stride 1':28s} {'operand':14s} {'ms':>8s} {'TFLOP/s':>8s}  equal")
+    for name, n, ci, h, co, k, st, tr, *rest in SHAPES:
+        if k != 3 or st != 1 or co < 128 or h < 8 or (args.match and args.match not in name):
+            continue
+        x = torch.randn([n, ci, h, h], device=dev)
+        w = torch.randn([co, ci, 3, 3], device=dev) * 0.05
+        cfg = cg._Cfg((False, 1, 1, 1, 0, 0, 1))
+        _native.amax_attach(x, cg.tensor_amax(x))
+        pieces, bound, shape = cg.pieces_pack(x)
+        y0 = cg._launch_conv(x, w, cfg)
+        try:
+            y1 = cg._launch_conv(pieces, w, cfg, pieces=(bound, shape))
+        except RuntimeError:        # not the eight-wave tile kernel's launch
+            continue
+        flops = 2.0 * n * ci * co * 9 * h * h
+        for tag, fn in (('fp32', lambda: cg._launch_conv(x, w, cfg)), ('pieces', lambda: cg._launch_conv(pieces, w, cfg, pieces=(bound, shape)))):
+            ms = timeit(fn, args.reps)
+            print(f'{name:28s} {tag:14s} {ms:8.3f} {flops / ms / 1e9:8.1f}  {bool(torch.equal(y0, y1))}', flush=True)
 
 
 if __name__ == '__main__':
