@@ -26,8 +26,12 @@ namespace pasta {
 // of 123 - 190 us.  An edge tile keeps the tile's shape and changes what a tile row / column means:
 //   * row edge:    tile row r = image n0 + r, tile columns = lattice columns j0 .. j0 + 31 of lattice row H: only the windows one row up
 //                  exist (taps 6, 7, 8: classes (0, 0) and (0, 1)), B image slot (ir, ic) = x[n0 + ir, H - 1, j0 - 1 + ic];
-//   * column edge: tile column c = image n0 + c, tile rows = lattice rows i0 .. i0 + 7 (up to H: the corner) of lattice column W: only the
-//                  windows one column to the left exist (taps 2, 5, 8: classes (0, 0) and (1, 0)), slot (ir, ic) = x[n0 + ic, i0 - 1 + ir, W - 1].
+//   * column edge: tile row r = image n0 + r, tile columns = lattice ROWS i0 .. i0 + 31 (up to H: the corner) of lattice column W: only the
+//                  windows one column to the left exist (taps 2, 5, 8: classes (0, 0) and (1, 0)); the row above is the tile column to the left:
+//                  slot (ir, ic) = x[n0 + ir - 1, i0 + ic - 1, W - 1], taps 2 and 5 at window position (0, 0), tap 8 at (0, -1).  The column
+//                  itself comes from p.x2 = x[:, :, :, W - 1] gathered as [N][C][H] by t2_column_gather_kernel in front of the launch: read in
+//                  place, a lane's four bytes are a cache line of their own whichever way the tile is laid (4752 line requests per chunk and
+//                  workgroup: a column tile then took 36 - 75 us, as long as a regular tile with three times its MFMAs).
 // The K loop, the weights and the fragment offsets are the regular tile's; the kind is uniform per workgroup.
 // ISC: p.iscale[n, channel] (the styles of a modulated layer: pasta_conv2d_modulated's x * s) multiplied onto the activations between
 // fetch and split, as in the other forward-type kernels.
@@ -61,7 +65,6 @@ __device__ __forceinline__ void conv_t2_body(const ConvFwdParams& p, const int n
     const int64_t a_chunk = (int64_t)6 * p.Og_pad * 8;             // elements of one packed 16-channel chunk of one tap
     const __bf16* const wb = (const __bf16*)p.wp + (int64_t)g * 9 * NC * a_chunk + (int64_t)o_blk * 8;
     unsigned a_off[APT];                                // byte offsets from the chunk's (uniform) base: scalar base + 32-bit lane offset addressing
-    unsigned a_need = 0;                                // edge tiles: the units of the three taps they multiply (bit j)
 #pragma unroll
     for (int j = 0; j < APT; j++) {
         int u = tid + NT * j;
@@ -69,22 +72,48 @@ __device__ __forceinline__ void conv_t2_body(const ConvFwdParams& p, const int n
         const int tap = u / (6 * BM), rem = u - tap * (6 * BM);
         const int seg = rem / BM, within = rem - seg * BM;
         a_off[j] = ((unsigned)tap * (unsigned)NC * (unsigned)a_chunk + (unsigned)(seg * p.Og_pad + within) * 8u) * 2u;
-        const bool need = tap == 8 || (kind == 1 ? tap >= 6 : (tap == 2 || tap == 5));
-        a_need |= need ? 1u << j : 0u;
     }
     auto glds_a = [&](int cc, int buf) {
         const char* const wc = (const char*)(wb + (int64_t)cc * a_chunk);
 #pragma unroll
         for (int j = 0; j < APT; j++) {
             __bf16* dst = As + buf * ABUF + (wave * 64 + NT * j) * 8;        // the wave's base: the hardware adds lane * 16 bytes
-            if (kind == 0 || (a_need >> j & 1u))         // (a lane that is switched off leaves its sixteen bytes of the buffer alone)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wc + a_off[j]), (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wc + a_off[j]), (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
-    glds_a(0, 0);
+    if constexpr (kind == 0) glds_a(0, 0);
+    // Edge tiles: the units of the THREE taps they multiply (row edge 6, 7, 8; column edge 2, 5, 8), 2.25 per thread, through registers and two
+    // chunks ahead (below): a third of a regular tile's bytes and MFMAs, and as a copy of the regular tile's schedule -- everything of the next
+    // chunk fetched at the head of a chunk and waited for at its end -- still three quarters of its time (the memory latency once per chunk).
+    constexpr int EUNITS = 3 * 6 * BM, EPT = (EUNITS + NT - 1) / NT;
+    unsigned e_off[EPT];
+    int e_lds[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+        const int u = tid + NT * j;
+        const int uu = u < EUNITS ? u : 0;
+        const int t3 = uu / (6 * BM), rem = uu - t3 * (6 * BM);
+        const int tap = kind == 1 ? 6 + t3 : 3 * t3 + 2;
+        const int seg = rem / BM, within = rem - seg * BM;
+        e_off[j] = ((unsigned)tap * (unsigned)NC * (unsigned)a_chunk + (unsigned)(seg * p.Og_pad + within) * 8u) * 2u;
+        e_lds[j] = u < EUNITS ? (tap * (6 * BM) + rem) * 8 : -1;
+    }
+    constexpr int SETS = kind == 0 ? 1 : 2;             // register sets of staged operands: chunks in flight
+    u32x4 ea[SETS][EPT];
+    auto load_a = [&](int cc, int set) {
+        const char* const wc = (const char*)(wb + (int64_t)cc * a_chunk);
+#pragma unroll
+        for (int j = 0; j < EPT; j++) ea[set][j] = *(const u32x4*)(wc + e_off[j]);
+    };
+    auto store_a = [&](int set, int buf) {
+#pragma unroll
+        for (int j = 0; j < EPT; j++)
+            if (e_lds[j] >= 0) *(u32x4*)(As + buf * ABUF + e_lds[j]) = ea[set][j];
+    };
 
     // ---- activations: staging unit k of this thread -> (slot, k-half); pixel offset and validity
-    const char* const xb = (const char*)p.x;            // (uniform; the planner keeps the tensor below 2^30 elements: 32-bit byte offsets)
+    const char* const xb = kind == 2 ? (const char*)p.x2 : (const char*)p.x;      // (uniform; the planner keeps the tensor below 2^30 elements: 32-bit byte offsets)
+    const unsigned cstride = kind == 2 ? (unsigned)p.H * 4u : (unsigned)HW * 4u;      // bytes from a channel to the next
     unsigned u_pix[2];
     int u_half[2], u_lds[2], u_isc[2];
     bool u_ok[2];
@@ -97,16 +126,16 @@ __device__ __forceinline__ void conv_t2_body(const ConvFwdParams& p, const int n
         int img = n0, y = i0 - 1 + ir, x = j0 - 1 + ic;
         bool in_tile = true;
         if (kind == 1) { img = n0 + ir; y = p.H - 1; in_tile = ir < R; }
-        if (kind == 2) { img = n0 + ic; x = p.W - 1; in_tile = ic < SEG; }
+        if (kind == 2) { img = n0 + ir - 1; y = i0 + ic - 1; x = p.W - 1; in_tile = ir >= 1; }
         u_ok[k] = (k == 0 || second) && in_tile && img < p.N && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
         u_isc[k] = u_ok[k] ? img * p.Cin + g * p.Ig : 0;
-        u_pix[k] = u_ok[k] ? ((unsigned)u_isc[k] * (unsigned)HW + (unsigned)(y * p.W + x)) * 4u : 0u;
+        u_pix[k] = !u_ok[k] ? 0u : kind == 2 ? ((unsigned)u_isc[k] * (unsigned)p.H + (unsigned)y) * 4u : ((unsigned)u_isc[k] * (unsigned)HW + (unsigned)(y * p.W + x)) * 4u;
         u_half[k] = half;
         u_lds[k] = (half * SLOTS + slot) * 8;
     }
-    float sb[2][8], sc[2][ISC ? 8 : 1];
-    int nv[2];
-    auto load_units = [&](int cc) {
+    float sb[SETS][2][8], sc[SETS][2][ISC ? 8 : 1];
+    int nv[SETS][2];
+    auto load_units = [&](int cc, int set = 0) {
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             if (k == 1 && !second) continue;
@@ -114,27 +143,27 @@ __device__ __forceinline__ void conv_t2_body(const ConvFwdParams& p, const int n
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int c = c0 + j < p.Ig ? c0 + j : p.Ig - 1;
-                sb[k][j] = io_ld<IO_F32>(xb, u_pix[k] + (unsigned)c * (unsigned)HW * 4u);
-                if constexpr (ISC) sc[k][j] = p.iscale[u_isc[k] + c];
+                sb[set][k][j] = io_ld<IO_F32>(xb, u_pix[k] + (unsigned)c * cstride);
+                if constexpr (ISC) sc[set][k][j] = p.iscale[u_isc[k] + c];
             }
-            nv[k] = u_ok[k] ? p.Ig - c0 : 0;
+            nv[set][k] = u_ok[k] ? p.Ig - c0 : 0;
         }
     };
     load_units(0);
 
     float x_scale, out_scale;
     scale_from_amax(amax_of_parts(p.x_amax), x_scale, out_scale);
-    auto store_units = [&](int buf) {
+    auto store_units = [&](int buf, int set = 0) {
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             if (k == 1 && !second) continue;
             uint32_t q1[4], q2[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                float v0 = sb[k][2 * j], v1 = sb[k][2 * j + 1];
-                if constexpr (ISC) { v0 *= sc[k][2 * j]; v1 *= sc[k][2 * j + 1]; }
-                v0 = 2 * j < nv[k] ? v0 : 0.f;
-                v1 = 2 * j + 1 < nv[k] ? v1 : 0.f;
+                float v0 = sb[set][k][2 * j], v1 = sb[set][k][2 * j + 1];
+                if constexpr (ISC) { v0 *= sc[set][k][2 * j]; v1 *= sc[set][k][2 * j + 1]; }
+                v0 = 2 * j < nv[set][k] ? v0 : 0.f;
+                v1 = 2 * j + 1 < nv[set][k] ? v1 : 0.f;
                 f16_split2(v0 * x_scale, v1 * x_scale, q1[j], q2[j]);
             }
             __bf16* const bd = Bs + buf * BBUF + u_lds[k];
@@ -181,15 +210,35 @@ __device__ __forceinline__ void conv_t2_body(const ConvFwdParams& p, const int n
             for (int b = 0; b < 2; b++) acc[cls][b] = mfma16<IO_F32, NP>(a0, bh[b], acc[cls][b]);
         };
         // tap (r, c) = 3 r + c: class (r & 1, c & 1), window position (-(r >> 1), -(c >> 1)); an edge tile has one row / column of windows
-        window(-IW - 1); tap(8, 0);
-        if (kind != 2) { window(-IW); tap(6, 0); tap(7, 1); }
-        if (kind != 1) { window(-1);  tap(2, 0); tap(5, 2); }
+        if (kind == 2) { window(-1); tap(8, 0); window(0); tap(2, 0); tap(5, 2); }      // (the column edge's own map: see the head of the file)
+        if (kind != 2) { window(-IW - 1); tap(8, 0); window(-IW); tap(6, 0); tap(7, 1); }
+        if (kind == 0) { window(-1);  tap(2, 0); tap(5, 2); }
         // the next chunk's activations: split and stored HERE, between the MFMA groups (their loads were issued at the head of the chunk, five
         // taps ago), so that this wave's vector instructions run beside the other wave's MFMAs instead of behind everybody's
         if (stage) store_units(buf ^ 1);
         if (kind == 0) { window(0);   tap(0, 0); tap(1, 1); tap(3, 2); tap(4, 3); }
     };
 
+    if constexpr (kind != 0) {
+        // edge tile: chunk cc + 2 is fetched into register set cc & 1 while chunk cc is multiplied and chunk cc + 1 -- fetched a chunk ago -- is
+        // split and stored: every load has a whole chunk to land (ordinary loads throughout: the compiler counts the waits)
+        load_a(0, 0);
+        if (NC > 1) { load_units(1, 1); load_a(1, 1); }
+        store_units(0, 0); store_a(0, 0);
+        __syncthreads();
+        for (int c = 0; c < NC; c += 2) {
+#pragma unroll
+            for (int par = 0; par < 2; par++) {
+                const int cc = c + par;
+                if (cc < NC) {                           // (uniform)
+                    if (cc + 2 < NC) { load_units(cc + 2, par); load_a(cc + 2, par); }
+                    compute(par, false);
+                    if (cc + 1 < NC) { store_units(par ^ 1, par ^ 1); store_a(par ^ 1, par ^ 1); }
+                    __syncthreads();
+                }
+            }
+        }
+    } else {
     // prologue: the first chunk's activations; the barrier's fence waits for the DMA of its weights
     store_units(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -215,6 +264,7 @@ __device__ __forceinline__ void conv_t2_body(const ConvFwdParams& p, const int n
             }
         }
     }
+    }
 
     // back to the operands' units: 1 / S_x for the tile, 1 / S_w per weight row (p.w_rowinv, written by the packing kernel)
     const float* const wri = p.w_rowinv + (int64_t)g * p.Og_pad + o_blk + wm * 32;
@@ -226,8 +276,8 @@ __device__ __forceinline__ void conv_t2_body(const ConvFwdParams& p, const int n
 #pragma unroll
     for (int b = 0; b < 2; b++) {
         const int tr = wn * 2 + b;                      // tile row / column of this lane's pixel
-        const int img = kind == 1 ? n0 + tr : kind == 2 ? n0 + jl : n0;
-        const int i = kind == 1 ? p.H : i0 + tr, j = kind == 2 ? p.W : j0 + jl;
+        const int img = kind == 0 ? n0 : n0 + tr;
+        const int i = kind == 1 ? p.H : kind == 2 ? i0 + jl : i0 + tr, j = kind == 2 ? p.W : j0 + jl;
         if (img >= p.N || 2 * i >= p.OH) continue;      // (edge tiles: images / rows past the end)
         float* const yb = (float*)p.y + ((int64_t)img * p.Cout + (int64_t)g * p.Og) * OHW + (int64_t)(2 * i) * p.OW + 2 * j;
 #pragma unroll
@@ -261,14 +311,14 @@ __global__ __launch_bounds__(512, 1) void conv_t2_f16x3_kernel(ConvFwdParams p) 
     // of a regular tile's work, and the CUs that start with one pick up regular tiles behind it -- at the end of the grid they would be a wave
     // of workgroups of their own behind a grid that fills the chip exactly.
     int bx = blockIdx.x;
-    const int rb = p.H / R + 1;                         // row blocks of the column edge: rows 0 .. H
+    const int rb = p.H / SEG + 1;                       // blocks of 32 lattice rows of the column edge: rows 0 .. H
     const int row_tiles = p.OH > 2 * p.H ? ((p.N + R - 1) / R) * cblocks : 0;
-    const int col_tiles = p.OW > 2 * p.W ? ((p.N + SEG - 1) / SEG) * rb : 0;
+    const int col_tiles = p.OW > 2 * p.W ? ((p.N + R - 1) / R) * rb : 0;
     if (bx < row_tiles) {
         conv_t2_body<ISC, 1>(p, (bx / cblocks) * R, p.H, (bx % cblocks) * SEG);
     } else if (bx < row_tiles + col_tiles) {
         bx -= row_tiles;
-        conv_t2_body<ISC, 2>(p, (bx / rb) * SEG, (bx % rb) * R, p.W);
+        conv_t2_body<ISC, 2>(p, (bx / rb) * R, (bx % rb) * SEG, p.W);
     } else {
         bx -= row_tiles + col_tiles;
         const int n0 = bx / tpi, t_in = bx - n0 * tpi;
@@ -276,15 +326,29 @@ __global__ __launch_bounds__(512, 1) void conv_t2_f16x3_kernel(ConvFwdParams p) 
     }
 }
 
+// x[:, :, :, W - 1] as [planes][H]: the column-edge tiles' operand (one thread per element; the reads are a cache line each, spread over the chip)
+__global__ __launch_bounds__(256) void t2_column_gather_kernel(const float* __restrict__ x, float* __restrict__ col, int64_t planes, int H, int W) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= planes * H) return;
+    const int64_t plane = e / H;
+    const int i = (int)(e - plane * H);
+    col[e] = x[(plane * H + i) * W + W - 1];
+}
+
 // Does the kernel take the MAIN lattice of this launch (pad 0, OH in {2 H, 2 H + 1}: rows / columns 2 H, 2 W are the remainder's)?
 static bool conv_t2_shape_ok(int H, int W) { return H % 8 == 0 && W % 32 == 0; }
 
+// (p.x2: N * C_in * H floats of workspace for the gathered column, used when OW = 2 W + 1)
 static void launch_conv_t2(const ConvFwdParams& p, hipStream_t s) {
+    if (p.OW > 2 * p.W) {
+        const int64_t planes = (int64_t)p.N * p.Cin;
+        hipLaunchKernelGGL(t2_column_gather_kernel, dim3((unsigned)((planes * p.H + 255) / 256)), dim3(256), 0, s, (const float*)p.x, (float*)p.x2, planes, p.H, p.W);
+    }
     constexpr int NT = 512, APT = (9 * 6 * 64 + NT - 1) / NT, SLOTS = 9 * 33;
     constexpr size_t lds = (size_t)(2 * APT * NT * 8 + 2 * 2 * 2 * SLOTS * 8) * sizeof(__bf16);
-    // regular tiles, then the edge tiles of lattice row H (eight images x 32 columns each) and of lattice column W (32 images x 8 rows, rows 0 .. H)
+    // the edge tiles of lattice row H (eight images x 32 columns each) and of lattice column W (eight images x 32 rows, rows 0 .. H), then the regular tiles
     const int64_t tiles = (int64_t)p.N * (p.H / 8) * (p.W / 32) + (p.OH > 2 * p.H ? (int64_t)((p.N + 7) / 8) * (p.W / 32) : 0) +
-                          (p.OW > 2 * p.W ? (int64_t)((p.N + 31) / 32) * (p.H / 8 + 1) : 0);
+                          (p.OW > 2 * p.W ? (int64_t)((p.N + 7) / 8) * (p.H / 32 + 1) : 0);
     const dim3 grid((unsigned)tiles, (unsigned)((p.Og + 63) / 64), (unsigned)p.G);
     if (p.iscale) {
         PASTA_SET_LDS(conv_t2_f16x3_kernel<true>, lds);

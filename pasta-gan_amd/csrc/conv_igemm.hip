@@ -298,6 +298,8 @@ static int64_t packed_input_floats(const pasta_conv_desc* d) {
 }
 }
 
+namespace pasta { static bool t2_launch_ok(const pasta_conv_desc* d, int pieces, int ksplit, int launch_flags); }
+
 extern "C" int64_t pasta_conv2d_workspace(const pasta_conv_desc* d) {
     using namespace pasta;
     if (check_desc(d, "conv2d_workspace")) return -1;
@@ -315,6 +317,7 @@ extern "C" int64_t pasta_conv2d_workspace(const pasta_conv_desc* d) {
         pack = pack > pk ? pack : pk;
         extra = kp + packed_input_floats(d);
     }
+    if (t2_launch_ok(d, math_pieces(d->math), ks, 0)) extra = (int64_t)d->N * d->C_in * d->H;      // conv_fwd_t2.h: the input's last column, gathered
     const int64_t rowinv = (int64_t)d->groups * round_up(Og, fwd_tile_bm(t));      // PASTA_MATH_F16X3: 1 / S_w per packed weight row
     return (WS_AMAX_FLOATS + rowinv + round_up((int)pack, 4) + partial + round_up((int)extra, 4)) * (int64_t)sizeof(float);
 }
@@ -342,7 +345,6 @@ static bool pieces_fwd_ok(const pasta_conv_desc* d, int launch_flags) {
            !(getenv("PASTA_CONV_S2") && getenv("PASTA_CONV_S2")[0] == '0');
 }
 static bool pair_launch_ok(const pasta_conv_desc* d, int pieces, int ksplit, FwdTile tile, bool plain);
-static bool t2_launch_ok(const pasta_conv_desc* d, int pieces, int ksplit, int launch_flags);
 // The parity-pair kernel carries no scales and no epilogue: ONE predicate for the planner and the launch.
 static inline bool pair_plain(int launch_flags) { return launch_flags == 0; }
 static inline int launch_flags_of(const float* iscale, const float* oscale, const pasta_conv_epilogue* ep) {
@@ -432,8 +434,9 @@ static bool t2_launch_ok(const pasta_conv_desc* d, int pieces, int ksplit, int l
     if (!enabled || !d->transposed || d->stride != 2 || d->kh != 3 || d->kw != 3 || d->pad_h != 0 || d->pad_w != 0) return false;
     if (pieces != NP_F16X3 || d->io_dtype != PASTA_F32 || (launch_flags & ~(PASTA_PLAN_ISCALE | PASTA_PLAN_MODULATED)) || ksplit != 1 || d->x2 || d->x_layout) return false;
     if (d->OH < 2 * d->H || d->OH > 2 * d->H + 1 || d->OW < 2 * d->W || d->OW > 2 * d->W + 1) return false;
-    // planes of 64 x 64 and larger: at 32 x 32 the regular tiles of a batch of 16 fill the chip exactly once and the edge tiles in front of them
-    // cost more than the four per-class launches did (0.204 -> 0.214 ms on 512 -> 256; PASTA_CONV_T2=2 takes them too)
+    // planes of 64 x 64 and larger: at 32 x 32 the regular tiles of a batch of 16 fill the chip exactly once, what the edge tiles in front of them
+    // take is added to the launch (0.204 -> 0.190 ms on 512 -> 256 alone, nothing on the training step: profiles/r5_ab_conv_t2.txt).
+    // PASTA_CONV_T2=2 takes the smaller planes too.
     static const bool small_too = getenv("PASTA_CONV_T2") && getenv("PASTA_CONV_T2")[0] == '2';
     return d->C_in / d->groups >= 16 && d->H % 8 == 0 && d->W % 32 == 0 && ((int64_t)d->H * d->W >= 4096 || small_too);
 }
@@ -788,6 +791,7 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
         const int u = d->stride;
         p.osy = u; p.osx = u; p.isy = 1; p.isx = 1;
         if (t2_launch_ok(d, p.bf16x6, p.ksplit, launch_flags_of(iscale, oscale, ep))) {
+            p.x2 = p.partial;                             // (no K slices: the region behind the packed weights holds the gathered column)
             tu_conv_t2(p, s);                             // the whole lattice, remainder row and column included, in one launch
             return launch_status("conv2d");
         }
