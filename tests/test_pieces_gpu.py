@@ -224,3 +224,35 @@ def test_discriminator_block_with_joined_gradients_on_pieces():
             cg._PIECES = old
     for i, (a, r) in enumerate(zip(*res)):
         assert _rel(a, r) < 5e-6, (i, _rel(a, r))
+
+
+@pytest.mark.parametrize('n,ci,co,h,transposed', [
+    (2, 32, 128, 32, False),         # one tile per image
+    (1, 40, 256, 64, False),         # an octet count that leaves half a chunk empty; two output tiles
+    (2, 64, 128, 32, True),          # the input gradient of a 3x3 layer (conv_transpose2d, stride 1)
+])
+def test_stride_one_tile_kernel_reads_pieces_bit_for_bit(n, ci, co, h, transposed):
+    """conv_fwd_rows2d_bf16x6_kernel<..., XP> (plan kernel 7 with x_layout = PASTA_LAYOUT_PIECES16): the same pieces the kernel forms in its
+    staging, written by pasta_pieces_pack -- not one bit of the result moves; pack and unpack are inverse up to the 22 bits kept."""
+    from torch_utils.ops import conv2d_gradfix as cg, _native
+    g = torch.Generator().manual_seed(n + ci + co)
+    x = torch.randn([n, ci, h, h], generator=g).cuda()
+    w = (torch.randn([ci, co, 3, 3] if transposed else [co, ci, 3, 3], generator=g) * 0.1).cuda()
+    cfg = cg._Cfg((transposed, 1, 1, 1, 0, 0, 1))
+    _native.amax_attach(x, cg.tensor_amax(x))
+    pieces, bound, shape = cg.pieces_pack(x)
+    assert _rel(cg.pieces_unpack(pieces, bound, shape), x) < 2.0 ** -21
+    y0 = cg._launch_conv(x, w, cfg)
+    y1 = cg._launch_conv(pieces, w, cfg, pieces=(bound, shape))
+    assert torch.equal(y0, y1)
+    ref = (torch.nn.functional.conv_transpose2d if transposed else torch.nn.functional.conv2d)(x.double(), w.double(), padding=1)
+    assert _rel(y1, ref) < 2e-6
+
+
+def test_pieces_on_a_launch_no_kernel_takes_are_refused():
+    from torch_utils.ops import conv2d_gradfix as cg
+    x = torch.randn([2, 32, 16, 16]).cuda()              # a plane without 8 x 32 tiles: the base kernel's launch
+    w = torch.randn([128, 32, 3, 3]).cuda()
+    pieces, bound, shape = cg.pieces_pack(x)
+    with pytest.raises(RuntimeError, match='PASTA_LAYOUT_PIECES16'):
+        cg._launch_conv(pieces, w, cg._Cfg((False, 1, 1, 1, 0, 0, 1)), pieces=(bound, shape))
