@@ -161,7 +161,10 @@ typedef struct pasta_conv_desc {
                                      16 bytes, fp16 h[8] / l'[8] of v S, and x_amax (REQUIRED then) is the 256-float row the producer wrote -- the bound
                                      both sides take the power-of-two scale S from.  Served by the 3x3 stride-2 forward kernel and its weight gradient
                                      (pasta_conv2d_plan kernel 10, pasta_conv2d_wgrad_plan kernel 6: fp32 y / dy, PASTA_MATH_F16X3, one group, C_in a
-                                     multiple of 8, pad 0); the planners return an error for every other launch and the caller keeps the fp32 tensor. */
+                                     multiple of 8, pad 0) and by the eight-wave 3x3 stride-1 tile kernel, convolution or input gradient
+                                     (pasta_conv2d_plan kernel 7: no input scale, one group, C_in a multiple of 8; pasta_pieces_pack writes such an
+                                     operand from an fp32 tensor); the planners return an error for every other launch and the caller keeps the
+                                     fp32 tensor. */
 } pasta_conv_desc;
 
 #define PASTA_LAYOUT_NCHW      0
@@ -236,7 +239,12 @@ int pasta_conv2d_tile(const pasta_conv_desc* d);
  * row once, de-interleaved by pixel parity, for its three taps; round 5: with pasta_conv_desc.x_layout = PASTA_LAYOUT_PIECES16 its staging is a copy of
  * the producer's sixteen-byte pieces, no split), 11 / 12 conv1x1_fewcin_kernel / conv1x1_fewcout_kernel (round 5: 1x1 stride-1 launches with <= 16 input
  * or <= 16 output channels over more than 8192 pixels, fp32 tensors, one group, planes of a multiple of four pixels -- the RGB / pose stems, the ToRGB and
- * parsing heads and their input gradients: streaming kernels of plain fp32 FMAs on the raw weights, no packing launch, *math = PASTA_MATH_F32).
+ * parsing heads and their input gradients: streaming kernels of plain fp32 FMAs on the raw weights, no packing launch, *math = PASTA_MATH_F32),
+ * 13 conv_t2_f16x3_kernel (round 5: 3x3 stride-2 conv_transpose2d with pad 0 onto 2H(+1) x 2W(+1) outputs under PASTA_MATH_F16X3, fp32 tensors, >= 16
+ * input channels, input planes of 8 x 32 tiles and at least 64 x 64, optionally an input scale, nothing behind the sum: ONE launch over the input
+ * lattice computes the four output parity classes of a tile from one staged (8 + 1) x (32 + 1) window image -- nine taps, weights by LDS-DMA --
+ * and the remainder row / column as edge tiles of the same grid; *launches = 1; the workspace also holds the input's last column, gathered by a
+ * small kernel in front).  Kernel 7 also takes pasta_conv_desc.x_layout = PASTA_LAYOUT_PIECES16 (round 5).
  * Any out pointer may be NULL. */
 #define PASTA_PLAN_ISCALE   1
 #define PASTA_PLAN_OSCALE   2
