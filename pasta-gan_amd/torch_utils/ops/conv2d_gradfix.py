@@ -400,6 +400,49 @@ def pieces_pack(x, x_amax=None):
         _native.check(lib.pasta_pieces_pack(_native.ptr(x), _native.ptr(parts), _native.ptr(pieces), n, c, h, wd, _native.stream()))
     return pieces, parts, (n, c, h, wd)
 
+# ---- one operand, several 3x3 layers (round 5): a tensor that several stride-1 3x3 convolutions read (the SPADE feature map: three
+# conv_mlp batches per generator pass, networks.py Spade_ResBlockV2) is packed ONCE and every forward launch copies the pieces (plan kernel 7
+# with x_layout = PASTA_LAYOUT_PIECES16: +10 % on 256 -> 384 at 128 x 128, profiles/r5_s1_pieces_microbench.txt).  The pieces ride on the tensor
+# object, keyed by version and address like the maxima rows; the weight gradients keep reading the fp32 tensor.
+_SHARED_PIECES = _os.environ.get('PASTA_SHARED_PIECES', '1') != '0'       # A/B switch: 0 = every launch splits the fp32 tensor itself
+_shared_cache = {}
+
+def _shared_pieces_ok(x, weight, cfg, has_epilogue):
+    """Does the eight-wave stride-1 tile kernel take conv2d(x, weight) with x as pieces?"""
+    if not (_SHARED_PIECES and _PIECES and x.device.type == 'cuda' and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and conv_math in ('default', 'f16x3') and _SCOPE == 'all' and cfg.groups == 1 and cfg.stride == 1 and not cfg.transposed
+            and tuple(weight.shape[2:]) == (3, 3) and x.ndim == 4 and x.shape[1] % 8 == 0):
+        return False
+    n, c, h, wd = (int(v) for v in x.shape)
+    key = (n, c, h, wd, int(weight.shape[0]), cfg.pad_h, cfg.pad_w, bool(has_epilogue))
+    hit = _shared_cache.get(key)
+    if hit is None:
+        oh, ow = _out_hw(cfg, h, wd, 3, 3)
+        desc = _desc(cfg, (n, c, h, wd), int(weight.shape[0]), oh, ow, 3, 3)
+        desc.x_layout = 1
+        k = ctypes.c_int()
+        hit = _native.lib().pasta_conv2d_plan(ctypes.byref(desc), 4 if has_epilogue else 0, None, None, None, None, ctypes.byref(k)) == 0 and k.value == 7
+        _shared_cache[key] = hit
+    return hit
+
+def share_pieces(x):
+    """Pack ``x`` for the stride-1 3x3 layers that will read it (a no-op where none of them could use the pieces); returns ``x``."""
+    if (_SHARED_PIECES and _PIECES and x.device.type == 'cuda' and x.dtype == torch.float32 and x.ndim == 4 and x.shape[1] % 8 == 0 and x.shape[1] >= 16
+            and conv_math in ('default', 'f16x3') and _SCOPE == 'all' and not x.is_inference() and x.is_contiguous()
+            and not torch.cuda.is_current_stream_capturing() and _shared_lookup(x) is None):
+        pieces, bound, shape = pieces_pack(x)
+        try:
+            x._pasta_pieces = (x._version, x.data_ptr(), pieces, bound, shape)
+        except AttributeError:
+            pass
+    return x
+
+def _shared_lookup(x):
+    hit = getattr(x, '_pasta_pieces', None)
+    if hit is not None and hit[0] == x._version and hit[1] == x.data_ptr():
+        return hit
+    return None
+
 def pieces_unpack(pieces, bound, shape):
     """(h + 2^-11 l') / S as an fp32 NCHW tensor (tests, diagnostics): the 22 bits the consumers multiply."""
     n, c, h, wd = shape
@@ -564,7 +607,13 @@ class _ConvBiasActHip(torch.autograd.Function):
         act, alpha, gain, clamp = act_cfg
         from . import bias_act as ba
         used = {}
-        y = _launch_conv(x, w, cfg, epilogue=(b, ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, res), used=used)
+        shared = _shared_lookup(x) if not x.is_inference() else None
+        if shared is not None and _shared_pieces_ok(x, w, cfg, True):
+            # x was packed for its several readers (share_pieces): this launch copies the pieces; its maxima are the pack's bound row
+            y = _launch_conv(shared[2], w, cfg, epilogue=(b, ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, res), pieces=(shared[3], shared[4]))
+            used['x_amax'] = shared[3]
+        else:
+            y = _launch_conv(x, w, cfg, epilogue=(b, ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, res), used=used)
         if ba.slope_tape is not None:               # test instrument (bias_act.SlopeTape)
             y = ba.slope_tape.visit(y, act)
         # y is needed by the backward only as the activation / clamp mask; a linear, unclamped layer (the residual
@@ -792,6 +841,9 @@ def conv2d_bias_act(input, weight, bias=None, stride=1, padding=0, groups=1, act
             hit = getattr(input, '_pasta_amax', None)      # the view autograd made of the input is the same data at the same version: its maxima go along
             if hit is not None and not again.is_inference():
                 again._pasta_amax = hit
+            hit = _shared_lookup(input)                     # ... and its packed pieces (share_pieces), for the next reader
+            if hit is not None and not again.is_inference():
+                again._pasta_pieces = (again._version, again.data_ptr()) + hit[2:]
             return y, again
         y = _ConvBiasActHip.apply(input, weight, bias, cfg, (act, alpha, gain, clampf), residual)
         return (y, input) if passthrough else y

@@ -964,6 +964,7 @@ class Spade_ResBlockV2(torch.nn.Module):
         if not ok:
             return None, feat
         mlp, g = norms[0].conv_mlp, norms[0].conv_gamma
+        conv2d_gradfix.share_pieces(feat)                # the blocks of a generator pass read ONE feature map: packed once, copied by every conv_mlp launch
         # (the feature map again as second result: the next SPADE block reads IT, and its gradient joins this convolution's input gradient
         # in that launch's epilogue -- the three blocks' gradients into the map without the two 268 MB additions autograd would make)
         actv = conv2d_resample.conv2d_resample_bias_act(x=feat, w=torch.cat([n.conv_mlp.weight for n in norms], dim=0), b=None, act='relu', gain=1,

@@ -256,3 +256,40 @@ def test_pieces_on_a_launch_no_kernel_takes_are_refused():
     pieces, bound, shape = cg.pieces_pack(x)
     with pytest.raises(RuntimeError, match='PASTA_LAYOUT_PIECES16'):
         cg._launch_conv(pieces, w, cg._Cfg((False, 1, 1, 1, 0, 0, 1)), pieces=(bound, shape))
+
+
+def test_one_operand_packed_once_for_several_three_by_three_layers():
+    """share_pieces (the SPADE feature map, networks.py Spade_ResBlockV2._batched_gamma_beta): the tensor is packed once, every conv_mlp launch
+    that reads it -- directly or through the pass-through output of the previous reader -- copies the pieces, and nothing moves: outputs and
+    gradients are bit-identical to the launches that split the fp32 tensor themselves."""
+    from torch_utils.ops import conv2d_gradfix as cg
+    g = torch.Generator().manual_seed(21)
+    x0 = torch.randn([2, 32, 32, 32], generator=g).cuda()
+    ws = [(torch.randn([128, 32, 3, 3], generator=g) * 0.1).cuda().requires_grad_(True) for _ in range(3)]
+    dys = [torch.randn([2, 128, 32, 32], generator=g).cuda() for _ in range(3)]
+
+    def run(share):
+        seen = []
+        def hook(kind, desc, launch, flags=0):
+            seen.append((kind, int(desc.x_layout)))
+            launch()
+        x = (x0 * 1.0).requires_grad_(True)          # (a non-leaf with a graph, like the feature map)
+        feat = x * 1.0
+        if share:
+            cg.share_pieces(feat)
+        outs = []
+        cg.launch_hook = hook
+        try:
+            for w in ws:
+                y, feat = cg.conv2d_bias_act(feat, w, None, padding=1, act='relu', passthrough=True)
+                outs.append(y)
+        finally:
+            cg.launch_hook = None
+        grads = torch.autograd.grad(outs, [x] + ws, dys)
+        return outs, grads, seen
+
+    o0, g0, s0 = run(False)
+    o1, g1, s1 = run(True)
+    assert [k for k in s0 if k[0] == 'conv'] == [('conv', 0)] * 3 and [k for k in s1 if k[0] == 'conv'] == [('conv', 1)] * 3
+    for a, b in zip(o0 + list(g0), o1 + list(g1)):
+        assert torch.equal(a, b)
