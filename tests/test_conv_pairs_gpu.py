@@ -34,7 +34,7 @@ def _plan_kernel(cfg_desc):
 @pytest.mark.parametrize('n,cin,cout,h,w,pad,opad', CASES)
 def test_transposed_stride2_pairs_match_fp64(n, cin, cout, h, w, pad, opad, math):
     """Both fp32-class arithmetics (six-product split-bf16, and the default three products of scaled fp16 pieces) run these
-    shapes on the pair kernel -- against fp64."""
+    shapes on the pair kernel -- the default arithmetic on the one-pass kernel where it applies (round 5) -- against fp64."""
     from torch_utils.ops import conv2d_gradfix as cg
     g = torch.Generator().manual_seed(h * 7 + cin)
     x = torch.randn([n, cin, h, w], generator=g)
@@ -50,7 +50,10 @@ def test_transposed_stride2_pairs_match_fp64(n, cin, cout, h, w, pad, opad, math
     assert y.shape == ref.shape
     err = float((y.cpu().double() - ref).abs().max() / ref.abs().max())
     assert err < 2e-6, err
-    if opad == 1:                   # even output planes: always the pair kernel
+    t2 = (math == 'default' and pad == 0 and h % 8 == 0 and w % 32 == 0 and h * w >= 4096 and cin >= 16 and os.environ.get('PASTA_CONV_T2') != '0')
+    if t2:                          # round 5: the one-pass kernel (conv_fwd_t2.h), remainder row / column inside the launch
+        assert kernel == 13 and launches == 1
+    elif opad == 1:                 # even output planes: always the pair kernel
         assert kernel == 3 and launches == 1
     elif h * w >= 128 * 128 or os.environ.get('PASTA_T2_PAIR') == '2':     # with a remainder row / column: planes of 128 x 128 and larger (csrc/conv_igemm.hip, pair_launch_ok)
         assert kernel == 3 and launches == 2
