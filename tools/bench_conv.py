@@ -100,7 +100,7 @@ def main():
 
     if 'down' in only or args.only == 'fwd,dgrad,wgrad':
         down_path(args)
-    if 's1pieces' in only:
+    if 's1pieces' in only or args.only == 'fwd,dgrad,wgrad':
         s1_pieces(args)
 
 
