@@ -39,10 +39,12 @@ namespace pasta {
 // in front of the barrier that ends a chunk (the activation loads of the chunk have been consumed by then: nothing else is in flight).
 // KIND is a template parameter of the body: with the kind as a (uniform) run-time value the branches around the window groups cut the K loop into
 // basic blocks and the regular tiles ran 30 - 60 % slower (0.152 -> 0.199 ms on 256 -> 128 at 64 x 64, 0.136 -> 0.223 ms on 512 -> 256 at 32 x 32).
-template <bool ISC, int KIND>
+// SEG: tile columns, 32 (tiles of 8 x 32 lattice pixels) or 16 (16 x 16: the 16 x 16 input planes; a 32-pixel MFMA block is then two tile rows).
+template <bool ISC, int KIND, int SEG>
 __device__ __forceinline__ void conv_t2_body(const ConvFwdParams& p, const int n0, const int i0, const int j0) {
     constexpr int kind = KIND;
-    constexpr int NP = NP_F16X3, BM = 64, R = 8, SEG = 32, NT = 512;
+    constexpr int NP = NP_F16X3, BM = 64, R = 256 / SEG, NT = 512;
+    static_assert(SEG == 32 || SEG == 16, "tiles of 8 x 32 or 16 x 16 lattice pixels");
     constexpr int IW = SEG + 1, SLOTS = (R + 1) * IW;           // B image: rows i0 - 1 .. i0 + R - 1, columns j0 - 1 .. j0 + SEG - 1
     constexpr int AUNITS = 9 * 6 * BM, APT = (AUNITS + NT - 1) / NT;
     constexpr int ABUF = APT * NT * 8;                          // 16-bit elements of an A buffer (padded to whole DMA instructions)
@@ -186,7 +188,10 @@ __device__ __forceinline__ void conv_t2_body(const ConvFwdParams& p, const int n
     const char* const a_lane = (const char*)(As + ((hl * BM) + wm * 32 + jl) * 8);
     const char* b_lane[2];
 #pragma unroll
-    for (int b = 0; b < 2; b++) b_lane[b] = (const char*)(Bs + (hl * SLOTS + (wn * 2 + b + 1) * IW + jl + 1) * 8);
+    for (int b = 0; b < 2; b++) {
+        const int t = (wn * 2 + b) * 32 + jl;           // this lane's pixel of block b: tile row t / SEG, column t % SEG
+        b_lane[b] = (const char*)(Bs + (hl * SLOTS + (t / SEG + 1) * IW + t % SEG + 1) * 8);
+    }
 
     auto compute = [&](int buf, bool stage) {
         bf16x8 bh[2], bl[2];
@@ -275,9 +280,10 @@ __device__ __forceinline__ void conv_t2_body(const ConvFwdParams& p, const int n
     const int64_t OHW = (int64_t)p.OH * p.OW;
 #pragma unroll
     for (int b = 0; b < 2; b++) {
-        const int tr = wn * 2 + b;                      // tile row / column of this lane's pixel
+        const int t = (wn * 2 + b) * 32 + jl;
+        const int tr = t / SEG, tc = t % SEG;           // tile row / column of this lane's pixel
         const int img = kind == 0 ? n0 : n0 + tr;
-        const int i = kind == 1 ? p.H : kind == 2 ? i0 + jl : i0 + tr, j = kind == 2 ? p.W : j0 + jl;
+        const int i = kind == 1 ? p.H : kind == 2 ? i0 + tc : i0 + tr, j = kind == 2 ? p.W : j0 + tc;
         if (img >= p.N || 2 * i >= p.OH) continue;      // (edge tiles: images / rows past the end)
         float* const yb = (float*)p.y + ((int64_t)img * p.Cout + (int64_t)g * p.Og) * OHW + (int64_t)(2 * i) * p.OW + 2 * j;
 #pragma unroll
@@ -303,9 +309,9 @@ __device__ __forceinline__ void conv_t2_body(const ConvFwdParams& p, const int n
     }
 }
 
-template <bool ISC>
+template <bool ISC, int SEG>
 __global__ __launch_bounds__(512, 1) void conv_t2_f16x3_kernel(ConvFwdParams p) {
-    constexpr int R = 8, SEG = 32;
+    constexpr int R = 256 / SEG;
     const int cblocks = p.W / SEG, tpi = (p.H / R) * cblocks;
     // tile kind (uniform): 0 regular, 1 row edge (lattice row H), 2 column edge (lattice column W).  The edge tiles come FIRST: they are a third
     // of a regular tile's work, and the CUs that start with one pick up regular tiles behind it -- at the end of the grid they would be a wave
@@ -315,14 +321,14 @@ __global__ __launch_bounds__(512, 1) void conv_t2_f16x3_kernel(ConvFwdParams p) 
     const int row_tiles = p.OH > 2 * p.H ? ((p.N + R - 1) / R) * cblocks : 0;
     const int col_tiles = p.OW > 2 * p.W ? ((p.N + R - 1) / R) * rb : 0;
     if (bx < row_tiles) {
-        conv_t2_body<ISC, 1>(p, (bx / cblocks) * R, p.H, (bx % cblocks) * SEG);
+        conv_t2_body<ISC, 1, SEG>(p, (bx / cblocks) * R, p.H, (bx % cblocks) * SEG);
     } else if (bx < row_tiles + col_tiles) {
         bx -= row_tiles;
-        conv_t2_body<ISC, 2>(p, (bx / rb) * R, (bx % rb) * SEG, p.W);
+        conv_t2_body<ISC, 2, SEG>(p, (bx / rb) * R, (bx % rb) * SEG, p.W);
     } else {
         bx -= row_tiles + col_tiles;
         const int n0 = bx / tpi, t_in = bx - n0 * tpi;
-        conv_t2_body<ISC, 0>(p, n0, (t_in / cblocks) * R, (t_in % cblocks) * SEG);
+        conv_t2_body<ISC, 0, SEG>(p, n0, (t_in / cblocks) * R, (t_in % cblocks) * SEG);
     }
 }
 
@@ -335,8 +341,20 @@ __global__ __launch_bounds__(256) void t2_column_gather_kernel(const float* __re
     col[e] = x[(plane * H + i) * W + W - 1];
 }
 
-// Does the kernel take the MAIN lattice of this launch (pad 0, OH in {2 H, 2 H + 1}: rows / columns 2 H, 2 W are the remainder's)?
-static bool conv_t2_shape_ok(int H, int W) { return H % 8 == 0 && W % 32 == 0; }
+// Does the kernel take the MAIN lattice of this launch (pad 0, OH in {2 H, 2 H + 1})?  Planes of 8 x 32 tiles, or of 16 x 16 tiles.
+static bool conv_t2_shape_ok(int H, int W) { return (H % 8 == 0 && W % 32 == 0) || (H % 16 == 0 && W % 16 == 0); }
+
+template <bool ISC, int SEG>
+static void launch_conv_t2_seg(const ConvFwdParams& p, hipStream_t s) {
+    constexpr int R = 256 / SEG, NT = 512, APT = (9 * 6 * 64 + NT - 1) / NT, SLOTS = (R + 1) * (SEG + 1);
+    constexpr size_t lds = (size_t)(2 * APT * NT * 8 + 2 * 2 * 2 * SLOTS * 8) * sizeof(__bf16);
+    // the edge tiles of lattice row H (R images x SEG columns each) and of lattice column W (R images x SEG rows, rows 0 .. H), then the regular tiles
+    const int64_t tiles = (int64_t)p.N * (p.H / R) * (p.W / SEG) + (p.OH > 2 * p.H ? (int64_t)((p.N + R - 1) / R) * (p.W / SEG) : 0) +
+                          (p.OW > 2 * p.W ? (int64_t)((p.N + R - 1) / R) * (p.H / SEG + 1) : 0);
+    const dim3 grid((unsigned)tiles, (unsigned)((p.Og + 63) / 64), (unsigned)p.G);
+    PASTA_SET_LDS((conv_t2_f16x3_kernel<ISC, SEG>), lds);
+    hipLaunchKernelGGL((conv_t2_f16x3_kernel<ISC, SEG>), grid, dim3(NT), lds, s, p);
+}
 
 // (p.x2: N * C_in * H floats of workspace for the gathered column, used when OW = 2 W + 1)
 static void launch_conv_t2(const ConvFwdParams& p, hipStream_t s) {
@@ -344,19 +362,9 @@ static void launch_conv_t2(const ConvFwdParams& p, hipStream_t s) {
         const int64_t planes = (int64_t)p.N * p.Cin;
         hipLaunchKernelGGL(t2_column_gather_kernel, dim3((unsigned)((planes * p.H + 255) / 256)), dim3(256), 0, s, (const float*)p.x, (float*)p.x2, planes, p.H, p.W);
     }
-    constexpr int NT = 512, APT = (9 * 6 * 64 + NT - 1) / NT, SLOTS = 9 * 33;
-    constexpr size_t lds = (size_t)(2 * APT * NT * 8 + 2 * 2 * 2 * SLOTS * 8) * sizeof(__bf16);
-    // the edge tiles of lattice row H (eight images x 32 columns each) and of lattice column W (eight images x 32 rows, rows 0 .. H), then the regular tiles
-    const int64_t tiles = (int64_t)p.N * (p.H / 8) * (p.W / 32) + (p.OH > 2 * p.H ? (int64_t)((p.N + 7) / 8) * (p.W / 32) : 0) +
-                          (p.OW > 2 * p.W ? (int64_t)((p.N + 7) / 8) * (p.H / 32 + 1) : 0);
-    const dim3 grid((unsigned)tiles, (unsigned)((p.Og + 63) / 64), (unsigned)p.G);
-    if (p.iscale) {
-        PASTA_SET_LDS(conv_t2_f16x3_kernel<true>, lds);
-        hipLaunchKernelGGL(conv_t2_f16x3_kernel<true>, grid, dim3(NT), lds, s, p);
-    } else {
-        PASTA_SET_LDS(conv_t2_f16x3_kernel<false>, lds);
-        hipLaunchKernelGGL(conv_t2_f16x3_kernel<false>, grid, dim3(NT), lds, s, p);
-    }
+    const bool wide = p.H % 8 == 0 && p.W % 32 == 0;
+    if (p.iscale) { if (wide) launch_conv_t2_seg<true, 32>(p, s); else launch_conv_t2_seg<true, 16>(p, s); }
+    else          { if (wide) launch_conv_t2_seg<false, 32>(p, s); else launch_conv_t2_seg<false, 16>(p, s); }
 }
 
 }  // namespace pasta

@@ -438,7 +438,7 @@ static bool t2_launch_ok(const pasta_conv_desc* d, int pieces, int ksplit, int l
     // take is added to the launch (0.204 -> 0.190 ms on 512 -> 256 alone, nothing on the training step: profiles/r5_ab_conv_t2.txt).
     // PASTA_CONV_T2=2 takes the smaller planes too.
     static const bool small_too = getenv("PASTA_CONV_T2") && getenv("PASTA_CONV_T2")[0] == '2';
-    return d->C_in / d->groups >= 16 && d->H % 8 == 0 && d->W % 32 == 0 && ((int64_t)d->H * d->W >= 4096 || small_too);
+    return d->C_in / d->groups >= 16 && ((d->H % 8 == 0 && d->W % 32 == 0) || (d->H % 16 == 0 && d->W % 16 == 0)) && ((int64_t)d->H * d->W >= 4096 || small_too);
 }
 
 // The remainder of the parity-pair launch: output row 2H and / or column 2W of a stride-2 conv_transpose2d onto an odd plane --

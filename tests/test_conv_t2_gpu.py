@@ -33,6 +33,7 @@ def _plan(n, ci, h, co, groups=1, pad=0, flags=0, w=None):
     (3, 48, 64, 96, 1),          # two output tiles, the second half empty; a channel count that is not a multiple of 32
     (2, 64, 64, 128, 2),         # groups
     (1, 24, 128, 72, 1),         # 128 x 128: five blocks of column rows; ragged channels on both sides
+    (3, 32, 80, 64, 1),          # 80 x 80: no 32-column tiles -- the 16 x 16 tile instance (a 32-pixel MFMA block = two tile rows)
 ])
 def test_one_pass_kernel_against_fp64(n, ci, h, co, groups):
     from torch_utils.ops import conv2d_gradfix as cg

@@ -4,7 +4,7 @@ import torch
 from torch_utils.ops import conv2d_gradfix as cg, _native
 dev = torch.device('cuda')
 torch.manual_seed(0)
-for (n, ci, h, co, groups, isc) in [(2, 32, 32, 64, 1, False), (2, 48, 32, 96, 1, False), (1, 64, 64, 40, 1, False), (2, 32, 32, 128, 2, False), (2, 32, 32, 64, 1, True), (3, 128, 32, 256, 1, True), (9, 32, 64, 64, 1, False), (33, 16, 32, 64, 1, False)]:
+for (n, ci, h, co, groups, isc) in [(2, 32, 32, 64, 1, False), (2, 48, 32, 96, 1, False), (1, 64, 64, 40, 1, False), (2, 32, 32, 128, 2, False), (2, 32, 32, 64, 1, True), (3, 128, 32, 256, 1, True), (9, 32, 64, 64, 1, False), (33, 16, 32, 64, 1, False), (5, 64, 16, 96, 1, False), (17, 32, 16, 64, 1, True), (2, 32, 48, 64, 1, False)]:
     x = torch.randn([n, ci, h, h], device=dev)
     w = torch.randn([ci, co // groups, 3, 3], device=dev) * 0.05
     s = (torch.rand([n, ci], device=dev) + 0.5) if isc else None
