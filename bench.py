@@ -85,20 +85,22 @@ class ConvMeter:
             self.lib.pasta_conv2d_plan(ctypes.byref(desc), int(flags) | int(isc), ctypes.byref(tile), ctypes.byref(ksplit), ctypes.byref(math), ctypes.byref(launches),
                                        ctypes.byref(kernel))
             family = {0: TILE_NAMES, 1: bf16x6_names(), 2: bf16x6_rows_names(), 3: bf16x6_pair_names(), 8: bf16x6_packed_names(),
-                      4: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,128,4,{_np()},{STORAGE_IO},false,256>'}, 5: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,128,2,{_np()},{STORAGE_IO},false,256>'},
-                      6: {1: f'conv_fwd_rows2d_bf16x6_kernel<64,256,8,{_np()},{STORAGE_IO},false,256>'},
-                      7: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,256,8,{_np()},0,false,512>'},
+                      4: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,128,4,{_np()},{STORAGE_IO},false,256,false,false>'}, 5: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,128,2,{_np()},{STORAGE_IO},false,256,false,false>'},
+                      6: {1: f'conv_fwd_rows2d_bf16x6_kernel<64,256,8,{_np()},{STORAGE_IO},false,256,false,false>'},
+                      7: {0: f'conv_fwd_rows2d_bf16x6_kernel<128,256,8,{_np()},0,false,512,false,false>'},      # <BM, BN, rows, pieces, storage, input scale, threads, x as pieces, weights by LDS-DMA>
                       9: {0: 'conv1x1_f16x3_kernel<128,128>', 1: 'conv1x1_f16x3_kernel<64,256>'},
                       10: {0: 'conv3x3s2_f16x3_kernel<128>', 1: 'conv3x3s2_f16x3_kernel<64>'},
                       11: {t: 'conv1x1_fewcin_kernel' for t in range(4)}, 12: {t: 'conv1x1_fewcout_kernel' for t in range(4)},
                       13: {t: 'conv_t2_f16x3_kernel<false>' for t in range(4)}}[kernel.value][tile.value]     # <BM, BN, rows per tile, pieces, storage, input scale, threads>
             if kernel.value == 10 and desc.x_layout:     # round 5: x as the producer wrote it (the blur's operand pieces): another instance
                 family = family.replace('>', ',true>')
+            if kernel.value == 7 and desc.x_layout:      # ... and the eight-wave tile reading pieces (the SPADE feature map)
+                family = family.replace(',false,false>', ',true,false>')
             if isc and kernel.value == 13:
                 family = 'conv_t2_f16x3_kernel<true>'
             elif isc and kernel.value != 0:       # the instance with the input scale: same family, another template argument (rocprofv3 names)
                 family = {1: family.replace(',3,3,0,false,false>', ',2,3,0,true,false>').replace(',3,4,0,false,false>', ',2,4,0,true,false>'), 2: family.replace(',false,false>', ',true,false>')}.get(
-                    kernel.value, family.replace(',false,256>', ',true,256>').replace(',false,512>', ',true,512>'))      # (round 4: the eight-wave tile has its instance too)
+                    kernel.value, family.replace(',false,256,false,false>', ',true,256,false,false>').replace(',false,512,false,false>', ',true,512,false,false>'))      # (round 4: the eight-wave tile has its instance too)
             kernels = launches.value
         else:
             which = ctypes.c_int()

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Counters of one kernel of a micro-benchmark run: bash tools/experiments/pmc_kernel.sh <kernel substring> <bench_conv args...>
+# Counters of one kernel of a micro-benchmark run: bash tools/pmc_kernel.sh <kernel substring> <bench_conv args...>
 export TMPDIR=/tmp
 K="$1"; shift
 OUT=gpurun_out/pmck; rm -rf $OUT; mkdir -p $OUT
