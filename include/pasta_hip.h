@@ -254,7 +254,7 @@ int pasta_conv2d_plan(const pasta_conv_desc* d, int launch_flags, int* tile, int
 
 /* Same for pasta_conv2d_wgrad: *kernel = 0 conv_wgrad_kernel (fp32 MFMA, taps x 64 x 64 tiles), 1
  * conv_wgrad_smallcin_kernel (<= 8 input channels: (channel, tap) pairs as GEMM columns), 2
- * conv_wgrad3x3_bf16x6_kernel (split-bf16; 3x3, stride 1, pad 1, row length a multiple of 32), 3
+ * conv_wgrad3x3_bf16x6_kernel (split-bf16; 3x3, stride 1, pad 1, row length a multiple of 32 -- round 5: or exactly 16, as half-filled chunks), 3
  * conv_wgrad3x3s2_bf16x6_kernel (split-bf16; 3x3, stride 2, pad 0 or 1, row length a multiple of 16), 4
  * conv_wgrad1x1_bf16x6_kernel (split-bf16; 1x1, stride 1, planes of a multiple of 32 pixels, >= 16 channels), 5
  * wgrad1x1_fewcin_kernel (round 4: 1x1, <= 8 input channels, planes of a multiple of 4 pixels: one bandwidth-bound fp32 pass over dy), 6

@@ -215,7 +215,21 @@ struct WgradPlan {
 
 // ks_multiple > 1 (pasta_conv2d_wgrad_modulated: the batch size): the number of K slices is rounded UP to a multiple of it, so that no slice
 // straddles two samples (the chunks are numbered sample-major and N divides their count where the caller checked)
-static WgradPlan plan_wgrad(int N, int P, int Q, int G, int Ag, int Bg, int kh, int kw, int st, int ks_multiple = 1) {
+// 3x3 stride-1 pad-1 weight gradients over planes of 16-pixel rows under a split arithmetic (round 5): the split kernel's chunk is 32 consecutive
+// pixels of a row, so these ran on the fp32-MFMA kernel (75 - 99 TFLOP/s: 157 peak).  A 16-pixel row is taken as a 32-pixel chunk whose second half
+// is zero (the S loads of the missing pixels are masked; the L halo's validity bits already zero the columns past the row): half of the MFMAs
+// multiply zeros, and the launch still runs twice as fast.  8-pixel rows (a quarter filled) stay where they are.  PASTA_WGRAD_WIDE16=0: off.
+static bool wgrad_wide16(const pasta_conv_desc* d) {
+    static const bool enabled = !(getenv("PASTA_WGRAD_WIDE16") && getenv("PASTA_WGRAD_WIDE16")[0] == '0');
+    const int P = d->transposed ? d->H : d->OH, Q = d->transposed ? d->W : d->OW;
+    const int LH = d->transposed ? d->OH : d->H, LW = d->transposed ? d->OW : d->W;
+    return enabled && (d->math != PASTA_MATH_F32 || d->io_dtype != PASTA_F32) && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 &&
+           Q == 16 && LH == P && LW == Q && !d->x_layout;
+}
+
+// wide16 (round 5): 16-pixel rows as HALF-FILLED 32-pixel chunks of the split 3x3 stride-1 kernel (wgrad_wide16 below) instead of two-row chunks
+// of the fp32 kernel
+static WgradPlan plan_wgrad(int N, int P, int Q, int G, int Ag, int Bg, int kh, int kw, int st, int ks_multiple = 1, bool wide16 = false) {
     WgradPlan w;
     if (kh == 3 && kw == 3) { w.TR = 3; w.TS = 3; }
     else if (kw == 7) { w.TR = 1; w.TS = 7; }
@@ -232,7 +246,7 @@ static WgradPlan plan_wgrad(int N, int P, int Q, int G, int Ag, int Bg, int kh, 
     int kp = 32;
     for (;;) {
         int cw = kp, lg = kp == 32 ? 5 : 4;
-        while (cw > 1 && cw / 2 >= Q) { cw /= 2; lg--; }
+        while (cw > 1 && cw / 2 >= Q && !wide16) { cw /= 2; lg--; }
         const int chh = kp / cw;
         const int lwid = (cw - 1) * st + w.TS;
         w.cw_log2 = lg; w.kp = kp; w.npos = chh * w.TR * lwid;
@@ -853,7 +867,7 @@ static bool wgrad_bf16x6(const pasta_conv_desc* d, const WgradPlan& w) {
     const int P = d->transposed ? d->H : d->OH, Q = d->transposed ? d->W : d->OW;
     const int LH = d->transposed ? d->OH : d->H, LW = d->transposed ? d->OW : d->W;
     return (d->math != PASTA_MATH_F32 || d->io_dtype != PASTA_F32) && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 &&
-           Q % 32 == 0 && LH == P && LW == Q && w.kp == 32 && w.cw_log2 == 5;
+           (Q % 32 == 0 || wgrad_wide16(d)) && LH == P && LW == Q && w.kp == 32 && w.cw_log2 == 5;
 }
 // ... and its stride-2 sibling: 3x3, stride 2, equal pads of 0 or 1, rows of a multiple of 16 pixels.
 static bool wgrad_s2_bf16x6(const pasta_conv_desc* d, const WgradPlan& w) {
@@ -885,8 +899,8 @@ extern "C" int pasta_conv2d_wgrad_plan(const pasta_conv_desc* d, int* kernel) {
     if (plan_wgrad1x1_fewcin(d, plan_wgrad_small(d))) k = 5;
     else if (plan_wgrad_small(d).use) k = 1;
     else {
-        const WgradPlan w = d->transposed ? plan_wgrad(d->N, d->H, d->W, d->groups, Ig, Og, d->kh, d->kw, d->stride)
-                                          : plan_wgrad(d->N, d->OH, d->OW, d->groups, Og, Ig, d->kh, d->kw, d->stride);
+        const WgradPlan w = d->transposed ? plan_wgrad(d->N, d->H, d->W, d->groups, Ig, Og, d->kh, d->kw, d->stride, 1, wgrad_wide16(d))
+                                          : plan_wgrad(d->N, d->OH, d->OW, d->groups, Og, Ig, d->kh, d->kw, d->stride, 1, wgrad_wide16(d));
         if (wgrad_bf16x6(d, w)) k = 2;
         else if (wgrad_s2_bf16x6(d, w)) k = wgrad_pieces_ok(d, w) ? 6 : 3;
         else if (wgrad_1x1_bf16x6(d, w)) k = 4;
@@ -906,8 +920,8 @@ extern "C" int64_t pasta_conv2d_wgrad_workspace(const pasta_conv_desc* d) {
     const int Ig = d->C_in / d->groups, Og = d->C_out / d->groups;
     const WgradSmallPlan ws = plan_wgrad_small(d);
     if (ws.use) return (WS_AMAX_FLOATS + ws.slab_floats) * (int64_t)sizeof(float);
-    const WgradPlan w = d->transposed ? plan_wgrad(d->N, d->H, d->W, d->groups, Ig, Og, d->kh, d->kw, d->stride)
-                                      : plan_wgrad(d->N, d->OH, d->OW, d->groups, Og, Ig, d->kh, d->kw, d->stride);
+    const WgradPlan w = d->transposed ? plan_wgrad(d->N, d->H, d->W, d->groups, Ig, Og, d->kh, d->kw, d->stride, 1, wgrad_wide16(d))
+                                      : plan_wgrad(d->N, d->OH, d->OW, d->groups, Og, Ig, d->kh, d->kw, d->stride, 1, wgrad_wide16(d));
     return (WS_AMAX_FLOATS + w.slab_floats) * (int64_t)sizeof(float);
 }
 
@@ -917,8 +931,8 @@ namespace pasta {
 static bool wgrad_modulated_ok(const pasta_conv_desc* d, WgradPlan* out) {
     if (d->groups != 1 || d->io_dtype != PASTA_F32 || d->N < 1 || d->N > 32 || plan_wgrad_small(d).use) return false;
     const int Ig = d->C_in, Og = d->C_out;
-    const WgradPlan w = d->transposed ? plan_wgrad(d->N, d->H, d->W, 1, Ig, Og, d->kh, d->kw, d->stride, d->N)
-                                      : plan_wgrad(d->N, d->OH, d->OW, 1, Og, Ig, d->kh, d->kw, d->stride, d->N);
+    const WgradPlan w = d->transposed ? plan_wgrad(d->N, d->H, d->W, 1, Ig, Og, d->kh, d->kw, d->stride, d->N, wgrad_wide16(d))
+                                      : plan_wgrad(d->N, d->OH, d->OW, 1, Og, Ig, d->kh, d->kw, d->stride, d->N, wgrad_wide16(d));
     if (!(wgrad_bf16x6(d, w) || wgrad_s2_bf16x6(d, w) || (wgrad_1x1_bf16x6(d, w) && !(w.TR == 3 && w.TS == 3) && w.TS != 7 && w.TS != 4))) return false;
     const int P = d->transposed ? d->H : d->OH;
     const int chh = w.kp >> w.cw_log2;
@@ -1012,7 +1026,7 @@ int pasta::wgrad_run(const void* xv, const void* dyv, float* dw, const pasta_con
         p.S = x;  p.SC = d->C_in;  p.P = d->H; p.Q = d->W; p.Ag = Ig;
         p.L = dy; p.LC = d->C_out; p.LH = d->OH; p.LW = d->OW; p.Bg = Og;
     }
-    const WgradPlan w = plan_wgrad(p.N, p.P, p.Q, p.G, p.Ag, p.Bg, p.kh, p.kw, p.st, mod_s ? d->N : 1);
+    const WgradPlan w = plan_wgrad(p.N, p.P, p.Q, p.G, p.Ag, p.Bg, p.kh, p.kw, p.st, mod_s ? d->N : 1, wgrad_wide16(d));
     p.cw_log2 = w.cw_log2; p.rows_total = w.rows_total; p.qblocks = w.qblocks; p.chunks_total = w.chunks_total;
     p.ksplit = w.ksplit; p.a_tiles = w.a_tiles; p.b_tiles = w.b_tiles; p.tap_groups_r = w.tgr; p.tap_groups_s = w.tgs;
     // measured (profiles/r3_ab_wgrad_xcd.txt): 256 -> 128 at 128^2 298.6 -> 303.4 TFLOP/s, stride 2 at 256^2 143 -> 154, at 257^2 140.7 -> 143.4,

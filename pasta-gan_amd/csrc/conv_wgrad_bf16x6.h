@@ -113,9 +113,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16x6_kernel(WgradParam
     auto fetch = [&](int n, int qb, int pp) {
         const int q0 = qb * 32;
         vmask = 0;
-        const char* sp = s_ch_ok ? Sg + ((int64_t)n * p.SC * PQ + (int64_t)s_a * PQ + pp * p.Q + q0 + 8 * s_grp) * ES : Sg;
+        const bool s_in = s_ch_ok && q0 + 8 * s_grp + 8 <= p.Q;         // (rows of 16 pixels: the second half of the chunk does not exist -- conv_igemm.hip, wgrad_wide16)
+        const char* sp = s_in ? Sg + ((int64_t)n * p.SC * PQ + (int64_t)s_a * PQ + pp * p.Q + q0 + 8 * s_grp) * ES : Sg;
         sreg[0] = io_ld4<IO>(sp); sreg[1] = io_ld4<IO>(sp + 4 * ES);
-        vmask |= s_ch_ok ? 3u : 0u;
+        vmask |= s_in ? 3u : 0u;
         vmask |= fetch_row(n, q0, pp + 1, lreg) << 2;
     };
     typedef float f32x2 __attribute__((ext_vector_type(2)));

@@ -169,6 +169,43 @@ def test_stride2_weight_gradient_split_bf16(transposed, n, cin, cout, hw, pad):
     assert kernel.value == 3
 
 
+@pytest.mark.parametrize('n,cin,cout,transposed', [(5, 72, 40, False), (16, 512, 512, False), (3, 48, 136, True)])
+def test_sixteen_pixel_rows_run_the_split_weight_gradient_half_filled(n, cin, cout, transposed):
+    """Round 5 (conv_igemm.hip, wgrad_wide16): 3x3 stride-1 weight gradients over 16 x 16 planes -- the 512-channel layers of both networks --
+    on conv_wgrad3x3_bf16x6_kernel with a row taken as a 32-pixel chunk whose second half is masked to zero (they ran on the fp32-MFMA kernel):
+    every arithmetic against fp64 autograd, channel tails, the transposed operator, the plan."""
+    import ctypes
+    from torch_utils.ops import conv2d_gradfix as cg
+    from torch_utils import custom_ops
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn([n, cin, 16, 16], generator=g)
+    w = torch.randn([cin, cout, 3, 3] if transposed else [cout, cin, 3, 3], generator=g) / (9 * cin) ** 0.5
+    dy = torch.randn([n, cout, 16, 16], generator=g)
+    ref_op = torch.nn.functional.conv_transpose2d if transposed else torch.nn.functional.conv2d
+    w64 = w.double().requires_grad_(True)
+    rw, = torch.autograd.grad(ref_op(x.double(), w64, padding=1), w64, dy.double())
+    res = {}
+    for mode in ['f32', 'bf16x6', 'f16x3']:
+        old = cg.conv_math
+        cg.conv_math = mode
+        try:
+            wc = w.cuda().requires_grad_(True)
+            op = cg.conv_transpose2d if transposed else cg.conv2d
+            gw, = torch.autograd.grad(op(x.cuda(), wc, padding=1), wc, dy.cuda())
+        finally:
+            cg.conv_math = old
+        res[mode] = float((gw.double().cpu() - rw).abs().max() / rw.abs().max())
+    assert res['f32'] < 1e-5 and res['bf16x6'] < 1e-5 and res['f16x3'] < 1e-5, res
+    desc = custom_ops.ConvDesc(N=n, C_in=cin, H=16, W=16, C_out=cout, OH=16, OW=16, kh=3, kw=3, stride=1, pad_h=1, pad_w=1, groups=1,
+                               transposed=int(transposed), flip=0, math=0, wscale=1.0)
+    kernel = ctypes.c_int()
+    custom_ops.get_plugin().pasta_conv2d_wgrad_plan(ctypes.byref(desc), ctypes.byref(kernel))
+    assert kernel.value == 2
+    desc.H = desc.W = desc.OH = desc.OW = 8          # a quarter filled would not pay: 8-pixel rows stay on the fp32-MFMA kernel
+    custom_ops.get_plugin().pasta_conv2d_wgrad_plan(ctypes.byref(desc), ctypes.byref(kernel))
+    assert kernel.value == 0
+
+
 @pytest.mark.parametrize('n,cin,cout,hw', [(2, 192, 128, 64), (2, 64, 40, 32), (1, 24, 200, 128), (3, 130, 130, 16), (16, 512, 512, 8), (16, 512, 512, 4)])
 def test_pointwise_weight_gradient_split_bf16(n, cin, cout, hw):
     """conv_wgrad1x1_bf16x6_kernel: 128x128 and 64x64 channel tiles, channel tails, small planes (K slicing over few
