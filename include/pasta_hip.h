@@ -165,6 +165,8 @@ typedef struct pasta_conv_desc {
                                      (pasta_conv2d_plan kernel 7: no input scale, one group, C_in a multiple of 8; pasta_pieces_pack writes such an
                                      operand from an fp32 tensor); the planners return an error for every other launch and the caller keeps the
                                      fp32 tensor. */
+    int32_t      w_prepacked;     /* ABI 21.  1 = the workspace already holds this launch's packed weights and row scales (pasta_conv2d_pack_pair wrote them
+                                     for THIS descriptor and these weights): the launch skips its packing kernel.  0 everywhere else.                 */
 } pasta_conv_desc;
 
 #define PASTA_LAYOUT_NCHW      0
@@ -216,6 +218,14 @@ int64_t pasta_conv2d_wgrad_workspace(const pasta_conv_desc* d);
 /* Which forward-type kernel instance the launch will use: 0 = 128x128 tile, 1 = 64x256,
  * 2 = 32x256, 3 = 64x64 (rows = output channels, columns = pixels).  Reporting only. */
 int pasta_conv2d_tile(const pasta_conv_desc* d);
+
+/* (ABI 21) One weight tensor packed for TWO launches by ONE kernel -- typically a convolution and its input gradient (the same weights, transposed and
+ * mirrored), so that the backward pass finds its operand packed: 120 of the 310 packing launches of a training step.  ws_a / ws_b: the workspaces the two
+ * launches will be given (pasta_conv2d_workspace(da / db) bytes); *packed_mask = 3 when both were packed (set pasta_conv_desc.w_prepacked = 1 in both
+ * launches), 0 when the pair is not served (16-bit storage, another arithmetic than PASTA_MATH_F16X3, few-channel or packed-K launches, scale vectors or
+ * modulated weights are the CALLER's business: it must not ask for those) -- the launches then pack for themselves as always. */
+int pasta_conv2d_pack_pair(const float* w, const pasta_conv_desc* da, void* ws_a, int64_t ws_a_bytes, const pasta_conv_desc* db, void* ws_b, int64_t ws_b_bytes,
+                           void* stream, int* packed_mask);
 
 /* The full launch plan of pasta_conv2d(_ex) for d, for reporting (bench.py attributes time and FLOPs to kernel
  * families with it): *tile as pasta_conv2d_tile, *ksplit = number of K slices (> 1: partial sums in the workspace,

@@ -20,7 +20,7 @@ int fail(const char* fmt, ...) {
 }  // namespace pasta
 
 extern "C" const char* pasta_last_error(void) { return pasta::error_buffer(); }
-extern "C" int pasta_abi_version(void) { return 20; }
+extern "C" int pasta_abi_version(void) { return 21; }
 extern "C" const char* pasta_build_info(void) {
 #define PASTA_STR2(x) #x
 #define PASTA_STR(x) PASTA_STR2(x)

@@ -256,6 +256,13 @@ __device__ __forceinline__ float conv_scale_noise(float v, const float* osb, int
 }
 
 // Parameters of the forward-type kernels (conv2d, conv_transpose2d and both input gradients).
+// One packing job of pack_weights_f16x3_(pair_)kernel: where the packed rows and their scales go, and how the weight tensor is read
+struct PackJob {
+    void* wp; float* rowinv;
+    int G, Ig, Og, Ig_pad, Og_pad, kh, kw, transposed, flip, pack_xcd_rows;
+    float wscale;
+};
+
 struct ConvFwdParams {
     const float* x; const float* wp; float* y;         // x, y (and res): elements of type `io` behind these pointers
     const float* iscale; const float* oscale;

@@ -76,13 +76,13 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __r
 // weight written behind autograd's back (`p.data.mul_()`, an optimiser that works on `.data`) cannot meet a stale scale, and
 // per-sample modulated weights (pasta_conv2d_modulated) get their own scale per (sample, output channel).
 constexpr int PACK_ROW_LDS = 8192;          // floats of a row kept in LDS; longer rows are re-read from global memory (L2)
-__global__ __launch_bounds__(256) void pack_weights_f16x3_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, float* __restrict__ rowinv,
-                                                                 int Ig, int Og, int Ig_pad, int Og_pad, int kh, int kw, int transposed, int flip,
-                                                                 float wscale, const float* __restrict__ mod_s, const float* __restrict__ mod_d, int pack_xcd_rows) {
+__device__ __forceinline__ void pack_row_f16x3(const float* __restrict__ w, __bf16* __restrict__ wp, float* __restrict__ rowinv,
+                                               int Ig, int Og, int Ig_pad, int Og_pad, int kh, int kw, int transposed, int flip,
+                                               float wscale, const float* __restrict__ mod_s, const float* __restrict__ mod_d, int pack_xcd_rows, const unsigned bx) {
     // one packed row.  Eight consecutive rows share every 128-byte line of the packed layout ([...][O_pad][8 x 2 bytes]) and workgroups go round-robin
     // to the eight XCDs: XCD x takes the rows [x O_pad / 8, (x + 1) O_pad / 8), so that the sixteen-byte stores of a line meet in ONE L2 and leave it
     // as a whole line (O_pad is a multiple of 64)
-    const int g = blockIdx.y, o = pack_xcd_rows ? (int)(blockIdx.x & 7u) * (Og_pad >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int g = blockIdx.y, o = pack_xcd_rows ? (int)(bx & 7u) * (Og_pad >> 3) + (int)(bx >> 3) : (int)bx;
     const int taps = kh * kw, NC = Ig_pad / 16, K = Ig * taps;
     const int tid = threadIdx.x;
     const int gs = mod_s ? 0 : g;
@@ -171,6 +171,20 @@ __global__ __launch_bounds__(256) void pack_weights_f16x3_kernel(const float* __
         *(uint4*)(d + 2 * Og_pad * 8) = make_uint4(lq[0], lq[1], lq[2], lq[3]);
         *(uint4*)(d + 4 * Og_pad * 8) = make_uint4(sq[0], sq[1], sq[2], sq[3]);
     }
+}
+__global__ __launch_bounds__(256) void pack_weights_f16x3_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, float* __restrict__ rowinv,
+                                                                 int Ig, int Og, int Ig_pad, int Og_pad, int kh, int kw, int transposed, int flip,
+                                                                 float wscale, const float* __restrict__ mod_s, const float* __restrict__ mod_d, int pack_xcd_rows) {
+    pack_row_f16x3(w, wp, rowinv, Ig, Og, Ig_pad, Og_pad, kh, kw, transposed, flip, wscale, mod_s, mod_d, pack_xcd_rows, blockIdx.x);
+}
+// Round 5: ONE weight tensor packed for TWO launches at once -- the forward convolution and its input gradient (the same weights transposed
+// and mirrored) -- so that the backward pass finds its operand packed (pasta_conv2d_pack_pair; 120 of the 310 packing launches of a step).
+// The first a.rows workgroups of the grid's x axis pack for a, the others for b.
+__global__ __launch_bounds__(256) void pack_weights_f16x3_pair_kernel(const float* __restrict__ w, PackJob a, PackJob b) {
+    const bool first = blockIdx.x < (unsigned)a.Og_pad;
+    const PackJob& j = first ? a : b;
+    pack_row_f16x3(w, (__bf16*)j.wp, j.rowinv, j.Ig, j.Og, j.Ig_pad, j.Og_pad, j.kh, j.kw, j.transposed, j.flip, j.wscale, nullptr, nullptr, j.pack_xcd_rows,
+                   first ? blockIdx.x : blockIdx.x - (unsigned)a.Og_pad);
 }
 #endif  // PASTA_TU_PACK
 

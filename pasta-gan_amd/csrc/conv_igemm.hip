@@ -649,6 +649,47 @@ extern "C" int pasta_conv2d_modulated(const void* x, const float* w, const float
     return conv2d_run(x, w, y, nullptr, nullptr, ep, d, workspace, workspace_bytes, stream, styles, dcoefs);
 }
 
+namespace pasta {
+// The packing job of a plain launch (no scale vectors, plain weights, one input tensor) of the default arithmetic on fp32 tensors, as conv2d_run
+// would perform it at the head of the launch: false where the launch packs differently or not at all (few-channel kernels, the packed-K
+// mode of the stems, 16-bit storage, the other arithmetics) -- the caller then leaves w_prepacked at 0.
+static bool pack_job_of(const pasta_conv_desc* d, void* workspace, PackJob& j) {
+    if (d->io_dtype != PASTA_F32 || math_pieces(d->math) != NP_F16X3 || d->x2) return false;
+    if (conv1x1_fewch_kind(d, false, false, false, false)) return false;
+    const FwdPlan plan = plan_fwd(d);
+    if (!plan.bf16x6 || plan.packed) return false;
+    const int Ig = d->C_in / d->groups, Og = d->C_out / d->groups;
+    float* const ws_rowinv = (float*)workspace + WS_AMAX_FLOATS;
+    j.rowinv = ws_rowinv;
+    j.wp = ws_rowinv + (int64_t)d->groups * round_up(Og, fwd_tile_bm(plan.tile));
+    j.G = d->groups; j.Ig = Ig; j.Og = Og;
+    j.Ig_pad = round_up(Ig, fwd_ipad(Ig, plan.tile)); j.Og_pad = round_up(Og, fwd_tile_bm(plan.tile));
+    j.kh = d->kh; j.kw = d->kw; j.transposed = d->transposed; j.flip = d->flip;
+    j.wscale = d->wscale == 0.f ? 1.f : d->wscale;
+    static const int pack_xcd = getenv("PASTA_PACK_XCD") ? atoi(getenv("PASTA_PACK_XCD")) : 1;
+    j.pack_xcd_rows = (j.Og_pad & 63) == 0 ? pack_xcd : 0;
+    return true;
+}
+}
+
+extern "C" int pasta_conv2d_pack_pair(const float* w, const pasta_conv_desc* da, void* ws_a, int64_t ws_a_bytes, const pasta_conv_desc* db, void* ws_b,
+                                      int64_t ws_b_bytes, void* stream, int* packed_mask) {
+    using namespace pasta;
+    PASTA_CHECK(w && da && db && ws_a && ws_b && packed_mask, "conv2d_pack_pair: null pointer");
+    *packed_mask = 0;
+    if (int e = check_desc(da, "conv2d_pack_pair")) return e;
+    if (int e = check_desc(db, "conv2d_pack_pair")) return e;
+    PASTA_CHECK(ws_a_bytes >= pasta_conv2d_workspace(da) && ws_b_bytes >= pasta_conv2d_workspace(db), "conv2d_pack_pair: workspace too small");
+    PASTA_CHECK((((uintptr_t)ws_a | (uintptr_t)ws_b) & 15) == 0, "conv2d_pack_pair: workspaces must be 16-byte aligned");
+    static const bool enabled = !(getenv("PASTA_PACK_PAIR") && getenv("PASTA_PACK_PAIR")[0] == '0');
+    PackJob a, b;
+    // both or nothing: one orientation alone is the launch the convolution would have made itself
+    if (!enabled || da->groups != db->groups || !pack_job_of(da, ws_a, a) || !pack_job_of(db, ws_b, b)) return 0;
+    tu_pack_weights_f16x3_pair(w, a, b, (hipStream_t)stream);
+    *packed_mask = 3;
+    return launch_status("conv2d_pack_pair");
+}
+
 int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscale, const float* oscale,
                       const pasta_conv_epilogue* ep, const pasta_conv_desc* d, void* workspace, int64_t workspace_bytes,
                       void* stream, const float* wmod_s, const float* wmod_d) {
@@ -761,7 +802,10 @@ int pasta::conv2d_run(const void* x, const float* w, void* y, const float* iscal
         p.Ig = K; p.Ig_pad = Kpad; p.KK = 1;
         pk_kh = pk_kw = 1; pk_tr = 0; pk_flip = 0;           // [O][C_in kh kw] as it lies: a 1x1 weight over the K "channels"
     }
-    {   // pack weights (times wscale)
+    if (d->w_prepacked) {
+        // the caller packed the weights for this very descriptor beforehand (pasta_conv2d_pack_pair): the kinds of launch pack_job_of describes
+        PASTA_CHECK(p.bf16x6 == NP_F16X3 && p.io == IO_F32 && !packed && !wmod_s && !p.x2, "conv2d: w_prepacked with a launch pasta_conv2d_pack_pair does not serve");
+    } else {   // pack weights (times wscale)
         if (p.bf16x6 == NP_F16X3 && p.io == IO_F32) {       // two fp16 pieces, one scale per output row found on the way
             static const int pack_xcd = getenv("PASTA_PACK_XCD") ? atoi(getenv("PASTA_PACK_XCD")) : 1;      // A/B switch: 0 = row = workgroup index
             tu_pack_weights_f16x3(w, workspace, ws_rowinv, p.G, p.Ig, p.Og, p.Ig_pad, p.Og_pad, pk_kh, pk_kw, pk_tr, pk_flip, wscale, wmod_s, wmod_d,

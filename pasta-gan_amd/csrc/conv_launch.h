@@ -16,6 +16,7 @@ void tu_pack_weights_bf16(const float* w, void* wp, int G, int Ig, int Og, int I
                           float wscale, int f16, const float* mod_s, const float* mod_d, hipStream_t s);
 void tu_pack_weights_f16x3(const float* w, void* wp, float* rowinv, int G, int Ig, int Og, int Ig_pad, int Og_pad, int kh, int kw, int transposed,
                            int flip, float wscale, const float* mod_s, const float* mod_d, int pack_xcd_rows, hipStream_t s);
+void tu_pack_weights_f16x3_pair(const float* w, const PackJob& a, const PackJob& b, hipStream_t s);      // one launch for two orientations (a.G == b.G)
 void tu_fwd_f32(FwdTile t, const ConvFwdParams& p, hipStream_t s);
 
 // conv_tu_fwd_base_{128,64}.hip: conv_fwd_bf16x6_kernel (q: o_tiles set, grid computed by the caller)

@@ -31,6 +31,10 @@ void tu_pack_weights_f16x3(const float* w, void* wp, float* rowinv, int G, int I
                        kh, kw, transposed, flip, wscale, mod_s, mod_d, pack_xcd_rows);
 }
 
+void tu_pack_weights_f16x3_pair(const float* w, const PackJob& a, const PackJob& b, hipStream_t s) {
+    hipLaunchKernelGGL(pack_weights_f16x3_pair_kernel, dim3((unsigned)(a.Og_pad + b.Og_pad), (unsigned)a.G), dim3(256), 0, s, w, a, b);
+}
+
 void tu_fwd_f32(FwdTile t, const ConvFwdParams& p, hipStream_t s) {
     constexpr int KC = 8;
     switch (t) {

@@ -30,7 +30,7 @@ _LIBDIR = os.path.join(_ROOT, 'lib')
 _OBJDIR = os.path.join(_ROOT, 'build')
 _INCLUDE = os.path.join(os.path.dirname(_ROOT), 'include')
 LIB_NAME = 'libpasta_hip.so'
-EXPECTED_ABI = 20                   # PASTA_ABI_VERSION of include/pasta_hip.h = pasta_abi_version() of csrc/common.hip
+EXPECTED_ABI = 21                   # PASTA_ABI_VERSION of include/pasta_hip.h = pasta_abi_version() of csrc/common.hip
 ARCH = 'gfx950'
 
 _lock = threading.Lock()
@@ -144,7 +144,7 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(name, _c_i32) for name in (
         'N', 'C_in', 'H', 'W', 'C_out', 'OH', 'OW', 'kh', 'kw', 'stride',
         'pad_h', 'pad_w', 'groups', 'transposed', 'flip', 'math')] + [('wscale', _c_f32), ('io_dtype', _c_i32),
-                                                                      ('x_amax', _c_ptr), ('x2', _c_ptr), ('x2_amax', _c_ptr), ('C1', _c_i32), ('dy_amax', _c_ptr), ('x_layout', _c_i32)]
+                                                                      ('x_amax', _c_ptr), ('x2', _c_ptr), ('x2_amax', _c_ptr), ('C1', _c_i32), ('dy_amax', _c_ptr), ('x_layout', _c_i32), ('w_prepacked', _c_i32)]
 
 class ConvEpilogue(ctypes.Structure):
     """Mirror of ``pasta_conv_epilogue`` (include/pasta_hip.h)."""
@@ -177,6 +177,7 @@ ABI = {
     'pasta_blur_pieces':   (ctypes.c_int, [_c_ptr] * 5 + [ctypes.c_int] * 9 + [_c_f32, _c_ptr]),
     'pasta_pieces_unpack': (ctypes.c_int, [_c_ptr] * 3 + [ctypes.c_int] * 4 + [_c_ptr]),
     'pasta_pieces_pack': (ctypes.c_int, [_c_ptr] * 3 + [ctypes.c_int] * 4 + [_c_ptr]),
+    'pasta_conv2d_pack_pair': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, ctypes.c_int64, _c_ptr, _c_ptr, ctypes.c_int64, _c_ptr, _c_ptr]),
     'pasta_conv2d_workspace':       (_c_i64, [ctypes.POINTER(ConvDesc)]),
     'pasta_conv2d_wgrad_workspace': (_c_i64, [ctypes.POINTER(ConvDesc)]),
     'pasta_conv2d_tile':  (ctypes.c_int, [ctypes.POINTER(ConvDesc)]),

@@ -199,7 +199,7 @@ launch_hook = None
 def _f32(t):
     return t if t.dtype == torch.float32 else t.float()
 
-def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, noise=None, x2=None, used=None, pieces=None):
+def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, noise=None, x2=None, used=None, pieces=None, prepacked=None):
     """y = conv(x * iscale[n,c]) * oscale[n,c'] through ``pasta_conv2d_ex``; fp32 accumulation.  fp32 tensors run the
     split-bf16 (fp32-equivalent) or fp32 matrix-core kernels; fp16 / bf16 tensors stay 16-bit in HBM where a kernel exists
     (``_native16``) and are converted for the launch otherwise.
@@ -214,7 +214,8 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, 
     autograd node can hand them to the weight gradient of the SAME saved tensor (a saved non-leaf tensor comes back from autograd as a new
     Python object without the attribute the maxima travel on: it would be scanned a second time).
     ``pieces`` = (bound row [256], logical shape (N, C, H, W)): ``x`` is not an NCHW tensor but the producer-written operand of the three-product
-    arithmetic (``blur_pieces``: PASTA_LAYOUT_PIECES16, include/pasta_hip.h) -- the launch copies its sixteen-byte pieces instead of splitting."""
+    arithmetic (``blur_pieces``: PASTA_LAYOUT_PIECES16, include/pasta_hip.h) -- the launch copies its sixteen-byte pieces instead of splitting.
+    ``prepacked`` = the workspace tensor of THIS launch with the weights already packed in it (``pack_pair``): no packing kernel."""
     _native.require_gpu(x, 'conv2d')
     if pieces is not None:
         assert iscale is None and oscale is None and wmod is None and noise is None and x2 is None
@@ -254,7 +255,11 @@ def _launch_conv(x, w, cfg, iscale=None, oscale=None, epilogue=None, wmod=None, 
     nbytes = lib.pasta_conv2d_workspace(ctypes.byref(desc))
     if nbytes < 0:
         _native.check(1)
-    work = torch.empty([max(nbytes // 4, 4)], dtype=torch.float32, device=x.device)
+    if prepacked is not None and prepacked.numel() * 4 >= nbytes and iscale is None and oscale is None and wmod is None and x2 is None and io is torch.float32:
+        work = prepacked
+        desc.w_prepacked = 1
+    else:
+        work = torch.empty([max(nbytes // 4, 4)], dtype=torch.float32, device=x.device)
     if iscale is not None:
         iscale = _f32(iscale).contiguous()
         assert iscale.shape == (x.shape[0], x.shape[1])
@@ -572,11 +577,47 @@ def _grad_cfg(cfg, x_hw, y_hw, kh, kw):
     opw = x_hw[1] - ((y_hw[1] - 1) * cfg.stride - 2 * cfg.pad_w + kw)
     return _Cfg((True, cfg.stride, cfg.pad_h, cfg.pad_w, oph, opw, cfg.groups, cfg.wgain))
 
+# ---- one packing launch for a convolution and its input gradient (round 5; include/pasta_hip.h, pasta_conv2d_pack_pair) -------------------
+# Every forward convolution whose input needs a gradient is followed, in the backward pass, by the same weights packed the other way round
+# (transposed and mirrored): 120 of the 310 packing launches of a training step.  The forward packs BOTH orientations with one kernel and the
+# autograd node carries the second workspace to its backward.
+_PACK_PAIR = _os.environ.get('PASTA_PACK_PAIR', '1') != '0'       # A/B switch: 0 = every launch packs for itself
+
+def _pack_pair(x, w, cfg):
+    """-> (workspace of the forward launch, workspace of its input-gradient launch), both with the weights packed, or (None, None)."""
+    if not (_PACK_PAIR and x.device.type == 'cuda' and x.dtype == torch.float32 and w.dtype == torch.float32 and conv_math in ('default', 'f16x3')
+            and _SCOPE == 'all' and x.ndim == 4 and w.ndim == 4 and x.numel() > 0 and not torch.cuda.is_current_stream_capturing()):
+        return None, None
+    kh, kw = int(w.shape[2]), int(w.shape[3])
+    n, c_in, h, wd = (int(v) for v in x.shape)
+    c_out = int(w.shape[1]) * cfg.groups if cfg.transposed else int(w.shape[0])
+    oh, ow = _out_hw(cfg, h, wd, kh, kw)
+    if oh < 1 or ow < 1:
+        return None, None
+    gcfg = _grad_cfg(cfg, (h, wd), (oh, ow), kh, kw)
+    da = _desc(cfg, (n, c_in, h, wd), c_out, oh, ow, kh, kw)
+    db = _desc(gcfg, (n, c_out, oh, ow), c_in, h, wd, kh, kw)
+    lib = _native.lib()
+    na, nb = lib.pasta_conv2d_workspace(ctypes.byref(da)), lib.pasta_conv2d_workspace(ctypes.byref(db))
+    if na < 0 or nb < 0:
+        return None, None
+    wa = torch.empty([max(na // 4, 4)], dtype=torch.float32, device=x.device)
+    wb = torch.empty([max(nb // 4, 4)], dtype=torch.float32, device=x.device)
+    mask = ctypes.c_int(0)
+    wc = w.contiguous()
+    with torch.cuda.device(x.device):
+        _native.check(lib.pasta_conv2d_pack_pair(_native.ptr(wc), ctypes.byref(da), _native.ptr(wa), wa.numel() * 4, ctypes.byref(db), _native.ptr(wb),
+                                                 wb.numel() * 4, _native.stream(), ctypes.byref(mask)))
+    return (wa, wb) if mask.value == 3 else (None, None)
+
 class _ConvHip(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, cfg):
+    def forward(ctx, x, w, cfg, prepacked=None):
         used = {}
-        y = _launch_conv(x, w, cfg, used=used)
+        ctx.dgrad_ws = None
+        if prepacked is None and ctx.needs_input_grad[0]:
+            prepacked, ctx.dgrad_ws = _pack_pair(x, w, cfg)
+        y = _launch_conv(x, w, cfg, used=used, prepacked=prepacked)
         ctx.save_for_backward(x, w)
         ctx.cfg, ctx.x_amax = cfg, (used.get('x_amax') if x.dtype == torch.float32 else None)
         return y
@@ -588,11 +629,11 @@ class _ConvHip(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             gcfg = _grad_cfg(cfg, x.shape[2:], dy.shape[2:], w.shape[2], w.shape[3])
-            dx = _ConvHip.apply(dy, w, gcfg)
+            dx = _ConvHip.apply(dy, w, gcfg, ctx.dgrad_ws)
             assert dx.shape == x.shape
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
             dw = _ConvWgradHip.apply(dy, x, cfg, tuple(w.shape), w.dtype, ctx.x_amax)
-        return dx, dw, None
+        return dx, dw, None, None
 
 class _ConvBiasActHip(torch.autograd.Function):
     """y = bias_act(conv(x, w), b) with the bias / activation / gain / clamp applied in the convolution's epilogue.
@@ -603,17 +644,20 @@ class _ConvBiasActHip(torch.autograd.Function):
     residual block's skip branch).  Their gradient then arrives here as ``dxp`` and joins this layer's input gradient in the epilogue of
     the input-gradient launch (one read of it) -- instead of autograd adding two full tensors afterwards (two reads and a write)."""
     @staticmethod
-    def forward(ctx, x, w, b, cfg, act_cfg, res=None, passthrough=False):
+    def forward(ctx, x, w, b, cfg, act_cfg, res=None, passthrough=False, prepacked=None):
         act, alpha, gain, clamp = act_cfg
         from . import bias_act as ba
         used = {}
+        ctx.dgrad_ws = None
         shared = _shared_lookup(x) if not x.is_inference() else None
         if shared is not None and _shared_pieces_ok(x, w, cfg, True):
             # x was packed for its several readers (share_pieces): this launch copies the pieces; its maxima are the pack's bound row
             y = _launch_conv(shared[2], w, cfg, epilogue=(b, ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, res), pieces=(shared[3], shared[4]))
             used['x_amax'] = shared[3]
         else:
-            y = _launch_conv(x, w, cfg, epilogue=(b, ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, res), used=used)
+            if prepacked is None and ctx.needs_input_grad[0]:
+                prepacked, ctx.dgrad_ws = _pack_pair(x, w, cfg)
+            y = _launch_conv(x, w, cfg, epilogue=(b, ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, res), used=used, prepacked=prepacked)
         if ba.slope_tape is not None:               # test instrument (bias_act.SlopeTape)
             y = ba.slope_tape.visit(y, act)
         # y is needed by the backward only as the activation / clamp mask; a linear, unclamped layer (the residual
@@ -631,7 +675,7 @@ class _ConvBiasActHip(torch.autograd.Function):
         from . import bias_act as ba
         x, w, b, y = ctx.saved_tensors
         if dy is None:                              # only the pass-through output was differentiated
-            return dxp, None, None, None, None, None, None
+            return dxp, None, None, None, None, None, None, None
         act, alpha, gain, clamp = ctx.act_cfg
         cfg = ctx.cfg
         dz = dy
@@ -645,9 +689,9 @@ class _ConvBiasActHip(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gcfg = _grad_cfg(cfg, x.shape[2:], dz.shape[2:], w.shape[2], w.shape[3])
             if dxp is not None and dxp.dtype == dz.dtype:
-                dx = _ConvBiasActHip.apply(dz, w, None, gcfg, _LINEAR_EPILOGUE, dxp)
+                dx = _ConvBiasActHip.apply(dz, w, None, gcfg, _LINEAR_EPILOGUE, dxp, False, ctx.dgrad_ws)
             else:
-                dx = _ConvHip.apply(dz, w, gcfg)
+                dx = _ConvHip.apply(dz, w, gcfg, ctx.dgrad_ws)
                 if dxp is not None:
                     dx = dx + dxp
             assert dx.shape == x.shape
@@ -656,7 +700,7 @@ class _ConvBiasActHip(torch.autograd.Function):
         if want_db and db is None:
             db = ba._BiasSum.apply(dz, 1)
         dres = dz if ctx.needs_input_grad[5] else None     # the residual enters before the activation
-        return dx, dw, db, None, None, dres, None
+        return dx, dw, db, None, None, dres, None, None
 
 class _BlurConvS2Hip(torch.autograd.Function):
     """``bias_act(conv2d(upfirdn2d(x, f, padding), w, stride=2) [+ res], b)`` -- the down path of conv2d_resample (reference :119-122 followed by the

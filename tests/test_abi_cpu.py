@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 def test_host_only_entry_points():
     from torch_utils import custom_ops
     lib = custom_ops.get_plugin()
-    assert lib.pasta_abi_version() == custom_ops.EXPECTED_ABI == 20
+    assert lib.pasta_abi_version() == custom_ops.EXPECTED_ABI == 21
     assert b'gfx950' in lib.pasta_build_info()
     d = custom_ops.ConvDesc(N=2, C_in=8, H=16, W=16, C_out=8, OH=16, OW=16, kh=3, kw=3, stride=1, pad_h=1, pad_w=1, groups=1, transposed=0, flip=0, math=0)
     # 2 x 256 partial operand maxima + 32 row scales of the packed weights (PASTA_MATH_F16X3) + [taps][I_pad8][O_pad32] packed weights, 6 B each
