@@ -91,13 +91,13 @@ class ConvMeter:
                       9: {0: 'conv1x1_f16x3_kernel<128,128>', 1: 'conv1x1_f16x3_kernel<64,256>'},
                       10: {0: 'conv3x3s2_f16x3_kernel<128>', 1: 'conv3x3s2_f16x3_kernel<64>'},
                       11: {t: 'conv1x1_fewcin_kernel' for t in range(4)}, 12: {t: 'conv1x1_fewcout_kernel' for t in range(4)},
-                      13: {t: 'conv_t2_f16x3_kernel<false>' for t in range(4)}}[kernel.value][tile.value]     # <BM, BN, rows per tile, pieces, storage, input scale, threads>
+                      13: {t: 'conv_t2_f16x3_kernel<false,%d>' % (32 if (desc.H % 8 == 0 and desc.W % 32 == 0) else 16) for t in range(4)}}[kernel.value][tile.value]     # <input scale, tile columns>     # <BM, BN, rows per tile, pieces, storage, input scale, threads>
             if kernel.value == 10 and desc.x_layout:     # round 5: x as the producer wrote it (the blur's operand pieces): another instance
                 family = family.replace('>', ',true>')
             if kernel.value == 7 and desc.x_layout:      # ... and the eight-wave tile reading pieces (the SPADE feature map)
                 family = family.replace(',false,false>', ',true,false>')
             if isc and kernel.value == 13:
-                family = 'conv_t2_f16x3_kernel<true>'
+                family = family.replace('<false,', '<true,')
             elif isc and kernel.value != 0:       # the instance with the input scale: same family, another template argument (rocprofv3 names)
                 family = {1: family.replace(',3,3,0,false,false>', ',2,3,0,true,false>').replace(',3,4,0,false,false>', ',2,4,0,true,false>'), 2: family.replace(',false,false>', ',true,false>')}.get(
                     kernel.value, family.replace(',false,256,false,false>', ',true,256,false,false>').replace(',false,512,false,false>', ',true,512,false,false>'))      # (round 4: the eight-wave tile has its instance too)
