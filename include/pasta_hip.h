@@ -251,7 +251,7 @@ int pasta_conv2d_pack_pair(const float* w, const pasta_conv_desc* da, void* ws_a
  * or <= 16 output channels over more than 8192 pixels, fp32 tensors, one group, planes of a multiple of four pixels -- the RGB / pose stems, the ToRGB and
  * parsing heads and their input gradients: streaming kernels of plain fp32 FMAs on the raw weights, no packing launch, *math = PASTA_MATH_F32),
  * 13 conv_t2_f16x3_kernel (round 5: 3x3 stride-2 conv_transpose2d with pad 0 onto 2H(+1) x 2W(+1) outputs under PASTA_MATH_F16X3, fp32 tensors, >= 16
- * input channels, input planes of 8 x 32 tiles and at least 64 x 64, optionally an input scale, nothing behind the sum: ONE launch over the input
+ * input channels, input planes of 8 x 32 or of 16 x 16 tiles, optionally an input scale, nothing behind the sum: ONE launch over the input
  * lattice computes the four output parity classes of a tile from one staged (8 + 1) x (32 + 1) window image -- nine taps, weights by LDS-DMA --
  * and the remainder row / column as edge tiles of the same grid; *launches = 1; the workspace also holds the input's last column, gathered by a
  * small kernel in front).  Kernel 7 also takes pasta_conv_desc.x_layout = PASTA_LAYOUT_PIECES16 (round 5).

@@ -448,11 +448,11 @@ static bool t2_launch_ok(const pasta_conv_desc* d, int pieces, int ksplit, int l
     if (!enabled || !d->transposed || d->stride != 2 || d->kh != 3 || d->kw != 3 || d->pad_h != 0 || d->pad_w != 0) return false;
     if (pieces != NP_F16X3 || d->io_dtype != PASTA_F32 || (launch_flags & ~(PASTA_PLAN_ISCALE | PASTA_PLAN_MODULATED)) || ksplit != 1 || d->x2 || d->x_layout) return false;
     if (d->OH < 2 * d->H || d->OH > 2 * d->H + 1 || d->OW < 2 * d->W || d->OW > 2 * d->W + 1) return false;
-    // planes of 64 x 64 and larger: at 32 x 32 the regular tiles of a batch of 16 fill the chip exactly once, what the edge tiles in front of them
-    // take is added to the launch (0.204 -> 0.190 ms on 512 -> 256 alone, nothing on the training step: profiles/r5_ab_conv_t2.txt).
-    // PASTA_CONV_T2=2 takes the smaller planes too.
-    static const bool small_too = getenv("PASTA_CONV_T2") && getenv("PASTA_CONV_T2")[0] == '2';
-    return d->C_in / d->groups >= 16 && ((d->H % 8 == 0 && d->W % 32 == 0) || (d->H % 16 == 0 && d->W % 16 == 0)) && ((int64_t)d->H * d->W >= 4096 || small_too);
+    // Every plane of 8 x 32 or 16 x 16 tiles.  (At 32 x 32 and 16 x 16 the regular tiles of a batch of 16 fill the chip once or half, and what the edge
+    // tiles in front of them take is added to the launch: +7 % / +12 % there, +30 % / +50 % on the discriminator's stacked batches of 48 --
+    // profiles/r5_ab_conv_t2.txt.)  PASTA_CONV_T2=1: planes of 64 x 64 and larger only.
+    static const bool large_only = getenv("PASTA_CONV_T2") && getenv("PASTA_CONV_T2")[0] == '1';
+    return d->C_in / d->groups >= 16 && ((d->H % 8 == 0 && d->W % 32 == 0) || (d->H % 16 == 0 && d->W % 16 == 0)) && ((int64_t)d->H * d->W >= 4096 || !large_only);
 }
 
 // The remainder of the parity-pair launch: output row 2H and / or column 2W of a stride-2 conv_transpose2d onto an odd plane --

@@ -34,6 +34,8 @@ def _plan(n, ci, h, co, groups=1, pad=0, flags=0, w=None):
     (2, 64, 64, 128, 2),         # groups
     (1, 24, 128, 72, 1),         # 128 x 128: five blocks of column rows; ragged channels on both sides
     (3, 32, 80, 64, 1),          # 80 x 80: no 32-column tiles -- the 16 x 16 tile instance (a 32-pixel MFMA block = two tile rows)
+    (17, 48, 16, 72, 1),         # 16 x 16 planes, seventeen images: the edge tiles of the 16 x 16 instance hold sixteen images each
+    (5, 64, 32, 96, 1),          # 32 x 32 planes
 ])
 def test_one_pass_kernel_against_fp64(n, ci, h, co, groups):
     from torch_utils.ops import conv2d_gradfix as cg
@@ -64,8 +66,8 @@ def test_input_scale_rides_in_the_staging_of_every_tile_kind():
 
 def test_what_the_kernel_leaves_to_the_other_paths():
     assert _plan(2, 32, 64, 64, pad=1)[0] != 13          # pad 1: the parity-pair mode or the per-class launches
-    assert _plan(2, 32, 16, 64)[0] != 13                 # planes below 8 x 32 tiles
-    assert _plan(16, 512, 32, 256)[0] != 13              # 32 x 32: left to the per-class launches by default (PASTA_CONV_T2=2 takes them)
+    assert _plan(16, 512, 32, 256) == (13, 1) and _plan(48, 512, 16, 512) == (13, 1)      # 32 x 32 and 16 x 16 planes: the 8 x 32 and the 16 x 16 tile instance
+    assert _plan(2, 32, 8, 64)[0] != 13                  # planes below 16 x 16
     assert _plan(2, 8, 64, 64)[0] != 13                  # fewer than sixteen input channels
     assert _plan(2, 32, 64, 64, flags=2)[0] != 13        # an output scale
 

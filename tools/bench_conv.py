@@ -29,6 +29,8 @@ SHAPES = [  # name, N, Cin, H, Cout, k, stride, transposed
     ('up 512->512 3x3 T2 @16', 16, 512, 16, 512, 3, 2, True),
     ('up 256->128 3x3 T2 @64', 16, 256, 64, 128, 3, 2, True),
     ('up 512->256 3x3 T2 @32', 16, 512, 32, 256, 3, 2, True),
+    ('up 512->256 3x3 T2 @32 x48', 48, 512, 32, 256, 3, 2, True),
+    ('up 512->512 3x3 T2 @16 x48', 48, 512, 16, 512, 3, 2, True),
     ('merge 192->128 1x1 @128', 16, 192, 128, 128, 1, 1, False),
     ('merge 128->64 1x1 @256', 16, 128, 256, 64, 1, 1, False),
     ('skip 64->64 1x1 @256', 16, 64, 256, 64, 1, 1, False),
